@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (/root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).
+Nothing from the reference is copied: the fixtures hold inputs (fields, momenta,
+uniforms, conv weights) and the outputs the reference's own functions return.
+
+    cd /root/repo && python tests/golden/make_golden.py
+
+The reference needs three import-time stubs here: tensorboard's
+SummaryWriter, IPython.display, and `np.float`.  fp64 is selected *after*
+importing fthmc.config because that module resets the default dtype (Q1).
+"""
+import os
+import sys
+import tempfile
+import types
+import math
+
+import numpy as np
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+np.float = float  # removed in NumPy 2; the reference's plot helpers still use it
+
+
+def _stub_modules():
+    tb = types.ModuleType('torch.utils.tensorboard')
+    tbw = types.ModuleType('torch.utils.tensorboard.writer')
+
+    class SummaryWriter:  # no-op
+        def __init__(self, *a, **k): pass
+        def add_scalar(self, *a, **k): pass
+        def add_histogram(self, *a, **k): pass
+        def close(self): pass
+    tb.SummaryWriter = SummaryWriter
+    tbw.SummaryWriter = SummaryWriter
+    tb.writer = tbw
+    sys.modules['torch.utils.tensorboard'] = tb
+    sys.modules['torch.utils.tensorboard.writer'] = tbw
+    ip = types.ModuleType('IPython')
+    ipd = types.ModuleType('IPython.display')
+
+    class DisplayHandle:
+        def __init__(self, *a, **k): pass
+        def update(self, *a, **k): pass
+    ipd.DisplayHandle = DisplayHandle
+    ipd.display = lambda *a, **k: None
+    ip.display = ipd
+    ip.get_ipython = lambda: None
+    sys.modules['IPython'] = ip
+    sys.modules['IPython.display'] = ipd
+
+
+def main():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import torch
+    _stub_modules()
+    work = tempfile.mkdtemp(prefix='fthmc_golden_')
+    os.chdir(work)                      # TrainConfig(debug=True) writes ./debug
+
+    import fthmc.config as cfg          # resets default dtype to fp32 (Q1)
+    torch.set_default_dtype(torch.float64)
+    import fthmc.utils.qed_helpers as qed
+    import fthmc.utils.layers as layers
+    import fthmc.utils.distributions as distributions
+    import fthmc.utils.samplers as samplers
+    import fthmc.ft_hmc as ft_hmc
+    import fthmc.train as train
+    cfg.DTYPE = torch.float64
+    ft_hmc.DTYPE = torch.float64
+    samplers.DTYPE = torch.float64
+
+    def npy(t):
+        return t.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(t) else np.asarray(t)
+
+    def make_flow(n_layers, L, seed, act='silu'):
+        torch.manual_seed(seed)
+        return layers.make_u1_equiv_layers(
+            n_layers=n_layers, n_mixture_comps=2, lattice_shape=(L, L),
+            hidden_sizes=[8, 8], kernel_size=3, activation_fn=act)
+
+    def flow_arrays(flow):
+        d = {'n_layers': np.int64(len(flow))}
+        for li, layer in enumerate(flow):
+            for pi, p in enumerate(layer.parameters()):
+                d[f'w{li}_{pi}'] = npy(p)
+        return d
+
+    def save(name, **arrs):
+        path = os.path.join(OUT, name + '.npz')
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+        print(f'{name}: {os.path.getsize(path)/1024:.1f} KiB')
+
+    # ---- 0. RNG-free known answer ---------------------------
+    B, L, beta = 2, 8, 2.0
+    b_, m_, i_, j_ = np.meshgrid(np.arange(B), np.arange(2), np.arange(L), np.arange(L), indexing='ij')
+    x = torch.tensor(2.5 * np.sin(0.7 * i_ + 1.3 * j_ ** 2 + 2.1 * m_ + 0.9 * b_))
+    flow = make_flow(2, L, 0)
+    with torch.no_grad():
+        for li, layer in enumerate(flow):
+            for pi, p in enumerate(layer.parameters()):
+                n = p.numel()
+                p.copy_((0.3 * torch.sin(1.0 + 0.37 * torch.arange(n, dtype=torch.float64) + li + 0.5 * pi)).reshape(p.shape))
+    param = cfg.Param(beta=beta, L=L)
+    S = qed.BatchAction(beta)(x)
+    y0, lj0 = flow[0].forward(x)
+    y1, lj1 = flow[1].forward(y0)
+    save('known_answer', x=npy(x), beta=beta, S=npy(S), Q=npy(qed.batch_charges(x)),
+         plaq=npy(-S / (beta * L * L)), F=npy(qed.force(param, x.clone())),
+         y0=npy(y0), logJ0=npy(lj0), y1=npy(y1), logJ1=npy(lj1),
+         S_eff=npy(qed.ft_action(param, flow, x)), ft_force=npy(qed.ft_force(param, flow, x.clone())),
+         **flow_arrays(flow))
+
+    # ---- 1. observables -------------------------------------------------
+    torch.manual_seed(101)
+    for (B, L, beta) in [(3, 8, 2.0), (2, 12, 3.5), (4, 16, 4.0)]:
+        x = (torch.rand(B, 2, L, L) * 2 - 1) * 3 * math.pi     # beyond [-pi,pi) on purpose
+        S = qed.BatchAction(beta)(x)
+        save(f'obs_L{L}', x=npy(x), beta=beta, S=npy(S), plaqs=npy(qed.batch_plaqs(x)),
+             Q=npy(qed.batch_charges(x)), plaq=npy(-S / (beta * L * L)),
+             topo=npy(qed.topo_charge(x)), regularize=npy(qed.regularize(x)),
+             wrap=npy(qed.torch_wrap(x)), layers_mod=npy(layers.torch_mod(x)))
+
+    # ---- 2. plain force / leapfrog / hmc --------------------------------
+    for (L, beta, tau, nstep, seed) in [(8, 2.0, 1.0, 10, 1331), (8, 2.0, 0.3, 1, 7), (16, 4.0, 0.5, 5, 11)]:
+        param = cfg.Param(beta=beta, L=L, tau=tau, nstep=nstep)
+        torch.manual_seed(seed)
+        x = torch.empty(1, 2, L, L).uniform_(-math.pi, math.pi)
+        p = torch.randn_like(x)
+        Fx = qed.force(param, x.clone())
+        x_, p_ = qed.leapfrog(param, x.clone(), p.clone(), verbose=False)
+        # hmc with captured v, u: re-seed, call, then replay the draws
+        torch.manual_seed(seed + 1)
+        dH, exp_mdH, acc, newx = qed.hmc(param, x.clone(), verbose=False)
+        torch.manual_seed(seed + 1)
+        v = torch.randn_like(x)
+        u = torch.rand([], dtype=torch.float64)
+        save(f'hmc_L{L}_n{nstep}', x=npy(x), p=npy(p), beta=beta, dt=param.dt, nstep=nstep,
+             force=npy(Fx), lf_x=npy(x_), lf_p=npy(p_),
+             v=npy(v), u=npy(u), dH=npy(dH), exp_mdH=npy(exp_mdH), acc=np.bool_(bool(acc)), newx=npy(newx))
+    # zero start (reference default randinit=False)
+    param = cfg.Param(beta=2.0, L=8, tau=1.0, nstep=10)
+    x = param.initializer().to(torch.float64)
+    torch.manual_seed(1331)
+    dH, exp_mdH, acc, newx = qed.hmc(param, x.clone(), verbose=False)
+    torch.manual_seed(1331)
+    v = torch.randn_like(x)
+    u = torch.rand([], dtype=torch.float64)
+    save('hmc_zero_L8', x=npy(x), beta=2.0, dt=param.dt, nstep=10, v=npy(v), u=npy(u),
+         dH=npy(dH), exp_mdH=npy(exp_mdH), acc=np.bool_(bool(acc)), newx=npy(newx))
+
+    # ---- 3. single layers: all 8 (mu, off) combos, fwd + VJP + wgrad ----
+    for (B, L, act) in [(2, 8, 'silu'), (2, 12, 'silu'), (1, 8, 'relu'), (1, 8, 'leaky_relu')]:
+        flow = make_flow(8, L, 500 + L)
+        if act != 'silu':
+            flow = make_flow(8, L, 500 + L, act)
+        torch.manual_seed(77 + L)
+        d = {'beta': 0.0, 'act': act, **flow_arrays(flow)}
+        for li, layer in enumerate(flow):
+            x = torch.empty(B, 2, L, L).uniform_(-math.pi, math.pi).requires_grad_(True)
+            c = torch.randn(B, 2, L, L)
+            dd = torch.randn(B)
+            y, lj = layer.forward(x)
+            obj = (c * y).sum() + (dd * lj).sum()
+            params = list(layer.parameters())
+            grads = torch.autograd.grad(obj, [x] + params)
+            d.update({f'x{li}': npy(x), f'c{li}': npy(c), f'd{li}': npy(dd), f'y{li}': npy(y),
+                      f'logJ{li}': npy(lj), f'gx{li}': npy(grads[0])})
+            for pi, g in enumerate(grads[1:]):
+                d[f'gw{li}_{pi}'] = npy(g)
+            with torch.no_grad():
+                xr, ljr = layer.reverse(y.detach())
+            d.update({f'rev_x{li}': npy(xr), f'rev_logJ{li}': npy(ljr)})
+        save(f'layers_L{L}_{act}', **d)
+
+    # ---- 4. ft_action / ft_force / round trip ---------------------------
+    for (B, L, beta, nl) in [(2, 8, 2.0, 2), (2, 8, 2.0, 8), (32, 16, 4.0, 4), (1, 8, 2.0, 16)]:
+        flow = make_flow(nl, L, 900 + nl)
+        param = cfg.Param(beta=beta, L=L)
+        torch.manual_seed(31 + nl)
+        x = torch.empty(B, 2, L, L).uniform_(-math.pi, math.pi)
+        ft = ft_hmc.FieldTransformation(flow, cfg.TrainConfig(L=L, beta=beta, debug=True, n_layers=nl),
+                                        cfg.lfConfig(tau=1.0, nstep=10))
+        with torch.no_grad():
+            y, logdet = ft.flow_forward(x)
+            xb, logdet_b = ft.flow_backward(y)
+            S_eff = qed.ft_action(param, flow, x)
+        Ff = qed.ft_force(param, flow, x.clone())
+        save(f'ft_L{L}_n{nl}', x=npy(x), beta=beta, y=npy(y), logdet=npy(logdet), S_eff=npy(S_eff),
+             ft_force=npy(Ff), rev_x=npy(xb), rev_logdet=npy(logdet_b),
+             Q=npy(qed.batch_charges(y)), **flow_arrays(flow))
+
+    # ---- 5. trajectories -------------------------------------------------
+    # (A) intended ftHMC: qed.leapfrog structure with ft_force / ft_action
+    #     (semantics of ipynb/ft_hmc.py:394-435 without the flow-inverse wrapper)
+    for (B, L, beta, nl, tau, nstep) in [(1, 8, 2.0, 4, 1.0, 10), (4, 16, 4.0, 4, 1.0, 10)]:
+        flow = make_flow(nl, L, 1200 + L)
+        param = cfg.Param(beta=beta, L=L, tau=tau, nstep=nstep)
+        torch.manual_seed(1331)
+        x = torch.empty(B, 2, L, L).uniform_(-math.pi, math.pi)
+        v = torch.randn_like(x)
+        u = torch.rand(B, dtype=torch.float64)
+        dt = param.dt
+        with torch.no_grad():
+            h0 = qed.ft_action(param, flow, x) + 0.5 * (v * v).flatten(1).sum(1)
+        x_ = x + 0.5 * dt * v
+        p_ = v + (-dt) * qed.ft_force(param, flow, x_)
+        for _ in range(nstep - 1):
+            x_ = x_ + dt * p_
+            p_ = p_ + (-dt) * qed.ft_force(param, flow, x_)
+        x_ = x_ + 0.5 * dt * p_
+        xr = qed.regularize(x_)
+        with torch.no_grad():
+            h1 = qed.ft_action(param, flow, xr) + 0.5 * (p_ * p_).flatten(1).sum(1)
+            dH = h1 - h0
+            acc = u < torch.exp(-dH)
+            newx = torch.where(acc[:, None, None, None], xr, x)
+            yphys = qed.ft_flow(flow, newx)
+        save(f'traj_md_L{L}', x=npy(x), v=npy(v), u=npy(u), beta=beta, dt=dt, nstep=nstep,
+             lf_x=npy(x_), lf_p=npy(p_), H0=npy(h0), H1=npy(h1), dH=npy(dH), acc=npy(acc).astype(bool),
+             newx=npy(newx), plaq=npy(-qed.BatchAction(beta)(yphys) / (beta * L * L)),
+             Q=npy(qed.batch_charges(yphys)), **flow_arrays(flow))
+    # (B) literal FieldTransformation.hmc (B=1 only)
+    L, beta, nl = 8, 2.0, 4
+    flow = make_flow(nl, L, 1300)
+    ft = ft_hmc.FieldTransformation(flow, cfg.TrainConfig(L=L, beta=beta, debug=True, n_layers=nl),
+                                    cfg.lfConfig(tau=1.0, nstep=10))
+    torch.manual_seed(4242)
+    x = torch.empty(1, 2, L, L).uniform_(0, 2 * math.pi)
+    torch.manual_seed(99)
+    xnew, metrics = ft.hmc(x.clone())
+    torch.manual_seed(99)
+    v = torch.randn_like(x)
+    u = torch.rand([], dtype=torch.float64)
+    with torch.no_grad():
+        yphys, _ = ft.flow_forward(xnew)
+        lm = ft.lattice_metrics(yphys, torch.zeros(1))
+    save('traj_literal_L8', x=npy(x), v=npy(v), u=npy(u), beta=beta, dt=ft.dt, nstep=10,
+         newx=npy(xnew), dH=npy(metrics['dh']), acc=np.bool_(bool(metrics['acc'])),
+         plaq=npy(lm['plaq']), Q=npy(lm['q']), **flow_arrays(flow))
+
+    # ---- 6. one training step -------------------------------------------
+    for (B, L, beta, nl) in [(4, 8, 2.0, 4), (8, 16, 4.0, 2)]:
+        tc = cfg.TrainConfig(L=L, beta=beta, debug=True, n_layers=nl, batch_size=B, base_lr=1e-3)
+        torch.manual_seed(2024 + L)
+        model = train.get_model(tc)
+        w_before = flow_arrays(model.layers)
+        optimizer = torch.optim.Adam(model.layers.parameters(), lr=tc.base_lr)
+        xi = model.prior.sample_n(B)
+        metrics = train.train_step(model, tc, qed.BatchAction(beta), optimizer, B, xi=xi.clone())
+        d = {'xi': npy(xi), 'beta': beta, 'lr': tc.base_lr}
+        d.update(w_before)
+        for li, layer in enumerate(model.layers):
+            for pi, p in enumerate(layer.parameters()):
+                d[f'gw{li}_{pi}'] = npy(p.grad)
+                d[f'w_after{li}_{pi}'] = npy(p)
+        for k in ('ess', 'logp', 'logq', 'loss_dkl', 'q', 'dq', 'plaq'):
+            d[k] = np.asarray(metrics[k], dtype=np.float64)
+        save(f'train_L{L}', **d)
+
+    # ---- 7. masks ---------------------------------------------------------
+    d = {}
+    for L in (8, 12):
+        for mu in (0, 1):
+            for off in range(4):
+                pm = layers.make_plaq_masks((L, L), mu, off)
+                d[f'L{L}_mu{mu}_off{off}_active'] = npy(pm['active'])
+                d[f'L{L}_mu{mu}_off{off}_frozen'] = npy(pm['frozen'])
+                d[f'L{L}_mu{mu}_off{off}_passive'] = npy(pm['passive'])
+                d[f'L{L}_mu{mu}_off{off}_link'] = npy(layers.make_2d_link_active_stripes((2, L, L), mu, off))
+    save('masks', **d)
+    d = {f'{b}': v for b, v in cfg.PLAQ_EXACT.items()}
+    save('plaq_exact', betas=np.array(list(cfg.PLAQ_EXACT.keys())), values=np.array(list(cfg.PLAQ_EXACT.values())))
+
+
+if __name__ == '__main__':
+    main()

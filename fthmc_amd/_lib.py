@@ -1,0 +1,78 @@
+"""ctypes binding of libfthmc_hip.so (C ABI: include/fthmc_hip.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback.  If the
+shared object is missing or a tensor is not on a HIP device, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfthmc_hip.so')
+
+W_PER_LAYER = 955
+ACT_CODES = {None: 0, 'silu': 0, 'swish': 0, 'relu': 1, 'leaky_relu': 2}
+MODE_MD, MODE_LITERAL = 0, 1
+
+_D = c_void_p          # device pointer
+_P = c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPE); must match include/fthmc_hip.h
+SIGNATURES = {
+    'fthmc_version': [],
+    'fthmc_strerror': [c_int],
+    'fthmc_ws_bytes': [c_int, c_int, c_int],
+    'fthmc_wrap': [_D, _D, c_size_t, _P],
+    'fthmc_regularize': [_D, _D, c_size_t, _P],
+    'fthmc_plaquettes': [_D, _D, c_int, c_int, _P],
+    'fthmc_wilson_action_charge': [_D, c_int, c_int, c_double, _D, _D, _D, _P],
+    'fthmc_wilson_force': [_D, c_int, c_int, c_double, _D, _P],
+    'fthmc_leapfrog': [_D, _D, c_int, c_int, c_double, c_double, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_kinetic': [_D, c_int, c_int, _D, _P],
+    'fthmc_hmc_trajectory': [_D, _D, _D, c_int, c_int, c_double, c_double, c_int, _D, _D, _D, _D, _D,
+                             _P, c_size_t, _P],
+    'fthmc_flow_layer_fwd': [_D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_layer_bwd': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_layer_rev': [_D, _D, c_int, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_forward': [_D, _D, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_reverse': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
+    'fthmc_ft_action': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
+    'fthmc_ft_force': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _P, c_size_t, _P],
+    'fthmc_ft_leapfrog': [_D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int, _D, _D,
+                          _P, c_size_t, _P],
+    'fthmc_ft_trajectory': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int,
+                            _D, _D, _D, _D, _D, _D, _D, _P, c_size_t, _P],
+    'fthmc_train_grad': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
+}
+_RESTYPE = {'fthmc_version': c_char_p, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
+
+_lib = None
+
+
+class FthmcError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen the HIP library and type every entry point; raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise FthmcError(
+            f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C fthmc_amd/csrc`.  fthmc_amd has no CPU fallback.')
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)                 # AttributeError if a symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise FthmcError(f'{what} failed: {load().fthmc_strerror(rc).decode()} (code {rc})')

@@ -1,0 +1,399 @@
+// extern "C" entry points of libfthmc_hip.so (include/fthmc_hip.h) and the host-side
+// kernel sequencing behind them.  Every function only enqueues work on the caller's
+// stream; scratch comes from the caller's workspace, so the whole sequence of a
+// trajectory can be captured into a hipGraph by the caller.
+#include "common.h"
+#include "kernels.h"
+#include <math.h>
+
+using namespace fthmc;
+
+namespace {
+
+constexpr size_t ALIGN = 32;   // doubles (256 B)
+inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
+
+struct WS {
+    double *wint, *X, *gp, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part;
+    size_t n2;       // doubles per field batch: B * 2 * L * L
+    size_t total;    // doubles
+};
+
+// scal slots, each B doubles
+enum { SC_S = 0, SC_Q, SC_PLAQ, SC_LOGDET, SC_K, SC_H0, SC_H1, SC_OLD0, SC_OLD1, SC_NEW0, SC_NEW1, SC_SEFF, SC_N };
+
+WS ws_layout(double* base, int B, int L, int nl) {
+    WS w{};
+    const size_t n1 = (size_t)B * L * L, n2 = 2 * n1;
+    const size_t nt = (size_t)flow_ntiles(L);
+    size_t o = 0;
+    auto take = [&](size_t n) { double* p = base ? base + o : nullptr; o += up(n); return p; };
+    w.n2 = n2;
+    w.wint = take((size_t)(nl > 0 ? nl : 1) * FLOW_WINT);
+    w.X = take((size_t)nl * n2);
+    w.gp = take(n1);
+    w.gp_part = take(nl > 0 ? (size_t)B * nt * FLOW_N0 : 0);
+    w.lj_part = take((size_t)B * nt);
+    w.scal = take((size_t)SC_N * B);
+    w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
+    w.gw_part = take(nl > 0 ? (size_t)B * nt * FLOW_GW_STRIDE : 0);
+    w.total = o;
+    return w;
+}
+
+inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
+
+#define FT_TRY(expr) do { int rc_ = (expr); if (rc_ != FTHMC_OK) return rc_; } while (0)
+
+// Forward sweep x -> X[0..nl-1] (X[l] = output of layer l).  logdet (device [B]) optional.
+int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, double* logdet,
+                  hipStream_t s) {
+    for (int l = 0; l < nl; ++l) {
+        FlowLayerArgs a{};
+        a.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
+        a.wint = w.wint + (size_t)l * FLOW_WINT;
+        a.y = w.X + (size_t)l * w.n2;
+        a.logj_part = logdet ? w.lj_part : nullptr;
+        a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
+        FT_TRY(launch_flow_fwd(a, s));
+        if (logdet) FT_TRY(launch_sum_parts(w.lj_part, B, flow_ntiles(L), 1.0, l > 0, logdet, s));
+    }
+    return FTHMC_OK;
+}
+
+inline const double* phys_field(const double* x, const WS& w, int nl) {
+    return nl == 0 ? x : w.X + (size_t)(nl - 1) * w.n2;
+}
+
+// S_eff (and friends) of x; leaves the checkpoints in w.X
+int eval_action(const double* x, const WS& w, int nl, int B, int L, int act, double beta,
+                double* S_eff, double* logdet, double* plaq, double* Q, hipStream_t s) {
+    double* ld = logdet ? logdet : w.scal + (size_t)SC_LOGDET * B;
+    if (nl > 0) FT_TRY(sweep_forward(x, w, nl, B, L, act, ld, s));
+    double* S = w.scal + (size_t)SC_S * B;
+    FT_TRY(launch_action_charge(phys_field(x, w, nl), B, L, beta, S, Q, plaq, s));
+    if (S_eff) FT_TRY(launch_lincomb(S, 1.0, nl > 0 ? ld : nullptr, -1.0, 0.0, S_eff, B, s));
+    return FTHMC_OK;
+}
+
+// Plaquette-gradient field of sum_b S_eff (scaled): gp = scale*beta*sin P(F(x)) + sum_l gP_l,
+// with dL/dlogJ = glogj.  gw != null also accumulates weight gradients (training).
+int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double beta_scaled,
+             double glogj, double* gw, hipStream_t s) {
+    if (nl > 0) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s));
+    FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, w.gp, s));
+    for (int l = nl - 1; l >= 0; --l) {
+        FlowLayerArgs a{};
+        a.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
+        a.wint = w.wint + (size_t)l * FLOW_WINT;
+        a.up_gp = w.gp;
+        a.glogj_const = glogj;
+        a.gp_part = w.gp_part;
+        a.gw_part = w.gw_part;
+        a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
+        FT_TRY(launch_flow_bwd(a, gw != nullptr, s));
+        if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_ntiles(L), 1.0, 0,
+                                        gw + (size_t)l * FTHMC_W_PER_LAYER, s));
+        FT_TRY(launch_gather_gp(w.gp_part, B, L, 1, w.gp, s));
+    }
+    return FTHMC_OK;
+}
+
+// leapfrog in the latent field; result in w.xa / w.va
+int ft_leapfrog_ws(const double* x, const double* v, const WS& w, int nl, int B, int L, int act,
+                   double beta, double dt, int nstep, hipStream_t s) {
+    FT_TRY(launch_axpy(x, v, 0.5 * dt, w.xa, w.n2, s));
+    if (hipMemcpyAsync(w.va, v, w.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return FTHMC_ERR_LAUNCH;
+    for (int k = 0; k < nstep; ++k) {
+        FT_TRY(force_gp(w.xa, w, nl, B, L, act, beta, -1.0, nullptr, s));
+        FT_TRY(launch_kick_from_gp(w.gp, w.va, w.xa, nullptr, B, L, dt, k == nstep - 1 ? 0.5 * dt : dt, s));
+    }
+    return FTHMC_OK;
+}
+
+// plain leapfrog; result pointers returned through xo/po (ping-pong inside the workspace)
+int leapfrog_ws(const double* x, const double* p, const WS& w, int B, int L, double beta, double dt,
+                int nstep, double** xo, double** po, hipStream_t s) {
+    const double* xi = x; const double* pi = p;
+    double* xs[2] = {w.xa, w.xb}; double* ps[2] = {w.va, w.vb};
+    int cur = 0;
+    for (int k = 0; k < nstep; ++k) {
+        FT_TRY(launch_leap_step(xi, pi, xs[cur], ps[cur], B, L, beta, k == 0 ? 0.5 * dt : dt, dt, s));
+        xi = xs[cur]; pi = ps[cur]; cur ^= 1;
+    }
+    // final half drift into the free x buffer
+    FT_TRY(launch_axpy(xi, pi, 0.5 * dt, xs[cur], w.n2, s));
+    *xo = xs[cur]; *po = const_cast<double*>(pi);
+    return FTHMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fthmc_version(void) { return "fthmc_hip 0.1 (gfx950)"; }
+
+const char* fthmc_strerror(int code) {
+    switch (code) {
+        case FTHMC_OK: return "ok";
+        case FTHMC_ERR_ARG: return "bad argument (null pointer or shape; L must be a multiple of 4)";
+        case FTHMC_ERR_UNSUPPORTED: return "unsupported configuration";
+        case FTHMC_ERR_LAUNCH: return "HIP launch failed";
+        case FTHMC_ERR_WS: return "workspace too small (see fthmc_ws_bytes)";
+        default: return "unknown error";
+    }
+}
+
+size_t fthmc_ws_bytes(int B, int L, int n_layers) {
+    if (B <= 0 || L <= 0 || n_layers < 0) return 0;
+    return ws_layout(nullptr, B, L, n_layers).total * sizeof(double);
+}
+
+#define FT_WS(nl)                                                                   \
+    if (!ws || ws_bytes < fthmc_ws_bytes(B, L, (nl))) return FTHMC_ERR_WS;          \
+    const WS W = ws_layout(static_cast<double*>(ws), B, L, (nl));                   \
+    hipStream_t s = ft_stream(stream)
+
+int fthmc_wrap(const double* x, double* out, size_t n, void* stream) {
+    if (!x || !out) return FTHMC_ERR_ARG;
+    return launch_wrap(x, out, n, 0, ft_stream(stream));
+}
+int fthmc_regularize(const double* x, double* out, size_t n, void* stream) {
+    if (!x || !out) return FTHMC_ERR_ARG;
+    return launch_wrap(x, out, n, 1, ft_stream(stream));
+}
+int fthmc_plaquettes(const double* x, double* P, int B, int L, void* stream) {
+    if (!x || !P || bad_shape(B, L)) return FTHMC_ERR_ARG;
+    return launch_plaq(x, P, B, L, ft_stream(stream));
+}
+int fthmc_wilson_action_charge(const double* x, int B, int L, double beta, double* S, double* Q,
+                               double* plaq, void* stream) {
+    if (!x || bad_shape(B, L)) return FTHMC_ERR_ARG;
+    return launch_action_charge(x, B, L, beta, S, Q, plaq, ft_stream(stream));
+}
+int fthmc_wilson_force(const double* x, int B, int L, double beta, double* F, void* stream) {
+    if (!x || !F || bad_shape(B, L)) return FTHMC_ERR_ARG;
+    return launch_wilson_force(x, B, L, beta, F, ft_stream(stream));
+}
+int fthmc_kinetic(const double* v, int B, int L, double* K, void* stream) {
+    if (!v || !K || bad_shape(B, L)) return FTHMC_ERR_ARG;
+    return launch_kinetic(v, B, L, K, ft_stream(stream));
+}
+
+int fthmc_leapfrog(const double* x, const double* p, int B, int L, double beta, double dt, int nstep,
+                   double* x_out, double* p_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !p || !x_out || !p_out || bad_shape(B, L) || nstep < 1) return FTHMC_ERR_ARG;
+    FT_WS(0);
+    double *xo, *po;
+    FT_TRY(leapfrog_ws(x, p, W, B, L, beta, dt, nstep, &xo, &po, s));
+    if (hipMemcpyAsync(x_out, xo, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(p_out, po, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return FTHMC_ERR_LAUNCH;
+    return FTHMC_OK;
+}
+
+int fthmc_hmc_trajectory(const double* x, const double* v, const double* u, int B, int L, double beta,
+                         double dt, int nstep, double* x_new, double* dH, double* acc, double* H0,
+                         double* H1, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !v || !u || !x_new || bad_shape(B, L) || nstep < 1) return FTHMC_ERR_ARG;
+    FT_WS(0);
+    double* S = W.scal + (size_t)SC_S * B; double* K = W.scal + (size_t)SC_K * B;
+    double* h0 = H0 ? H0 : W.scal + (size_t)SC_H0 * B;
+    double* h1 = H1 ? H1 : W.scal + (size_t)SC_H1 * B;
+    FT_TRY(launch_action_charge(x, B, L, beta, S, nullptr, nullptr, s));
+    FT_TRY(launch_kinetic(v, B, L, K, s));
+    FT_TRY(launch_lincomb(S, 1.0, K, 0.5, 0.0, h0, B, s));
+    double *xo, *po;
+    FT_TRY(leapfrog_ws(x, v, W, B, L, beta, dt, nstep, &xo, &po, s));
+    FT_TRY(launch_wrap(xo, xo, W.n2, 1, s));                       // xr = regularize(x_)
+    FT_TRY(launch_action_charge(xo, B, L, beta, S, nullptr, nullptr, s));
+    FT_TRY(launch_kinetic(po, B, L, K, s));
+    FT_TRY(launch_lincomb(S, 1.0, K, 0.5, 0.0, h1, B, s));
+    return launch_metropolis(x, xo, u, h0, h1, B, L, 0, x_new, dH, acc, nullptr, nullptr, nullptr, 0, s);
+}
+
+int fthmc_flow_layer_fwd(const double* x, const double* w, int B, int L, int mu, int off, int act,
+                         double* y, double* logJ, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !y || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(1);
+    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FlowLayerArgs a{};
+    a.x = x; a.wint = W.wint; a.y = y; a.logj_part = W.lj_part;
+    a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+    FT_TRY(launch_flow_fwd(a, s));
+    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_ntiles(L), 1.0, 0, logJ, s));
+    return FTHMC_OK;
+}
+
+int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu, int off, int act,
+                         double tol, double* x, double* logJ, void* ws, size_t ws_bytes, void* stream) {
+    if (!y || !w || !x || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(1);
+    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FlowLayerArgs a{};
+    a.x = y; a.wint = W.wint; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
+    a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+    FT_TRY(launch_flow_rev(a, s));
+    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_ntiles(L), 1.0, 0, logJ, s));
+    return FTHMC_OK;
+}
+
+int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, const double* glogJ,
+                         int B, int L, int mu, int off, int act, double* gx, double* gw, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (!x || !w || !gy || !glogJ || !gx || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3)
+        return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(1);
+    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FlowLayerArgs a{};
+    a.x = x; a.wint = W.wint; a.up_link = gy; a.glogj = glogJ;
+    a.gp_part = W.gp_part; a.gw_part = W.gw_part;
+    a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+    FT_TRY(launch_flow_bwd(a, gw != nullptr, s));
+    if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_ntiles(L), 1.0, 0, gw, s));
+    FT_TRY(launch_gather_gp(W.gp_part, B, L, 0, W.gp, s));
+    return launch_adj_add(W.gp, gy, B, L, gx, s);
+}
+
+int fthmc_flow_forward(const double* x, const double* w, int n_layers, int B, int L, int act,
+                       double* y, double* logdet, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(n_layers);
+    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
+    if (n_layers == 0 && hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    FT_TRY(sweep_forward(x, W, n_layers, B, L, act, ld, s));
+    if (y && hipMemcpyAsync(y, phys_field(x, W, n_layers), W.n2 * sizeof(double),
+                            hipMemcpyDeviceToDevice, s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    return FTHMC_OK;
+}
+
+int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, int L, int act, double tol,
+                       double* x, double* logdet, void* ws, size_t ws_bytes, void* stream) {
+    if (!y || !x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(n_layers);
+    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
+    if (hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    if (x != y && hipMemcpyAsync(x, y, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return FTHMC_ERR_LAUNCH;
+    for (int l = n_layers - 1; l >= 0; --l) {
+        FlowLayerArgs a{};
+        a.x = x; a.wint = W.wint + (size_t)l * FLOW_WINT; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
+        a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
+        FT_TRY(launch_flow_rev(a, s));
+        FT_TRY(launch_sum_parts(W.lj_part, B, flow_ntiles(L), 1.0, 1, ld, s));
+    }
+    return FTHMC_OK;
+}
+
+int fthmc_ft_action(const double* x, const double* w, int n_layers, int B, int L, int act, double beta,
+                    double* S_eff, double* logdet, double* plaq, double* Q, void* ws, size_t ws_bytes,
+                    void* stream) {
+    if (!x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(n_layers);
+    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    if (n_layers == 0 && logdet && hipMemsetAsync(logdet, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    return eval_action(x, W, n_layers, B, L, act, beta, S_eff, logdet, plaq, Q, s);
+}
+
+int fthmc_ft_force(const double* x, const double* w, int n_layers, int B, int L, int act, double beta,
+                   double* F, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !F || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(n_layers);
+    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(force_gp(x, W, n_layers, B, L, act, beta, -1.0, nullptr, s));
+    return launch_kick_from_gp(W.gp, nullptr, nullptr, F, B, L, 0.0, 0.0, s);
+}
+
+int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, int n_layers, int B, int L,
+                      int act, double beta, double dt, int nstep, double* x_out, double* v_out,
+                      void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !v || !x_out || !v_out || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0 || nstep < 1)
+        return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(n_layers);
+    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(ft_leapfrog_ws(x, v, W, n_layers, B, L, act, beta, dt, nstep, s));
+    if (hipMemcpyAsync(x_out, W.xa, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(v_out, W.va, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return FTHMC_ERR_LAUNCH;
+    return FTHMC_OK;
+}
+
+int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w, int n_layers,
+                        int B, int L, int act, double beta, double dt, int nstep, int mode, double* x_new,
+                        double* dH, double* acc, double* H0, double* H1, double* plaq, double* Q,
+                        void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !v || !u || !x_new || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0 || nstep < 1)
+        return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2 || (mode != FTHMC_MODE_MD && mode != FTHMC_MODE_LITERAL)) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(n_layers);
+    double* K = W.scal + (size_t)SC_K * B; double* Se = W.scal + (size_t)SC_SEFF * B;
+    double* h0 = H0 ? H0 : W.scal + (size_t)SC_H0 * B;
+    double* h1 = H1 ? H1 : W.scal + (size_t)SC_H1 * B;
+    double* old = W.scal + (size_t)SC_OLD0 * B;      // [plaq, Q] of F(x)
+    double* neu = W.scal + (size_t)SC_NEW0 * B;      // [plaq, Q] of F(proposal)
+    double* obs = nullptr;
+    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(eval_action(x, W, n_layers, B, L, act, beta, Se, nullptr, old, old + B, s));
+    FT_TRY(launch_kinetic(v, B, L, K, s));
+    FT_TRY(launch_lincomb(Se, 1.0, K, 0.5, 0.0, h0, B, s));
+    const double* vend;
+    if (mode == FTHMC_MODE_MD) {
+        FT_TRY(ft_leapfrog_ws(x, v, W, n_layers, B, L, act, beta, dt, nstep, s));
+        FT_TRY(launch_wrap(W.xa, W.xb, W.n2, 1, s));              // regularize (ipynb/ft_hmc.py:426)
+        vend = W.va;
+    } else {
+        FT_TRY(launch_axpy(x, v, 0.5 * dt, W.xa, W.n2, s));       // ft_hmc.py:187 (Q2)
+        FT_TRY(launch_wrap(W.xa, W.xb, W.n2, 0, s));              // wrap (ft_hmc.py:208)
+        vend = v;
+    }
+    FT_TRY(eval_action(W.xb, W, n_layers, B, L, act, beta, Se, nullptr, neu, neu + B, s));
+    FT_TRY(launch_kinetic(vend, B, L, K, s));
+    FT_TRY(launch_lincomb(Se, 1.0, K, 0.5, 0.0, h1, B, s));
+    // observables of F(x_new) without another sweep: select per chain
+    double* sel = W.scal + (size_t)SC_S * B;          // reuse S, Q slots (adjacent) as [plaq, Q] out
+    if (plaq || Q) obs = sel;
+    FT_TRY(launch_metropolis(x, W.xb, u, h0, h1, B, L, 0, x_new, dH, acc, old, neu, obs, obs ? 2 : 0, s));
+    if (plaq && hipMemcpyAsync(plaq, sel, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return FTHMC_ERR_LAUNCH;
+    if (Q && hipMemcpyAsync(Q, sel + B, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return FTHMC_ERR_LAUNCH;
+    return FTHMC_OK;
+}
+
+int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int L, int act, double beta,
+                     double* x, double* logq, double* logp, double* gw, void* ws, size_t ws_bytes,
+                     void* stream) {
+    if (!xi || !w || bad_shape(B, L) || n_layers < 1) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(n_layers);
+    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    double* ld = W.scal + (size_t)SC_LOGDET * B;
+    double* S = W.scal + (size_t)SC_S * B;
+    if (gw) {
+        // d mean_b(S_W - logdet) / dw : seed beta/B on the Wilson term, -1/B on every logJ
+        FT_TRY(force_gp(xi, W, n_layers, B, L, act, beta / B, -1.0 / B, gw, s));
+    }
+    if (x || logq || logp) {
+        FT_TRY(sweep_forward(xi, W, n_layers, B, L, act, ld, s));
+        FT_TRY(launch_action_charge(phys_field(xi, W, n_layers), B, L, beta, S, nullptr, nullptr, s));
+        const double lp0 = -(double)(2 * L * L) * log(FT_TWO_PI);
+        if (logq) FT_TRY(launch_lincomb(ld, -1.0, nullptr, 0.0, lp0, logq, B, s));
+        if (logp) FT_TRY(launch_lincomb(S, -1.0, nullptr, 0.0, 0.0, logp, B, s));
+        if (x && hipMemcpyAsync(x, phys_field(xi, W, n_layers), W.n2 * sizeof(double),
+                                hipMemcpyDeviceToDevice, s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    }
+    return FTHMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// Internal launch interface between the translation units of libfthmc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace fthmc {
+
+// ---- wilson.hip
+int launch_wrap(const double* x, double* o, size_t n, int reg, hipStream_t s);
+int launch_axpy(const double* x, const double* p, double a, double* o, size_t n, hipStream_t s);
+int launch_plaq(const double* x, double* P, int B, int L, hipStream_t s);
+int launch_action_charge(const double* x, int B, int L, double beta, double* S, double* Q,
+                         double* plaq, hipStream_t s);
+int launch_kinetic(const double* v, int B, int L, double* K, hipStream_t s);
+int launch_lincomb(const double* a, double ca, const double* b, double cb, double c0, double* out,
+                   int B, hipStream_t s);
+int launch_wilson_force(const double* x, int B, int L, double beta, double* F, hipStream_t s);
+int launch_leap_step(const double* x, const double* p, double* xo, double* po, int B, int L,
+                     double beta, double a, double dt, hipStream_t s);
+int launch_wilson_gp(const double* x, int B, int L, double beta, double* gp, hipStream_t s);
+int launch_kick_from_gp(const double* gp, double* v, double* xq, double* Fout, int B, int L,
+                        double dt, double a, hipStream_t s);
+int launch_metropolis(const double* x_old, const double* x_prop, const double* u, const double* H0,
+                      const double* H1, int B, int L, int xform, double* x_new, double* dH,
+                      double* acc, const double* obs_old, const double* obs_new, double* obs_out,
+                      int n_obs, hipStream_t s);
+
+// ---- flow.hip
+constexpr int FLOW_TILE = 16;                 // sites per tile edge
+constexpr int FLOW_R0 = FLOW_TILE + 6;        // plaquette / net-input window edge
+constexpr int FLOW_N0 = FLOW_R0 * FLOW_R0;    // window size of one gP partial
+constexpr int FLOW_WINT = 1968;               // doubles per layer, kernel-side weight layout
+constexpr int FLOW_GW_STRIDE = 960;           // doubles per (chain, tile) weight-gradient partial
+
+inline int flow_ntiles(int L) { int t = (L + FLOW_TILE - 1) / FLOW_TILE; return t * t; }
+
+// canonical (955/layer, PyTorch order) -> kernel layout (FLOW_WINT/layer)
+int launch_pack_weights(const double* w, int n_layers, double* wint, hipStream_t s);
+
+struct FlowLayerArgs {
+    const double* x;         // [B][2][L][L] layer input
+    const double* wint;      // this layer's weights, kernel layout
+    double* y;               // fwd / rev: output field (may alias x)
+    double* logj_part;       // fwd / rev: [B][ntiles]
+    const double* up_link;   // bwd: upstream link gradient [B][2][L][L] or null
+    const double* up_gp;     // bwd: upstream plaquette-gradient field [B][L][L] or null
+    const double* glogj;     // bwd: [B] or null (then glogj_const)
+    double glogj_const;
+    double* gp_part;         // bwd: [B][ntiles][FLOW_N0]
+    double* gw_part;         // bwd with wgrad: [B*ntiles][FLOW_GW_STRIDE]
+    double tol;              // rev
+    int B, L, mu, off, act;
+};
+int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);
+int launch_flow_rev(const FlowLayerArgs& a, hipStream_t s);
+int launch_flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s);
+// out[b] (+)= sign * sum_t part[b][t]
+int launch_sum_parts(const double* part, int B, int nparts, double sign, int accumulate,
+                     double* out, hipStream_t s);
+// gp[b][i][j] (+)= sum of every partial window position that maps to (i, j)
+int launch_gather_gp(const double* gp_part, int B, int L, int accumulate, double* gp, hipStream_t s);
+// gx = gy + adj(gp)
+int launch_adj_add(const double* gp, const double* gy, int B, int L, double* gx, hipStream_t s);
+// gw[idx] (+)= scale * sum_p gw_part[p][idx], idx < 955
+int launch_reduce_gw(const double* gw_part, int nparts, double scale, int accumulate, double* gw,
+                     hipStream_t s);
+
+}  // namespace fthmc

@@ -1,0 +1,266 @@
+// Wilson-action stencil kernels for 2D U(1): plaquette, action, topological
+// charge, gauge force, fused leapfrog step, Metropolis select.
+// HBM-bound: every kernel reads each link once per pass (coalesced, rows of the
+// [B][2][L][L] field are contiguous in j) and shares plaquettes through LDS.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TS = 16;          // stencil tile (TS x TS sites, 256 threads)
+
+// ---------------------------------------------------------------- elementwise
+__global__ void k_wrap(const double* __restrict__ x, double* __restrict__ o, size_t n, int reg) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) o[i] = reg ? ft_regularize(x[i]) : ft_wrap(x[i]);
+}
+
+__global__ void k_axpy(const double* __restrict__ x, const double* __restrict__ p, double a,
+                       double* __restrict__ o, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) o[i] = x[i] + a * p[i];
+}
+
+// ---------------------------------------------------------------- plaquettes
+__global__ void k_plaq(const double* __restrict__ x, double* __restrict__ P, int L) {
+    const int b = blockIdx.y;
+    const int n = L * L;
+    const double* x0 = x + (size_t)b * 2 * n;
+    const double* x1 = x0 + n;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        const int i = s / L, j = s - i * L;
+        const int ip = i + 1 == L ? 0 : i + 1, jp = j + 1 == L ? 0 : j + 1;
+        P[(size_t)b * n + s] = x0[s] - x1[s] - x0[i * L + jp] + x1[ip * L + j];
+    }
+}
+
+// One workgroup per chain: S = -beta sum cos P, Q = sum wrap(P) / 2pi.
+// xform: 0 none, 1 regularize links first (end of an HMC trajectory).
+template <int XFORM>
+__device__ __forceinline__ void chain_action_charge(const double* __restrict__ x0, int L,
+                                                    double& csum, double& qsum) {
+    const int n = L * L;
+    const double* x1 = x0 + n;
+    double c = 0.0, q = 0.0;
+    for (int s = threadIdx.x; s < n; s += blockDim.x) {
+        const int i = s / L, j = s - i * L;
+        const int ip = i + 1 == L ? 0 : i + 1, jp = j + 1 == L ? 0 : j + 1;
+        double a = x0[s], bb = x1[s], cc = x0[i * L + jp], d = x1[ip * L + j];
+        if (XFORM) { a = ft_regularize(a); bb = ft_regularize(bb); cc = ft_regularize(cc); d = ft_regularize(d); }
+        c += cos(a + d - cc - bb);           // summation order of BatchAction._u1_plaq
+        q += ft_wrap(a - bb - cc + d);       // summation order of batch_plaqs
+    }
+    csum = c; qsum = q;
+}
+
+__global__ void k_action_charge(const double* __restrict__ x, int L, double beta,
+                                double* __restrict__ S, double* __restrict__ Q,
+                                double* __restrict__ plaq) {
+    __shared__ double red[16];
+    const int b = blockIdx.x;
+    double c, q;
+    chain_action_charge<0>(x + (size_t)b * 2 * L * L, L, c, q);
+    c = ft_block_sum(c, red);
+    q = ft_block_sum(q, red);
+    if (threadIdx.x == 0) {
+        const double s = (-beta) * c;
+        if (S) S[b] = s;
+        if (Q) Q[b] = q / FT_TWO_PI;
+        if (plaq) plaq[b] = (-s) / (beta * (double)(L * L));
+    }
+}
+
+__global__ void k_kinetic(const double* __restrict__ v, int n, double* __restrict__ K) {
+    __shared__ double red[16];
+    const int b = blockIdx.x;
+    const double* vb = v + (size_t)b * n;
+    double a = 0.0;
+    for (int s = threadIdx.x; s < n; s += blockDim.x) a += vb[s] * vb[s];
+    a = ft_block_sum(a, red);
+    if (threadIdx.x == 0) K[b] = a;
+}
+
+// ---------------------------------------------------------------- force
+// Tile of TS x TS sites; sin P is evaluated once per plaquette on a
+// (TS+1) x (TS+1) region (one extra row above / column to the left) in LDS.
+// MODE 0: F = dS/dx of x.
+// MODE 1: fused leapfrog step  x' = x + a p ; p' = p - dt F(x')  (ping-pong buffers)
+// MODE 2: gP = beta sin P (plaquette-gradient field that seeds the flow backward sweep)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_force(const double* __restrict__ x,
+                                               const double* __restrict__ p,
+                                               double* __restrict__ o0,   // F | x' | gP
+                                               double* __restrict__ o1,   // - | p' | -
+                                               int L, double beta, double a, double dt) {
+    __shared__ double sp[(TS + 1) * (TS + 1)];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * TS, j0 = blockIdx.x * TS;
+    const int n = L * L;
+    const double* x0 = x + (size_t)b * 2 * n;
+    const double* x1 = x0 + n;
+    const double* p0 = MODE == 1 ? p + (size_t)b * 2 * n : nullptr;
+    const double* p1 = MODE == 1 ? p0 + n : nullptr;
+    for (int t = threadIdx.x; t < (TS + 1) * (TS + 1); t += blockDim.x) {
+        const int r = t / (TS + 1), c = t - r * (TS + 1);
+        const int i = ft_modL(i0 - 1 + r, L), j = ft_modL(j0 - 1 + c, L);
+        const int ip = i + 1 == L ? 0 : i + 1, jp = j + 1 == L ? 0 : j + 1;
+        double a00 = x0[i * L + j], b00 = x1[i * L + j], a01 = x0[i * L + jp], b10 = x1[ip * L + j];
+        if (MODE == 1) {
+            a00 += a * p0[i * L + j];  b00 += a * p1[i * L + j];
+            a01 += a * p0[i * L + jp]; b10 += a * p1[ip * L + j];
+        }
+        sp[t] = beta * sin(a00 - b00 - a01 + b10);
+    }
+    __syncthreads();
+    const int r = threadIdx.x / TS, c = threadIdx.x - r * TS;
+    const int i = i0 + r, j = j0 + c;
+    if (i < L && j < L) {
+        const double s = sp[(r + 1) * (TS + 1) + c + 1];
+        const size_t s0 = (size_t)b * 2 * n + (size_t)i * L + j, s1 = s0 + n;
+        if (MODE == 2) {
+            o0[(size_t)b * n + (size_t)i * L + j] = s;
+        } else {
+            const double f0 = s - sp[(r + 1) * (TS + 1) + c];
+            const double f1 = sp[r * (TS + 1) + c + 1] - s;
+            if (MODE == 0) { o0[s0] = f0; o0[s1] = f1; }
+            else {
+                const double q0 = p[s0], q1 = p[s1];
+                o0[s0] = x[s0] + a * q0; o0[s1] = x[s1] + a * q1;
+                o1[s0] = q0 - dt * f0;   o1[s1] = q1 - dt * f1;
+            }
+        }
+    }
+}
+
+// v' = v - dt * adj(gP)   (adjoint of the plaquette stencil applied to a plaquette-
+// gradient field; closes one flowed leapfrog kick), optionally followed by the
+// drift x' = x + a v'.  In place on v (and x): every thread touches its own site only.
+__global__ void k_kick_from_gp(const double* __restrict__ gp, double* __restrict__ v,
+                               double* __restrict__ xq, double* __restrict__ Fout,
+                               int L, double dt, double a) {
+    const int b = blockIdx.y;
+    const int n = L * L;
+    const double* g = gp + (size_t)b * n;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+        const int i = s / L, j = s - i * L;
+        const int im = i == 0 ? L - 1 : i - 1, jm = j == 0 ? L - 1 : j - 1;
+        const double gc = g[s];
+        const double f0 = gc - g[i * L + jm];
+        const double f1 = g[im * L + j] - gc;
+        const size_t s0 = (size_t)b * 2 * n + s, s1 = s0 + n;
+        if (Fout) { Fout[s0] = f0; Fout[s1] = f1; }
+        if (v) {
+            const double v0 = v[s0] - dt * f0, v1 = v[s1] - dt * f1;
+            v[s0] = v0; v[s1] = v1;
+            if (xq) { xq[s0] += a * v0; xq[s1] += a * v1; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- Metropolis
+// Per chain: H1 = S1 + K1/2, dH = H1 - H0, acc = u < exp(-dH),
+// x_new = acc ? xform(x_prop) : x_old.   xform: 0 none, 1 regularize, 2 wrap.
+__global__ void k_metropolis(const double* __restrict__ x_old, const double* __restrict__ x_prop,
+                             const double* __restrict__ u, const double* __restrict__ H0,
+                             const double* __restrict__ H1, int n2, int xform,
+                             double* __restrict__ x_new, double* __restrict__ dH,
+                             double* __restrict__ acc,
+                             const double* __restrict__ obs_old, const double* __restrict__ obs_new,
+                             double* __restrict__ obs_out, int n_obs, int B) {
+    const int b = blockIdx.x;
+    const double d = H1[b] - H0[b];
+    const bool a = u[b] < exp(-d);
+    if (threadIdx.x == 0) {
+        if (dH) dH[b] = d;
+        if (acc) acc[b] = a ? 1.0 : 0.0;
+        for (int k = 0; k < n_obs; ++k)
+            if (obs_out) obs_out[k * B + b] = a ? obs_new[k * B + b] : obs_old[k * B + b];
+    }
+    const size_t o = (size_t)b * n2;
+    for (int s = threadIdx.x; s < n2; s += blockDim.x) {
+        double v;
+        if (a) {
+            v = x_prop[o + s];
+            if (xform == 1) v = ft_regularize(v); else if (xform == 2) v = ft_wrap(v);
+        } else v = x_old[o + s];
+        x_new[o + s] = v;
+    }
+}
+
+// out = ca * a + cb * b + c0 for every chain (tiny; H = S + K/2, S_eff = S_W - logdet, ...)
+__global__ void k_lincomb(const double* __restrict__ a, double ca, const double* __restrict__ bv,
+                          double cb, double c0, double* __restrict__ out, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = ca * a[b] + (bv ? cb * bv[b] : 0.0) + c0;
+}
+
+inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 2048 ? 2048 : (g ? g : 1)); }
+inline dim3 tile_grid(int B, int L) { return dim3((L + TS - 1) / TS, (L + TS - 1) / TS, B); }
+
+}  // namespace
+
+namespace fthmc {
+
+int launch_wrap(const double* x, double* o, size_t n, int reg, hipStream_t s) {
+    if (n == 0) return FTHMC_OK;
+    hipLaunchKernelGGL(k_wrap, dim3(ew_grid(n)), dim3(256), 0, s, x, o, n, reg);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_axpy(const double* x, const double* p, double a, double* o, size_t n, hipStream_t s) {
+    if (n == 0) return FTHMC_OK;
+    hipLaunchKernelGGL(k_axpy, dim3(ew_grid(n)), dim3(256), 0, s, x, p, a, o, n);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_plaq(const double* x, double* P, int B, int L, hipStream_t s) {
+    int gx = (L * L + 255) / 256; if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_plaq, dim3(gx, B), dim3(256), 0, s, x, P, L);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_action_charge(const double* x, int B, int L, double beta, double* S, double* Q,
+                         double* plaq, hipStream_t s) {
+    const int nt = L * L >= 4096 ? 1024 : (L * L >= 1024 ? 512 : 256);
+    hipLaunchKernelGGL(k_action_charge, dim3(B), dim3(nt), 0, s, x, L, beta, S, Q, plaq);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_kinetic(const double* v, int B, int L, double* K, hipStream_t s) {
+    const int n = 2 * L * L;
+    const int nt = n >= 8192 ? 1024 : (n >= 2048 ? 512 : 256);
+    hipLaunchKernelGGL(k_kinetic, dim3(B), dim3(nt), 0, s, v, n, K);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_lincomb(const double* a, double ca, const double* b, double cb, double c0, double* out,
+                   int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_lincomb, dim3((B + 255) / 256), dim3(256), 0, s, a, ca, b, cb, c0, out, B);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_wilson_force(const double* x, int B, int L, double beta, double* F, hipStream_t s) {
+    hipLaunchKernelGGL(k_force<0>, tile_grid(B, L), dim3(256), 0, s, x, nullptr, F, nullptr, L, beta, 0.0, 0.0);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_leap_step(const double* x, const double* p, double* xo, double* po, int B, int L,
+                     double beta, double a, double dt, hipStream_t s) {
+    hipLaunchKernelGGL(k_force<1>, tile_grid(B, L), dim3(256), 0, s, x, p, xo, po, L, beta, a, dt);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_wilson_gp(const double* x, int B, int L, double beta, double* gp, hipStream_t s) {
+    hipLaunchKernelGGL(k_force<2>, tile_grid(B, L), dim3(256), 0, s, x, nullptr, gp, nullptr, L, beta, 0.0, 0.0);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_kick_from_gp(const double* gp, double* v, double* xq, double* Fout, int B, int L,
+                        double dt, double a, hipStream_t s) {
+    int gx = (L * L + 255) / 256; if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_kick_from_gp, dim3(gx, B), dim3(256), 0, s, gp, v, xq, Fout, L, dt, a);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_metropolis(const double* x_old, const double* x_prop, const double* u, const double* H0,
+                      const double* H1, int B, int L, int xform, double* x_new, double* dH,
+                      double* acc, const double* obs_old, const double* obs_new, double* obs_out,
+                      int n_obs, hipStream_t s) {
+    hipLaunchKernelGGL(k_metropolis, dim3(B), dim3(256), 0, s, x_old, x_prop, u, H0, H1,
+                       2 * L * L, xform, x_new, dH, acc, obs_old, obs_new, obs_out, n_obs, B);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+
+}  // namespace fthmc

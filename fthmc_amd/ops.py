@@ -1,0 +1,293 @@
+"""Tensor-level operators over the C ABI (one function per entry point of
+include/fthmc_hip.h).  Inputs must be fp64 tensors on a HIP device; PyTorch only
+provides device memory and the current stream."""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_CODES, MODE_LITERAL, MODE_MD, W_PER_LAYER, FthmcError, check
+
+_WS = {}       # (device index) -> workspace tensor (grown on demand)
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name}: expected a torch.Tensor')
+    if not t.is_cuda:
+        raise FthmcError(f'{name}: tensor lives on {t.device}; fthmc_amd runs on the MI355X only '
+                         f'(no CPU fallback) -- move it with .cuda()')
+    if t.dtype != torch.float64:
+        raise FthmcError(f'{name}: dtype {t.dtype}; the HIP path computes in float64')
+    return t.contiguous()
+
+
+def _field(t, name='x'):
+    t = _dev(t, name)
+    if t.dim() != 4 or t.shape[1] != 2 or t.shape[2] != t.shape[3]:
+        raise FthmcError(f'{name}: expected [B, 2, L, L], got {tuple(t.shape)}')
+    if t.shape[2] % 4 != 0:
+        raise FthmcError(f'{name}: L={t.shape[2]} must be a multiple of 4 (stripe masks have period 4)')
+    return t
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def ws_bytes(B: int, L: int, n_layers: int) -> int:
+    return int(_lib.load().fthmc_ws_bytes(B, L, n_layers))
+
+
+def _ws(t: torch.Tensor, B: int, L: int, nl: int):
+    need = ws_bytes(B, L, nl)
+    key = t.device.index
+    buf = _WS.get(key)
+    if buf is None or buf.numel() * 8 < need:
+        buf = torch.empty((need + 7) // 8, dtype=torch.float64, device=t.device)
+        _WS[key] = buf
+    return buf.data_ptr(), buf.numel() * 8
+
+
+def act_code(act) -> int:
+    key = act.lower() if isinstance(act, str) else act
+    if key not in ACT_CODES:
+        key = 'silu'                  # reference falls back to SiLU (layers.py:127-133)
+    return ACT_CODES[key]
+
+
+def pack_weights(nets: Sequence[Sequence[torch.Tensor]], device=None) -> torch.Tensor:
+    """[(w0,b0,w1,b1,w2,b2), ...] -> flat [n_layers*955] fp64 (PyTorch order)."""
+    rows = []
+    for w in nets:
+        w = list(w)
+        shapes = [tuple(t.shape) for t in w]
+        if shapes != [(8, 2, 3, 3), (8,), (8, 8, 3, 3), (8,), (3, 8, 3, 3), (3,)]:
+            raise FthmcError(f'unsupported s/t net {shapes}: the HIP kernels implement the reference '
+                             f'default hidden_sizes=[8,8], kernel_size=3, n_mixture_comps=2')
+        rows.append(torch.cat([t.detach().reshape(-1).to(torch.float64) for t in w]))
+    out = torch.stack(rows).contiguous() if rows else torch.zeros(0, W_PER_LAYER, dtype=torch.float64)
+    if device is not None:
+        out = out.to(device)
+    return out.reshape(-1)
+
+
+def unpack_weight_grads(gw: torch.Tensor, n_layers: int):
+    """flat [n_layers*955] -> list of 6-tuples shaped like the conv parameters."""
+    sizes = [(8, 2, 3, 3), (8,), (8, 8, 3, 3), (8,), (3, 8, 3, 3), (3,)]
+    out = []
+    g = gw.reshape(n_layers, W_PER_LAYER)
+    for l in range(n_layers):
+        o, row = 0, []
+        for s in sizes:
+            n = 1
+            for d in s:
+                n *= d
+            row.append(g[l, o:o + n].reshape(s))
+            o += n
+        out.append(tuple(row))
+    return out
+
+
+# ---------------------------------------------------------------- angle maps
+def wrap(x):
+    x = _dev(x, 'x'); out = torch.empty_like(x)
+    check(_lib.load().fthmc_wrap(_p(x), _p(out), x.numel(), _stream(x)), 'fthmc_wrap')
+    return out
+
+
+def regularize(x):
+    x = _dev(x, 'x'); out = torch.empty_like(x)
+    check(_lib.load().fthmc_regularize(_p(x), _p(out), x.numel(), _stream(x)), 'fthmc_regularize')
+    return out
+
+
+# ---------------------------------------------------------------- Wilson
+def plaquettes(x):
+    x = _field(x); B, _, L, _ = x.shape
+    P = torch.empty(B, L, L, dtype=x.dtype, device=x.device)
+    check(_lib.load().fthmc_plaquettes(_p(x), _p(P), B, L, _stream(x)), 'fthmc_plaquettes')
+    return P
+
+
+def wilson_action_charge(x, beta: float):
+    x = _field(x); B, _, L, _ = x.shape
+    S, Q, plaq = (torch.empty(B, dtype=x.dtype, device=x.device) for _ in range(3))
+    check(_lib.load().fthmc_wilson_action_charge(_p(x), B, L, float(beta), _p(S), _p(Q), _p(plaq), _stream(x)),
+          'fthmc_wilson_action_charge')
+    return S, Q, plaq
+
+
+def wilson_force(x, beta: float):
+    x = _field(x); B, _, L, _ = x.shape
+    F = torch.empty_like(x)
+    check(_lib.load().fthmc_wilson_force(_p(x), B, L, float(beta), _p(F), _stream(x)), 'fthmc_wilson_force')
+    return F
+
+
+def kinetic(v):
+    v = _field(v, 'v'); B, _, L, _ = v.shape
+    K = torch.empty(B, dtype=v.dtype, device=v.device)
+    check(_lib.load().fthmc_kinetic(_p(v), B, L, _p(K), _stream(v)), 'fthmc_kinetic')
+    return K
+
+
+def leapfrog(x, p, beta: float, dt: float, nstep: int):
+    x = _field(x); p = _field(p, 'p'); B, _, L, _ = x.shape
+    xo, po = torch.empty_like(x), torch.empty_like(p)
+    ws, nb = _ws(x, B, L, 0)
+    check(_lib.load().fthmc_leapfrog(_p(x), _p(p), B, L, float(beta), float(dt), int(nstep), _p(xo), _p(po),
+                                     ws, nb, _stream(x)), 'fthmc_leapfrog')
+    return xo, po
+
+
+def hmc_trajectory(x, v, u, beta: float, dt: float, nstep: int):
+    """-> dict(x_new, dH, acc, H0, H1), per chain."""
+    x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
+    if u.numel() != B:
+        raise FthmcError(f'u: expected {B} uniforms, got {u.numel()}')
+    xn = torch.empty_like(x)
+    dH, acc, H0, H1 = (torch.empty(B, dtype=x.dtype, device=x.device) for _ in range(4))
+    ws, nb = _ws(x, B, L, 0)
+    check(_lib.load().fthmc_hmc_trajectory(_p(x), _p(v), _p(u), B, L, float(beta), float(dt), int(nstep),
+                                           _p(xn), _p(dH), _p(acc), _p(H0), _p(H1), ws, nb, _stream(x)),
+          'fthmc_hmc_trajectory')
+    return {'x_new': xn, 'dH': dH, 'acc': acc, 'H0': H0, 'H1': H1}
+
+
+# ---------------------------------------------------------------- coupling layer
+def _w1(w, x):
+    w = _dev(w, 'w').reshape(-1)
+    if w.numel() != W_PER_LAYER:
+        raise FthmcError(f'w: expected {W_PER_LAYER} doubles for one layer, got {w.numel()}')
+    return w
+
+
+def flow_layer_fwd(x, w, mu: int, off: int, act='silu'):
+    x = _field(x); w = _w1(w, x); B, _, L, _ = x.shape
+    y = torch.empty_like(x); logJ = torch.empty(B, dtype=x.dtype, device=x.device)
+    ws, nb = _ws(x, B, L, 1)
+    check(_lib.load().fthmc_flow_layer_fwd(_p(x), _p(w), B, L, int(mu), int(off), act_code(act), _p(y), _p(logJ),
+                                           ws, nb, _stream(x)), 'fthmc_flow_layer_fwd')
+    return y, logJ
+
+
+def flow_layer_bwd(x, w, gy, glogJ, mu: int, off: int, act='silu', need_gw=False):
+    x = _field(x); w = _w1(w, x); gy = _field(gy, 'gy'); glogJ = _dev(glogJ, 'glogJ').reshape(-1)
+    B, _, L, _ = x.shape
+    gx = torch.empty_like(x)
+    gw = torch.empty(W_PER_LAYER, dtype=x.dtype, device=x.device) if need_gw else None
+    ws, nb = _ws(x, B, L, 1)
+    check(_lib.load().fthmc_flow_layer_bwd(_p(x), _p(w), _p(gy), _p(glogJ), B, L, int(mu), int(off), act_code(act),
+                                           _p(gx), _p(gw), ws, nb, _stream(x)), 'fthmc_flow_layer_bwd')
+    return gx, gw
+
+
+def flow_layer_rev(y, w, mu: int, off: int, act='silu', tol: float = 1e-12):
+    y = _field(y, 'y'); w = _w1(w, y); B, _, L, _ = y.shape
+    x = torch.empty_like(y); logJ = torch.empty(B, dtype=y.dtype, device=y.device)
+    ws, nb = _ws(y, B, L, 1)
+    check(_lib.load().fthmc_flow_layer_rev(_p(y), _p(w), B, L, int(mu), int(off), act_code(act), float(tol),
+                                           _p(x), _p(logJ), ws, nb, _stream(y)), 'fthmc_flow_layer_rev')
+    return x, logJ
+
+
+# ---------------------------------------------------------------- whole flow
+def _wall(w, n_layers):
+    w = _dev(w, 'w').reshape(-1)
+    if w.numel() != n_layers * W_PER_LAYER:
+        raise FthmcError(f'w: expected {n_layers}*{W_PER_LAYER} doubles, got {w.numel()}')
+    return w
+
+
+def flow_forward(x, w, n_layers: int, act='silu'):
+    x = _field(x); B, _, L, _ = x.shape
+    w = _wall(w, n_layers) if n_layers else None
+    y = torch.empty_like(x); ld = torch.empty(B, dtype=x.dtype, device=x.device)
+    ws, nb = _ws(x, B, L, n_layers)
+    check(_lib.load().fthmc_flow_forward(_p(x), _p(w), n_layers, B, L, act_code(act), _p(y), _p(ld), ws, nb,
+                                         _stream(x)), 'fthmc_flow_forward')
+    return y, ld
+
+
+def flow_reverse(y, w, n_layers: int, act='silu', tol: float = 1e-12):
+    y = _field(y, 'y'); B, _, L, _ = y.shape
+    w = _wall(w, n_layers) if n_layers else None
+    x = torch.empty_like(y); ld = torch.empty(B, dtype=y.dtype, device=y.device)
+    ws, nb = _ws(y, B, L, n_layers)
+    check(_lib.load().fthmc_flow_reverse(_p(y), _p(w), n_layers, B, L, act_code(act), float(tol), _p(x), _p(ld),
+                                         ws, nb, _stream(y)), 'fthmc_flow_reverse')
+    return x, ld
+
+
+def ft_action(x, w, n_layers: int, beta: float, act='silu'):
+    """-> (S_eff, logdet, plaq, Q) each [B]."""
+    x = _field(x); B, _, L, _ = x.shape
+    w = _wall(w, n_layers) if n_layers else None
+    S, ld, plaq, Q = (torch.empty(B, dtype=x.dtype, device=x.device) for _ in range(4))
+    ws, nb = _ws(x, B, L, n_layers)
+    check(_lib.load().fthmc_ft_action(_p(x), _p(w), n_layers, B, L, act_code(act), float(beta), _p(S), _p(ld),
+                                      _p(plaq), _p(Q), ws, nb, _stream(x)), 'fthmc_ft_action')
+    return S, ld, plaq, Q
+
+
+def ft_force(x, w, n_layers: int, beta: float, act='silu'):
+    x = _field(x); B, _, L, _ = x.shape
+    w = _wall(w, n_layers) if n_layers else None
+    F = torch.empty_like(x)
+    ws, nb = _ws(x, B, L, n_layers)
+    check(_lib.load().fthmc_ft_force(_p(x), _p(w), n_layers, B, L, act_code(act), float(beta), _p(F), ws, nb,
+                                     _stream(x)), 'fthmc_ft_force')
+    return F
+
+
+def ft_leapfrog(x, v, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu'):
+    x = _field(x); v = _field(v, 'v'); B, _, L, _ = x.shape
+    w = _wall(w, n_layers) if n_layers else None
+    xo, vo = torch.empty_like(x), torch.empty_like(v)
+    ws, nb = _ws(x, B, L, n_layers)
+    check(_lib.load().fthmc_ft_leapfrog(_p(x), _p(v), _p(w), n_layers, B, L, act_code(act), float(beta), float(dt),
+                                        int(nstep), _p(xo), _p(vo), ws, nb, _stream(x)), 'fthmc_ft_leapfrog')
+    return xo, vo
+
+
+def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', mode='md',
+                  out: Optional[dict] = None):
+    """One ftHMC trajectory per chain -> dict(x_new, dH, acc, H0, H1, plaq, Q).
+
+    `out` may carry preallocated output tensors (same keys) so that a caller can
+    replay the call inside a captured graph."""
+    x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
+    if u.numel() != B:
+        raise FthmcError(f'u: expected {B} uniforms, got {u.numel()}')
+    w = _wall(w, n_layers) if n_layers else None
+    if out is None:
+        out = {'x_new': torch.empty_like(x)}
+        for k in ('dH', 'acc', 'H0', 'H1', 'plaq', 'Q'):
+            out[k] = torch.empty(B, dtype=x.dtype, device=x.device)
+    m = {'md': MODE_MD, 'literal': MODE_LITERAL, 'reference_literal': MODE_LITERAL}[mode]
+    ws, nb = _ws(x, B, L, n_layers)
+    check(_lib.load().fthmc_ft_trajectory(_p(x), _p(v), _p(u), _p(w), n_layers, B, L, act_code(act), float(beta),
+                                          float(dt), int(nstep), m, _p(out['x_new']), _p(out['dH']), _p(out['acc']),
+                                          _p(out['H0']), _p(out['H1']), _p(out['plaq']), _p(out['Q']), ws, nb,
+                                          _stream(x)), 'fthmc_ft_trajectory')
+    return out
+
+
+def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True):
+    """-> dict(x, logq, logp, gw): pieces of train.train_step for a fixed prior draw."""
+    xi = _field(xi, 'xi'); B, _, L, _ = xi.shape
+    w = _wall(w, n_layers)
+    x = torch.empty_like(xi)
+    logq, logp = (torch.empty(B, dtype=xi.dtype, device=xi.device) for _ in range(2))
+    gw = torch.empty(n_layers * W_PER_LAYER, dtype=xi.dtype, device=xi.device) if need_gw else None
+    ws, nb = _ws(xi, B, L, n_layers)
+    check(_lib.load().fthmc_train_grad(_p(xi), _p(w), n_layers, B, L, act_code(act), float(beta), _p(x), _p(logq),
+                                       _p(logp), _p(gw), ws, nb, _stream(xi)), 'fthmc_train_grad')
+    return {'x': x, 'logq': logq, 'logp': logp, 'gw': gw}

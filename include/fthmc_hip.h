@@ -1,0 +1,161 @@
+/* fthmc_hip.h -- C ABI of the MI355X (gfx950) ftHMC hot path.
+ *
+ * The reference (nftqcd/fthmc) is pure Python on PyTorch and has no FFI of its
+ * own; each entry point below replaces the Python callable cited next to it
+ * (paths relative to the reference root).  All pointers are DEVICE pointers to
+ * contiguous fp64 data unless marked `host`.  Nothing here allocates or
+ * synchronises: every call only enqueues kernels on `stream` (a hipStream_t
+ * passed as void*; NULL = the null stream) and returns 0 or a negative
+ * FTHMC_ERR_* code.  Scratch space is caller-owned (`ws`, sized by
+ * fthmc_ws_bytes) so that calls can be captured into a hipGraph.
+ *
+ * Field layout: x[B][2][L][L], angle of the U(1) link in radians, mu-major
+ * (the reference's [batch, Nd, Nt, Nx]).  L % 4 == 0.
+ * Flow weights: n_layers * FTHMC_W_PER_LAYER doubles; per layer the six
+ * nn.Conv2d tensors of `layers[i].plaq_coupling.net` in state_dict order and
+ * PyTorch [Cout][Cin][kh][kw] layout:
+ *     w0[8][2][3][3] b0[8] w1[8][8][3][3] b1[8] w2[3][8][3][3] b2[3]
+ * (hidden_sizes=[8,8], kernel_size=3, n_mixture_comps=2: the reference default,
+ * fthmc/config.py:283-303).  Layer i uses mu = i % 2, off = (i / 2) % 4
+ * (fthmc/utils/layers.py:409-412).
+ */
+#ifndef FTHMC_HIP_H
+#define FTHMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTHMC_W_PER_LAYER 955
+
+#define FTHMC_OK               0
+#define FTHMC_ERR_ARG         -1   /* bad shape / null pointer              */
+#define FTHMC_ERR_UNSUPPORTED -2   /* architecture outside the built kernels */
+#define FTHMC_ERR_LAUNCH      -3   /* hipGetLastError() after a launch       */
+#define FTHMC_ERR_WS          -4   /* workspace too small                    */
+
+/* activation_fn of the s/t conv net (fthmc/utils/layers.py:117-135) */
+#define FTHMC_ACT_SILU        0
+#define FTHMC_ACT_RELU        1
+#define FTHMC_ACT_LEAKY_RELU  2
+
+/* trajectory modes */
+#define FTHMC_MODE_MD         0   /* intended integrator, ipynb/ft_hmc.py:394-435 */
+#define FTHMC_MODE_LITERAL    1   /* FieldTransformation.leapfrog as packaged, fthmc/ft_hmc.py:180-188 */
+
+const char* fthmc_version(void);
+const char* fthmc_strerror(int code);
+
+/* Bytes of scratch the flow / trajectory entry points need for (B, L, n_layers). */
+size_t fthmc_ws_bytes(int B, int L, int n_layers);
+
+/* ---- angle maps ------------------------------------------------------- */
+/* out = remainder(x + pi, 2 pi) - pi.  fthmc/utils/layers.py:41-43 (torch_mod),
+ * fthmc/utils/qed_helpers.py:49-50 (torch_wrap), fthmc/ft_hmc.py:173-175 (wrap). */
+int fthmc_wrap(const double* x, double* out, size_t n, void* stream);
+/* fthmc/utils/qed_helpers.py:40-42 (regularize) */
+int fthmc_regularize(const double* x, double* out, size_t n, void* stream);
+
+/* ---- Wilson action / plaquette / topological charge ------------------- */
+/* P[b][i][j] = x0 - x1 - x0[i][j+1] + x1[i+1][j].
+ * fthmc/utils/qed_helpers.py:94-105 (batch_plaqs), :80-90 (compute_u1_plaq). */
+int fthmc_plaquettes(const double* x, double* P, int B, int L, void* stream);
+/* S[b] = -beta sum cos P; Q[b] = sum wrap(P) / 2pi; plaq[b] = -S / (beta L^2).
+ * Any of S/Q/plaq may be NULL.  fthmc/utils/qed_helpers.py:177-186 (BatchAction),
+ * :108-116 (batch_charges), fthmc/hmc.py:125 (plaq). */
+int fthmc_wilson_action_charge(const double* x, int B, int L, double beta,
+                               double* S, double* Q, double* plaq, void* stream);
+/* F = dS/dx.  fthmc/utils/qed_helpers.py:265-272 (force, via autograd there). */
+int fthmc_wilson_force(const double* x, int B, int L, double beta, double* F, void* stream);
+
+/* ---- plain HMC --------------------------------------------------------- */
+/* x_, p_ = leapfrog(x, p): fthmc/utils/qed_helpers.py:275-295.  x_out/p_out must
+ * not alias x/p.  ws: fthmc_ws_bytes(B, L, 0). */
+int fthmc_leapfrog(const double* x, const double* p, int B, int L, double beta,
+                   double dt, int nstep, double* x_out, double* p_out,
+                   void* ws, size_t ws_bytes, void* stream);
+/* K[b] = sum_b v^2 (no 1/2).  Used for H = S + K/2 (qed_helpers.py:301) */
+int fthmc_kinetic(const double* v, int B, int L, double* K, void* stream);
+/* One trajectory per chain with supplied momenta v[B][2][L][L] and uniforms u[B]:
+ * H0 = S(x) + v^2/2; leapfrog; xr = regularize(x_); dH = H1 - H0;
+ * acc = u < exp(-dH); x_new = acc ? xr : x.   fthmc/utils/qed_helpers.py:298-311
+ * (there the whole tensor is one system; chains are independent here, identical
+ * for B = 1).  Outputs dH[B], acc[B] (0.0 / 1.0); H0/H1 may be NULL. */
+int fthmc_hmc_trajectory(const double* x, const double* v, const double* u,
+                         int B, int L, double beta, double dt, int nstep,
+                         double* x_new, double* dH, double* acc, double* H0, double* H1,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- coupling layers ---------------------------------------------------- */
+/* (y, logJ[B]) = GaugeEquivCouplingLayer.forward(x): fthmc/utils/layers.py:196-202
+ * with NCPPlaqCouplingLayer.forward :348-371.  w: one layer (955 doubles).
+ * y may alias x. */
+int fthmc_flow_layer_fwd(const double* x, const double* w, int B, int L, int mu, int off,
+                         int act, double* y, double* logJ,
+                         void* ws, size_t ws_bytes, void* stream);
+/* VJP of the layer wrt x: gx = d/dx [ sum(gy * y) + sum_b glogJ[b] logJ[b] ]
+ * (what autograd does for fthmc/utils/qed_helpers.py:226-242 and train.py:210).
+ * gw != NULL additionally returns the same VJP wrt the 955 weights. */
+int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, const double* glogJ,
+                         int B, int L, int mu, int off, int act,
+                         double* gx, double* gw,
+                         void* ws, size_t ws_bytes, void* stream);
+/* (x, logJ[B]) = GaugeEquivCouplingLayer.reverse(y): fthmc/utils/layers.py:204-210,
+ * :373-396.  The scalar inverse is solved per site to |f(x) - y| <= tol by
+ * safeguarded Newton/bisection on [-pi, pi] (the reference bisects to a global
+ * 1e-6, layers.py:294-320). */
+int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu, int off,
+                         int act, double tol, double* x, double* logJ,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- whole flow ---------------------------------------------------------- */
+/* y = F(x), logdet[B] = sum_l logJ_l.  fthmc/ft_hmc.py:143-150 (flow_forward),
+ * fthmc/utils/qed_helpers.py:191-198 (ft_flow).  y, logdet may be NULL. */
+int fthmc_flow_forward(const double* x, const double* w, int n_layers, int B, int L, int act,
+                       double* y, double* logdet, void* ws, size_t ws_bytes, void* stream);
+/* x = F^-1(y), logdet[B].  fthmc/ft_hmc.py:152-160, qed_helpers.py:201-209. */
+int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, int L, int act,
+                       double tol, double* x, double* logdet,
+                       void* ws, size_t ws_bytes, void* stream);
+/* S_eff[b] = S_W(F(x)) - logdet.  fthmc/utils/qed_helpers.py:212-223 (ft_action),
+ * fthmc/ft_hmc.py:135-141.  Optional outputs (NULL to skip): logdet[B],
+ * plaq[B], Q[B] of the physical field F(x). */
+int fthmc_ft_action(const double* x, const double* w, int n_layers, int B, int L, int act,
+                    double beta, double* S_eff, double* logdet, double* plaq, double* Q,
+                    void* ws, size_t ws_bytes, void* stream);
+/* F = d(sum_b S_eff)/dx.  fthmc/utils/qed_helpers.py:226-242 (ft_force),
+ * fthmc/ft_hmc.py:162-171. */
+int fthmc_ft_force(const double* x, const double* w, int n_layers, int B, int L, int act,
+                   double beta, double* F, void* ws, size_t ws_bytes, void* stream);
+/* x_, v_ = leapfrog with ft_force.  ipynb/ft_hmc.py:394-418. */
+int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, int n_layers,
+                      int B, int L, int act, double beta, double dt, int nstep,
+                      double* x_out, double* v_out, void* ws, size_t ws_bytes, void* stream);
+/* One ftHMC trajectory per chain in the latent field x with supplied v, u[B].
+ * mode FTHMC_MODE_MD: ipynb/ft_hmc.py:420-435 without the flow-inverse wrapper;
+ * FTHMC_MODE_LITERAL: fthmc/ft_hmc.py:190-224 as packaged.
+ * Outputs: x_new (latent), dH[B], acc[B] (0/1), and plaq[B], Q[B] of F(x_new)
+ * (fthmc/ft_hmc.py:266-270, 311-313); H0/H1/plaq/Q may be NULL. */
+int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w,
+                        int n_layers, int B, int L, int act, double beta, double dt, int nstep,
+                        int mode, double* x_new, double* dH, double* acc,
+                        double* H0, double* H1, double* plaq, double* Q,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ---- training ------------------------------------------------------------ */
+/* Reverse-KL loss pieces and weight gradients for a fixed prior draw xi
+ * (fthmc/train.py:191-210, fthmc/utils/samplers.py:40-56):
+ *   x = F(xi); logq = -2 L^2 log(2 pi) - logdet; logp = -S_W(x);
+ *   loss = mean(logq - logp); gw = d loss / d w  (n_layers*955).
+ * Outputs (any may be NULL): x[B][2][L][L], logq[B], logp[B], gw. */
+int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int L, int act,
+                     double beta, double* x, double* logq, double* logp, double* gw,
+                     void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTHMC_HIP_H */

@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- leapfrog-steps/sec of batched ftHMC chains on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]): 2D U(1), L=64, beta=6.0, 8-layer flow
+(hidden [8,8], k=3, n_mix=2, SiLU, PyTorch default init), 128 chains per GPU,
+tau=1.0, nstep=10, fp64.  One bench "step" = one whole ftHMC trajectory of the
+batch (momentum refresh, H0, 10 leapfrog steps = 10 force evaluations, H1,
+Metropolis, observables of the accepted field).  Chains shard over ranks with no
+data-path collective (weak scaling, 128 chains per GPU); the only exchange is the
+8-double SUM all-reduce of run statistics per trajectory (RCCL), which is inside
+the timed region.
+
+Prints ONE JSON line on rank 0.  `value` = chain-leapfrog-steps per second over
+all ranks (= batch x leapfrog-steps/s).  Also reports
+  roofline     -- dominant kernel (coupling-layer backward) against the fp64 peak,
+                  duration measured here with HIP events on the launch stream;
+  cpu_baseline -- the oracle (oracle/ref_cpu.py, PyTorch CPU fp64, "port") timed on
+                  this host on a bounded sample of the same workload, and the
+                  parity of the HIP trajectory against it on that sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+L, BETA, N_LAYERS, B_PER_GPU, TAU, NSTEP, SEED = 64, 6.0, 8, 128, 1.0, 10, 1331
+FP64_PEAK_TFLOPS = 78.6        # MI355X fp64 vector = matrix peak (spec); MFMA f64 measured 77.5 (tools/microbench)
+CONV_FLOPS_PER_SITE = 1872     # dense 3x3 conv net 2->8->8->3, one direction
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=B_PER_GPU, help='chains per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-chains', type=int, default=8)
+    ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
+    return ap.parse_args()
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """CPU threads this process may really use (cgroup/affinity aware), capped at 16 = one GPU's share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, p = f.read().split()
+            if q != 'max':
+                n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def make_flow(gen):
+    from oracle import ref_cpu as R      # only for the shared default-init recipe + cpu_baseline
+    return R.default_flow(N_LAYERS, gen)
+
+
+def main():
+    args = parse()
+    from fthmc_amd import ops, parallel
+    rank, world, local = parallel.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    B = args.batch
+    lo, hi = parallel.shard_range(B * world, rank, world)
+    assert hi - lo == B
+    dt = TAU / NSTEP
+
+    # synthetic inputs, identical for the CPU and GPU paths
+    gen = torch.Generator(device='cpu').manual_seed(SEED)
+    flow = make_flow(gen)
+    w = ops.pack_weights(flow, device=dev)
+    gx = torch.Generator(device='cpu').manual_seed(SEED + 1 + rank)
+    x0 = ((torch.rand(B, 2, L, L, generator=gx, dtype=torch.float64) * 2 - 1) * math.pi)
+    x = x0.to(dev)
+
+    stats = parallel.RunStats.zeros(dev)
+    out = {'x_new': torch.empty_like(x)}
+    for k in ('dH', 'acc', 'H0', 'H1', 'plaq', 'Q'):
+        out[k] = torch.empty(B, dtype=torch.float64, device=dev)
+    qold = ops.ft_action(x, w, N_LAYERS, BETA)[3].clone()
+    seeds = torch.empty(B, dtype=torch.int64, device=dev)
+    v = torch.empty_like(x)
+    u = torch.empty(B, dtype=torch.float64, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+
+    def enqueue(xin):
+        """momentum refresh + one trajectory of the batch, all on the current stream"""
+        vv, uu = ops.random_momenta(seeds, xin.shape)
+        v.copy_(vv); u.copy_(uu)
+        ops.ft_trajectory(xin, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out)
+
+    graph = None
+    if not args.no_graph:
+        # the ~300 launches of a trajectory are captured once and replayed (launch-bound otherwise)
+        with torch.cuda.stream(stream):
+            seeds.copy_(parallel.chain_seeds(SEED, lo, hi, 0).to(dev))
+            enqueue(x)                      # warm allocator / workspace before capture
+            stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                enqueue(x)
+
+    traj = [0]
+    pending = [None]
+
+    def step():
+        seeds.copy_(parallel.chain_seeds(SEED, lo, hi, traj[0]).to(dev, non_blocking=True))
+        if graph is not None:
+            graph.replay()
+        else:
+            enqueue(x)
+        x.copy_(out['x_new'])
+        dq = out['Q'] - qold
+        stats.add(out['acc'], out['plaq'], out['Q'], dq, out['dH'])
+        qold.copy_(out['Q'])
+        if pending[0] is not None:
+            pending[0].wait()
+        pending[0] = stats.reduce(async_op=world > 1)
+        traj[0] += 1
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    log(f'rank {rank}/{world}: setup done, graph={"yes" if graph is not None else "no"}; warmup {args.warmup}')
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        log('timed region ...')
+        stats.vec.zero_(); stats.glob = None
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if pending[0] is not None:
+            pending[0].wait()
+        barrier()
+        t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(elapsed)
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    log(f'timed region done: {elapsed:.3f} s for {args.steps} trajectories')
+    chain_steps = B * world * NSTEP * args.steps
+    value = chain_steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (coupling-layer backward), HIP events on this stream
+    with torch.cuda.stream(stream):
+        w0 = w[:955].contiguous()
+        ms_bwd = ops.time_kernel('flow_bwd', x, w0, mu=0, off=0, beta=BETA, reps=40)
+        ms_fwd = ops.time_kernel('flow_fwd', x, w0, mu=0, off=0, beta=BETA, reps=40)
+        ms_leap = ops.time_kernel('leap_step', x, beta=BETA, reps=40)
+    log(f'kernel timing: bwd {ms_bwd:.4f} ms fwd {ms_fwd:.4f} ms leap {ms_leap:.5f} ms')
+    flops_launch = CONV_FLOPS_PER_SITE * L * L * B          # dense dgrad of one layer, B chains
+    achieved = flops_launch / (ms_bwd * 1e-3) / 1e12
+    step_flops = 2 * CONV_FLOPS_PER_SITE * L * L * N_LAYERS * B    # fwd + dgrad, per batched leapfrog step
+    roofline = {
+        'bound': 'mfma', 'kernel': 'k_flow_layer<1> (coupling-layer backward wrt x)',
+        'achieved': round(achieved, 3), 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(achieved / FP64_PEAK_TFLOPS, 4), 'traffic': None,
+        'avg_launch_ms': round(ms_bwd, 4),
+        'algorithmic_flops_per_launch': flops_launch,
+        'fwd_kernel_ms': round(ms_fwd, 4),
+        'whole_step_tflops': round(step_flops * (NSTEP * args.steps) / elapsed / 1e12, 3),
+        'stencil': {'kernel': 'k_force<1> (fused plain-HMC leapfrog step)', 'avg_launch_ms': round(ms_leap, 5),
+                    'achieved_GBps': round(64.0 * L * L * B / (ms_leap * 1e-3) / 1e9, 1), 'peak_GBps': 8000.0},
+    }
+
+    # ---- CPU baseline (oracle = "port") on a bounded sample + parity of the HIP path on it
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import ref_cpu as R
+        nb = min(args.cpu_chains, B)
+        torch.set_num_threads(host_threads())
+        log(f'cpu baseline: {nb} chains on {torch.get_num_threads()} threads ...')
+        xs = x0[:nb].clone()
+        gs = torch.Generator(device='cpu').manual_seed(SEED + 99)
+        vs = torch.randn(nb, 2, L, L, generator=gs, dtype=torch.float64)
+        us = torch.rand(nb, generator=gs, dtype=torch.float64)
+        tc0 = time.perf_counter()
+        dH_c, _, acc_c, newx_c, h0_c, h1_c = R.ft_hmc(xs, vs, us, flow, BETA, dt, NSTEP, mode='md')
+        tc = time.perf_counter() - tc0
+        log(f'cpu baseline done in {tc:.1f} s')
+        r = ops.ft_trajectory(xs.to(dev), vs.to(dev), us.to(dev), w, N_LAYERS, BETA, dt, NSTEP, mode='md')
+        rel = lambda a, b: float(((a.cpu() - b).abs() / b.abs().clamp_min(1e-300)).max())
+        border = (us - torch.exp(-dH_c)).abs() < 1e-9
+        acc_ok = bool(((r['acc'].cpu() > 0.5) == acc_c)[~border].all())
+        cpu = {
+            'value': round(nb * NSTEP / tc, 3), 'unit': 'chain-leapfrog-steps/s',
+            'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'one trajectory ({NSTEP} leapfrog steps + H0/H1) of {nb} of the {B} chains, '
+                      f'oracle/ref_cpu.py (PyTorch CPU fp64 autograd), {tc:.1f} s',
+            'parity': {'H0_rel': rel(r['H0'], h0_c), 'H1_rel': rel(r['H1'], h1_c),
+                       'dH_abs': float((r['dH'].cpu() - dH_c).abs().max()), 'accept_equal': acc_ok,
+                       'tolerance': 1e-6},
+        }
+
+    m = stats.means()
+    line = {
+        'metric': 'leapfrog-steps/sec (batched chains)', 'value': round(value, 2),
+        'unit': 'chain-leapfrog-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': '2D U(1) L=64 beta=6.0 8-layer flow ftHMC, 128 chains per GPU, tau=1.0 nstep=10 '
+                               '(BASELINE.json configs[2]; configs[3] = the same per GPU on 8 GPUs)',
+                   'chains_per_gpu': B, 'chains_total': B * world, 'L': L, 'beta': BETA, 'n_layers': N_LAYERS,
+                   'nstep': NSTEP, 'tau': TAU, 'parallelism': f'chains sharded x{world}',
+                   'launch': 'eager' if graph is None else 'hipGraph replay'},
+        'batched_leapfrog_steps_per_s': round(NSTEP * args.steps / elapsed, 3),
+        'acceptance': round(m['acc'], 4), 'plaq': round(m['plaq'], 6),
+        'roofline': roofline, 'cpu_baseline': cpu,
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

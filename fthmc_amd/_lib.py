@@ -7,6 +7,11 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+# PyTorch-ROCm ships its own libamdhip64.so.7; importing it first makes the dynamic loader
+# resolve this library's DT_NEEDED libamdhip64.so.7 to that same runtime instance, so torch's
+# streams / allocations and our launches live in ONE HIP runtime (two would not share streams).
+import torch  # noqa: F401  (keep before the CDLL below)
 from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -23,6 +28,7 @@ _P = c_void_p
 SIGNATURES = {
     'fthmc_version': [],
     'fthmc_strerror': [c_int],
+    'fthmc_last_error': [],
     'fthmc_ws_bytes': [c_int, c_int, c_int],
     'fthmc_wrap': [_D, _D, c_size_t, _P],
     'fthmc_regularize': [_D, _D, c_size_t, _P],
@@ -31,6 +37,7 @@ SIGNATURES = {
     'fthmc_wilson_force': [_D, c_int, c_int, c_double, _D, _P],
     'fthmc_leapfrog': [_D, _D, c_int, c_int, c_double, c_double, c_int, _D, _D, _P, c_size_t, _P],
     'fthmc_kinetic': [_D, c_int, c_int, _D, _P],
+    'fthmc_random_momenta': [_D, c_int, c_int, _D, _D, _P],
     'fthmc_hmc_trajectory': [_D, _D, _D, c_int, c_int, c_double, c_double, c_int, _D, _D, _D, _D, _D,
                              _P, c_size_t, _P],
     'fthmc_flow_layer_fwd': [_D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
@@ -45,8 +52,10 @@ SIGNATURES = {
     'fthmc_ft_trajectory': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int,
                             _D, _D, _D, _D, _D, _D, _D, _P, c_size_t, _P],
     'fthmc_train_grad': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
+    'fthmc_time_kernel': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double, c_int,
+                          ctypes.POINTER(c_double), _P, c_size_t, _P],
 }
-_RESTYPE = {'fthmc_version': c_char_p, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
+_RESTYPE = {'fthmc_version': c_char_p, 'fthmc_last_error': c_char_p, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
 
 _lib = None
 
@@ -75,4 +84,5 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
 
 def check(rc: int, what: str):
     if rc != 0:
-        raise FthmcError(f'{what} failed: {load().fthmc_strerror(rc).decode()} (code {rc})')
+        detail = load().fthmc_last_error().decode() if rc == -3 else ''
+        raise FthmcError(f'{what} failed: {load().fthmc_strerror(rc).decode()} (code {rc}) {detail}')

@@ -6,7 +6,16 @@
 #include "kernels.h"
 #include <math.h>
 
+#include <stdio.h>
+
 using namespace fthmc;
+
+namespace fthmc {
+static thread_local char g_last_error[256] = "";
+void note_hip_error(hipError_t e, const char* file, int line) {
+    snprintf(g_last_error, sizeof(g_last_error), "%s (%s:%d)", hipGetErrorString(e), file, line);
+}
+}  // namespace fthmc
 
 namespace {
 
@@ -134,6 +143,8 @@ extern "C" {
 
 const char* fthmc_version(void) { return "fthmc_hip 0.1 (gfx950)"; }
 
+const char* fthmc_last_error(void) { return fthmc::g_last_error; }
+
 const char* fthmc_strerror(int code) {
     switch (code) {
         case FTHMC_OK: return "ok";
@@ -151,6 +162,7 @@ size_t fthmc_ws_bytes(int B, int L, int n_layers) {
 }
 
 #define FT_WS(nl)                                                                   \
+    (void)hipGetLastError();   /* drop stale (non-sticky) errors left by the host framework */ \
     if (!ws || ws_bytes < fthmc_ws_bytes(B, L, (nl))) return FTHMC_ERR_WS;          \
     const WS W = ws_layout(static_cast<double*>(ws), B, L, (nl));                   \
     hipStream_t s = ft_stream(stream)
@@ -179,6 +191,11 @@ int fthmc_wilson_force(const double* x, int B, int L, double beta, double* F, vo
 int fthmc_kinetic(const double* v, int B, int L, double* K, void* stream) {
     if (!v || !K || bad_shape(B, L)) return FTHMC_ERR_ARG;
     return launch_kinetic(v, B, L, K, ft_stream(stream));
+}
+
+int fthmc_random_momenta(const int64_t* seeds, int B, int n_per_chain, double* v, double* u, void* stream) {
+    if (!seeds || !v || B <= 0 || n_per_chain <= 0) return FTHMC_ERR_ARG;
+    return launch_random_momenta(seeds, B, n_per_chain, v, u, ft_stream(stream));
 }
 
 int fthmc_leapfrog(const double* x, const double* p, int B, int L, double beta, double dt, int nstep,
@@ -394,6 +411,39 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
                                 hipMemcpyDeviceToDevice, s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     }
     return FTHMC_OK;
+}
+
+int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
+                      double beta, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
+    if (kind < 2 && !w) return FTHMC_ERR_ARG;
+    FT_WS(1);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    FlowLayerArgs a{};
+    if (kind < 2) {
+        FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+        FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
+        a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
+        a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part;
+        a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+    } else {
+        FT_TRY(launch_random_momenta(reinterpret_cast<const int64_t*>(x), B, 2 * L * L, W.va, nullptr, s));
+    }
+    int rc = FTHMC_OK;
+    for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
+        if (it == 0) hipEventRecord(e0, s);
+        if (kind == 0) rc = launch_flow_fwd(a, s);
+        else if (kind == 1) rc = launch_flow_bwd(a, false, s);
+        else rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
+    }
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_avg_host = (double)ms / reps;
+    return rc;
 }
 
 }  // extern "C"

@@ -10,8 +10,10 @@
 
 #define FT_WAVE 64
 
-#define FT_LAUNCH_CHECK()                                        \
-    do { if (hipGetLastError() != hipSuccess) return FTHMC_ERR_LAUNCH; } while (0)
+namespace fthmc { void note_hip_error(hipError_t e, const char* file, int line); }
+#define FT_LAUNCH_CHECK()                                                              \
+    do { hipError_t e_ = hipGetLastError();                                            \
+         if (e_ != hipSuccess) { fthmc::note_hip_error(e_, __FILE__, __LINE__); return FTHMC_ERR_LAUNCH; } } while (0)
 
 // torch.remainder(x + pi, 2 pi) - pi   (fmod is exact; sign fix as ATen does)
 __device__ __forceinline__ double ft_wrap(double x) {
@@ -59,4 +61,6 @@ __device__ __forceinline__ int ft_stripe(int i, int j, int mu, int off) {
     return (s - off) & 3;            // L % 4 == 0 and s >= 0
 }
 
-static inline hipStream_t ft_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// Also drops any stale, non-sticky error a previous runtime call of the host framework left
+// behind, so that FT_LAUNCH_CHECK only reports our own launches.
+static inline hipStream_t ft_stream(void* s) { (void)hipGetLastError(); return reinterpret_cast<hipStream_t>(s); }

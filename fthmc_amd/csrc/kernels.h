@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdint.h>
 
 namespace fthmc {
 
@@ -24,6 +25,9 @@ int launch_metropolis(const double* x_old, const double* x_prop, const double* u
                       const double* H1, int B, int L, int xform, double* x_new, double* dH,
                       double* acc, const double* obs_old, const double* obs_new, double* obs_out,
                       int n_obs, hipStream_t s);
+
+// ---- rng.hip
+int launch_random_momenta(const int64_t* seeds, int B, int n, double* v, double* u, hipStream_t s);
 
 // ---- flow.hip
 constexpr int FLOW_TILE = 16;                 // sites per tile edge

@@ -138,6 +138,22 @@ def kinetic(v):
     return K
 
 
+def random_momenta(seeds, shape, need_u=True):
+    """v ~ N(0,1) of `shape` = (B, 2, L, L) and u ~ U[0,1) [B] from per-chain int64 seeds."""
+    if not seeds.is_cuda or seeds.dtype != torch.int64:
+        raise FthmcError('seeds: expected an int64 tensor on the HIP device')
+    seeds = seeds.contiguous()
+    B = int(shape[0]); n = 1
+    for d in shape[1:]:
+        n *= int(d)
+    if seeds.numel() != B:
+        raise FthmcError(f'seeds: expected {B}, got {seeds.numel()}')
+    v = torch.empty(tuple(shape), dtype=torch.float64, device=seeds.device)
+    u = torch.empty(B, dtype=torch.float64, device=seeds.device) if need_u else None
+    check(_lib.load().fthmc_random_momenta(_p(seeds), B, n, _p(v), _p(u), _stream(v)), 'fthmc_random_momenta')
+    return v, u
+
+
 def leapfrog(x, p, beta: float, dt: float, nstep: int):
     x = _field(x); p = _field(p, 'p'); B, _, L, _ = x.shape
     xo, po = torch.empty_like(x), torch.empty_like(p)
@@ -291,3 +307,17 @@ def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True):
     check(_lib.load().fthmc_train_grad(_p(xi), _p(w), n_layers, B, L, act_code(act), float(beta), _p(x), _p(logq),
                                        _p(logp), _p(gw), ws, nb, _stream(xi)), 'fthmc_train_grad')
     return {'x': x, 'logq': logq, 'logp': logp, 'gw': gw}
+
+
+def time_kernel(kind: str, x, w=None, mu=0, off=0, act='silu', beta=1.0, reps=20) -> float:
+    """Average milliseconds per launch of one kernel ('flow_fwd', 'flow_bwd', 'leap_step'),
+    measured with HIP events on the current stream (synchronises)."""
+    import ctypes
+    x = _field(x); B, _, L, _ = x.shape
+    k = {'flow_fwd': 0, 'flow_bwd': 1, 'leap_step': 2}[kind]
+    wp = _p(_w1(w, x)) if k < 2 else None
+    ms = ctypes.c_double(0.0)
+    ws, nb = _ws(x, B, L, 1)
+    check(_lib.load().fthmc_time_kernel(k, _p(x), wp, B, L, int(mu), int(off), act_code(act), float(beta),
+                                        int(reps), ctypes.byref(ms), ws, nb, _stream(x)), 'fthmc_time_kernel')
+    return ms.value

@@ -1,0 +1,118 @@
+"""Multi-GPU layer: independent Markov chains sharded over one process per GPU.
+
+The path shards by chain: no data-path collective exists.  The only
+exchange is the small SUM all-reduce of run statistics (C1: acceptance and
+observables, 8 doubles) and, for training, of weight gradients plus the
+logsumexp pieces of the ESS (C2).  `torch.distributed` backend "nccl" is RCCL
+over xGMI on ROCm; the same code runs on "gloo" for the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+STAT_KEYS = ('n', 'acc', 'plaq', 'q', 'q2', 'absdq', 'dh', 'exp_mdh')
+
+
+def world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun environment (1 process = 1 GPU)."""
+    return (int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)),
+            int(os.environ.get('LOCAL_RANK', 0)))
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, ws, local = world()
+    if ws > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+    return rank, ws, local
+
+
+def shard_range(n_chains: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of global chain ids owned by `rank` (remainder to the
+    first ranks), so that a chain's id -- and with it its RNG stream -- never depends
+    on the number of GPUs."""
+    base, rem = divmod(n_chains, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def chain_seeds(seed: int, lo: int, hi: int, traj: int) -> torch.Tensor:
+    """One 63-bit seed per (global chain id, trajectory): SplitMix64 of the triple, so
+    the momenta / uniform draws of a chain are the same on 1 or 8 GPUs."""
+    import numpy as np
+    M = (1 << 64) - 1
+    base = ((seed * 2 + 1) * 0x2545F4914F6CDD1D + traj * 0xBF58476D1CE4E5B9) & M
+    with np.errstate(over='ignore'):
+        z = np.arange(lo, hi, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(base)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return torch.from_numpy((z & np.uint64(0x7FFFFFFFFFFFFFFF)).astype(np.int64))
+
+
+class RunStats:
+    """Running sums over chains and trajectories.  `vec` holds this rank's sums; `reduce()`
+    all-reduces a snapshot of it into `glob` (C1), so it can be issued asynchronously every
+    trajectory without ever double counting."""
+
+    def __init__(self, vec: torch.Tensor):
+        self.vec = vec                # [len(STAT_KEYS)] float64 on the compute device
+        self.glob = None
+
+    @classmethod
+    def zeros(cls, device):
+        return cls(torch.zeros(len(STAT_KEYS), dtype=torch.float64, device=device))
+
+    def add(self, acc, plaq, q, dq, dh):
+        """Accumulate one trajectory's per-chain results (device tensors [B_local])."""
+        n = torch.full((), float(acc.numel()), dtype=torch.float64, device=acc.device)
+        self.vec += torch.stack([n, acc.sum(), plaq.sum(), q.sum(), (q * q).sum(), dq.abs().sum(),
+                                 dh.sum(), torch.exp(-dh).sum()])
+
+    def reduce(self, async_op: bool = False):
+        """C1: SUM all-reduce of a snapshot over ranks (plain copy for one process)."""
+        self.glob = self.vec.clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.all_reduce(self.glob, op=dist.ReduceOp.SUM, async_op=async_op)
+        return None
+
+    def means(self) -> dict:
+        v = (self.glob if self.glob is not None else self.vec).detach().cpu()
+        n = max(float(v[0]), 1.0)
+        out = {k: float(v[i]) / n for i, k in enumerate(STAT_KEYS) if k != 'n'}
+        out['n'] = float(v[0])
+        out['chi_q'] = out['q2'] - out['q'] ** 2
+        return out
+
+
+def allreduce_grads(gw: torch.Tensor, world_size: Optional[int] = None) -> torch.Tensor:
+    """C2: SUM all-reduce of the flat weight-gradient buffer (955 * n_layers doubles)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(gw, op=dist.ReduceOp.SUM)
+    return gw
+
+
+def global_logsumexp(logw: torch.Tensor) -> torch.Tensor:
+    """logsumexp over the chains of all ranks: MAX all-reduce, then SUM all-reduce."""
+    m = logw.max()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        s = torch.exp(logw - m).sum()
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        return m + torch.log(s)
+    return m + torch.log(torch.exp(logw - m).sum())
+
+
+def global_mean(t: torch.Tensor, n_global: int) -> torch.Tensor:
+    s = t.sum()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    return s / n_global

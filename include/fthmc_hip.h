@@ -48,6 +48,8 @@ extern "C" {
 
 const char* fthmc_version(void);
 const char* fthmc_strerror(int code);
+/* text of the HIP error behind the last FTHMC_ERR_LAUNCH on this thread ("" if none) */
+const char* fthmc_last_error(void);
 
 /* Bytes of scratch the flow / trajectory entry points need for (B, L, n_layers). */
 size_t fthmc_ws_bytes(int B, int L, int n_layers);
@@ -88,6 +90,14 @@ int fthmc_hmc_trajectory(const double* x, const double* v, const double* u,
                          int B, int L, double beta, double dt, int nstep,
                          double* x_new, double* dH, double* acc, double* H0, double* H1,
                          void* ws, size_t ws_bytes, void* stream);
+
+/* Momentum refresh for the production path: v[b][0..n) ~ N(0,1), u[b] ~ U[0,1) from a
+ * Philox4x32-10 stream keyed by seeds[b] (device int64[B]).  Replaces torch.randn_like /
+ * torch.rand of fthmc/utils/qed_helpers.py:300,306 and fthmc/ft_hmc.py:204,212; a chain's
+ * draws depend only on its seed, so sharding chains over GPUs does not change them.
+ * u may be NULL. */
+int fthmc_random_momenta(const int64_t* seeds, int B, int n_per_chain, double* v, double* u,
+                         void* stream);
 
 /* ---- coupling layers ---------------------------------------------------- */
 /* (y, logJ[B]) = GaugeEquivCouplingLayer.forward(x): fthmc/utils/layers.py:196-202
@@ -154,6 +164,15 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
 int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int L, int act,
                      double beta, double* x, double* logq, double* logp, double* gw,
                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---- measurement hook (the only entry point that synchronises) ---------- */
+/* Average duration in milliseconds (host double) of `reps` back-to-back launches of one
+ * coupling-layer kernel on `stream`, bracketed by HIP events recorded on that stream.
+ * kind 0: forward kernel; 1: backward-wrt-x kernel (forward recompute + adjoint);
+ * 2: fused plain-HMC leapfrog step (Wilson force stencil). */
+int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off,
+                      int act, double beta, int reps, double* ms_avg_host,
+                      void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,8 @@ SIGNATURES = {
     'fthmc_version': [],
     'fthmc_strerror': [c_int],
     'fthmc_last_error': [],
+    'fthmc_set_variant': [c_int],
+    'fthmc_get_variant': [],
     'fthmc_ws_bytes': [c_int, c_int, c_int],
     'fthmc_wrap': [_D, _D, c_size_t, _P],
     'fthmc_regularize': [_D, _D, c_size_t, _P],

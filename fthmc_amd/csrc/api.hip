@@ -50,6 +50,13 @@ WS ws_layout(double* base, int B, int L, int nl) {
     return w;
 }
 
+inline int flow_fwd(const FlowLayerArgs& a, hipStream_t s) {
+    return get_flow_variant() == 1 ? launch_flow_fwd_mfma(a, s) : launch_flow_fwd(a, s);
+}
+inline int flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s) {
+    return (!wgrad && get_flow_variant() == 1) ? launch_flow_bwd_mfma(a, s) : launch_flow_bwd(a, wgrad, s);
+}
+
 inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
 
 #define FT_TRY(expr) do { int rc_ = (expr); if (rc_ != FTHMC_OK) return rc_; } while (0)
@@ -64,7 +71,7 @@ int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, d
         a.y = w.X + (size_t)l * w.n2;
         a.logj_part = logdet ? w.lj_part : nullptr;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
-        FT_TRY(launch_flow_fwd(a, s));
+        FT_TRY(flow_fwd(a, s));
         if (logdet) FT_TRY(launch_sum_parts(w.lj_part, B, flow_ntiles(L), 1.0, l > 0, logdet, s));
     }
     return FTHMC_OK;
@@ -100,7 +107,7 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
         a.gp_part = w.gp_part;
         a.gw_part = w.gw_part;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
-        FT_TRY(launch_flow_bwd(a, gw != nullptr, s));
+        FT_TRY(flow_bwd(a, gw != nullptr, s));
         if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_ntiles(L), 1.0, 0,
                                         gw + (size_t)l * FTHMC_W_PER_LAYER, s));
         FT_TRY(launch_gather_gp(w.gp_part, B, L, 1, w.gp, s));
@@ -142,6 +149,13 @@ int leapfrog_ws(const double* x, const double* p, const WS& w, int B, int L, dou
 extern "C" {
 
 const char* fthmc_version(void) { return "fthmc_hip 0.1 (gfx950)"; }
+
+int fthmc_set_variant(int v) {
+    if (v != 0 && v != 1) return FTHMC_ERR_ARG;
+    set_flow_variant(v);
+    return FTHMC_OK;
+}
+int fthmc_get_variant(void) { return get_flow_variant(); }
 
 const char* fthmc_last_error(void) { return fthmc::g_last_error; }
 
@@ -239,7 +253,7 @@ int fthmc_flow_layer_fwd(const double* x, const double* w, int B, int L, int mu,
     FlowLayerArgs a{};
     a.x = x; a.wint = W.wint; a.y = y; a.logj_part = W.lj_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    FT_TRY(launch_flow_fwd(a, s));
+    FT_TRY(flow_fwd(a, s));
     if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_ntiles(L), 1.0, 0, logJ, s));
     return FTHMC_OK;
 }
@@ -270,7 +284,7 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
     a.x = x; a.wint = W.wint; a.up_link = gy; a.glogj = glogJ;
     a.gp_part = W.gp_part; a.gw_part = W.gw_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    FT_TRY(launch_flow_bwd(a, gw != nullptr, s));
+    FT_TRY(flow_bwd(a, gw != nullptr, s));
     if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_ntiles(L), 1.0, 0, gw, s));
     FT_TRY(launch_gather_gp(W.gp_part, B, L, 0, W.gp, s));
     return launch_adj_add(W.gp, gy, B, L, gx, s);
@@ -433,8 +447,8 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     int rc = FTHMC_OK;
     for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
         if (it == 0) hipEventRecord(e0, s);
-        if (kind == 0) rc = launch_flow_fwd(a, s);
-        else if (kind == 1) rc = launch_flow_bwd(a, false, s);
+        if (kind == 0) rc = flow_fwd(a, s);
+        else if (kind == 1) rc = flow_bwd(a, false, s);
         else rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
     }
     hipEventRecord(e1, s);

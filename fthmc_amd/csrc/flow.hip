@@ -12,32 +12,12 @@
 //
 // Convs run on the fp64 VALU with weights streamed through SGPRs (wave-uniform
 // addresses => s_load): each lane owns one site and half of the output channels.
-#include "common.h"
-#include "kernels.h"
+#include "flow_common.h"
 
 namespace {
 
 using namespace fthmc;
-
-constexpr int FT = FLOW_TILE;
-constexpr int R0 = FT + 6, R1 = FT + 4, R2 = FT + 2;
-constexpr int N0 = R0 * R0, N1 = R1 * R1, N2 = R2 * R2, N3 = FT * FT;
-constexpr int NACT = N3 / 4;                  // active sites per tile (64 = one wave)
-constexpr int NMIX = 2;
-
-// canonical per-layer offsets (PyTorch [Cout][Cin][3][3])
-constexpr int CW0 = 0, CB0 = 144, CW1 = 152, CB1 = 728, CW2 = 736, CB2 = 952;
-// kernel layout offsets
-constexpr int W1F = 0;      // [ci 2][tap 9][co 8]
-constexpr int B1 = 144;     // [8]
-constexpr int W2F = 152;    // [ci 8][tap 9][co 8]
-constexpr int B2 = 728;     // [8]
-constexpr int W3F = 736;    // [ci 8][tap 9][co 4] (co 3 = 0)
-constexpr int B3 = 1024;    // [4]
-constexpr int W3B = 1028;   // [co 3][tap 9][ci 8]
-constexpr int W2B = 1244;   // [co 8][tap 9][ci 8]
-constexpr int W1B = 1820;   // [co 8][tap 9][ci 2]
-static_assert(W1B + 144 <= FLOW_WINT, "weight layout");
+using namespace fthmc_flow;
 
 __global__ void k_pack_weights(const double* __restrict__ w, int n_layers, double* __restrict__ o) {
     const int l = blockIdx.x;
@@ -54,21 +34,28 @@ __global__ void k_pack_weights(const double* __restrict__ w, int n_layers, doubl
         else if (t < W2B) { int u = t - W3B; int ci = u % 8, tap = (u / 8) % 9, co = u / 72; v = c[CW2 + (co * 8 + ci) * 9 + tap]; }
         else if (t < W1B) { int u = t - W2B; int ci = u % 8, tap = (u / 8) % 9, co = u / 72; v = c[CW1 + (co * 8 + ci) * 9 + tap]; }
         else if (t < W1B + 144) { int u = t - W1B; int ci = u % 2, tap = (u / 2) % 9, co = u / 18; v = c[CW0 + (co * 2 + ci) * 9 + tap]; }
+        else if (t >= WB1 && t < WB2T + 24 * 64) {
+            // MFMA f64 16x16x4 B operand: lane l holds B[k = 4*step + (l>>4)][n = l&15].
+            // n = cN + 8*d packs two output rows (d = 0, 1) of one site column; k enumerates
+            // (tap of a 4x3 window, input channel) with the channel fastest.
+            int u, KC, stage;
+            if (t < WB2) { u = t - WB1; KC = 2; stage = 0; }
+            else if (t < WB3T) { u = t - WB2; KC = 8; stage = 1; }
+            else if (t < WB2T) { u = t - WB3T; KC = 3; stage = 2; }
+            else { u = t - WB2T; KC = 8; stage = 3; }
+            const int step = u / 64, l = u % 64, g = l >> 4, j = l & 15, cN = j & 7, dd = j >> 3;
+            const int k = 4 * step + g, tap = k / KC, cK = k % KC, ky4 = tap / 3, kx = tap % 3, ky = ky4 - dd;
+            if (ky >= 0 && ky <= 2) {
+                if (stage == 0) v = c[CW0 + (cN * 2 + cK) * 9 + ky * 3 + kx];
+                else if (stage == 1) v = c[CW1 + (cN * 8 + cK) * 9 + ky * 3 + kx];
+                else if (stage == 2) v = c[CW2 + (cK * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx)];
+                else v = c[CW1 + (cK * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx)];
+            }
+        }
         d[t] = v;
     }
 }
 
-__device__ __forceinline__ void act_eval(double z, int act, double& h, double& d) {
-    if (act == FTHMC_ACT_SILU) {
-        const double sg = 1.0 / (1.0 + exp(-z));
-        h = z * sg;
-        d = sg * (1.0 + z * (1.0 - sg));
-    } else if (act == FTHMC_ACT_RELU) {
-        h = z > 0.0 ? z : 0.0;  d = z > 0.0 ? 1.0 : 0.0;
-    } else {
-        h = z > 0.0 ? z : 0.01 * z;  d = z > 0.0 ? 1.0 : 0.01;
-    }
-}
 
 // LDS plan (doubles)
 template <int MODE> struct Smem {

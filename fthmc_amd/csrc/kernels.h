@@ -33,7 +33,7 @@ int launch_random_momenta(const int64_t* seeds, int B, int n, double* v, double*
 constexpr int FLOW_TILE = 16;                 // sites per tile edge
 constexpr int FLOW_R0 = FLOW_TILE + 6;        // plaquette / net-input window edge
 constexpr int FLOW_N0 = FLOW_R0 * FLOW_R0;    // window size of one gP partial
-constexpr int FLOW_WINT = 1968;               // doubles per layer, kernel-side weight layout
+constexpr int FLOW_WINT = 6016;               // doubles per layer, kernel-side weight layout
 constexpr int FLOW_GW_STRIDE = 960;           // doubles per (chain, tile) weight-gradient partial
 
 inline int flow_ntiles(int L) { int t = (L + FLOW_TILE - 1) / FLOW_TILE; return t * t; }
@@ -58,6 +58,12 @@ struct FlowLayerArgs {
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_rev(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s);
+// flow_mfma.hip: MFMA variants of forward / backward-wrt-x (same arguments and results)
+int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s);
+int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s);
+// 0: VALU kernels everywhere; 1 (default): MFMA kernels for forward and backward-wrt-x
+void set_flow_variant(int v);
+int get_flow_variant();
 // out[b] (+)= sign * sum_t part[b][t]
 int launch_sum_parts(const double* part, int B, int nparts, double sign, int accumulate,
                      double* out, hipStream_t s);

@@ -55,6 +55,15 @@ def _ws(t: torch.Tensor, B: int, L: int, nl: int):
     return buf.data_ptr(), buf.numel() * 8
 
 
+def set_variant(v: int):
+    """1: MFMA conv kernels (default), 0: VALU conv kernels."""
+    check(_lib.load().fthmc_set_variant(int(v)), 'fthmc_set_variant')
+
+
+def get_variant() -> int:
+    return int(_lib.load().fthmc_get_variant())
+
+
 def act_code(act) -> int:
     key = act.lower() if isinstance(act, str) else act
     if key not in ACT_CODES:

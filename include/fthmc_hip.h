@@ -51,6 +51,12 @@ const char* fthmc_strerror(int code);
 /* text of the HIP error behind the last FTHMC_ERR_LAUNCH on this thread ("" if none) */
 const char* fthmc_last_error(void);
 
+/* Kernel variant of the coupling-layer forward / backward-wrt-x kernels (process-wide):
+ * 1 (default) MFMA f64 16x16x4 implicit-GEMM convolutions, 0 fp64-VALU convolutions.
+ * Same results to rounding; kept selectable for A/B measurement and cross-checks. */
+int fthmc_set_variant(int v);
+int fthmc_get_variant(void);
+
 /* Bytes of scratch the flow / trajectory entry points need for (B, L, n_layers). */
 size_t fthmc_ws_bytes(int B, int L, int n_layers);
 

@@ -24,6 +24,14 @@ def _mods():
     ops, R = _ops, _R
 
 
+@pytest.fixture(params=[1, 0], ids=['mfma', 'valu'], autouse=True)
+def variant(request, _mods):
+    """Every parity test runs against both conv-kernel variants (C ABI: fthmc_set_variant)."""
+    ops.set_variant(request.param)
+    yield request.param
+    ops.set_variant(1)
+
+
 def D(a):
     return torch.from_numpy(np.asarray(a, dtype=np.float64).copy()).cuda()
 

@@ -56,6 +56,8 @@ SIGNATURES = {
     'fthmc_train_grad': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
     'fthmc_time_kernel': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double, c_int,
                           ctypes.POINTER(c_double), _P, c_size_t, _P],
+    'fthmc_profile_stages': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double,
+                             ctypes.POINTER(c_double), _P, c_size_t, _P],
 }
 _RESTYPE = {'fthmc_version': c_char_p, 'fthmc_last_error': c_char_p, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
 

@@ -7,6 +7,7 @@
 #include <math.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 
 using namespace fthmc;
 
@@ -458,6 +459,34 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     hipEventDestroy(e0); hipEventDestroy(e1);
     *ms_avg_host = (double)ms / reps;
     return rc;
+}
+
+int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
+                         double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 1) return FTHMC_ERR_ARG;
+    FT_WS(1);
+    const size_t nrec = (size_t)B * flow_ntiles(L);
+    long long* dbg = reinterpret_cast<long long*>(W.gw_part);      // B*ntiles*960 doubles >> 16 stamps each
+    if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
+    FlowLayerArgs a{};
+    a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
+    a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.dbg = dbg;
+    a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : launch_flow_bwd_mfma(a, s));
+    long long* h = (long long*)malloc(nrec * 16 * sizeof(long long));
+    if (!h) return FTHMC_ERR_ARG;
+    if (hipMemcpyAsync(h, dbg, nrec * 16 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) { free(h); return FTHMC_ERR_LAUNCH; }
+    for (int k = 0; k < 16; ++k) cycles_host16[k] = 0.0;
+    for (size_t r = 0; r < nrec; ++r)
+        for (int k = 1; k < 16; ++k) {
+            const int ref = k <= 10 ? k - 1 : 2;           // slots 11..15: cycles since the start of conv2
+            if (h[r * 16 + k] && h[r * 16 + ref]) cycles_host16[k] += (double)(h[r * 16 + k] - h[r * 16 + ref]) / nrec;
+        }
+    free(h);
+    return FTHMC_OK;
 }
 
 }  // extern "C"

@@ -35,9 +35,44 @@ constexpr int WB3T = WB2 + 24 * 64;  // conv3^T (K = 3 co x 12 taps = 36)  ->  9
 constexpr int WB2T = WB3T + 9 * 64;  // conv2^T (K = 8 co x 12 taps = 96)  -> 24 steps
 static_assert(WB2T + 24 * 64 <= FLOW_WINT, "weight layout");
 
+// exp(-a) for a >= 0: range reduction by ln2 (hi/lo split) + degree-13 Taylor (|r| <= ln2/2:
+// truncation 4e-18) + v_ldexp.  ~20 dependent DP ops instead of ocml exp's ~60, < 1.5 ulp.
+__device__ __forceinline__ double ft_exp_neg(double a) {
+    a = fmin(a, 745.0);
+    const double n = rint(a * 1.4426950408889634074);
+    double r = fma(n, 6.93147180369123816490e-01, -a);
+    r = fma(n, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;               // 1/13!
+    p = fma(p, r, 2.0876756987868100e-09);           // 1/12!
+    p = fma(p, r, 2.5052108385441720e-08);           // 1/11!
+    p = fma(p, r, 2.7557319223985888e-07);           // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);           // 1/9!
+    p = fma(p, r, 2.4801587301587302e-05);           // 1/8!
+    p = fma(p, r, 1.9841269841269841e-04);           // 1/7!
+    p = fma(p, r, 1.3888888888888889e-03);           // 1/6!
+    p = fma(p, r, 8.3333333333333332e-03);           // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);           // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);           // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, -(int)n);
+}
+
+// sigmoid(z) = 1 / (1 + exp(-z)) without overflow or cancellation; reciprocal by v_rcp_f64 +
+// two Newton steps (no div_scale / div_fmas / div_fixup chain).
+__device__ __forceinline__ double ft_sigmoid(double z) {
+    const double e = ft_exp_neg(fabs(z));
+    const double t = 1.0 + e;
+    double y = __builtin_amdgcn_rcp(t);
+    y = fma(fma(-t, y, 1.0), y, y);
+    y = fma(fma(-t, y, 1.0), y, y);
+    return z >= 0.0 ? y : e * y;
+}
+
 __device__ __forceinline__ void act_eval(double z, int act, double& h, double& d) {
     if (act == FTHMC_ACT_SILU) {
-        const double sg = 1.0 / (1.0 + exp(-z));
+        const double sg = ft_sigmoid(z);
         h = z * sg;
         d = sg * (1.0 + z * (1.0 - sg));
     } else if (act == FTHMC_ACT_RELU) {
@@ -47,5 +82,22 @@ __device__ __forceinline__ void act_eval(double z, int act, double& h, double& d
     }
 }
 
+// four independent activations at once: the act switch is taken once and the four sigmoid
+// chains interleave (the epilogue of an MFMA tile is latency-bound otherwise)
+__device__ __forceinline__ void act_eval4(const double (&z)[4], int act, double (&h)[4], double (&d)[4]) {
+    if (act == FTHMC_ACT_SILU) {
+        double sg[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sg[q] = ft_sigmoid(z[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h[q] = z[q] * sg[q]; d[q] = sg[q] * (1.0 + z[q] * (1.0 - sg[q])); }
+    } else if (act == FTHMC_ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h[q] = z[q] > 0.0 ? z[q] : 0.0; d[q] = z[q] > 0.0 ? 1.0 : 0.0; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h[q] = z[q] > 0.0 ? z[q] : 0.01 * z[q]; d[q] = z[q] > 0.0 ? 1.0 : 0.01; }
+    }
+}
 
 }  // namespace fthmc_flow

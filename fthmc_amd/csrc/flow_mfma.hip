@@ -32,16 +32,21 @@ constexpr int PS2 = 336;                // 18x18 planes (h2, d2)
 static_assert(PS0 % 32 == 16 && PS1 % 32 == 16 && PS2 % 32 == 16, "bank layout");
 static_assert(PS0 >= N0 && PS1 >= N1 && PS2 >= N2, "plane size");
 
+// LDS copy of the weights the VALU stages use (scalar loads in an LDS-heavy loop serialise on
+// lgkmcnt(0)): [W3F | B3](292) [W1B](144) [B1](8) [B2](8)
+constexpr int SW_W3F = 0, SW_B3 = 288, SW_W1B = 292, SW_B1 = 436, SW_B2 = 444, SW_SIZE = 452 + 12;
+
 template <int MODE> struct SmemM {
     static constexpr bool BWD = (MODE == 1);
     static constexpr int P = 0;                          // [N0]
     static constexpr int IN = P + N0 + 12;               // [2][PS0]      (+12: keep 32-double alignment)
     static constexpr int H1 = IN + 2 * PS0;              // [8][PS1]  | bwd: padded gz2 [8][PS0] over H1|H2
     static constexpr int H2 = H1 + 8 * PS1;              // [8][PS2]
-    static constexpr int ST = H2 + 8 * PS2;              // [8 waves][3][64]
-    static constexpr int T2 = ST + NW * 3 * NACT;        // [NMIX][4][64]
+    static constexpr int ST = H2 + 8 * PS2;              // [8 channels][3][64]
+    static constexpr int T2 = ST + 8 * 3 * NACT;        // [NMIX][4][64]
     static constexpr int DL = T2 + NMIX * 4 * NACT;      // [N3]
-    static constexpr int D1 = DL + N3;                   // [8][PS1]   (bwd)
+    static constexpr int SW = DL + N3;                   // [SW_SIZE] small weights read by VALU stages
+    static constexpr int D1 = SW + SW_SIZE;              // [8][PS1]   (bwd)
     static constexpr int D2 = D1 + (BWD ? 8 * PS1 : 0);  // [8][PS2]
     static constexpr int GO = D2 + (BWD ? 8 * PS2 : 0);  // padded g_out [3][PS1] (20x20, ring 2)
     static constexpr int GP = GO + (BWD ? 3 * PS1 : 0);  // [N0]
@@ -52,39 +57,70 @@ template <int MODE> struct SmemM {
 // One implicit-GEMM stage.  Output region HOUT x WOUT (HOUT even) whose input planes are one
 // site larger on every side (forward conv) or ring-2 padded (transposed conv): input index of
 // output (r, c) and window tap (ky4, kx) is (r + ky4, c + kx) for the pair's upper row r = 2q.
+// B operand of a stage: issued before the barrier that precedes the stage so that the global
+// (L2) latency overlaps the tail of the previous stage.
+template <int NSTEP>
+__device__ __forceinline__ void stage_prefetch(const double* __restrict__ wB, int lane, double (&breg)[NSTEP]) {
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) breg[t] = wB[t * 64 + lane];
+}
+
 template <int NSTEP, int KC, int HOUT, int WOUT, int RSA, int PSA, class Epi>
-__device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ wB,
-                                           double cinit, int wave, int lane, Epi epi) {
+__device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double (&breg)[NSTEP],
+                                           double cinit, int wave, int lane, Epi epi, long long* dbg = nullptr) {
+#define DSTAMP(k) do { if (dbg && wave == 0 && lane == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     constexpr int NPAIR = (HOUT / 2) * WOUT;
     constexpr int NTILE = (NPAIR + 15) / 16;
     const int g = lane >> 4, i = lane & 15;
-    int koff[NSTEP];
-    double breg[NSTEP];
+    // A-operand offset of k = 4 t + g: k -> (tap = k / KC, channel = k % KC).  For KC = 8 the lane
+    // part is just g * PSA and the rest is a compile-time immediate; otherwise a small table.
+    int koff[KC == 8 ? 1 : NSTEP];
+    if (KC != 8) {
 #pragma unroll
-    for (int t = 0; t < NSTEP; ++t) {
-        const int k = 4 * t + g, tap = k / KC, cK = k - tap * KC;
-        koff[t] = cK * PSA + (tap / 3) * RSA + (tap % 3);
-        breg[t] = wB[t * 64 + lane];
+        for (int t = 0; t < NSTEP; ++t) {
+            const int k = 4 * t + g, tap = k / KC, cK = k - tap * KC;
+            koff[t] = cK * PSA + (tap / 3) * RSA + (tap % 3);
+        }
     }
     const int cN = i & 7, dd = i >> 3;
+    DSTAMP(11);
     for (int tile = wave; tile < NTILE; tile += NW) {
         int p = tile * 16 + i;
         if (p >= NPAIR) p = NPAIR - 1;                       // padding lanes: any valid address
         const int pr = p / WOUT, pc = p - pr * WOUT;
-        const double* a0 = A + (2 * pr) * RSA + pc;
-        double4_t acc = {cinit, cinit, cinit, cinit};
+        const double* a0 = A + (2 * pr) * RSA + pc + (KC == 8 ? g * PSA : 0);
+        // NCH independent accumulator chains: a dependent f64 MFMA waits ~4 issue slots for its
+        // predecessor, so one chain per tile leaves the matrix pipe 3/4 idle at 2 waves per SIMD.
+        constexpr int NCH = NSTEP >= 8 ? 4 : 3;
+        double4_t accs[NCH];
 #pragma unroll
-        for (int t = 0; t < NSTEP; ++t)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[koff[t]], breg[t], acc, 0, 0, 0);
-        // D[row = g + 4 q][col = i]: row = pair site, col = (channel, row of the pair)
+        for (int ch = 0; ch < NCH; ++ch) accs[ch] = double4_t{0.0, 0.0, 0.0, 0.0};
+        accs[0] = double4_t{cinit, cinit, cinit, cinit};
+#pragma unroll
+        for (int t = 0; t < NSTEP; ++t) {
+            double av;
+            if (KC == 8) av = a0[(t & 1) * 4 * PSA + ((t >> 1) / 3) * RSA + ((t >> 1) % 3)];
+            else av = a0[koff[t]];
+            accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, breg[t], accs[t % NCH], 0, 0, 0);
+        }
+        double4_t acc = accs[0];
+#pragma unroll
+        for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
+        if (dbg && wave == 0 && lane == 0) { dbg[tile == 0 ? 12 : 14] = (long long)__builtin_readcyclecounter() + (long long)(acc[0] == 12345.678); }
+        // D[row = g + 4 q][col = i]: row = pair site, col = (channel, row of the pair).
+        // All four values go to the epilogue together so their activation chains interleave.
+        int off4[4]; bool ok4[4]; double z4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int pp = tile * 16 + g + 4 * q;
-            if (pp < NPAIR) {
-                const int qr = pp / WOUT, qc = pp - qr * WOUT;
-                epi(cN, 2 * qr + dd, qc, acc[q]);
-            }
+            int pp = tile * 16 + g + 4 * q;
+            ok4[q] = pp < NPAIR;
+            if (!ok4[q]) pp = NPAIR - 1;
+            const int qr = pp / WOUT, qc = pp - qr * WOUT;
+            off4[q] = (2 * qr + dd) * WOUT + qc;             // index inside the HOUT x WOUT plane
+            z4[q] = acc[q];
         }
+        epi(cN, off4, ok4, z4);
+        if (dbg && wave == 0 && lane == 0) dbg[tile == 0 ? 13 : 15] = (long long)__builtin_readcyclecounter();
     }
 }
 
@@ -97,7 +133,7 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
     double* sP = sm + S::P;   double* sIn = sm + S::IN;
     double* sH1 = sm + S::H1; double* sH2 = sm + S::H2;
     double* sST = sm + S::ST; double* sT2 = sm + S::T2;
-    double* sDL = sm + S::DL;
+    double* sDL = sm + S::DL; double* sW = sm + S::SW;
     double* sD1 = sm + S::D1; double* sD2 = sm + S::D2;
     double* sGO = sm + S::GO; double* sGP = sm + S::GP;
     double* sGZ2 = sm + S::H1;                     // padded gz2 [8][PS0] (22x22, ring 2), bwd only
@@ -114,6 +150,9 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
     const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
     const double* __restrict__ x1 = x0 + n;
     const double* __restrict__ w = A.wint;
+    long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
+#define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+    STAMP(0);
 
     // ---- plaquette window + net input ------------------------------------
     for (int t = tid; t < N0; t += NT) {
@@ -130,32 +169,53 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
     }
     if (MODE == 0) { if (tid < N3) sDL[tid] = 0.0; }
     if (BWD) { for (int t = tid; t < 3 * PS1; t += NT) sGO[t] = 0.0; }
+    if (tid < 292) sW[SW_W3F + tid] = w[W3F + tid];
+    else if (tid < 292 + 144) sW[SW_W1B + tid - 292] = w[W1B + tid - 292];
+    else if (tid < 292 + 144 + 8) sW[SW_B1 + tid - 436] = w[B1 + tid - 436];
+    else if (tid < 292 + 144 + 16) sW[SW_B2 + tid - 444] = w[B2 + tid - 444];
+    double breg1[6];
+    stage_prefetch<6>(w + WB1, lane, breg1);
     __syncthreads();
+    STAMP(1);
 
     // ---- conv1 (2 -> 8) + act on the tile+2 window (20x20) ------------------
-    mfma_stage<6, 2, R1, R1, R0, PS0>(sIn, w + WB1, 0.0, wave, lane,
-        [&](int co, int r, int c, double z) {
-            double h, d; act_eval(z + w[B1 + co], act, h, d);
-            sH1[co * PS1 + r * R1 + c] = h;
-            if (BWD) sD1[co * PS1 + r * R1 + c] = d;
+    mfma_stage<6, 2, R1, R1, R0, PS0>(sIn, breg1, 0.0, wave, lane,
+        [&](int co, const int (&o)[4], const bool (&ok)[4], double (&z)[4]) {
+            const double bias = sW[SW_B1 + co];
+            double h[4], d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] += bias;
+            act_eval4(z, act, h, d);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ok[q]) { sH1[co * PS1 + o[q]] = h[q]; if (BWD) sD1[co * PS1 + o[q]] = d[q]; }
         });
+    double breg2[24];
+    stage_prefetch<24>(w + WB2, lane, breg2);
     __syncthreads();
+    STAMP(2);
 
     // ---- conv2 (8 -> 8) + act on the tile+1 window (18x18) ------------------
-    mfma_stage<24, 8, R2, R2, R1, PS1>(sH1, w + WB2, 0.0, wave, lane,
-        [&](int co, int r, int c, double z) {
-            double h, d; act_eval(z + w[B2 + co], act, h, d);
-            sH2[co * PS2 + r * R2 + c] = h;
-            if (BWD) sD2[co * PS2 + r * R2 + c] = d;
-        });
+    mfma_stage<24, 8, R2, R2, R1, PS1>(sH1, breg2, 0.0, wave, lane,
+        [&](int co, const int (&o)[4], const bool (&ok)[4], double (&z)[4]) {
+            const double bias = sW[SW_B2 + co];
+            double h[4], d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] += bias;
+            act_eval4(z, act, h, d);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ok[q]) { sH2[co * PS2 + o[q]] = h[q]; if (BWD) sD2[co * PS2 + o[q]] = d[q]; }
+        }, dbg);
     __syncthreads();
+    STAMP(3);
 
     // ---- conv3 (8 -> 3) at the 64 active sites; one input channel per wave ---
     const int ar = mu == 0 ? (lane >> 2) : off + 4 * (lane >> 4);
     const int ac = mu == 0 ? off + 4 * (lane & 3) : (lane & 15);
     const int ai = i0 + ar, aj = j0 + ac;
     const bool avalid = (ai < L) && (aj < L);
-    {
+    if (wave < 8) {
         double acc[3] = {0.0, 0.0, 0.0};
         const int ci = wave;
 #pragma unroll
@@ -163,7 +223,7 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const double v = sH2[ci * PS2 + (ar + ky) * R2 + ac + kx];
-                const double* wp = w + W3F + (ci * 9 + ky * 3 + kx) * 4;
+                const double* wp = sW + SW_W3F + (ci * 9 + ky * 3 + kx) * 4;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) acc[k] = fma(v, wp[k], acc[k]);
             }
@@ -171,14 +231,15 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
         for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NACT + lane] = acc[k];
     }
     __syncthreads();
+    STAMP(4);
 
     // ---- tan-mixture transform: wave k evaluates mixture component k -------
     double Pa = 0.0, tval = 0.0, es = 0.0, ems = 0.0, cs2 = 0.0, sn2 = 0.0, Dk = 1.0, yk = 0.0, ljk = 0.0;
     if (wave < NMIX) {
         Pa = sP[(ar + 3) * R0 + ac + 3];
-        double sk = w[B3 + wave];
+        double sk = sW[SW_B3 + wave];
 #pragma unroll
-        for (int q = 0; q < NW; ++q) sk += sST[(q * 3 + wave) * NACT + lane];
+        for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NACT + lane];
         const double hx = Pa / 2;
         es = exp(sk); ems = exp(-sk);
         const double cs = cos(hx), sn = sin(hx);
@@ -190,12 +251,13 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
         sT2[(wave * 4 + 1) * NACT + lane] = ljk;
     }
     __syncthreads();
+    STAMP(5);
 
     if (MODE == 0) {
         if (wave == 0) {
-            tval = w[B3 + 2];
+            tval = sW[SW_B3 + 2];
 #pragma unroll
-            for (int q = 0; q < NW; ++q) tval += sST[(q * 3 + 2) * NACT + lane];
+            for (int q = 0; q < 8; ++q) tval += sST[(q * 3 + 2) * NACT + lane];
             double ysum = 0.0, m = -INFINITY;
 #pragma unroll
             for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * 4) * NACT + lane]; m = fmax(m, sT2[(k * 4 + 1) * NACT + lane]); }
@@ -222,6 +284,7 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
                 y0[i * L + j] = v0; y0[n + i * L + j] = v1;
             }
         }
+        STAMP(6);
         return;
     }
 
@@ -265,21 +328,35 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
             sGP[(ar + 3) * R0 + ac + 3] = gsum;
             sGO[NMIX * PS1 + (ar + 2) * R1 + ac + 2] = gdelta;      // dL/dt
         }
+        double breg3[9];
+        stage_prefetch<9>(w + WB3T, lane, breg3);
         __syncthreads();
+        STAMP(6);
 
         // ---- conv3^T, times act'(z2) -> gz2 into the ring-2 padded 22x22 planes ----
-        mfma_stage<9, 3, R2, R2, R1, PS1>(sGO, w + WB3T, 0.0, wave, lane,
-            [&](int ci, int r, int c, double gh) {
-                sGZ2[ci * PS0 + (r + 2) * R0 + c + 2] = gh * sD2[ci * PS2 + r * R2 + c];
+        mfma_stage<9, 3, R2, R2, R1, PS1>(sGO, breg3, 0.0, wave, lane,
+            [&](int ci, const int (&o)[4], const bool (&ok)[4], double (&gh)[4]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ok[q]) {
+                        const int r = o[q] / R2, c = o[q] - r * R2;
+                        sGZ2[ci * PS0 + (r + 2) * R0 + c + 2] = gh[q] * sD2[ci * PS2 + o[q]];
+                    }
             });
+        double breg4[24];
+        stage_prefetch<24>(w + WB2T, lane, breg4);
         __syncthreads();
+        STAMP(7);
 
         // ---- conv2^T, times act'(z1) -> gz1 in place over d1 -------------------------
-        mfma_stage<24, 8, R1, R1, R0, PS0>(sGZ2, w + WB2T, 0.0, wave, lane,
-            [&](int ci, int r, int c, double gh) {
-                sD1[ci * PS1 + r * R1 + c] *= gh;
+        mfma_stage<24, 8, R1, R1, R0, PS0>(sGZ2, breg4, 0.0, wave, lane,
+            [&](int ci, const int (&o)[4], const bool (&ok)[4], double (&gh)[4]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ok[q]) sD1[ci * PS1 + o[q]] *= gh[q];
             });
         __syncthreads();
+        STAMP(8);
 
         // ---- conv1^T and the (cos, sin) adjoint at frozen plaquettes ----------------
         for (int t = tid; t < N0; t += NT) {
@@ -288,23 +365,35 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
             const int sel = ft_stripe(i, j, mu, off);
             if (sel == 1 || sel == 2) {
                 double gc = 0.0, gs = 0.0;
-                for (int co = 0; co < 8; ++co)
+                // clamped addresses + zero mask: no per-tap branches, nothing to hoist across co
+                int aoff[9]; double msk[9];
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int rr = r - ky, cc = c - kx;
-                            const bool ok = (rr >= 0) && (rr < R1) && (cc >= 0) && (cc < R1);
-                            const double gv = ok ? sD1[co * PS1 + rr * R1 + cc] : 0.0;
-                            const double* wp = w + W1B + (co * 9 + ky * 3 + kx) * 2;
-                            gc = fma(gv, wp[0], gc); gs = fma(gv, wp[1], gs);
-                        }
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int rr = r - ky, cc = c - kx;
+                        const bool ok = (rr >= 0) && (rr < R1) && (cc >= 0) && (cc < R1);
+                        aoff[ky * 3 + kx] = ok ? rr * R1 + cc : 0;
+                        msk[ky * 3 + kx] = ok ? 1.0 : 0.0;
+                    }
+#pragma unroll 1
+                for (int co = 0; co < 8; ++co) {
+                    const double* gz = sD1 + co * PS1;
+                    const double* wp = sW + SW_W1B + co * 18;
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) {
+                        const double gv = gz[aoff[tp]] * msk[tp];
+                        gc = fma(gv, wp[tp * 2], gc); gs = fma(gv, wp[tp * 2 + 1], gs);
+                    }
+                }
                 sGP[t] = -sIn[PS0 + t] * gc + sIn[t] * gs;
             }
         }
         __syncthreads();
+        STAMP(9);
         double* out = A.gp_part + ((size_t)b * ntiles + tile) * N0;
         for (int t = tid; t < N0; t += NT) out[t] = sGP[t];
+        STAMP(10);
     }
 }
 

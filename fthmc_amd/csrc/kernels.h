@@ -53,6 +53,7 @@ struct FlowLayerArgs {
     double* gp_part;         // bwd: [B][ntiles][FLOW_N0]
     double* gw_part;         // bwd with wgrad: [B*ntiles][FLOW_GW_STRIDE]
     double tol;              // rev
+    long long* dbg;          // optional: per-(chain,tile) stage time stamps [16] (diagnostic runs only)
     int B, L, mu, off, act;
 };
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);

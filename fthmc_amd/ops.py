@@ -330,3 +330,15 @@ def time_kernel(kind: str, x, w=None, mu=0, off=0, act='silu', beta=1.0, reps=20
     check(_lib.load().fthmc_time_kernel(k, _p(x), wp, B, L, int(mu), int(off), act_code(act), float(beta),
                                         int(reps), ctypes.byref(ms), ws, nb, _stream(x)), 'fthmc_time_kernel')
     return ms.value
+
+
+def profile_stages(kind: str, x, w, mu=0, off=0, act='silu', beta=1.0):
+    """Mean cycles per stage of one MFMA coupling-layer kernel launch ('flow_fwd' | 'flow_bwd')."""
+    import ctypes
+    x = _field(x); B, _, L, _ = x.shape
+    k = {'flow_fwd': 0, 'flow_bwd': 1}[kind]
+    buf = (ctypes.c_double * 16)()
+    ws, nb = _ws(x, B, L, 1)
+    check(_lib.load().fthmc_profile_stages(k, _p(x), _p(_w1(w, x)), B, L, int(mu), int(off), act_code(act),
+                                           float(beta), buf, ws, nb, _stream(x)), 'fthmc_profile_stages')
+    return list(buf)

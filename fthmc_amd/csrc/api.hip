@@ -35,14 +35,14 @@ enum { SC_S = 0, SC_Q, SC_PLAQ, SC_LOGDET, SC_K, SC_H0, SC_H1, SC_OLD0, SC_OLD1,
 WS ws_layout(double* base, int B, int L, int nl) {
     WS w{};
     const size_t n1 = (size_t)B * L * L, n2 = 2 * n1;
-    const size_t nt = (size_t)flow_ntiles(L);
+    const size_t nt = flow_ntiles_max(L);
     size_t o = 0;
     auto take = [&](size_t n) { double* p = base ? base + o : nullptr; o += up(n); return p; };
     w.n2 = n2;
     w.wint = take((size_t)(nl > 0 ? nl : 1) * FLOW_WINT);
     w.X = take((size_t)nl * n2);
     w.gp = take(n1);
-    w.gp_part = take(nl > 0 ? (size_t)B * nt * FLOW_N0 : 0);
+    w.gp_part = take(nl > 0 ? (size_t)B * flow_gp_part_max(L) : 0);
     w.lj_part = take((size_t)B * nt);
     w.scal = take((size_t)SC_N * B);
     w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
@@ -51,11 +51,14 @@ WS ws_layout(double* base, int B, int L, int nl) {
     return w;
 }
 
+// which kernel family serves a call, and with it the tile geometry of its partial buffers
+inline bool fwd_is_mfma() { return get_flow_variant() == 1; }
+inline bool bwd_is_mfma(bool wgrad) { return !wgrad && get_flow_variant() == 1; }
 inline int flow_fwd(const FlowLayerArgs& a, hipStream_t s) {
-    return get_flow_variant() == 1 ? launch_flow_fwd_mfma(a, s) : launch_flow_fwd(a, s);
+    return fwd_is_mfma() ? launch_flow_fwd_mfma(a, s) : launch_flow_fwd(a, s);
 }
 inline int flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s) {
-    return (!wgrad && get_flow_variant() == 1) ? launch_flow_bwd_mfma(a, s) : launch_flow_bwd(a, wgrad, s);
+    return bwd_is_mfma(wgrad) ? launch_flow_bwd_mfma(a, s) : launch_flow_bwd(a, wgrad, s);
 }
 
 inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
@@ -73,7 +76,7 @@ int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, d
         a.logj_part = logdet ? w.lj_part : nullptr;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
         FT_TRY(flow_fwd(a, s));
-        if (logdet) FT_TRY(launch_sum_parts(w.lj_part, B, flow_ntiles(L), 1.0, l > 0, logdet, s));
+        if (logdet) FT_TRY(launch_sum_parts(w.lj_part, B, flow_geom(fwd_is_mfma()).ntiles(L), 1.0, l > 0, logdet, s));
     }
     return FTHMC_OK;
 }
@@ -109,9 +112,9 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
         a.gw_part = w.gw_part;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
         FT_TRY(flow_bwd(a, gw != nullptr, s));
-        if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_ntiles(L), 1.0, 0,
+        if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0,
                                         gw + (size_t)l * FTHMC_W_PER_LAYER, s));
-        FT_TRY(launch_gather_gp(w.gp_part, B, L, 1, w.gp, s));
+        FT_TRY(launch_gather_gp(w.gp_part, B, L, flow_geom(bwd_is_mfma(gw != nullptr)), 1, w.gp, s));
     }
     return FTHMC_OK;
 }
@@ -255,7 +258,7 @@ int fthmc_flow_layer_fwd(const double* x, const double* w, int B, int L, int mu,
     a.x = x; a.wint = W.wint; a.y = y; a.logj_part = W.lj_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
     FT_TRY(flow_fwd(a, s));
-    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_ntiles(L), 1.0, 0, logJ, s));
+    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(fwd_is_mfma()).ntiles(L), 1.0, 0, logJ, s));
     return FTHMC_OK;
 }
 
@@ -269,7 +272,7 @@ int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu,
     a.x = y; a.wint = W.wint; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
     FT_TRY(launch_flow_rev(a, s));
-    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_ntiles(L), 1.0, 0, logJ, s));
+    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(false).ntiles(L), 1.0, 0, logJ, s));
     return FTHMC_OK;
 }
 
@@ -286,8 +289,8 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
     a.gp_part = W.gp_part; a.gw_part = W.gw_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
     FT_TRY(flow_bwd(a, gw != nullptr, s));
-    if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_ntiles(L), 1.0, 0, gw, s));
-    FT_TRY(launch_gather_gp(W.gp_part, B, L, 0, W.gp, s));
+    if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0, gw, s));
+    FT_TRY(launch_gather_gp(W.gp_part, B, L, flow_geom(bwd_is_mfma(gw != nullptr)), 0, W.gp, s));
     return launch_adj_add(W.gp, gy, B, L, gx, s);
 }
 
@@ -320,7 +323,7 @@ int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, in
         a.x = x; a.wint = W.wint + (size_t)l * FLOW_WINT; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
         FT_TRY(launch_flow_rev(a, s));
-        FT_TRY(launch_sum_parts(W.lj_part, B, flow_ntiles(L), 1.0, 1, ld, s));
+        FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(false).ntiles(L), 1.0, 1, ld, s));
     }
     return FTHMC_OK;
 }
@@ -465,7 +468,7 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 1) return FTHMC_ERR_ARG;
     FT_WS(1);
-    const size_t nrec = (size_t)B * flow_ntiles(L);
+    const size_t nrec = (size_t)B * flow_geom(true).ntiles(L);
     long long* dbg = reinterpret_cast<long long*>(W.gw_part);      // B*ntiles*960 doubles >> 16 stamps each
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FT_TRY(launch_pack_weights(w, 1, W.wint, s));
@@ -482,7 +485,7 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
     for (int k = 0; k < 16; ++k) cycles_host16[k] = 0.0;
     for (size_t r = 0; r < nrec; ++r)
         for (int k = 1; k < 16; ++k) {
-            const int ref = k <= 10 ? k - 1 : 2;           // slots 11..15: cycles since the start of conv2
+            const int ref = k <= 10 ? k - 1 : 1;           // slots 11..15: cycles since the start of conv1
             if (h[r * 16 + k] && h[r * 16 + ref]) cycles_host16[k] += (double)(h[r * 16 + k] - h[r * 16 + ref]) / nrec;
         }
     free(h);

@@ -486,28 +486,29 @@ __global__ void k_sum_parts(const double* __restrict__ part, int B, int np, doub
     out[b] = (accumulate ? out[b] : 0.0) + sign * a;
 }
 
-// gp[b][i][j] (+)= sum over tiles and over every window position that wraps onto (i, j)
-__global__ void k_gather_gp(const double* __restrict__ part, int L, int nt, int accumulate,
-                            double* __restrict__ gp) {
+// gp[b][i][j] (+)= sum over tiles and over every window position that wraps onto (i, j).
+// Tiles are tr x tc sites, their windows (tr+6) x (tc+6) at offset -3; fixed summation order.
+__global__ void k_gather_gp(const double* __restrict__ part, int L, int tr, int tc, int nti, int ntj,
+                            int accumulate, double* __restrict__ gp) {
     const int b = blockIdx.y;
     const int n = L * L;
-    const int ntiles = nt * nt;
+    const int ntiles = nti * ntj;
+    const int wr = tr + 6, wc = tc + 6, n0 = wr * wc;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         const int i = s / L, j = s - i * L;
         double acc = 0.0;
         // candidate tiles per dimension: all of them when there are <= 3, else own and both neighbours
-        const int ci = i / FT, cj = j / FT;
-        const int ni = nt <= 3 ? nt : 3, bi = nt <= 3 ? 0 : ci - 1;
-        const int bj = nt <= 3 ? 0 : cj - 1;
+        const int ni = nti <= 3 ? nti : 3, bi = nti <= 3 ? 0 : i / tr - 1;
+        const int nj = ntj <= 3 ? ntj : 3, bj = ntj <= 3 ? 0 : j / tc - 1;
         for (int di = 0; di < ni; ++di) {
-            const int ti = (bi + di + nt) % nt;
-            const int r0 = ft_modL(i - ti * FT + 3, L);
-            for (int r = r0; r < R0; r += L)
-                for (int dj = 0; dj < ni; ++dj) {
-                    const int tj = (bj + dj + nt) % nt;
-                    const int c0 = ft_modL(j - tj * FT + 3, L);
-                    const double* p = part + ((size_t)b * ntiles + ti * nt + tj) * N0 + r * R0;
-                    for (int c = c0; c < R0; c += L) acc += p[c];
+            const int ti = (bi + di + nti) % nti;
+            const int r0 = ft_modL(i - ti * tr + 3, L);
+            for (int r = r0; r < wr; r += L)
+                for (int dj = 0; dj < nj; ++dj) {
+                    const int tj = (bj + dj + ntj) % ntj;
+                    const int c0 = ft_modL(j - tj * tc + 3, L);
+                    const double* p = part + ((size_t)b * ntiles + ti * ntj + tj) * n0 + r * wc;
+                    for (int c = c0; c < wc; c += L) acc += p[c];
                 }
         }
         const size_t o = (size_t)b * n + s;
@@ -577,9 +578,9 @@ int launch_sum_parts(const double* part, int B, int nparts, double sign, int acc
     hipLaunchKernelGGL(k_sum_parts, dim3((B + 63) / 64), dim3(64), 0, s, part, B, nparts, sign, accumulate, out);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
-int launch_gather_gp(const double* gp_part, int B, int L, int accumulate, double* gp, hipStream_t s) {
+int launch_gather_gp(const double* gp_part, int B, int L, FlowGeom g, int accumulate, double* gp, hipStream_t s) {
     int gx = (L * L + 255) / 256; if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(k_gather_gp, dim3(gx, B), dim3(256), 0, s, gp_part, L, (L + FT - 1) / FT, accumulate, gp);
+    hipLaunchKernelGGL(k_gather_gp, dim3(gx, B), dim3(256), 0, s, gp_part, L, g.tr, g.tc, g.nti(L), g.ntj(L), accumulate, gp);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_adj_add(const double* gp, const double* gy, int B, int L, double* gx, hipStream_t s) {

@@ -1,19 +1,28 @@
 // MFMA variant of the coupling-layer forward / backward-wrt-x kernels.
 //
-// Same tiling, LDS staging and scatter-form adjoint as flow.hip, but the four big
-// convolutions (conv1, conv2, conv3^T, conv2^T) run as implicit GEMMs on
-// v_mfma_f64_16x16x4_f64:
+// A workgroup (512 threads) owns a TR x TC = 8 x 16 tile of one chain; everything between
+// the link field and the link update lives in LDS (see flow.hip for the scheme: plaquette
+// window = tile + 3 halo, hidden activations on tile + 2 / + 1, scatter-form adjoint whose
+// partial plaquette-gradient window is summed across tiles by k_gather_gp).
+// The tile is sized so that the backward kernel needs < 80 KB of LDS: two workgroups share
+// a CU and the serial, transcendental-heavy stages of one (plaquettes, tan-mixture
+// transform) overlap with the matrix stages of the other.
+//
+// conv1, conv2 and conv2^T run as implicit GEMMs on v_mfma_f64_16x16x4_f64:
 //   M = 16 "pair sites" (a site column c and the two rows 2q, 2q+1 it stands for),
 //   N = 16 = 8 output channels x 2 rows of the pair,
 //   K = (4 x 3 input window that covers both rows) x input channels.
-// Packing two output rows into N fills the 16-wide tile that 8 channels alone
-// would leave half empty (75 % of the issued MACs are useful instead of 50 %).
-// The weights are the B operand and stay in VGPRs for a whole stage (one double
-// per lane per k-step, pre-swizzled by k_pack_weights); the A operand is one
-// ds_read_b64 per MFMA straight out of the activation planes, whose strides are
-// = 16 (mod 32) doubles so the four k-lanes hit disjoint banks.
-// Measured on MI355X: fp64 MFMA and fp64 VALU share the DP pipe (tools/microbench
-// "both"), so MFMA buys issue efficiency and register-resident weights, not flops.
+// Packing two output rows into N fills the 16-wide tile that 8 channels alone would leave
+// half empty (75 % of the issued MACs are useful instead of 50 %).  The weights are the B
+// operand and stay in VGPRs for a whole stage (one double per lane per k-step, pre-swizzled
+// by k_pack_weights, fetched before the preceding barrier); the A operand is one
+// ds_read_b64 per MFMA straight out of the activation planes (plane strides = 16 mod 32
+// doubles, so the k-lanes of one read hit disjoint banks).
+// conv3 (8 -> 3, active sites only), conv3^T (its input is non-zero on the active stripe
+// only: 9 of 27 taps) and conv1^T (2 output channels) stay on the fp64 VALU with their
+// weights cached in LDS.
+// Measured on MI355X (tools/microbench): fp64 MFMA and fp64 VALU share one DP pipe, so the
+// matrix path buys issue efficiency and register-resident weights, not extra flops.
 #include "flow_common.h"
 
 namespace {
@@ -23,40 +32,50 @@ using namespace fthmc_flow;
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 512;                 // threads per workgroup (8 waves, 2 per SIMD)
+constexpr int NT = 512;                 // threads per workgroup (8 waves)
 constexpr int NW = NT / 64;
-// plane strides (doubles), all = 16 (mod 32)
-constexpr int PS0 = 496;                // 22x22 planes (net input, padded gz2)
-constexpr int PS1 = 400;                // 20x20 planes (h1, d1, padded g_out)
-constexpr int PS2 = 336;                // 18x18 planes (h2, d2)
-static_assert(PS0 % 32 == 16 && PS1 % 32 == 16 && PS2 % 32 == 16, "bank layout");
-static_assert(PS0 >= N0 && PS1 >= N1 && PS2 >= N2, "plane size");
 
-// LDS copy of the weights the VALU stages use (scalar loads in an LDS-heavy loop serialise on
-// lgkmcnt(0)): [W3F | B3](292) [W1B](144) [B1](8) [B2](8)
-constexpr int SW_W3F = 0, SW_B3 = 288, SW_W1B = 292, SW_B1 = 436, SW_B2 = 444, SW_SIZE = 452 + 12;
+// Plane stride (doubles): smallest value >= n that is = 18 (mod 32).  The four k-lanes of an
+// A read (ds_read_b64, 64 banks) then overlap in only 2 of 32 doubles, and the eight channel
+// lanes of an epilogue ds_write_b64 (32 banks = 16 doubles) land on eight different bank pairs
+// (with = 16 (mod 32) they would all hit the same pair: 8-way conflict on every store).
+constexpr int ps_round(int n) { return ((n - 18 + 31) / 32) * 32 + 18; }
 
-template <int MODE> struct SmemM {
-    static constexpr bool BWD = (MODE == 1);
-    static constexpr int P = 0;                          // [N0]
-    static constexpr int IN = P + N0 + 12;               // [2][PS0]      (+12: keep 32-double alignment)
-    static constexpr int H1 = IN + 2 * PS0;              // [8][PS1]  | bwd: padded gz2 [8][PS0] over H1|H2
-    static constexpr int H2 = H1 + 8 * PS1;              // [8][PS2]
-    static constexpr int ST = H2 + 8 * PS2;              // [8 channels][3][64]
-    static constexpr int T2 = ST + 8 * 3 * NACT;        // [NMIX][4][64]
-    static constexpr int DL = T2 + NMIX * 4 * NACT;      // [N3]
-    static constexpr int SW = DL + N3;                   // [SW_SIZE] small weights read by VALU stages
-    static constexpr int D1 = SW + SW_SIZE;              // [8][PS1]   (bwd)
-    static constexpr int D2 = D1 + (BWD ? 8 * PS1 : 0);  // [8][PS2]
-    static constexpr int GO = D2 + (BWD ? 8 * PS2 : 0);  // padded g_out [3][PS1] (20x20, ring 2)
-    static constexpr int GP = GO + (BWD ? 3 * PS1 : 0);  // [N0]
-    static constexpr int SIZE = GP + (BWD ? N0 : 0);
-    static_assert(8 * PS1 + 8 * PS2 >= 8 * PS0, "padded gz2 must fit over h1|h2");
+template <int TR, int TC> struct Geom {
+    static constexpr int R0R = TR + 6, R0C = TC + 6, N0 = R0R * R0C;   // plaquette / input window
+    static constexpr int R1R = TR + 4, R1C = TC + 4, N1 = R1R * R1C;   // h1 window
+    static constexpr int R2R = TR + 2, R2C = TC + 2, N2 = R2R * R2C;   // h2 window
+    static constexpr int N3 = TR * TC, NA = N3 / 4;                    // tile, active sites
+    static constexpr int NAS = NA <= 32 ? 32 : 64;                     // lane stride of per-active-site scratch
+    static constexpr int PS0 = ps_round(N0), PS1 = ps_round(N1), PS2 = ps_round(N2);
+    static_assert(PS0 % 32 == 18 && PS1 % 32 == 18 && PS2 % 32 == 18, "bank layout");
+    static_assert(PS0 >= N0 && PS1 >= N1 && PS2 >= N2, "plane size");
+    static_assert(TR % 4 == 0 && TC % 4 == 0 && NA <= 64, "tile shape");
 };
 
-// One implicit-GEMM stage.  Output region HOUT x WOUT (HOUT even) whose input planes are one
-// site larger on every side (forward conv) or ring-2 padded (transposed conv): input index of
-// output (r, c) and window tap (ky4, kx) is (r + ky4, c + kx) for the pair's upper row r = 2q.
+// LDS copy of the weights the VALU stages use (scalar loads inside an LDS-heavy loop
+// serialise on lgkmcnt(0)): [W3F | B3](292) [W1B](144) [B1](8) [B2](8) [W3B](216)
+constexpr int SW_W3F = 0, SW_B3 = 288, SW_W1B = 292, SW_B1 = 436, SW_B2 = 444, SW_W3B = 452,
+              SW_USED = 452 + 216, SW_SIZE = SW_USED + 4;
+
+template <int MODE, int TR, int TC> struct SmemM {
+    using G = Geom<TR, TC>;
+    static constexpr bool BWD = (MODE == 1);
+    static constexpr int IN = 0;                              // [2][PS0] cos, sin
+    static constexpr int PG = IN + 2 * G::PS0;                // [N0] plaquettes, later partial gP (bwd)
+    static constexpr int H1 = PG + G::PS0;                    // [8][PS1] | bwd: padded gz2 [8][PS0] over H1|H2
+    static constexpr int H2 = H1 + 8 * G::PS1;                // [8][PS2]
+    static constexpr int ST = H2 + 8 * G::PS2;                // [8][3][NAS] conv3 partials | bwd: g_out [3][N3]
+    static constexpr int T2 = ST + 8 * 3 * G::NAS;            // [NMIX][4][NAS]
+    static constexpr int DL = T2 + NMIX * 4 * G::NAS;         // [N3] delta (fwd)
+    static constexpr int SW = DL + (BWD ? 0 : G::N3);         // [SW_SIZE]
+    static constexpr int D1 = SW + SW_SIZE;                   // [8][PS1] act'(z1) -> gz1   (bwd)
+    static constexpr int D2 = D1 + (BWD ? 8 * G::PS1 : 0);    // [8][PS2] act'(z2)          (bwd)
+    static constexpr int SIZE = D2 + (BWD ? 8 * G::PS2 : 0);
+    static_assert(8 * G::PS1 + 8 * G::PS2 >= 8 * G::PS0, "padded gz2 must fit over h1|h2");
+    static_assert(3 * G::N3 <= 8 * 3 * G::NAS, "g_out must fit over the conv3 partials");
+};
+
 // B operand of a stage: issued before the barrier that precedes the stage so that the global
 // (L2) latency overlaps the tail of the previous stage.
 template <int NSTEP>
@@ -65,10 +84,13 @@ __device__ __forceinline__ void stage_prefetch(const double* __restrict__ wB, in
     for (int t = 0; t < NSTEP; ++t) breg[t] = wB[t * 64 + lane];
 }
 
+// One implicit-GEMM stage.  Output region HOUT x WOUT (HOUT even) whose input planes are one
+// site larger on every side (forward conv) or ring-2 padded (transposed conv): input index of
+// output (r, c) and window tap (ky4, kx) is (r + ky4, c + kx) for the pair's upper row r = 2q.
+// The epilogue gets the four values of a lane at once so that their chains interleave.
 template <int NSTEP, int KC, int HOUT, int WOUT, int RSA, int PSA, class Epi>
 __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double (&breg)[NSTEP],
-                                           double cinit, int wave, int lane, Epi epi, long long* dbg = nullptr) {
-#define DSTAMP(k) do { if (dbg && wave == 0 && lane == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+                                           int wave, int lane, Epi epi) {
     constexpr int NPAIR = (HOUT / 2) * WOUT;
     constexpr int NTILE = (NPAIR + 15) / 16;
     const int g = lane >> 4, i = lane & 15;
@@ -83,19 +105,16 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
         }
     }
     const int cN = i & 7, dd = i >> 3;
-    DSTAMP(11);
     for (int tile = wave; tile < NTILE; tile += NW) {
         int p = tile * 16 + i;
         if (p >= NPAIR) p = NPAIR - 1;                       // padding lanes: any valid address
         const int pr = p / WOUT, pc = p - pr * WOUT;
         const double* a0 = A + (2 * pr) * RSA + pc + (KC == 8 ? g * PSA : 0);
-        // NCH independent accumulator chains: a dependent f64 MFMA waits ~4 issue slots for its
-        // predecessor, so one chain per tile leaves the matrix pipe 3/4 idle at 2 waves per SIMD.
+        // independent accumulator chains keep the matrix pipe busy when a wave is alone on it
         constexpr int NCH = NSTEP >= 8 ? 4 : 3;
         double4_t accs[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) accs[ch] = double4_t{0.0, 0.0, 0.0, 0.0};
-        accs[0] = double4_t{cinit, cinit, cinit, cinit};
 #pragma unroll
         for (int t = 0; t < NSTEP; ++t) {
             double av;
@@ -106,9 +125,7 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
         double4_t acc = accs[0];
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
-        if (dbg && wave == 0 && lane == 0) { dbg[tile == 0 ? 12 : 14] = (long long)__builtin_readcyclecounter() + (long long)(acc[0] == 12345.678); }
-        // D[row = g + 4 q][col = i]: row = pair site, col = (channel, row of the pair).
-        // All four values go to the epilogue together so their activation chains interleave.
+        // D[row = g + 4 q][col = i]: row = pair site, col = (channel, row of the pair)
         int off4[4]; bool ok4[4]; double z4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -120,23 +137,24 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
             z4[q] = acc[q];
         }
         epi(cN, off4, ok4, z4);
-        if (dbg && wave == 0 && lane == 0) dbg[tile == 0 ? 13 : 15] = (long long)__builtin_readcyclecounter();
     }
 }
 
 // MODE 0 forward, 1 backward wrt x
-template <int MODE>
-__global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
-    using S = SmemM<MODE>;
+template <int MODE, int TR, int TC>
+__global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
+    using S = SmemM<MODE, TR, TC>;
+    using G = Geom<TR, TC>;
     constexpr bool BWD = S::BWD;
+    constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
+    constexpr int N0 = G::N0, N2 = G::N2, N3 = G::N3, NA = G::NA, NAS = G::NAS;
+    constexpr int PS0 = G::PS0, PS1 = G::PS1, PS2 = G::PS2;
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
-    double* sP = sm + S::P;   double* sIn = sm + S::IN;
-    double* sH1 = sm + S::H1; double* sH2 = sm + S::H2;
-    double* sST = sm + S::ST; double* sT2 = sm + S::T2;
-    double* sDL = sm + S::DL; double* sW = sm + S::SW;
-    double* sD1 = sm + S::D1; double* sD2 = sm + S::D2;
-    double* sGO = sm + S::GO; double* sGP = sm + S::GP;
-    double* sGZ2 = sm + S::H1;                     // padded gz2 [8][PS0] (22x22, ring 2), bwd only
+    double* sIn = sm + S::IN;  double* sP = sm + S::PG;   double* sGP = sm + S::PG;
+    double* sH1 = sm + S::H1;  double* sH2 = sm + S::H2;  double* sGZ2 = sm + S::H1;
+    double* sST = sm + S::ST;  double* sGO = sm + S::ST;  double* sT2 = sm + S::T2;
+    double* sDL = sm + S::DL;  double* sW = sm + S::SW;
+    double* sD1 = sm + S::D1;  double* sD2 = sm + S::D2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -146,40 +164,47 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
     const int b = blockIdx.z;
     const int tile = blockIdx.y * gridDim.x + blockIdx.x;
     const int ntiles = gridDim.x * gridDim.y;
-    const int i0 = blockIdx.y * FT, j0 = blockIdx.x * FT;
+    const int i0 = blockIdx.y * TR, j0 = blockIdx.x * TC;
     const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
     const double* __restrict__ x1 = x0 + n;
     const double* __restrict__ w = A.wint;
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
+    double breg1[6];
+    stage_prefetch<6>(w + WB1, lane, breg1);
 
-    // ---- plaquette window + net input ------------------------------------
+    // ---- plaquette window + net input; small weights -> LDS ------------------
     for (int t = tid; t < N0; t += NT) {
-        const int r = t / R0, c = t - r * R0;
+        const int r = t / R0C, c = t - r * R0C;
         const int i = ft_modL(i0 - 3 + r, L), j = ft_modL(j0 - 3 + c, L);
         const int ip = i + 1 == L ? 0 : i + 1, jp = j + 1 == L ? 0 : j + 1;
         const double p = x0[i * L + j] - x1[i * L + j] - x0[i * L + jp] + x1[ip * L + j];
         const int sel = ft_stripe(i, j, mu, off);
         const bool frozen = (sel == 1 || sel == 2);
+        double sn = 0.0, cs = 1.0;
+        if (frozen) sincos(p, &sn, &cs);
         sP[t] = p;
-        sIn[t] = frozen ? cos(p) : 1.0;
-        sIn[PS0 + t] = frozen ? sin(p) : 0.0;
-        if (BWD) sGP[t] = 0.0;
+        sIn[t] = cs;
+        sIn[PS0 + t] = sn;
     }
-    if (MODE == 0) { if (tid < N3) sDL[tid] = 0.0; }
-    if (BWD) { for (int t = tid; t < 3 * PS1; t += NT) sGO[t] = 0.0; }
-    if (tid < 292) sW[SW_W3F + tid] = w[W3F + tid];
-    else if (tid < 292 + 144) sW[SW_W1B + tid - 292] = w[W1B + tid - 292];
-    else if (tid < 292 + 144 + 8) sW[SW_B1 + tid - 436] = w[B1 + tid - 436];
-    else if (tid < 292 + 144 + 16) sW[SW_B2 + tid - 444] = w[B2 + tid - 444];
-    double breg1[6];
-    stage_prefetch<6>(w + WB1, lane, breg1);
+    if (MODE == 0) { for (int t = tid; t < N3; t += NT) sDL[t] = 0.0; }
+    for (int t = tid; t < SW_USED; t += NT) {
+        int src;
+        if (t < SW_W1B) src = W3F + t;                       // W3F | B3 (contiguous in the kernel layout)
+        else if (t < SW_B1) src = W1B + t - SW_W1B;
+        else if (t < SW_B2) src = B1 + t - SW_B1;
+        else if (t < SW_W3B) src = B2 + t - SW_B2;
+        else src = W3B + t - SW_W3B;
+        sW[t] = w[src];
+    }
     __syncthreads();
     STAMP(1);
 
-    // ---- conv1 (2 -> 8) + act on the tile+2 window (20x20) ------------------
-    mfma_stage<6, 2, R1, R1, R0, PS0>(sIn, breg1, 0.0, wave, lane,
+    // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
+    double breg2[24];
+    stage_prefetch<24>(w + WB2, lane, breg2);                 // conv2's weights fly during conv1
+    mfma_stage<6, 2, R1R, R1C, R0C, PS0>(sIn, breg1, wave, lane,
         [&](int co, const int (&o)[4], const bool (&ok)[4], double (&z)[4]) {
             const double bias = sW[SW_B1 + co];
             double h[4], d[4];
@@ -190,13 +215,11 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
             for (int q = 0; q < 4; ++q)
                 if (ok[q]) { sH1[co * PS1 + o[q]] = h[q]; if (BWD) sD1[co * PS1 + o[q]] = d[q]; }
         });
-    double breg2[24];
-    stage_prefetch<24>(w + WB2, lane, breg2);
     __syncthreads();
     STAMP(2);
 
-    // ---- conv2 (8 -> 8) + act on the tile+1 window (18x18) ------------------
-    mfma_stage<24, 8, R2, R2, R1, PS1>(sH1, breg2, 0.0, wave, lane,
+    // ---- conv2 (8 -> 8) + act on the tile+1 window ---------------------------
+    mfma_stage<24, 8, R2R, R2C, R1C, PS1>(sH1, breg2, wave, lane,
         [&](int co, const int (&o)[4], const bool (&ok)[4], double (&z)[4]) {
             const double bias = sW[SW_B2 + co];
             double h[4], d[4];
@@ -206,73 +229,75 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (ok[q]) { sH2[co * PS2 + o[q]] = h[q]; if (BWD) sD2[co * PS2 + o[q]] = d[q]; }
-        }, dbg);
+        });
     __syncthreads();
     STAMP(3);
 
-    // ---- conv3 (8 -> 3) at the 64 active sites; one input channel per wave ---
-    const int ar = mu == 0 ? (lane >> 2) : off + 4 * (lane >> 4);
-    const int ac = mu == 0 ? off + 4 * (lane & 3) : (lane & 15);
+    // ---- conv3 (8 -> 3) at the NA active sites; one input channel per wave ------
+    // active site `lane`: mu=0 columns off+4m, mu=1 rows off+4m (tile origin % 4 == 0)
+    const int ar = mu == 0 ? lane / (TC / 4) : off + 4 * (lane / TC);
+    const int ac = mu == 0 ? off + 4 * (lane % (TC / 4)) : lane % TC;
     const int ai = i0 + ar, aj = j0 + ac;
-    const bool avalid = (ai < L) && (aj < L);
-    if (wave < 8) {
+    const bool alane = lane < NA;
+    const bool avalid = alane && (ai < L) && (aj < L);
+    if (alane) {
         double acc[3] = {0.0, 0.0, 0.0};
         const int ci = wave;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const double v = sH2[ci * PS2 + (ar + ky) * R2 + ac + kx];
+                const double v = sH2[ci * PS2 + (ar + ky) * R2C + ac + kx];
                 const double* wp = sW + SW_W3F + (ci * 9 + ky * 3 + kx) * 4;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) acc[k] = fma(v, wp[k], acc[k]);
             }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NACT + lane] = acc[k];
+        for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NAS + lane] = acc[k];
     }
     __syncthreads();
     STAMP(4);
 
-    // ---- tan-mixture transform: wave k evaluates mixture component k -------
-    double Pa = 0.0, tval = 0.0, es = 0.0, ems = 0.0, cs2 = 0.0, sn2 = 0.0, Dk = 1.0, yk = 0.0, ljk = 0.0;
-    if (wave < NMIX) {
-        Pa = sP[(ar + 3) * R0 + ac + 3];
+    // ---- tan-mixture transform: wave k evaluates mixture component k -------------
+    //   y_k = wrap(2 atan(e^{s_k} tan(P/2))),  D_k = e^{-s_k} cos^2(P/2) + e^{s_k} sin^2(P/2),
+    //   log J = log(sum_k 1/D_k) - log K   (= logsumexp_k(-log D_k) - log K of layers.py:85-90)
+    double Pa = 0.0, es = 0.0, ems = 0.0, cs2 = 0.0, sn2 = 0.0, sincs = 0.0, invD = 1.0;
+    if (wave < NMIX && alane) {
+        Pa = sP[(ar + 3) * R0C + ac + 3];
         double sk = sW[SW_B3 + wave];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NACT + lane];
-        const double hx = Pa / 2;
+        for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
+        double sn, cs;
+        sincos(Pa / 2, &sn, &cs);
         es = exp(sk); ems = exp(-sk);
-        const double cs = cos(hx), sn = sin(hx);
-        cs2 = cs * cs; sn2 = sn * sn;
-        yk = ft_wrap(2 * atan(es * tan(hx)));
-        Dk = ems * cs2 + es * sn2;
-        ljk = -log(Dk);
-        sT2[(wave * 4 + 0) * NACT + lane] = yk;
-        sT2[(wave * 4 + 1) * NACT + lane] = ljk;
+        cs2 = cs * cs; sn2 = sn * sn; sincs = sn * cs;
+        invD = 1.0 / (ems * cs2 + es * sn2);
+        sT2[(wave * 4 + 1) * NAS + lane] = invD;
+        if (MODE == 0) sT2[(wave * 4 + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
+    }
+    double tval = 0.0;
+    if (MODE == 0 && wave == 0 && alane) {
+        tval = sW[SW_B3 + 2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tval += sST[(q * 3 + 2) * NAS + lane];
     }
     __syncthreads();
     STAMP(5);
 
     if (MODE == 0) {
         if (wave == 0) {
-            tval = sW[SW_B3 + 2];
+            double ysum = 0.0, si = 0.0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) tval += sST[(q * 3 + 2) * NACT + lane];
-            double ysum = 0.0, m = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * 4) * NACT + lane]; m = fmax(m, sT2[(k * 4 + 1) * NACT + lane]); }
-            double se = 0.0;
-#pragma unroll
-            for (int k = 0; k < NMIX; ++k) se += exp(sT2[(k * 4 + 1) * NACT + lane] - m);
-            const double lj = m + log(se) - log((double)NMIX);
+            for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * 4) * NAS + (lane & (NAS - 1))]; si += sT2[(k * 4 + 1) * NAS + (lane & (NAS - 1))]; }
+            const double lj = avalid ? log(si) - log((double)NMIX) : 0.0;
             const double newP = ft_wrap(ysum / NMIX + tval);
-            if (avalid) sDL[ar * FT + ac] = newP - Pa;
-            const double tot = ft_wave_sum(avalid ? lj : 0.0);
+            if (avalid) sDL[ar * TC + ac] = newP - Pa;
+            const double tot = ft_wave_sum(lj);
             if (lane == 0 && A.logj_part) A.logj_part[(size_t)b * ntiles + tile] = tot;
         }
         __syncthreads();
         if (A.y && tid < N3) {
-            const int r = tid / FT, c = tid - r * FT;
+            const int r = tid / TC, c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
             if (i < L && j < L) {
                 double v0 = x0[i * L + j], v1 = x1[i * L + j];
@@ -289,67 +314,84 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
     }
 
     if (BWD) {
-        // ---- adjoint of the transform at the tile's own active sites -------
-        double gdelta = 0.0, cb = 0.0;
-        if (wave < NMIX) {
-            cb = A.glogj ? A.glogj[b] : A.glogj_const;
-            if (avalid) {
-                if (A.up_link) {
-                    const double gl = A.up_link[(size_t)b * 2 * n + (size_t)mu * n + ai * L + aj];
-                    gdelta = mu == 0 ? gl : -gl;
-                } else {
-                    const double* gp = A.up_gp + (size_t)b * n;
-                    const int im = ai == 0 ? L - 1 : ai - 1, jm = aj == 0 ? L - 1 : aj - 1;
-                    gdelta = gp[ai * L + aj] - (mu == 0 ? gp[ai * L + jm] : gp[im * L + aj]);
-                }
+        // ---- adjoint of the transform at the tile's own active sites (no transcendentals) ----
+        // conv3 partials and plaquettes are consumed: g_out takes over sST, partial gP takes over sP
+        double gdelta = 0.0;
+        double gs = 0.0, gpk = 0.0;
+        if (wave < NMIX && avalid) {
+            const double cb = A.glogj ? A.glogj[b] : A.glogj_const;
+            if (A.up_link) {
+                const double gl = A.up_link[(size_t)b * 2 * n + (size_t)mu * n + ai * L + aj];
+                gdelta = mu == 0 ? gl : -gl;
+            } else {
+                const double* gp = A.up_gp + (size_t)b * n;
+                const int im = ai == 0 ? L - 1 : ai - 1, jm = aj == 0 ? L - 1 : aj - 1;
+                gdelta = gp[ai * L + aj] - (mu == 0 ? gp[ai * L + jm] : gp[im * L + aj]);
             }
-            double m = -INFINITY;
+            double si = 0.0;
 #pragma unroll
-            for (int k = 0; k < NMIX; ++k) m = fmax(m, sT2[(k * 4 + 1) * NACT + lane]);
-            double se = 0.0;
-#pragma unroll
-            for (int k = 0; k < NMIX; ++k) se += exp(sT2[(k * 4 + 1) * NACT + lane] - m);
-            const double wk = exp(ljk - m) / se;
-            const double sinP = sin(Pa);
-            const double elj = 1.0 / Dk;
-            const double gs = avalid ? gdelta * (sinP * elj / NMIX) + cb * wk * (ems * cs2 - es * sn2) * elj : 0.0;
-            const double gpk = avalid ? gdelta * (elj / NMIX) - cb * wk * sinP * 0.5 * (es - ems) * elj : 0.0;
-            if (avalid) sGO[wave * PS1 + (ar + 2) * R1 + ac + 2] = gs;
-            sT2[(wave * 4 + 2) * NACT + lane] = gpk;
+            for (int k = 0; k < NMIX; ++k) si += sT2[(k * 4 + 1) * NAS + lane];
+            const double wk = invD / si;                           // softmax_k(-log D_k)
+            const double sinP = 2.0 * sincs;
+            gs = gdelta * (sinP * invD / NMIX) + cb * wk * (ems * cs2 - es * sn2) * invD;
+            gpk = gdelta * (invD / NMIX) - cb * wk * sinP * 0.5 * (es - ems) * invD;
         }
-        // h1 / h2 are dead from here on: clear the padded gz2 planes that alias them
-        // (conv3 above is complete: every wave passed the barrier after the sST writes)
+        // h1 / h2 are dead: clear the padded gz2 planes that alias them
         for (int t = tid; t < 8 * PS0; t += NT) sGZ2[t] = 0.0;
+        double breg4[24];
+        stage_prefetch<24>(w + WB2T, lane, breg4);
+        __syncthreads();                                           // sST / sP / sT2[.][1] reads done
+        for (int t = tid; t < 3 * N3; t += NT) sGO[t] = 0.0;
+        for (int t = tid; t < N0; t += NT) sGP[t] = 0.0;
+        if (wave < NMIX && alane) sT2[(wave * 4 + 2) * NAS + lane] = gpk;
         __syncthreads();
+        if (wave < NMIX && avalid) sGO[wave * N3 + ar * TC + ac] = gs;
         if (wave == 0 && avalid) {
             double gsum = -gdelta;
 #pragma unroll
-            for (int k = 0; k < NMIX; ++k) gsum += sT2[(k * 4 + 2) * NACT + lane];
-            sGP[(ar + 3) * R0 + ac + 3] = gsum;
-            sGO[NMIX * PS1 + (ar + 2) * R1 + ac + 2] = gdelta;      // dL/dt
+            for (int k = 0; k < NMIX; ++k) gsum += sT2[(k * 4 + 2) * NAS + lane];
+            sGP[(ar + 3) * R0C + ac + 3] = gsum;
+            sGO[NMIX * N3 + ar * TC + ac] = gdelta;               // dL/dt
         }
-        double breg3[9];
-        stage_prefetch<9>(w + WB3T, lane, breg3);
         __syncthreads();
         STAMP(6);
 
-        // ---- conv3^T, times act'(z2) -> gz2 into the ring-2 padded 22x22 planes ----
-        mfma_stage<9, 3, R2, R2, R1, PS1>(sGO, breg3, 0.0, wave, lane,
-            [&](int ci, const int (&o)[4], const bool (&ok)[4], double (&gh)[4]) {
+        // ---- conv3^T on the VALU: g_out lives on the active stripe only, so of the 9 taps of
+        //      an h2 site at most 3 (one stripe line) contribute; times act'(z2) -> padded gz2 ----
+        for (int t = tid; t < 2 * N2; t += NT) {
+            const int half = t >= N2;
+            const int s = half ? t - N2 : t;
+            const int r = s / R2C, c = s - r * R2C;
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            // source tile site (rr, cc) = (r - ky, c - kx); the stripe line through the window
+            const int ksel = ((mu == 0 ? c : r) - off) & 3;        // the one kx (mu=0) / ky (mu=1)
+            if (ksel <= 2) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ok[q]) {
-                        const int r = o[q] / R2, c = o[q] - r * R2;
-                        sGZ2[ci * PS0 + (r + 2) * R0 + c + 2] = gh[q] * sD2[ci * PS2 + o[q]];
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
+                    const int rr = r - ky, cc = c - kx;
+                    if (rr >= 0 && rr < TR && cc >= 0 && cc < TC) {
+#pragma unroll
+                        for (int co = 0; co < 3; ++co) {
+                            const double gv = sGO[co * N3 + rr * TC + cc];
+                            const double* wp = sW + SW_W3B + ((co * 9 + ky * 3 + kx) * 8 + half * 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[k] = fma(gv, wp[k], acc[k]);
+                        }
                     }
-            });
-        double breg4[24];
-        stage_prefetch<24>(w + WB2T, lane, breg4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ci = half * 4 + k;
+                sGZ2[ci * PS0 + (r + 2) * R0C + c + 2] = acc[k] * sD2[ci * PS2 + s];
+            }
+        }
         __syncthreads();
         STAMP(7);
 
-        // ---- conv2^T, times act'(z1) -> gz1 in place over d1 -------------------------
-        mfma_stage<24, 8, R1, R1, R0, PS0>(sGZ2, breg4, 0.0, wave, lane,
+        // ---- conv2^T, times act'(z1) -> gz1 in place over d1 ------------------------
+        mfma_stage<24, 8, R1R, R1C, R0C, PS0>(sGZ2, breg4, wave, lane,
             [&](int ci, const int (&o)[4], const bool (&ok)[4], double (&gh)[4]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -360,33 +402,38 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
 
         // ---- conv1^T and the (cos, sin) adjoint at frozen plaquettes ----------------
         for (int t = tid; t < N0; t += NT) {
-            const int r = t / R0, c = t - r * R0;
+            const int r = t / R0C, c = t - r * R0C;
             const int i = ft_modL(i0 - 3 + r, L), j = ft_modL(j0 - 3 + c, L);
             const int sel = ft_stripe(i, j, mu, off);
             if (sel == 1 || sel == 2) {
-                double gc = 0.0, gs = 0.0;
-                // clamped addresses + zero mask: no per-tap branches, nothing to hoist across co
+                // clamped addresses + zero mask: no per-tap branches; four co chains interleave
                 int aoff[9]; double msk[9];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int rr = r - ky, cc = c - kx;
-                        const bool ok = (rr >= 0) && (rr < R1) && (cc >= 0) && (cc < R1);
-                        aoff[ky * 3 + kx] = ok ? rr * R1 + cc : 0;
+                        const bool ok = (rr >= 0) && (rr < R1R) && (cc >= 0) && (cc < R1C);
+                        aoff[ky * 3 + kx] = ok ? rr * R1C + cc : 0;
                         msk[ky * 3 + kx] = ok ? 1.0 : 0.0;
                     }
+                double gc[4] = {0.0, 0.0, 0.0, 0.0}, gsn[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
-                for (int co = 0; co < 8; ++co) {
-                    const double* gz = sD1 + co * PS1;
-                    const double* wp = sW + SW_W1B + co * 18;
+                for (int cg = 0; cg < 2; ++cg) {
 #pragma unroll
                     for (int tp = 0; tp < 9; ++tp) {
-                        const double gv = gz[aoff[tp]] * msk[tp];
-                        gc = fma(gv, wp[tp * 2], gc); gs = fma(gv, wp[tp * 2 + 1], gs);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int co = cg * 4 + u;
+                            const double gv = sD1[co * PS1 + aoff[tp]] * msk[tp];
+                            const double* wp = sW + SW_W1B + co * 18 + tp * 2;
+                            gc[u] = fma(gv, wp[0], gc[u]); gsn[u] = fma(gv, wp[1], gsn[u]);
+                        }
                     }
                 }
-                sGP[t] = -sIn[PS0 + t] * gc + sIn[t] * gs;
+                const double gct = (gc[0] + gc[1]) + (gc[2] + gc[3]);
+                const double gst = (gsn[0] + gsn[1]) + (gsn[2] + gsn[3]);
+                sGP[t] = -sIn[PS0 + t] * gct + sIn[t] * gst;
             }
         }
         __syncthreads();
@@ -397,7 +444,6 @@ __global__ __launch_bounds__(NT) void k_flow_mfma(FlowLayerArgs A) {
     }
 }
 
-inline dim3 flow_grid(int B, int L) { int t = (L + FT - 1) / FT; return dim3(t, t, B); }
 int g_variant = 1;
 
 }  // namespace
@@ -408,11 +454,13 @@ void set_flow_variant(int v) { g_variant = v; }
 int get_flow_variant() { return g_variant; }
 
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_flow_mfma<0>, flow_grid(a.B, a.L), dim3(NT), 0, s, a);
+    const dim3 grid((a.L + MF_TC - 1) / MF_TC, (a.L + MF_TR - 1) / MF_TR, a.B);
+    hipLaunchKernelGGL((k_flow_mfma<0, MF_TR, MF_TC>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_flow_mfma<1>, flow_grid(a.B, a.L), dim3(NT), 0, s, a);
+    const dim3 grid((a.L + MF_TC - 1) / MF_TC, (a.L + MF_TR - 1) / MF_TR, a.B);
+    hipLaunchKernelGGL((k_flow_mfma<1, MF_TR, MF_TC>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

@@ -30,13 +30,30 @@ int launch_metropolis(const double* x_old, const double* x_prop, const double* u
 int launch_random_momenta(const int64_t* seeds, int B, int n, double* v, double* u, hipStream_t s);
 
 // ---- flow.hip
-constexpr int FLOW_TILE = 16;                 // sites per tile edge
+constexpr int FLOW_TILE = 16;                 // VALU variant (flow.hip): 16 x 16 sites per tile
 constexpr int FLOW_R0 = FLOW_TILE + 6;        // plaquette / net-input window edge
 constexpr int FLOW_N0 = FLOW_R0 * FLOW_R0;    // window size of one gP partial
+constexpr int MF_TR = 8, MF_TC = 16;          // MFMA variant (flow_mfma.hip): 8 x 16 sites per tile
 constexpr int FLOW_WINT = 6016;               // doubles per layer, kernel-side weight layout
 constexpr int FLOW_GW_STRIDE = 960;           // doubles per (chain, tile) weight-gradient partial
 
-inline int flow_ntiles(int L) { int t = (L + FLOW_TILE - 1) / FLOW_TILE; return t * t; }
+// tile geometry of a variant: partial buffers are indexed [chain][tile][window]
+struct FlowGeom {
+    int tr, tc;
+    int nti(int L) const { return (L + tr - 1) / tr; }
+    int ntj(int L) const { return (L + tc - 1) / tc; }
+    int ntiles(int L) const { return nti(L) * ntj(L); }
+    int n0() const { return (tr + 6) * (tc + 6); }
+};
+inline FlowGeom flow_geom(bool mfma) { return mfma ? FlowGeom{MF_TR, MF_TC} : FlowGeom{FLOW_TILE, FLOW_TILE}; }
+// workspace sizing: the larger of the two variants
+inline size_t flow_ntiles_max(int L) {
+    size_t a = flow_geom(false).ntiles(L), b = flow_geom(true).ntiles(L); return a > b ? a : b;
+}
+inline size_t flow_gp_part_max(int L) {
+    size_t a = (size_t)flow_geom(false).ntiles(L) * flow_geom(false).n0();
+    size_t b = (size_t)flow_geom(true).ntiles(L) * flow_geom(true).n0(); return a > b ? a : b;
+}
 
 // canonical (955/layer, PyTorch order) -> kernel layout (FLOW_WINT/layer)
 int launch_pack_weights(const double* w, int n_layers, double* wint, hipStream_t s);
@@ -69,7 +86,7 @@ int get_flow_variant();
 int launch_sum_parts(const double* part, int B, int nparts, double sign, int accumulate,
                      double* out, hipStream_t s);
 // gp[b][i][j] (+)= sum of every partial window position that maps to (i, j)
-int launch_gather_gp(const double* gp_part, int B, int L, int accumulate, double* gp, hipStream_t s);
+int launch_gather_gp(const double* gp_part, int B, int L, FlowGeom g, int accumulate, double* gp, hipStream_t s);
 // gx = gy + adj(gp)
 int launch_adj_add(const double* gp, const double* gy, int B, int L, double* gx, hipStream_t s);
 // gw[idx] (+)= scale * sum_p gw_part[p][idx], idx < 955

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fthmc_amd import ops
 from oracle import ref_cpu as R
 
-B, L = 128, 64
+import sys as _s
+B, L = (int(_s.argv[1]) if len(_s.argv) > 1 else 128), 64
 gen = torch.Generator().manual_seed(1331)
 flow = R.default_flow(1, gen)
 w = ops.pack_weights(flow, device='cuda')
@@ -18,5 +19,4 @@ for kind in ('flow_fwd', 'flow_bwd'):
         cyc = ops.profile_stages(kind, x, w, mu=mu, off=1, beta=6.0)
         tot = sum(cyc)
         print(f'{kind} mu={mu}: total {tot:.0f} cycles/WG; ' + ', '.join(f'{n} {c:.0f}' for n, c in zip(names[kind][1:], cyc[1:]) if n))
-    print('   conv2 wave0 timeline (cycles since conv2 start): prologue %.0f | tile0 mfma %.0f epi %.0f | tile1 mfma %.0f epi %.0f' % tuple(cyc[11:16]))
     print(kind, 'ms/launch', ops.time_kernel(kind, x, w, mu=0, off=1, beta=6.0, reps=20))

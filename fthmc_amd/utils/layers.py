@@ -1,0 +1,254 @@
+"""Gauge-equivariant coupling layers with the API of fthmc/utils/layers.py, running on the
+HIP kernels (fthmc_amd/csrc/flow*.hip) through the C ABI.
+
+The conv nets stay `nn.Conv2d` parameter containers so that `state_dict` keeps the reference
+layout `"{i}.plaq_coupling.net.{0,2,4}.{weight,bias}"` and `get_nets` /
+`make_net_from_layers` (transfer to a larger lattice) keep working; the numbers are computed
+by the fused layer kernels, forward and backward (autograd.Function below).
+"""
+from __future__ import annotations
+
+from math import pi as PI
+from typing import List, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..config import DTYPE, device
+
+TWO_PI = 2 * PI
+TOL = 1e-6            # reference inverse tolerance (layers.py:32); the HIP inverse defaults tighter
+
+
+def torch_mod(x: torch.Tensor):
+    """layers.py:41-43: remainder(x + pi, 2 pi) - pi."""
+    return ops.wrap(x)
+
+
+def torch_wrap(x: torch.Tensor):
+    """layers.py:46-47 (kept literally: torch_mod(x + pi) - pi; unused by the reference)."""
+    return ops.wrap(x + PI) - PI
+
+
+def grab(var: torch.Tensor):
+    return var.detach().cpu().numpy()
+
+
+def get_nets(layers: nn.ModuleList) -> List[nn.Module]:
+    """layers.py:54-55."""
+    return [layer.plaq_coupling.net for layer in layers]
+
+
+ACTIVATION_FNS = {'relu': nn.ReLU, 'silu': nn.SiLU, 'swish': nn.SiLU, 'leaky_relu': nn.LeakyReLU}
+
+
+def _act_name(actfn) -> str:
+    key = str(actfn).lower() if actfn is not None else 'silu'
+    return key if key in ACTIVATION_FNS else 'silu'       # reference falls back to SiLU (layers.py:124-135)
+
+
+def make_conv_net(*, hidden_sizes: Sequence[int], kernel_size: int, in_channels: int, out_channels: int,
+                  use_final_tanh: bool = False, activation_fn: str = None):
+    """layers.py:138-167: Conv2d(k, circular padding) + activation, no final activation."""
+    assert kernel_size % 2 == 1, 'kernel size must be odd'
+    if use_final_tanh:
+        raise NotImplementedError('use_final_tanh=True is never used by the reference (layers.py:419)')
+    act = _act_name(activation_fn)
+    sizes = [in_channels] + list(hidden_sizes) + [out_channels]
+    net = []
+    for i in range(len(sizes) - 1):
+        net.append(nn.Conv2d(sizes[i], sizes[i + 1], kernel_size, stride=1, padding=kernel_size // 2,
+                             padding_mode='circular', dtype=DTYPE, device=device()))
+        if i != len(sizes) - 2:
+            net.append(ACTIVATION_FNS[act]())
+    seq = nn.Sequential(*net)
+    seq.activation_fn = act
+    return seq
+
+
+def set_weights(m):
+    """layers.py:170-174 (a no-op when called on a ModuleList, as train.get_model does: SURVEY Q6)."""
+    if hasattr(m, 'weight') and m.weight is not None:
+        nn.init.normal_(m.weight, mean=1, std=2)
+    if hasattr(m, 'bias') and m.bias is not None:
+        m.bias.data.fill_(-1)
+
+
+def gauge_transform(links, alpha):
+    """layers.py:177-180."""
+    for mu in range(len(links.shape[2:])):
+        links[:, mu] = alpha + links[:, mu] - torch.roll(alpha, -1, mu + 1)
+    return links
+
+
+def random_gauge_transform(x):
+    """layers.py:183-185."""
+    return gauge_transform(x, TWO_PI * torch.rand((x.shape[0],) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device))
+
+
+# ---------------------------------------------------------------- stripe masks (host logic)
+def make_2d_link_active_stripes(shape, mu, off):
+    """layers.py:213-237: channel `mu`, every 4th line across the other axis, rolled by `off`."""
+    assert len(shape) == 3 and shape[0] == 2, 'need a (2, L, L) shape'
+    assert mu in (0, 1)
+    mask = np.zeros(shape).astype(np.uint8)
+    if mu == 0:
+        mask[mu, :, 0::4] = 1
+    else:
+        mask[mu, 0::4] = 1
+    return np.roll(mask, off, axis=(1 - mu) + 1).astype(np.float32)
+
+
+def make_single_stripes(shape, mu, off):
+    """layers.py:240-259."""
+    assert len(shape) == 2 and mu in (0, 1)
+    mask = np.zeros(shape).astype(np.uint8)
+    if mu == 0:
+        mask[:, 0::4] = 1
+    else:
+        mask[0::4] = 1
+    return np.roll(mask, off, axis=1 - mu)
+
+
+def make_double_stripes(shape, mu, off):
+    """layers.py:261-284."""
+    assert len(shape) == 2 and mu in (0, 1)
+    mask = np.zeros(shape).astype(np.uint8)
+    if mu == 0:
+        mask[:, 0::4] = 1
+        mask[:, 1::4] = 1
+    else:
+        mask[0::4] = 1
+        mask[1::4] = 1
+    return np.roll(mask, off, axis=1 - mu)
+
+
+def make_plaq_masks(mask_shape, mask_mu, mask_off):
+    """layers.py:287-292.  The kernels derive these from (mu, off) on the fly; the arrays are
+    kept for inspection and for the host-side tests."""
+    mask = {'frozen': make_double_stripes(mask_shape, mask_mu, mask_off + 1),
+            'active': make_single_stripes(mask_shape, mask_mu, mask_off)}
+    mask['passive'] = 1 - mask['frozen'] - mask['active']
+    return mask
+
+
+# ---------------------------------------------------------------- autograd bridge
+def net_weights(net: nn.Module) -> List[torch.Tensor]:
+    return [p for m in net if isinstance(m, nn.Conv2d) for p in (m.weight, m.bias)]
+
+
+class _CouplingFn(torch.autograd.Function):
+    """y, logJ = layer(x): forward = fthmc_flow_layer_fwd, backward = fthmc_flow_layer_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, mu, off, act, *params):
+        w = ops.pack_weights([params], device=x.device)
+        y, logJ = ops.flow_layer_fwd(x, w, mu, off, act)
+        ctx.save_for_backward(x, w)
+        ctx.meta = (mu, off, act, [p.shape for p in params], any(p.requires_grad for p in params))
+        return y, logJ
+
+    @staticmethod
+    def backward(ctx, gy, glogJ):
+        x, w = ctx.saved_tensors
+        mu, off, act, shapes, need_gw = ctx.meta
+        gy = torch.zeros_like(x) if gy is None else gy.contiguous()
+        glogJ = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device) if glogJ is None else glogJ.contiguous()
+        gx, gw = ops.flow_layer_bwd(x, w, gy, glogJ, mu, off, act, need_gw=need_gw)
+        gparams = list(ops.unpack_weight_grads(gw, 1)[0]) if need_gw else [None] * len(shapes)
+        return (gx, None, None, None, *gparams)
+
+
+class NCPPlaqCouplingLayer(nn.Module):
+    """Holder of the s/t conv net and stripe geometry (layers.py:324-396).  The plaquette-level
+    map itself is fused into the link-level kernels used by GaugeEquivCouplingLayer."""
+
+    def __init__(self, net: nn.Module, *, mask_shape, mask_mu: int, mask_off: int, inv_prec: float = TOL,
+                 inv_max_iter: int = 1000):
+        super().__init__()
+        assert len(mask_shape) == 2, 'NCPPlaqCouplingLayer is implemented only in 2D'
+        self.mask = make_plaq_masks(mask_shape, mask_mu, mask_off)
+        self.mask_mu, self.mask_off = mask_mu, mask_off % 4
+        self.net = net
+        self.inv_prec, self.inv_max_iter = inv_prec, inv_max_iter
+
+    def forward(self, x):
+        raise NotImplementedError('the plaquette-level map runs fused inside GaugeEquivCouplingLayer on the GPU')
+
+
+class GaugeEquivCouplingLayer(nn.Module):
+    """layers.py:188-210.  forward / reverse return (field, logJ[B])."""
+
+    def __init__(self, *, lattice_shape, mask_mu, mask_off, plaq_coupling):
+        super().__init__()
+        self.active_mask = make_2d_link_active_stripes((len(lattice_shape),) + tuple(lattice_shape), mask_mu, mask_off)
+        self.plaq_coupling = plaq_coupling
+        self.mask_mu, self.mask_off = mask_mu, mask_off % 4
+
+    @property
+    def activation_fn(self):
+        return getattr(self.plaq_coupling.net, 'activation_fn', 'silu')
+
+    def forward(self, x):
+        params = net_weights(self.plaq_coupling.net)
+        return _CouplingFn.apply(x, self.mask_mu, self.mask_off, self.activation_fn, *params)
+
+    def reverse(self, fx, tol: float = 1e-12):
+        w = ops.pack_weights([net_weights(self.plaq_coupling.net)], device=fx.device)
+        return ops.flow_layer_rev(fx.detach(), w, self.mask_mu, self.mask_off, self.activation_fn, tol=tol)
+
+
+def _check_arch(hidden_sizes, kernel_size, n_mix):
+    if list(hidden_sizes) != [8, 8] or kernel_size != 3 or n_mix != 2:
+        raise NotImplementedError(
+            f'HIP kernels are built for the reference default net (hidden_sizes=[8, 8], kernel_size=3, '
+            f'n_mixture_comps=2); got {list(hidden_sizes)}, {kernel_size}, {n_mix}')
+
+
+def make_u1_equiv_layers(*, n_layers, n_mixture_comps, lattice_shape, hidden_sizes, kernel_size,
+                         activation_fn: str = None):
+    """layers.py:399-429: layer i uses mu = i % 2, off = (i // 2) % 4."""
+    _check_arch(hidden_sizes, kernel_size, n_mixture_comps)
+    layers = []
+    for i in range(n_layers):
+        mu, off = i % 2, (i // 2) % 4
+        net = make_conv_net(in_channels=2, out_channels=n_mixture_comps + 1, hidden_sizes=hidden_sizes,
+                            kernel_size=kernel_size, use_final_tanh=False, activation_fn=activation_fn)
+        plaq_coupling = NCPPlaqCouplingLayer(net, mask_shape=lattice_shape, mask_mu=mu, mask_off=off)
+        layers.append(GaugeEquivCouplingLayer(lattice_shape=lattice_shape, mask_mu=mu, mask_off=off,
+                                              plaq_coupling=plaq_coupling))
+    return nn.ModuleList(layers)
+
+
+def make_net_from_layers(*, lattice_shape: tuple, nets: List[nn.Module]):
+    """layers.py:93-114: reuse trained (translation-equivariant) nets on another lattice size."""
+    layers = []
+    for i, net in enumerate(nets):
+        mu, off = i % 2, (i // 2) % 4
+        plaq_coupling = NCPPlaqCouplingLayer(net, mask_shape=lattice_shape, mask_mu=mu, mask_off=off)
+        layers.append(GaugeEquivCouplingLayer(lattice_shape=lattice_shape, mask_mu=mu, mask_off=off,
+                                              plaq_coupling=plaq_coupling))
+    return nn.ModuleList(layers)
+
+
+def flow_weights(flow: nn.ModuleList, dev=None) -> torch.Tensor:
+    """All layers' conv parameters as the flat [n_layers * 955] buffer of the C ABI, checking
+    that the layers follow the reference mask schedule."""
+    rows = []
+    for i, layer in enumerate(flow):
+        if (layer.mask_mu, layer.mask_off) != (i % 2, (i // 2) % 4):
+            raise ValueError(f'layer {i}: masks (mu={layer.mask_mu}, off={layer.mask_off}) are not the reference '
+                             f'schedule mu = i % 2, off = (i // 2) % 4')
+        rows.append(net_weights(layer.plaq_coupling.net))
+    if dev is None:
+        dev = rows[0][0].device if rows else device()
+    return ops.pack_weights(rows, device=dev)
+
+
+def flow_activation(flow: nn.ModuleList) -> str:
+    acts = {layer.activation_fn for layer in flow}
+    if len(acts) > 1:
+        raise ValueError(f'mixed activations {acts} in one flow')
+    return acts.pop() if acts else 'silu'

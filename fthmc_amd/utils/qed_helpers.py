@@ -1,0 +1,179 @@
+"""fthmc/utils/qed_helpers.py on the HIP kernels: plaquettes, Wilson action, topological
+charge, plain force / leapfrog / HMC, flow drivers, ft_action, ft_force."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from math import pi as PI
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .layers import flow_activation, flow_weights
+
+TWO_PI = 2 * PI
+
+
+def grab(var):
+    return var.detach().cpu().numpy()
+
+
+def regularize(f):
+    """qed_helpers.py:40-42."""
+    return ops.regularize(f)
+
+
+def torch_mod(x):
+    """qed_helpers.py:45-46: remainder(x, 2 pi) in [0, 2 pi) (not the flow's [-pi, pi) map)."""
+    return torch.remainder(x, TWO_PI)
+
+
+def torch_wrap(x):
+    """qed_helpers.py:49-50: [-pi, pi)."""
+    return ops.wrap(x)
+
+
+def _batched(x):
+    return x if x.dim() == 4 else x[None]
+
+
+def compute_u1_plaq(links, mu=0, nu=1):
+    """qed_helpers.py:80-90."""
+    assert (mu, nu) == (0, 1)
+    P = ops.plaquettes(_batched(links))
+    return P if links.dim() == 4 else P[0]
+
+
+def batch_plaqs(x, mu: int = 0, nu: int = 1):
+    """qed_helpers.py:94-105."""
+    return compute_u1_plaq(x, mu, nu)
+
+
+def u1_plaq(x, mu: int, nu: int):
+    """qed_helpers.py:66-70 (same plaquette, other summation order)."""
+    return compute_u1_plaq(x, mu, nu)
+
+
+def plaq_phase(f, mu=0, nu=1):
+    """qed_helpers.py:246-257 (squeezes a leading batch of 1)."""
+    f = torch.squeeze(f)
+    return compute_u1_plaq(f, mu, nu)
+
+
+def batch_charges(x: torch.Tensor = None, plaqs: torch.Tensor = None):
+    """qed_helpers.py:108-116."""
+    if plaqs is None:
+        if x is None:
+            raise ValueError('Either `x` or `plaq` must be specified.')
+        return ops.wilson_action_charge(_batched(x), 1.0)[1]
+    return ops.wrap(plaqs).flatten(1).sum(1) / TWO_PI
+
+
+def topo_charge(x):
+    """qed_helpers.py:73-77."""
+    return batch_charges(x=x)
+
+
+class BatchAction:
+    """qed_helpers.py:166-186: S_b = -beta sum cos P."""
+
+    def __init__(self, beta):
+        self.beta = beta
+
+    def __call__(self, x: torch.Tensor):
+        return ops.wilson_action_charge(x, self.beta)[0]
+
+
+@dataclass
+class LatticeMetrics:
+    beta: float
+    plaqs: torch.Tensor
+    action: torch.Tensor
+    charges: torch.Tensor
+
+
+class BatchObservables:
+    """qed_helpers.py:130-163."""
+
+    def __init__(self, beta: float = 1.):
+        self.beta = beta
+
+    def get_plaqs(self, x):
+        return torch.cos(batch_plaqs(x))
+
+    def get_action(self, x=None, plaqs=None):
+        if x is None:
+            raise ValueError('`x` must be specified.')
+        return ops.wilson_action_charge(x, self.beta)[0]
+
+    def get_charges(self, x=None, plaqs=None):
+        return batch_charges(x=x, plaqs=plaqs)
+
+    def get_observables(self, x):
+        S, Q, _ = ops.wilson_action_charge(x, self.beta)
+        return LatticeMetrics(self.beta, self.get_plaqs(x), S, Q)
+
+
+# ---------------------------------------------------------------- flow drivers
+def ft_flow(flow: nn.ModuleList, x: torch.Tensor):
+    """qed_helpers.py:191-198: x -> F(x)."""
+    return ops.flow_forward(x, flow_weights(flow, x.device), len(flow), flow_activation(flow))[0]
+
+
+def ft_flow_inv(flow: nn.ModuleList, x: torch.Tensor, tol: float = 1e-12):
+    """qed_helpers.py:201-209: x -> F^-1(x)."""
+    return ops.flow_reverse(x, flow_weights(flow, x.device), len(flow), flow_activation(flow), tol=tol)[0]
+
+
+def ft_action(param, flow, x: torch.Tensor):
+    """qed_helpers.py:212-223: S_W(F(x)) - sum_l logJ_l, per chain."""
+    return ops.ft_action(x, flow_weights(flow, x.device), len(flow), param.beta, flow_activation(flow))[0]
+
+
+def ft_force(param, flow, field: torch.Tensor, create_graph=False):
+    """qed_helpers.py:226-242: d(sum_b S_eff)/dx."""
+    if create_graph:
+        raise NotImplementedError('second-order graphs through the force are not part of the HIP path')
+    return ops.ft_force(field, flow_weights(flow, field.device), len(flow), param.beta, flow_activation(flow))
+
+
+# ---------------------------------------------------------------- plain HMC
+def action(param, x: torch.Tensor):
+    """qed_helpers.py:261-262: one scalar for the whole tensor."""
+    return ops.wilson_action_charge(_batched(x), param.beta)[0].sum()
+
+
+def force(param, x: torch.Tensor):
+    """qed_helpers.py:265-272."""
+    return ops.wilson_force(_batched(x), param.beta).reshape(x.shape)
+
+
+def leapfrog(param, x: torch.Tensor, p: torch.Tensor, verbose: bool = True):
+    """qed_helpers.py:275-295."""
+    xo, po = ops.leapfrog(_batched(x), _batched(p), param.beta, param.dt, param.nstep)
+    return xo.reshape(x.shape), po.reshape(p.shape)
+
+
+def hmc(param, x, verbose=True, v: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None):
+    """qed_helpers.py:298-311: one trajectory; the whole tensor is ONE system (one H, one
+    accept), as in the reference.  `v`, `u` may be supplied for reproducible checks."""
+    xb = _batched(x)
+    if v is None:
+        v = torch.randn_like(xb)
+    if u is None:
+        u = torch.rand([], dtype=torch.float64, device=x.device)
+    vb = _batched(v)
+    if xb.shape[0] == 1:
+        r = ops.hmc_trajectory(xb, vb, u.reshape(1), param.beta, param.dt, param.nstep)
+        dH = r['dH'][0]
+        acc = r['acc'][0] > 0.5
+        return dH, torch.exp(-dH), acc, r['x_new'].reshape(x.shape)
+    h0 = ops.wilson_action_charge(xb, param.beta)[0].sum() + 0.5 * ops.kinetic(vb).sum()
+    x_, v_ = ops.leapfrog(xb, vb, param.beta, param.dt, param.nstep)
+    xr = ops.regularize(x_)
+    dH = ops.wilson_action_charge(xr, param.beta)[0].sum() + 0.5 * ops.kinetic(v_).sum() - h0
+    exp_mdH = torch.exp(-dH)
+    acc = u < exp_mdH
+    newx = xr if bool(acc) else xb
+    return dH, exp_mdH, acc, newx.reshape(x.shape)

@@ -1,0 +1,159 @@
+"""CPU-only tests: host logic of the package (config types, stripe masks, weight packing,
+sharding, multi-process statistics over gloo) and that the C-ABI library loads and exports
+every symbol include/fthmc_hip.h declares.  No compute calls: there is no GPU here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from fthmc_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'fthmc_hip.h')).read()
+    declared = set(re.findall(r'\b(fthmc_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in include/fthmc_hip.h but not exported'
+        assert name in _lib.SIGNATURES, f'{name} has no ctypes signature'
+    assert set(_lib.SIGNATURES) <= declared
+    assert lib.fthmc_version().startswith(b'fthmc_hip')
+    assert lib.fthmc_ws_bytes(128, 64, 8) > 128 * 2 * 64 * 64 * 8 * 9
+    assert b'workspace' in lib.fthmc_strerror(-4)
+
+
+def test_no_cpu_fallback():
+    from fthmc_amd import ops
+    from fthmc_amd._lib import FthmcError
+    with pytest.raises(FthmcError):
+        ops.wilson_action_charge(torch.zeros(1, 2, 8, 8, dtype=torch.float64), 1.0)
+    # nothing under fthmc_amd/ may import the oracle
+    for dp, _, files in os.walk(os.path.join(ROOT, 'fthmc_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert 'oracle' not in src, f'{f} mentions the oracle'
+
+
+def test_masks_match_reference():
+    from fthmc_amd.utils import layers as Lyr
+    g = load_golden('masks')
+    for L in (8, 12):
+        for mu in (0, 1):
+            for off in range(4):
+                pm = Lyr.make_plaq_masks((L, L), mu, off)
+                k = f'L{L}_mu{mu}_off{off}_'
+                assert np.array_equal(pm['active'], g[k + 'active'])
+                assert np.array_equal(pm['frozen'], g[k + 'frozen'])
+                assert np.array_equal(pm['passive'], g[k + 'passive'])
+                assert np.array_equal(Lyr.make_2d_link_active_stripes((2, L, L), mu, off), g[k + 'link'])
+
+
+def test_config_types():
+    from fthmc_amd import config as C
+    g = load_golden('plaq_exact')
+    assert [C.PLAQ_EXACT[float(b)] for b in g['betas']] == list(g['values'])
+    p = C.Param(beta=2.0, L=8, tau=1.0, nstep=10)
+    assert p.dt == 0.1 and p.volume == 64 and p.shape == [2, 8, 8] and p.lat == [8, 8]
+    assert p.uniquestr() == 't8x8_b2.0_n256_t1.0_s10'
+    lf = C.lfConfig(tau=2.0, nstep=8)
+    assert lf.dt == 0.25 and lf.uniquestr() == 't2.0_s8_dt0.25'
+    cwd_before = set(os.listdir('.'))
+    tc = C.TrainConfig(L=16, beta=4.0, n_layers=4)
+    assert tc.volume == 256 and tc.hidden_sizes == [8, 8] and tc.n_s_nets == 2
+    assert set(os.listdir('.')) == cwd_before          # no directories created (reference Q11)
+    assert 'L16_b4.0' in tc.uniquestr()
+
+
+def test_pack_weights_layout_and_checks():
+    from fthmc_amd import ops
+    from fthmc_amd._lib import FthmcError
+    w = [torch.arange(144.).reshape(8, 2, 3, 3), torch.arange(8.), torch.arange(576.).reshape(8, 8, 3, 3),
+         torch.arange(8.), torch.arange(216.).reshape(3, 8, 3, 3), torch.arange(3.)]
+    flat = ops.pack_weights([w, w])
+    assert flat.shape == (2 * 955,) and flat.dtype == torch.float64
+    assert float(flat[144 + 3]) == 3.0 and float(flat[152 + 575]) == 575.0 and float(flat[954]) == 2.0
+    back = ops.unpack_weight_grads(flat, 2)
+    assert all(torch.equal(a.double(), b) for a, b in zip(w, back[1]))
+    with pytest.raises(FthmcError):
+        ops.pack_weights([[torch.zeros(16, 2, 3, 3)] + w[1:]])
+
+
+def test_shard_ranges_and_chain_seeds():
+    from fthmc_amd import parallel as P
+    for n, ws in [(128, 8), (1024, 8), (10, 3), (5, 8)]:
+        spans = [P.shard_range(n, r, ws) for r in range(ws)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    # a chain's seed depends on its global id and the trajectory only, not on the sharding
+    full = P.chain_seeds(1331, 0, 1024, 7)
+    for r in range(8):
+        lo, hi = P.shard_range(1024, r, 8)
+        assert torch.equal(P.chain_seeds(1331, lo, hi, 7), full[lo:hi])
+    assert len(set(full.tolist())) == 1024 and not torch.equal(full, P.chain_seeds(1331, 0, 1024, 8))
+
+
+_WORKER = r'''
+import os, sys, math
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["FT_ROOT"])
+from fthmc_amd import parallel as P
+from oracle import ref_cpu as R            # the oracle stands in for the GPU trajectory in this CPU test
+rank, world, _ = P.init("gloo")
+B, L, nl, beta, dt, nstep = 4, 8, 2, 2.0, 0.1, 3
+gen = torch.Generator().manual_seed(11)
+flow = R.default_flow(nl, gen)
+x_all = (torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+lo, hi = P.shard_range(B, rank, world)
+stats = P.RunStats.zeros("cpu")
+gw_local = torch.zeros(3)
+qold = R.charge(R.flow_forward(x_all[lo:hi], flow)[0])
+for traj in range(2):
+    seeds = P.chain_seeds(5, lo, hi, traj)
+    v = torch.stack([torch.randn(2, L, L, generator=torch.Generator().manual_seed(int(s)), dtype=torch.float64) for s in seeds])
+    u = torch.stack([torch.rand([], generator=torch.Generator().manual_seed(int(s) ^ 1), dtype=torch.float64) for s in seeds])
+    dH, _, acc, newx, _, _ = R.ft_hmc(x_all[lo:hi], v, u, flow, beta, dt, nstep)
+    y = R.flow_forward(newx, flow)[0]
+    q = R.charge(y)
+    stats.add(acc.double(), R.plaq_mean(y, beta), q, q - qold, dH)
+    w = stats.reduce(async_op=world > 1)
+    if w is not None: w.wait()
+    qold = q
+m = stats.means()
+lw = torch.arange(lo, hi, dtype=torch.float64) * 0.3
+lse = float(P.global_logsumexp(lw)); mean = float(P.global_mean(lw, B))
+g = torch.full((3,), float(rank + 1)); P.allreduce_grads(g)
+if rank == 0:
+    print("RESULT", m["n"], m["acc"], m["plaq"], m["q"], m["dh"], lse, mean, float(g[0]))
+if world > 1: dist.destroy_process_group()
+'''
+
+
+def _run_workers(world):
+    env = dict(os.environ, FT_ROOT=ROOT, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29500 + world + os.getpid() % 500),
+               OMP_NUM_THREADS='1')
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, '-c', _WORKER], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith('RESULT')][0]
+    return [float(t) for t in line.split()[1:]]
+
+
+def test_two_rank_gloo_equals_single_process():
+    """Chains sharded over 2 ranks (gloo) + C1 all-reduce == the same chains in one process."""
+    one = _run_workers(1)
+    two = _run_workers(2)
+    assert one[0] == two[0] == 8.0                                   # 4 chains x 2 trajectories
+    np.testing.assert_allclose(two[:7], one[:7], rtol=1e-12, atol=1e-12)
+    assert one[7] == 1.0 and two[7] == 3.0                           # SUM all-reduce of "gradients"

@@ -75,6 +75,22 @@ def topo_charge(x):
     return batch_charges(x=x)
 
 
+class _WilsonActionFn(torch.autograd.Function):
+    """S_b(x) with its gradient dS_b/dx = fthmc_wilson_force (so flows trained through
+    `action(x)` by autograd, train.py:202-210, see the Wilson term)."""
+
+    @staticmethod
+    def forward(ctx, x, beta):
+        ctx.save_for_backward(x)
+        ctx.beta = beta
+        return ops.wilson_action_charge(x, beta)[0]
+
+    @staticmethod
+    def backward(ctx, gS):
+        (x,) = ctx.saved_tensors
+        return ops.wilson_force(x, ctx.beta) * gS[:, None, None, None], None
+
+
 class BatchAction:
     """qed_helpers.py:166-186: S_b = -beta sum cos P."""
 
@@ -82,6 +98,8 @@ class BatchAction:
         self.beta = beta
 
     def __call__(self, x: torch.Tensor):
+        if x.requires_grad:
+            return _WilsonActionFn.apply(x, self.beta)
         return ops.wilson_action_charge(x, self.beta)[0]
 
 

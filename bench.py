@@ -45,7 +45,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='chains per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-chains', type=int, default=8)
+    ap.add_argument('--cpu-chains', type=int, default=128)
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     return ap.parse_args()
 
@@ -68,6 +68,18 @@ def host_threads():
     except (OSError, ValueError):
         pass
     return max(1, min(n, 16))
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (profiles/r01_pmc_summary.json: FETCH_SIZE + WRITE_SIZE, KiB, raw)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
+            k = json.load(f)['kernels']
+        k = next(v for n, v in k.items() if 'k_flow_mfma<1' in n)
+        return round((k['FETCH_SIZE']['mean_per_launch'] + k['WRITE_SIZE']['mean_per_launch']) * 1024)
+    except Exception:
+        return None
 
 
 def make_flow(gen):
@@ -187,9 +199,9 @@ def main():
     achieved = flops_launch / (ms_bwd * 1e-3) / 1e12
     step_flops = 2 * CONV_FLOPS_PER_SITE * L * L * N_LAYERS * B    # fwd + dgrad, per batched leapfrog step
     roofline = {
-        'bound': 'mfma', 'kernel': 'k_flow_layer<1> (coupling-layer backward wrt x)',
+        'bound': 'mfma', 'kernel': 'k_flow_mfma<1,8,16> (coupling-layer backward wrt x)',
         'achieved': round(achieved, 3), 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / FP64_PEAK_TFLOPS, 4), 'traffic': None,
+        'frac': round(achieved / FP64_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(),
         'avg_launch_ms': round(ms_bwd, 4),
         'algorithmic_flops_per_launch': flops_launch,
         'fwd_kernel_ms': round(ms_fwd, 4),

@@ -69,7 +69,7 @@ template <int MODE, int TR, int TC> struct SmemM {
     static constexpr int T2 = ST + 8 * 3 * G::NAS;            // [NMIX][4][NAS]
     static constexpr int DL = T2 + NMIX * 4 * G::NAS;         // [N3] delta (fwd)
     static constexpr int SW = DL + (BWD ? 0 : G::N3);         // [SW_SIZE]
-    static constexpr int D1 = SW + SW_SIZE;                   // [8][PS1] act'(z1) -> gz1   (bwd)
+    static constexpr int D1 = SW + (BWD ? SW_SIZE : SW_W3B + 4);   // [8][PS1] act'(z1) -> gz1 (bwd); fwd needs no W3B
     static constexpr int D2 = D1 + (BWD ? 8 * G::PS1 : 0);    // [8][PS2] act'(z2)          (bwd)
     static constexpr int SIZE = D2 + (BWD ? 8 * G::PS2 : 0);
     static_assert(8 * G::PS1 + 8 * G::PS2 >= 8 * G::PS0, "padded gz2 must fit over h1|h2");
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         sIn[PS0 + t] = sn;
     }
     if (MODE == 0) { for (int t = tid; t < N3; t += NT) sDL[t] = 0.0; }
-    for (int t = tid; t < SW_USED; t += NT) {
+    for (int t = tid; t < (BWD ? SW_USED : SW_W3B); t += NT) {
         int src;
         if (t < SW_W1B) src = W3F + t;                       // W3F | B3 (contiguous in the kernel layout)
         else if (t < SW_B1) src = W1B + t - SW_W1B;
@@ -401,39 +401,65 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         STAMP(8);
 
         // ---- conv1^T and the (cos, sin) adjoint at frozen plaquettes ----------------
-        for (int t = tid; t < N0; t += NT) {
-            const int r = t / R0C, c = t - r * R0C;
-            const int i = ft_modL(i0 - 3 + r, L), j = ft_modL(j0 - 3 + c, L);
-            const int sel = ft_stripe(i, j, mu, off);
-            if (sel == 1 || sel == 2) {
-                // clamped addresses + zero mask: no per-tap branches; four co chains interleave
+        // Frozen and non-frozen window lines alternate in pairs (columns for mu = 0, rows for mu = 1).
+        // A non-frozen site has nothing of its own to do here, so it takes output-channel half
+        // [4, 8) of the frozen site two lines before it: every lane works and the per-lane
+        // dependent chain (LDS read -> mul -> 2 FMA per tap) is half as long.
+        {
+            constexpr int R0R_ = G::R0R;
+            double* sHalf = sST;                                         // [2][N0] partial (g_cos, g_sin); g_out is dead
+            static_assert(2 * N0 <= 8 * 3 * NAS + NMIX * 4 * NAS, "helper partials must fit over ST|T2");
+            for (int t = tid; t < N0; t += NT) {
+                const int r = t / R0C, c = t - r * R0C;
+                const int line = mu == 0 ? c : r, nline = mu == 0 ? R0C : R0R_;
+                const int cls = ((mu == 0 ? j0 : i0) - 3 + line - off) & 3;      // stripe class of this window line
+                const bool frozen = (cls == 1 || cls == 2);
+                const bool helper = !frozen && line >= 2;                        // helps line - 2 (class 1 or 2)
+                if (!frozen && !helper) continue;
+                const int tr_ = frozen ? r : (mu == 0 ? r : r - 2);
+                const int tc_ = frozen ? c : (mu == 0 ? c - 2 : c);
+                const bool has_helper = frozen && (line + 2 < nline);
+                const int co0 = frozen ? 0 : 4, co1 = (frozen && !has_helper) ? 8 : co0 + 4;
                 int aoff[9]; double msk[9];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int rr = r - ky, cc = c - kx;
+                        const int rr = tr_ - ky, cc = tc_ - kx;
                         const bool ok = (rr >= 0) && (rr < R1R) && (cc >= 0) && (cc < R1C);
                         aoff[ky * 3 + kx] = ok ? rr * R1C + cc : 0;
                         msk[ky * 3 + kx] = ok ? 1.0 : 0.0;
                     }
-                double gc[4] = {0.0, 0.0, 0.0, 0.0}, gsn[4] = {0.0, 0.0, 0.0, 0.0};
+                // per output channel: issue all 18 LDS reads (9 taps of gz1, 9 weight pairs) first,
+                // then the 18 FMAs; left to itself the compiler waits after every single read
+                double gc[3] = {0.0, 0.0, 0.0}, gsn[3] = {0.0, 0.0, 0.0};
 #pragma unroll 1
-                for (int cg = 0; cg < 2; ++cg) {
+                for (int co = co0; co < co1; ++co) {
+                    double gv[9], w0[9], w1[9];
+                    const double* gz = sD1 + co * PS1;
+                    const double* wp = sW + SW_W1B + co * 18;
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) { gv[tp] = gz[aoff[tp]]; w0[tp] = wp[tp * 2]; w1[tp] = wp[tp * 2 + 1]; }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int tp = 0; tp < 9; ++tp) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int co = cg * 4 + u;
-                            const double gv = sD1[co * PS1 + aoff[tp]] * msk[tp];
-                            const double* wp = sW + SW_W1B + co * 18 + tp * 2;
-                            gc[u] = fma(gv, wp[0], gc[u]); gsn[u] = fma(gv, wp[1], gsn[u]);
-                        }
+                        const double g_ = gv[tp] * msk[tp];
+                        gc[tp % 3] = fma(g_, w0[tp], gc[tp % 3]); gsn[tp % 3] = fma(g_, w1[tp], gsn[tp % 3]);
                     }
                 }
-                const double gct = (gc[0] + gc[1]) + (gc[2] + gc[3]);
-                const double gst = (gsn[0] + gsn[1]) + (gsn[2] + gsn[3]);
-                sGP[t] = -sIn[PS0 + t] * gct + sIn[t] * gst;
+                const double gct = (gc[0] + gc[1]) + gc[2];
+                const double gst = (gsn[0] + gsn[1]) + gsn[2];
+                if (frozen) sGP[t] = -sIn[PS0 + t] * gct + sIn[t] * gst;           // own channels
+                else { const int wt = tr_ * R0C + tc_; sHalf[wt] = gct; sHalf[N0 + wt] = gst; }
+            }
+            __syncthreads();
+            // second half: frozen sites with a helper add the helper's channels [4, 8)
+            for (int t = tid; t < N0; t += NT) {
+                const int r = t / R0C, c = t - r * R0C;
+                const int line = mu == 0 ? c : r, nline = mu == 0 ? R0C : R0R_;
+                const int cls = ((mu == 0 ? j0 : i0) - 3 + line - off) & 3;
+                if ((cls == 1 || cls == 2) && line + 2 < nline)
+                    sGP[t] += -sIn[PS0 + t] * sHalf[t] + sIn[t] * sHalf[N0 + t];
             }
         }
         __syncthreads();
@@ -454,8 +480,9 @@ void set_flow_variant(int v) { g_variant = v; }
 int get_flow_variant() { return g_variant; }
 
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
-    const dim3 grid((a.L + MF_TC - 1) / MF_TC, (a.L + MF_TR - 1) / MF_TR, a.B);
-    hipLaunchKernelGGL((k_flow_mfma<0, MF_TR, MF_TC>), grid, dim3(NT), 0, s, a);
+    // forward needs half the LDS of backward: 16 x 16 tiles (less halo work) still fit twice per CU
+    const dim3 grid((a.L + FLOW_TILE - 1) / FLOW_TILE, (a.L + FLOW_TILE - 1) / FLOW_TILE, a.B);
+    hipLaunchKernelGGL((k_flow_mfma<0, FLOW_TILE, FLOW_TILE>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s) {

@@ -34,24 +34,7 @@ __global__ void k_pack_weights(const double* __restrict__ w, int n_layers, doubl
         else if (t < W2B) { int u = t - W3B; int ci = u % 8, tap = (u / 8) % 9, co = u / 72; v = c[CW2 + (co * 8 + ci) * 9 + tap]; }
         else if (t < W1B) { int u = t - W2B; int ci = u % 8, tap = (u / 8) % 9, co = u / 72; v = c[CW1 + (co * 8 + ci) * 9 + tap]; }
         else if (t < W1B + 144) { int u = t - W1B; int ci = u % 2, tap = (u / 2) % 9, co = u / 18; v = c[CW0 + (co * 2 + ci) * 9 + tap]; }
-        else if (t >= WB1 && t < WB2T + 24 * 64) {
-            // MFMA f64 16x16x4 B operand: lane l holds B[k = 4*step + (l>>4)][n = l&15].
-            // n = cN + 8*d packs two output rows (d = 0, 1) of one site column; k enumerates
-            // (tap of a 4x3 window, input channel) with the channel fastest.
-            int u, KC, stage;
-            if (t < WB2) { u = t - WB1; KC = 2; stage = 0; }
-            else if (t < WB3T) { u = t - WB2; KC = 8; stage = 1; }
-            else if (t < WB2T) { u = t - WB3T; KC = 3; stage = 2; }
-            else { u = t - WB2T; KC = 8; stage = 3; }
-            const int step = u / 64, l = u % 64, g = l >> 4, j = l & 15, cN = j & 7, dd = j >> 3;
-            const int k = 4 * step + g, tap = k / KC, cK = k % KC, ky4 = tap / 3, kx = tap % 3, ky = ky4 - dd;
-            if (ky >= 0 && ky <= 2) {
-                if (stage == 0) v = c[CW0 + (cN * 2 + cK) * 9 + ky * 3 + kx];
-                else if (stage == 1) v = c[CW1 + (cN * 8 + cK) * 9 + ky * 3 + kx];
-                else if (stage == 2) v = c[CW2 + (cK * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx)];
-                else v = c[CW1 + (cK * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx)];
-            }
-        }
+        else if (t >= WCAN && t < WCAN + WCAN_SIZE) { const int u = t - WCAN; v = u < FTHMC_W_PER_LAYER ? c[u] : 0.0; }
         d[t] = v;
     }
 }

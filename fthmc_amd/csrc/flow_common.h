@@ -28,12 +28,12 @@ constexpr int W2B = 1244;   // [co 8][tap 9][ci 8]
 constexpr int W1B = 1820;   // [co 8][tap 9][ci 2]
 static_assert(W1B + 144 <= FLOW_WINT, "weight layout");
 
-// MFMA B-operand packs (one double per lane per k-step; see flow_mfma.hip)
-constexpr int WB1 = 1968;            // conv1   (K = 2 ci x 12 taps = 24)  ->  6 steps x 64 lanes
-constexpr int WB2 = WB1 + 6 * 64;    // conv2   (K = 8 ci x 12 taps = 96)  -> 24 steps
-constexpr int WB3T = WB2 + 24 * 64;  // conv3^T (K = 3 co x 12 taps = 36)  ->  9 steps
-constexpr int WB2T = WB3T + 9 * 64;  // conv2^T (K = 8 co x 12 taps = 96)  -> 24 steps
-static_assert(WB2T + 24 * 64 <= FLOW_WINT, "weight layout");
+// verbatim copy of the layer's canonical weights (955 doubles, PyTorch order) + zeros: the MFMA
+// kernels keep it in LDS and read both conv operands straight from it
+constexpr int WCAN = 1968;            // [960]
+constexpr int WCAN_SIZE = 960;
+constexpr int WZERO = CB2 + 4;        // a 0.0 inside the canonical copy (index 956)
+static_assert(WCAN + WCAN_SIZE <= FLOW_WINT, "weight layout");
 
 // exp(-a) for a >= 0: range reduction by ln2 (hi/lo split) + degree-13 Taylor (|r| <= ln2/2:
 // truncation 4e-18) + v_ldexp.  ~20 dependent DP ops instead of ocml exp's ~60, < 1.5 ulp.

@@ -53,10 +53,8 @@ template <int TR, int TC> struct Geom {
     static_assert(TR % 4 == 0 && TC % 4 == 0 && NA <= 64, "tile shape");
 };
 
-// LDS copy of the weights the VALU stages use (scalar loads inside an LDS-heavy loop
-// serialise on lgkmcnt(0)): [W3F | B3](292) [W1B](144) [B1](8) [B2](8) [W3B](216)
-constexpr int SW_W3F = 0, SW_B3 = 288, SW_W1B = 292, SW_B1 = 436, SW_B2 = 444, SW_W3B = 452,
-              SW_USED = 452 + 216, SW_SIZE = SW_USED + 4;
+// LDS copy of the layer's canonical weights (flow_common.h: CW0 CB0 CW1 CB1 CW2 CB2, WZERO)
+constexpr int SW_SIZE = WCAN_SIZE;
 
 template <int MODE, int TR, int TC> struct SmemM {
     using G = Geom<TR, TC>;
@@ -66,31 +64,25 @@ template <int MODE, int TR, int TC> struct SmemM {
     static constexpr int H1 = PG + G::PS0;                    // [8][PS1] | bwd: padded gz2 [8][PS0] over H1|H2
     static constexpr int H2 = H1 + 8 * G::PS1;                // [8][PS2]
     static constexpr int ST = H2 + 8 * G::PS2;                // [8][3][NAS] conv3 partials | bwd: g_out [3][N3]
-    static constexpr int T2 = ST + 8 * 3 * G::NAS;            // [NMIX][4][NAS]
-    static constexpr int DL = T2 + NMIX * 4 * G::NAS;         // [N3] delta (fwd)
-    static constexpr int SW = DL + (BWD ? 0 : G::N3);         // [SW_SIZE]
-    static constexpr int D1 = SW + (BWD ? SW_SIZE : SW_W3B + 4);   // [8][PS1] act'(z1) -> gz1 (bwd); fwd needs no W3B
+    static constexpr int T2 = ST + 8 * 3 * G::NAS;            // [NMIX][4 (bwd) | 2 (fwd)][NAS]
+    static constexpr int T2Q = BWD ? 4 : 2;                   // slots per component: y, 1/D, (gP part, spare)
+    static constexpr int DL = ST;                             // [N3] delta (fwd): over the consumed conv3 partials
+    static constexpr int SW = T2 + NMIX * T2Q * G::NAS;       // [SW_SIZE]
+    static constexpr int D1 = SW + SW_SIZE;                   // [8][PS1] act'(z1) -> gz1   (bwd)
     static constexpr int D2 = D1 + (BWD ? 8 * G::PS1 : 0);    // [8][PS2] act'(z2)          (bwd)
     static constexpr int SIZE = D2 + (BWD ? 8 * G::PS2 : 0);
     static_assert(8 * G::PS1 + 8 * G::PS2 >= 8 * G::PS0, "padded gz2 must fit over h1|h2");
-    static_assert(3 * G::N3 <= 8 * 3 * G::NAS, "g_out must fit over the conv3 partials");
+    static_assert(3 * G::N3 <= 8 * 3 * G::NAS, "g_out / delta must fit over the conv3 partials");
 };
-
-// B operand of a stage: issued before the barrier that precedes the stage so that the global
-// (L2) latency overlaps the tail of the previous stage.
-template <int NSTEP>
-__device__ __forceinline__ void stage_prefetch(const double* __restrict__ wB, int lane, double (&breg)[NSTEP]) {
-#pragma unroll
-    for (int t = 0; t < NSTEP; ++t) breg[t] = wB[t * 64 + lane];
-}
 
 // One implicit-GEMM stage.  Output region HOUT x WOUT (HOUT even) whose input planes are one
 // site larger on every side (forward conv) or ring-2 padded (transposed conv): input index of
 // output (r, c) and window tap (ky4, kx) is (r + ky4, c + kx) for the pair's upper row r = 2q.
 // The epilogue gets the four values of a lane at once so that their chains interleave.
-template <int NSTEP, int KC, int HOUT, int WOUT, int RSA, int PSA, class Epi>
-__device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double (&breg)[NSTEP],
-                                           int wave, int lane, Epi epi) {
+// bidx(t, g, cN, dd) -> index of B[k = 4 t + g][n = cN + 8 dd] in the LDS weight copy sW.
+template <int NSTEP, int KC, int HOUT, int WOUT, int RSA, int PSA, class BIdx, class Epi>
+__device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ sW,
+                                           int wave, int lane, BIdx bidx, Epi epi) {
     constexpr int NPAIR = (HOUT / 2) * WOUT;
     constexpr int NTILE = (NPAIR + 15) / 16;
     const int g = lane >> 4, i = lane & 15;
@@ -105,6 +97,9 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
         }
     }
     const int cN = i & 7, dd = i >> 3;
+    int boff[NSTEP];
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) boff[t] = bidx(t, g, cN, dd);
     for (int tile = wave; tile < NTILE; tile += NW) {
         int p = tile * 16 + i;
         if (p >= NPAIR) p = NPAIR - 1;                       // padding lanes: any valid address
@@ -120,7 +115,7 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
             double av;
             if (KC == 8) av = a0[(t & 1) * 4 * PSA + ((t >> 1) / 3) * RSA + ((t >> 1) % 3)];
             else av = a0[koff[t]];
-            accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, breg[t], accs[t % NCH], 0, 0, 0);
+            accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, sW[boff[t]], accs[t % NCH], 0, 0, 0);
         }
         double4_t acc = accs[0];
 #pragma unroll
@@ -147,7 +142,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
     using G = Geom<TR, TC>;
     constexpr bool BWD = S::BWD;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
-    constexpr int N0 = G::N0, N2 = G::N2, N3 = G::N3, NA = G::NA, NAS = G::NAS;
+    constexpr int N0 = G::N0, N2 = G::N2, N3 = G::N3, NA = G::NA, NAS = G::NAS, TQ = S::T2Q;
     constexpr int PS0 = G::PS0, PS1 = G::PS1, PS2 = G::PS2;
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
     double* sIn = sm + S::IN;  double* sP = sm + S::PG;   double* sGP = sm + S::PG;
@@ -171,8 +166,6 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
-    double breg1[6];
-    stage_prefetch<6>(w + WB1, lane, breg1);
 
     // ---- plaquette window + net input; small weights -> LDS ------------------
     for (int t = tid; t < N0; t += NT) {
@@ -188,25 +181,19 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         sIn[t] = cs;
         sIn[PS0 + t] = sn;
     }
-    if (MODE == 0) { for (int t = tid; t < N3; t += NT) sDL[t] = 0.0; }
-    for (int t = tid; t < (BWD ? SW_USED : SW_W3B); t += NT) {
-        int src;
-        if (t < SW_W1B) src = W3F + t;                       // W3F | B3 (contiguous in the kernel layout)
-        else if (t < SW_B1) src = W1B + t - SW_W1B;
-        else if (t < SW_B2) src = B1 + t - SW_B1;
-        else if (t < SW_W3B) src = B2 + t - SW_B2;
-        else src = W3B + t - SW_W3B;
-        sW[t] = w[src];
-    }
+    for (int t = tid; t < SW_SIZE; t += NT) sW[t] = w[WCAN + t];
     __syncthreads();
     STAMP(1);
 
     // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
-    double breg2[24];
-    stage_prefetch<24>(w + WB2, lane, breg2);                 // conv2's weights fly during conv1
-    mfma_stage<6, 2, R1R, R1C, R0C, PS0>(sIn, breg1, wave, lane,
+    // B[k = (tap, ci)][n = (co, dd)] = W0[co][ci][ky4 - dd][kx]
+    auto bidx1 = [](int t, int g, int cN, int dd) {
+        const int k = 4 * t + g, tap = k / 2, ci = k - 2 * tap, ky = tap / 3 - dd, kx = tap % 3;
+        return (ky >= 0 && ky <= 2) ? CW0 + (cN * 2 + ci) * 9 + ky * 3 + kx : WZERO;
+    };
+    mfma_stage<6, 2, R1R, R1C, R0C, PS0>(sIn, sW, wave, lane, bidx1,
         [&](int co, const int (&o)[4], const bool (&ok)[4], double (&z)[4]) {
-            const double bias = sW[SW_B1 + co];
+            const double bias = sW[CB0 + co];
             double h[4], d[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) z[q] += bias;
@@ -219,9 +206,14 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
     STAMP(2);
 
     // ---- conv2 (8 -> 8) + act on the tile+1 window ---------------------------
-    mfma_stage<24, 8, R2R, R2C, R1C, PS1>(sH1, breg2, wave, lane,
+    // B[k = (tap, ci)][n = (co, dd)] = W1[co][ci][ky4 - dd][kx]
+    auto bidx2 = [](int t, int g, int cN, int dd) {
+        const int tap = t >> 1, ci = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
+        return (ky >= 0 && ky <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
+    };
+    mfma_stage<24, 8, R2R, R2C, R1C, PS1>(sH1, sW, wave, lane, bidx2,
         [&](int co, const int (&o)[4], const bool (&ok)[4], double (&z)[4]) {
-            const double bias = sW[SW_B2 + co];
+            const double bias = sW[CB1 + co];
             double h[4], d[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) z[q] += bias;
@@ -248,9 +240,8 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const double v = sH2[ci * PS2 + (ar + ky) * R2C + ac + kx];
-                const double* wp = sW + SW_W3F + (ci * 9 + ky * 3 + kx) * 4;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc[k] = fma(v, wp[k], acc[k]);
+                for (int k = 0; k < 3; ++k) acc[k] = fma(v, sW[CW2 + (k * 8 + ci) * 9 + ky * 3 + kx], acc[k]);
             }
 #pragma unroll
         for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NAS + lane] = acc[k];
@@ -264,7 +255,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
     double Pa = 0.0, es = 0.0, ems = 0.0, cs2 = 0.0, sn2 = 0.0, sincs = 0.0, invD = 1.0;
     if (wave < NMIX && alane) {
         Pa = sP[(ar + 3) * R0C + ac + 3];
-        double sk = sW[SW_B3 + wave];
+        double sk = sW[CB2 + wave];
 #pragma unroll
         for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
         double sn, cs;
@@ -272,12 +263,12 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         es = exp(sk); ems = exp(-sk);
         cs2 = cs * cs; sn2 = sn * sn; sincs = sn * cs;
         invD = 1.0 / (ems * cs2 + es * sn2);
-        sT2[(wave * 4 + 1) * NAS + lane] = invD;
-        if (MODE == 0) sT2[(wave * 4 + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
+        sT2[(wave * TQ + 1) * NAS + lane] = invD;
+        if (MODE == 0) sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
     }
     double tval = 0.0;
     if (MODE == 0 && wave == 0 && alane) {
-        tval = sW[SW_B3 + 2];
+        tval = sW[CB2 + 2];
 #pragma unroll
         for (int q = 0; q < 8; ++q) tval += sST[(q * 3 + 2) * NAS + lane];
     }
@@ -288,7 +279,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         if (wave == 0) {
             double ysum = 0.0, si = 0.0;
 #pragma unroll
-            for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * 4) * NAS + (lane & (NAS - 1))]; si += sT2[(k * 4 + 1) * NAS + (lane & (NAS - 1))]; }
+            for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * TQ) * NAS + (lane & (NAS - 1))]; si += sT2[(k * TQ + 1) * NAS + (lane & (NAS - 1))]; }
             const double lj = avalid ? log(si) - log((double)NMIX) : 0.0;
             const double newP = ft_wrap(ysum / NMIX + tval);
             if (avalid) sDL[ar * TC + ac] = newP - Pa;
@@ -330,7 +321,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
             }
             double si = 0.0;
 #pragma unroll
-            for (int k = 0; k < NMIX; ++k) si += sT2[(k * 4 + 1) * NAS + lane];
+            for (int k = 0; k < NMIX; ++k) si += sT2[(k * TQ + 1) * NAS + lane];
             const double wk = invD / si;                           // softmax_k(-log D_k)
             const double sinP = 2.0 * sincs;
             gs = gdelta * (sinP * invD / NMIX) + cb * wk * (ems * cs2 - es * sn2) * invD;
@@ -338,18 +329,16 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         }
         // h1 / h2 are dead: clear the padded gz2 planes that alias them
         for (int t = tid; t < 8 * PS0; t += NT) sGZ2[t] = 0.0;
-        double breg4[24];
-        stage_prefetch<24>(w + WB2T, lane, breg4);
         __syncthreads();                                           // sST / sP / sT2[.][1] reads done
         for (int t = tid; t < 3 * N3; t += NT) sGO[t] = 0.0;
         for (int t = tid; t < N0; t += NT) sGP[t] = 0.0;
-        if (wave < NMIX && alane) sT2[(wave * 4 + 2) * NAS + lane] = gpk;
+        if (wave < NMIX && alane) sT2[(wave * TQ + 2) * NAS + lane] = gpk;
         __syncthreads();
         if (wave < NMIX && avalid) sGO[wave * N3 + ar * TC + ac] = gs;
         if (wave == 0 && avalid) {
             double gsum = -gdelta;
 #pragma unroll
-            for (int k = 0; k < NMIX; ++k) gsum += sT2[(k * 4 + 2) * NAS + lane];
+            for (int k = 0; k < NMIX; ++k) gsum += sT2[(k * TQ + 2) * NAS + lane];
             sGP[(ar + 3) * R0C + ac + 3] = gsum;
             sGO[NMIX * N3 + ar * TC + ac] = gdelta;               // dL/dt
         }
@@ -374,9 +363,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
 #pragma unroll
                         for (int co = 0; co < 3; ++co) {
                             const double gv = sGO[co * N3 + rr * TC + cc];
-                            const double* wp = sW + SW_W3B + ((co * 9 + ky * 3 + kx) * 8 + half * 4);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) acc[k] = fma(gv, wp[k], acc[k]);
+                            for (int k = 0; k < 4; ++k)
+                                acc[k] = fma(gv, sW[CW2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx], acc[k]);
                         }
                     }
                 }
@@ -391,7 +380,12 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         STAMP(7);
 
         // ---- conv2^T, times act'(z1) -> gz1 in place over d1 ------------------------
-        mfma_stage<24, 8, R1R, R1C, R0C, PS0>(sGZ2, breg4, wave, lane,
+        // B[k = (tap, co)][n = (ci, dd)] = W1[co][ci][2 - (ky4 - dd)][2 - kx]
+        auto bidx4 = [](int t, int g, int cN, int dd) {
+            const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
+            return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
+        };
+        mfma_stage<24, 8, R1R, R1C, R0C, PS0>(sGZ2, sW, wave, lane, bidx4,
             [&](int ci, const int (&o)[4], const bool (&ok)[4], double (&gh)[4]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -437,9 +431,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
                 for (int co = co0; co < co1; ++co) {
                     double gv[9], w0[9], w1[9];
                     const double* gz = sD1 + co * PS1;
-                    const double* wp = sW + SW_W1B + co * 18;
+                    const double* wp = sW + CW0 + co * 18;                     // W0[co][ci][tap]
 #pragma unroll
-                    for (int tp = 0; tp < 9; ++tp) { gv[tp] = gz[aoff[tp]]; w0[tp] = wp[tp * 2]; w1[tp] = wp[tp * 2 + 1]; }
+                    for (int tp = 0; tp < 9; ++tp) { gv[tp] = gz[aoff[tp]]; w0[tp] = wp[tp]; w1[tp] = wp[9 + tp]; }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int tp = 0; tp < 9; ++tp) {

@@ -34,7 +34,7 @@ constexpr int FLOW_TILE = 16;                 // VALU variant (flow.hip): 16 x 1
 constexpr int FLOW_R0 = FLOW_TILE + 6;        // plaquette / net-input window edge
 constexpr int FLOW_N0 = FLOW_R0 * FLOW_R0;    // window size of one gP partial
 constexpr int MF_TR = 8, MF_TC = 16;          // MFMA backward kernel: 8 x 16 sites per tile (forward: 16 x 16)
-constexpr int FLOW_WINT = 6016;               // doubles per layer, kernel-side weight layout
+constexpr int FLOW_WINT = 2944;               // doubles per layer, kernel-side weight layout
 constexpr int FLOW_GW_STRIDE = 960;           // doubles per (chain, tile) weight-gradient partial
 
 // tile geometry of a variant: partial buffers are indexed [chain][tile][window]

@@ -95,6 +95,7 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
+    local = local % torch.cuda.device_count()          # ranks may share a GPU in a gloo rehearsal
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     B = args.batch

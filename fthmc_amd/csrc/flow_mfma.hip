@@ -395,31 +395,35 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         STAMP(8);
 
         // ---- conv1^T and the (cos, sin) adjoint at frozen plaquettes ----------------
-        // Frozen and non-frozen window lines alternate in pairs (columns for mu = 0, rows for mu = 1).
-        // A non-frozen site has nothing of its own to do here, so it takes output-channel half
-        // [4, 8) of the frozen site two lines before it: every lane works and the per-lane
-        // dependent chain (LDS read -> mul -> 2 FMA per tap) is half as long.
+        // Frozen window lines come in pairs every 4 lines (columns for mu = 0, rows for mu = 1).
+        // Tasks = (frozen site, half of the 8 output channels), enumerated compactly: one round,
+        // every task a 4-channel chain (the stage is bound by the per-lane LDS-read -> FMA chain).
         {
             constexpr int R0R_ = G::R0R;
-            double* sHalf = sST;                                         // [2][N0] partial (g_cos, g_sin); g_out is dead
-            static_assert(2 * N0 <= 8 * 3 * NAS + NMIX * 4 * NAS, "helper partials must fit over ST|T2");
-            for (int t = tid; t < N0; t += NT) {
-                const int r = t / R0C, c = t - r * R0C;
-                const int line = mu == 0 ? c : r, nline = mu == 0 ? R0C : R0R_;
-                const int cls = ((mu == 0 ? j0 : i0) - 3 + line - off) & 3;      // stripe class of this window line
-                const bool frozen = (cls == 1 || cls == 2);
-                const bool helper = !frozen && line >= 2;                        // helps line - 2 (class 1 or 2)
-                if (!frozen && !helper) continue;
-                const int tr_ = frozen ? r : (mu == 0 ? r : r - 2);
-                const int tc_ = frozen ? c : (mu == 0 ? c - 2 : c);
-                const bool has_helper = frozen && (line + 2 < nline);
-                const int co0 = frozen ? 0 : 4, co1 = (frozen && !has_helper) ? 8 : co0 + 4;
+            double* sHalf = sST;                                         // [2 halves][2][N0] partial (g_cos, g_sin); g_out is dead
+            static_assert(2 * N0 <= 8 * 3 * NAS + NMIX * 4 * NAS, "half partials must fit over ST|T2");
+            const int nline = mu == 0 ? R0C : R0R_, nother = mu == 0 ? R0R_ : R0C;
+            const int phase = ((mu == 0 ? j0 : i0) - 3 - off) & 3;      // stripe class of window line 0
+            const int s1 = (1 - phase) & 3;                              // first line of class 1
+            const int lead = s1 == 3 ? 1 : 0;                            // line 0 is the 2nd half of a pair
+            const int nfl = lead + 2 * ((nline - s1 + 3) / 4);           // slots; a trailing one may fall outside
+            const int ntask = nfl * nother;
+            for (int t2 = tid; t2 < 2 * ntask; t2 += NT) {
+                const int half = t2 >= ntask, t = half ? t2 - ntask : t2;
+                // frozen-line index k fastest for mu = 0 (lanes walk along a window row), slowest for mu = 1
+                const int k = mu == 0 ? t % nfl : t / nother;
+                const int o = mu == 0 ? t / nfl : t % nother;
+                const int kk = k - lead;
+                const int line = (lead && k == 0) ? 0 : s1 + 4 * (kk >> 1) + (kk & 1);
+                if (line >= nline) continue;
+                const int r = mu == 0 ? o : line, c = mu == 0 ? line : o;
+                const int wt = r * R0C + c;
                 int aoff[9]; double msk[9];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const int rr = tr_ - ky, cc = tc_ - kx;
+                        const int rr = r - ky, cc = c - kx;
                         const bool ok = (rr >= 0) && (rr < R1R) && (cc >= 0) && (cc < R1C);
                         aoff[ky * 3 + kx] = ok ? rr * R1C + cc : 0;
                         msk[ky * 3 + kx] = ok ? 1.0 : 0.0;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
                 // then the 18 FMAs; left to itself the compiler waits after every single read
                 double gc[3] = {0.0, 0.0, 0.0}, gsn[3] = {0.0, 0.0, 0.0};
 #pragma unroll 1
-                for (int co = co0; co < co1; ++co) {
+                for (int co = half * 4; co < half * 4 + 4; ++co) {
                     double gv[9], w0[9], w1[9];
                     const double* gz = sD1 + co * PS1;
                     const double* wp = sW + CW0 + co * 18;                     // W0[co][ci][tap]
@@ -443,17 +447,14 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
                 }
                 const double gct = (gc[0] + gc[1]) + gc[2];
                 const double gst = (gsn[0] + gsn[1]) + gsn[2];
-                if (frozen) sGP[t] = -sIn[PS0 + t] * gct + sIn[t] * gst;           // own channels
-                else { const int wt = tr_ * R0C + tc_; sHalf[wt] = gct; sHalf[N0 + wt] = gst; }
+                if (half == 0) sGP[wt] = -sIn[PS0 + wt] * gct + sIn[wt] * gst;           // channels [0, 4)
+                else { sHalf[wt] = gct; sHalf[N0 + wt] = gst; }                           // channels [4, 8)
             }
             __syncthreads();
-            // second half: frozen sites with a helper add the helper's channels [4, 8)
             for (int t = tid; t < N0; t += NT) {
                 const int r = t / R0C, c = t - r * R0C;
-                const int line = mu == 0 ? c : r, nline = mu == 0 ? R0C : R0R_;
-                const int cls = ((mu == 0 ? j0 : i0) - 3 + line - off) & 3;
-                if ((cls == 1 || cls == 2) && line + 2 < nline)
-                    sGP[t] += -sIn[PS0 + t] * sHalf[t] + sIn[t] * sHalf[N0 + t];
+                const int cls = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;
+                if (cls == 1 || cls == 2) sGP[t] += -sIn[PS0 + t] * sHalf[t] + sIn[t] * sHalf[N0 + t];
             }
         }
         __syncthreads();

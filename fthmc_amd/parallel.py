@@ -27,9 +27,11 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, ws, local = world()
     if ws > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # FTHMC_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a 1-GPU box;
+            # RCCL refuses two ranks on the same device)
+            backend = os.environ.get('FTHMC_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
     return rank, ws, local

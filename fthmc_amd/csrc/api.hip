@@ -24,13 +24,13 @@ constexpr size_t ALIGN = 32;   // doubles (256 B)
 inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct WS {
-    double *wint, *X, *gp, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part;
+    double *wint, *X, *gp, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *stash;
     size_t n2;       // doubles per field batch: B * 2 * L * L
     size_t total;    // doubles
 };
 
 // scal slots, each B doubles
-enum { SC_S = 0, SC_Q, SC_PLAQ, SC_LOGDET, SC_K, SC_H0, SC_H1, SC_OLD0, SC_OLD1, SC_NEW0, SC_NEW1, SC_SEFF, SC_N };
+enum { SC_S = 0, SC_Q, SC_PLAQ, SC_LOGDET, SC_K, SC_H0, SC_H1, SC_OLD0, SC_OLD1, SC_OLD2, SC_NEW0, SC_NEW1, SC_NEW2, SC_SEFF, SC_N };
 
 WS ws_layout(double* base, int B, int L, int nl) {
     WS w{};
@@ -47,6 +47,7 @@ WS ws_layout(double* base, int B, int L, int nl) {
     w.scal = take((size_t)SC_N * B);
     w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
     w.gw_part = take(nl > 0 ? (size_t)B * nt * FLOW_GW_STRIDE : 0);
+    w.stash = take((size_t)nl * flow_stash_doubles(B, L));      // activation stash of a force evaluation
     w.total = o;
     return w;
 }
@@ -67,9 +68,10 @@ inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
 
 // Forward sweep x -> X[0..nl-1] (X[l] = output of layer l).  logdet (device [B]) optional.
 int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, double* logdet,
-                  hipStream_t s) {
+                  hipStream_t s, bool stash = false) {
     for (int l = 0; l < nl; ++l) {
         FlowLayerArgs a{};
+        a.stash = stash ? w.stash + (size_t)l * flow_stash_doubles(B, L) : nullptr;
         a.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
         a.wint = w.wint + (size_t)l * FLOW_WINT;
         a.y = w.X + (size_t)l * w.n2;
@@ -100,7 +102,10 @@ int eval_action(const double* x, const WS& w, int nl, int B, int L, int act, dou
 // with dL/dlogJ = glogj.  gw != null also accumulates weight gradients (training).
 int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double beta_scaled,
              double glogj, double* gw, hipStream_t s) {
-    if (nl > 0) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s));
+    // MFMA path without weight gradients: the forward sweep stashes act'(z1), act'(z2), s per site
+    // and the backward kernels read them back instead of recomputing the network
+    const bool stash = (gw == nullptr) && get_flow_variant() == 1;
+    if (nl > 0) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s, stash));
     FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, w.gp, s));
     for (int l = nl - 1; l >= 0; --l) {
         FlowLayerArgs a{};
@@ -111,7 +116,8 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
         a.gp_part = w.gp_part;
         a.gw_part = w.gw_part;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
-        FT_TRY(flow_bwd(a, gw != nullptr, s));
+        a.stash = stash ? w.stash + (size_t)l * flow_stash_doubles(B, L) : nullptr;
+        FT_TRY(stash ? launch_flow_bwd_stash(a, s) : flow_bwd(a, gw != nullptr, s));
         if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0,
                                         gw + (size_t)l * FTHMC_W_PER_LAYER, s));
         FT_TRY(launch_gather_gp(w.gp_part, B, L, flow_geom(bwd_is_mfma(gw != nullptr)), 1, w.gp, s));
@@ -367,21 +373,28 @@ int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, int n_l
 int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w, int n_layers,
                         int B, int L, int act, double beta, double dt, int nstep, int mode, double* x_new,
                         double* dH, double* acc, double* H0, double* H1, double* plaq, double* Q,
+                        const double* state_in, double* state_out,
                         void* ws, size_t ws_bytes, void* stream) {
     if (!x || !v || !u || !x_new || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0 || nstep < 1)
         return FTHMC_ERR_ARG;
     if (act < 0 || act > 2 || (mode != FTHMC_MODE_MD && mode != FTHMC_MODE_LITERAL)) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
-    double* K = W.scal + (size_t)SC_K * B; double* Se = W.scal + (size_t)SC_SEFF * B;
+    double* K = W.scal + (size_t)SC_K * B;
     double* h0 = H0 ? H0 : W.scal + (size_t)SC_H0 * B;
     double* h1 = H1 ? H1 : W.scal + (size_t)SC_H1 * B;
-    double* old = W.scal + (size_t)SC_OLD0 * B;      // [plaq, Q] of F(x)
-    double* neu = W.scal + (size_t)SC_NEW0 * B;      // [plaq, Q] of F(proposal)
-    double* obs = nullptr;
+    // per-chain state triples [S_eff, plaq, Q]: of x (old), of the proposal (neu), of x_new (sel)
+    double* old = W.scal + (size_t)SC_OLD0 * B;      // slots SC_OLD0.. : 3 consecutive
+    double* neu = W.scal + (size_t)SC_NEW0 * B;
+    double* sel = state_out ? state_out : W.scal + (size_t)SC_S * B;
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
-    FT_TRY(eval_action(x, W, n_layers, B, L, act, beta, Se, nullptr, old, old + B, s));
+    if (state_in) {       // chained trajectories: S_eff and observables of x are the previous call's state_out
+        if (hipMemcpyAsync(old, state_in, (size_t)3 * B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return FTHMC_ERR_LAUNCH;
+    } else {
+        FT_TRY(eval_action(x, W, n_layers, B, L, act, beta, old, nullptr, old + B, old + 2 * B, s));
+    }
     FT_TRY(launch_kinetic(v, B, L, K, s));
-    FT_TRY(launch_lincomb(Se, 1.0, K, 0.5, 0.0, h0, B, s));
+    FT_TRY(launch_lincomb(old, 1.0, K, 0.5, 0.0, h0, B, s));
     const double* vend;
     if (mode == FTHMC_MODE_MD) {
         FT_TRY(ft_leapfrog_ws(x, v, W, n_layers, B, L, act, beta, dt, nstep, s));
@@ -392,16 +405,14 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
         FT_TRY(launch_wrap(W.xa, W.xb, W.n2, 0, s));              // wrap (ft_hmc.py:208)
         vend = v;
     }
-    FT_TRY(eval_action(W.xb, W, n_layers, B, L, act, beta, Se, nullptr, neu, neu + B, s));
+    FT_TRY(eval_action(W.xb, W, n_layers, B, L, act, beta, neu, nullptr, neu + B, neu + 2 * B, s));
     FT_TRY(launch_kinetic(vend, B, L, K, s));
-    FT_TRY(launch_lincomb(Se, 1.0, K, 0.5, 0.0, h1, B, s));
-    // observables of F(x_new) without another sweep: select per chain
-    double* sel = W.scal + (size_t)SC_S * B;          // reuse S, Q slots (adjacent) as [plaq, Q] out
-    if (plaq || Q) obs = sel;
-    FT_TRY(launch_metropolis(x, W.xb, u, h0, h1, B, L, 0, x_new, dH, acc, old, neu, obs, obs ? 2 : 0, s));
-    if (plaq && hipMemcpyAsync(plaq, sel, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    FT_TRY(launch_lincomb(neu, 1.0, K, 0.5, 0.0, h1, B, s));
+    // state of x_new without another sweep: select per chain
+    FT_TRY(launch_metropolis(x, W.xb, u, h0, h1, B, L, 0, x_new, dH, acc, old, neu, sel, 3, s));
+    if (plaq && hipMemcpyAsync(plaq, sel + B, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return FTHMC_ERR_LAUNCH;
-    if (Q && hipMemcpyAsync(Q, sel + B, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    if (Q && hipMemcpyAsync(Q, sel + 2 * B, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return FTHMC_ERR_LAUNCH;
     return FTHMC_OK;
 }
@@ -445,6 +456,10 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
         a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
         a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part;
         a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+        if (get_flow_variant() == 1) {            // the hot path: forward stashes, backward reads the stash
+            a.stash = W.stash;
+            FT_TRY(launch_flow_fwd_mfma(a, s));
+        }
     } else {
         FT_TRY(launch_random_momenta(reinterpret_cast<const int64_t*>(x), B, 2 * L * L, W.va, nullptr, s));
     }
@@ -452,7 +467,7 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
         if (it == 0) hipEventRecord(e0, s);
         if (kind == 0) rc = flow_fwd(a, s);
-        else if (kind == 1) rc = flow_bwd(a, false, s);
+        else if (kind == 1) rc = a.stash ? launch_flow_bwd_stash(a, s) : flow_bwd(a, false, s);
         else rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
     }
     hipEventRecord(e1, s);
@@ -466,9 +481,9 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
 
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 1) return FTHMC_ERR_ARG;
+    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
     FT_WS(1);
-    const size_t nrec = (size_t)B * flow_geom(kind == 1).ntiles(L);   // forward runs on 16 x 16 tiles
+    const size_t nrec = (size_t)B * flow_geom(kind >= 1).ntiles(L);   // forward runs on 16 x 16 tiles
     long long* dbg = reinterpret_cast<long long*>(W.gw_part);      // B*ntiles*960 doubles >> 16 stamps each
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FT_TRY(launch_pack_weights(w, 1, W.wint, s));
@@ -477,7 +492,12 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
     a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
     a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.dbg = dbg;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : launch_flow_bwd_mfma(a, s));
+    if (kind == 1) {                              // stash backward needs the forward's stash first
+        a.stash = W.stash; a.dbg = nullptr;
+        FT_TRY(launch_flow_fwd_mfma(a, s));
+        a.dbg = dbg;
+    }
+    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : kind == 1 ? launch_flow_bwd_stash(a, s) : launch_flow_bwd_mfma(a, s));
     long long* h = (long long*)malloc(nrec * 16 * sizeof(long long));
     if (!h) return FTHMC_ERR_ARG;
     if (hipMemcpyAsync(h, dbg, nrec * 16 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -485,7 +505,7 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
     for (int k = 0; k < 16; ++k) cycles_host16[k] = 0.0;
     for (size_t r = 0; r < nrec; ++r)
         for (int k = 1; k < 16; ++k) {
-            const int ref = k <= 10 ? k - 1 : 1;           // slots 11..15: cycles since the start of conv1
+            const int ref = k - 1;
             if (h[r * 16 + k] && h[r * 16 + ref]) cycles_host16[k] += (double)(h[r * 16 + k] - h[r * 16 + ref]) / nrec;
         }
     free(h);

@@ -477,9 +477,28 @@ __global__ void k_gather_gp(const double* __restrict__ part, int L, int tr, int 
     const int n = L * L;
     const int ntiles = nti * ntj;
     const int wr = tr + 6, wc = tc + 6, n0 = wr * wc;
+    const bool fast = nti >= 4 && ntj >= 4 && nti * tr == L && ntj * tc == L;   // windows never wrap onto themselves
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
         const int i = s / L, j = s - i * L;
         double acc = 0.0;
+        if (fast) {
+            // a site lies in its own tile's window and in at most one neighbour's per dimension
+            const int ci = i / tr, cj = j / tc, li = i - ci * tr, lj = j - cj * tc;
+            int ti[2], ri[2], tj[2], rj[2];
+            int ni = 1, nj = 1;
+            ti[0] = ci; ri[0] = li + 3;
+            if (li < 3) { ti[1] = ci == 0 ? nti - 1 : ci - 1; ri[1] = li + tr + 3; ni = 2; }
+            else if (li >= tr - 3) { ti[1] = ci + 1 == nti ? 0 : ci + 1; ri[1] = li - tr + 3; ni = 2; }
+            tj[0] = cj; rj[0] = lj + 3;
+            if (lj < 3) { tj[1] = cj == 0 ? ntj - 1 : cj - 1; rj[1] = lj + tc + 3; nj = 2; }
+            else if (lj >= tc - 3) { tj[1] = cj + 1 == ntj ? 0 : cj + 1; rj[1] = lj - tc + 3; nj = 2; }
+            // same fixed order as the general path: tiles ascending in (di, dj) of [c-1, c, c+1]
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int a = 0; a < ni; ++a)
+                for (int c2 = 0; c2 < nj; ++c2)
+                    v[a * 2 + c2] = part[((size_t)b * ntiles + ti[a] * ntj + tj[c2]) * n0 + ri[a] * wc + rj[c2]];
+            acc = ((v[0] + v[1]) + v[2]) + v[3];
+        } else {
         // candidate tiles per dimension: all of them when there are <= 3, else own and both neighbours
         const int ni = nti <= 3 ? nti : 3, bi = nti <= 3 ? 0 : i / tr - 1;
         const int nj = ntj <= 3 ? ntj : 3, bj = ntj <= 3 ? 0 : j / tc - 1;
@@ -493,6 +512,7 @@ __global__ void k_gather_gp(const double* __restrict__ part, int L, int tr, int 
                     const double* p = part + ((size_t)b * ntiles + ti * ntj + tj) * n0 + r * wc;
                     for (int c = c0; c < wc; c += L) acc += p[c];
                 }
+        }
         }
         const size_t o = (size_t)b * n + s;
         gp[o] = (accumulate ? gp[o] : 0.0) + acc;

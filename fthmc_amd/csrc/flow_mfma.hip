@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         const int sel = ft_stripe(i, j, mu, off);
         const bool frozen = (sel == 1 || sel == 2);
         double sn = 0.0, cs = 1.0;
-        if (frozen) sincos(p, &sn, &cs);
+        if (frozen) ft_sincos(p, &sn, &cs);
         sP[t] = p;
         sIn[t] = cs;
         sIn[PS0 + t] = sn;
@@ -201,6 +201,14 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (ok[q]) { sH1[co * PS1 + o[q]] = h[q]; if (BWD) sD1[co * PS1 + o[q]] = d[q]; }
+            if (MODE == 0 && A.stash) {                                  // act'(z1) of the tile's own sites
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = o[q] / R1C - 2, c = o[q] % R1C - 2, i = i0 + r, j = j0 + c;
+                    if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L)
+                        A.stash[(((size_t)b * 8 + co) * L + i) * L + j] = d[q];
+                }
+            }
         });
     __syncthreads();
     STAMP(2);
@@ -221,6 +229,14 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (ok[q]) { sH2[co * PS2 + o[q]] = h[q]; if (BWD) sD2[co * PS2 + o[q]] = d[q]; }
+            if (MODE == 0 && A.stash) {                                  // act'(z2) of the tile's own sites
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = o[q] / R2C - 1, c = o[q] % R2C - 1, i = i0 + r, j = j0 + c;
+                    if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L)
+                        A.stash[(((size_t)(A.B + b) * 8 + co) * L + i) * L + j] = d[q];
+                }
+            }
         });
     __syncthreads();
     STAMP(3);
@@ -258,9 +274,11 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
         double sk = sW[CB2 + wave];
 #pragma unroll
         for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
+        if (MODE == 0 && A.stash && avalid)
+            A.stash[(((size_t)A.B * 16 + (size_t)b * 2 + wave) * L + ai) * L + aj] = sk;
         double sn, cs;
-        sincos(Pa / 2, &sn, &cs);
-        es = exp(sk); ems = exp(-sk);
+        ft_sincos(Pa / 2, &sn, &cs);
+        es = ft_exp(sk); ems = ft_exp(-sk);
         cs2 = cs * cs; sn2 = sn * sn; sincs = sn * cs;
         invD = 1.0 / (ems * cs2 + es * sn2);
         sT2[(wave * TQ + 1) * NAS + lane] = invD;
@@ -465,6 +483,282 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward wrt x from stashed activations: the forward sweep of a force evaluation already
+// produced act'(z1), act'(z2) and s for every site (16 + 2 doubles per site and layer, written by
+// k_flow_mfma<0>), so this kernel skips conv1, conv2, both activation passes and conv3 and only
+// walks the adjoint: transform adjoint -> conv3^T -> conv2^T (MFMA) -> conv1^T.
+// HBM: 144 B/site/layer read here (+ halo re-reads out of L2) instead of ~50 % more DP work.
+template <int TR, int TC> struct SmemS {
+    using G = Geom<TR, TC>;
+    static constexpr int IN = 0;                              // [2][PS0] cos, sin of frozen plaquettes
+    static constexpr int GP = IN + 2 * G::PS0;                // [N0] partial plaquette gradient
+    static constexpr int GZ2 = GP + G::PS0;                   // [8][PS0] ring-2 padded gz2
+    static constexpr int D1 = GZ2 + 8 * G::PS0;               // [8][PS1] act'(z1) -> gz1
+    static constexpr int D2 = D1 + 8 * G::PS1;                // [8][PS2] act'(z2)
+    static constexpr int GO = D2 + 8 * G::PS2;                // [3][N3] g(s0, s1, t)
+    static constexpr int T2 = GO + 3 * G::N3;                 // [NMIX][4][NAS]
+    static constexpr int SW = T2 + NMIX * 4 * G::NAS;         // [SW_SIZE]
+    static constexpr int SIZE = SW + SW_SIZE;
+};
+
+template <int TR, int TC>
+__global__ __launch_bounds__(NT, 4) void k_flow_bwd_stash(FlowLayerArgs A) {
+    using S = SmemS<TR, TC>;
+    using G = Geom<TR, TC>;
+    constexpr int R0R = G::R0R, R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
+    constexpr int N0 = G::N0, N1 = G::N1, N2 = G::N2, N3 = G::N3, NA = G::NA, NAS = G::NAS;
+    constexpr int PS0 = G::PS0, PS1 = G::PS1, PS2 = G::PS2;
+    __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
+    double* sIn = sm + S::IN;  double* sGP = sm + S::GP;  double* sGZ2 = sm + S::GZ2;
+    double* sD1 = sm + S::D1;  double* sD2 = sm + S::D2;  double* sGO = sm + S::GO;
+    double* sT2 = sm + S::T2;  double* sW = sm + S::SW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = A.L, mu = A.mu, off = A.off;
+    const int n = L * L;
+    const int b = blockIdx.z;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    const int ntiles = gridDim.x * gridDim.y;
+    const int i0 = blockIdx.y * TR, j0 = blockIdx.x * TC;
+    const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
+    const double* __restrict__ x1 = x0 + n;
+    const double* __restrict__ w = A.wint;
+    const double* __restrict__ st1 = A.stash + (size_t)b * 8 * n;                   // act'(z1)[8][L][L]
+    const double* __restrict__ st2 = A.stash + ((size_t)A.B + b) * 8 * n;           // act'(z2)[8][L][L]
+    const double* __restrict__ sts = A.stash + ((size_t)A.B * 16 + (size_t)b * 2) * n;   // s[2][L][L]
+    long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
+    STAMP(0);
+
+    // Wrapped lattice coordinates of the window lines, once per workgroup (row offsets premultiplied
+    // by L): the loaders below do no integer division.
+    __shared__ int sWrapI[R0R + 1], sWrapJ[R0C + 1];
+    if (tid <= R0R) sWrapI[tid] = ft_modL(i0 - 3 + tid, L) * L;
+    else if (tid >= 64 && tid <= 64 + R0C) sWrapJ[tid - 64] = ft_modL(j0 - 3 + tid - 64, L);
+    __syncthreads();
+
+    // ---- load phase: every global load of the kernel is issued here, back to back, before any of
+    //      them is consumed (three dependent round trips to L2/HBM cost ~12k cycles otherwise) ----
+    const int ar = mu == 0 ? lane / (TC / 4) : off + 4 * (lane / TC);
+    const int ac = mu == 0 ? off + 4 * (lane % (TC / 4)) : lane % TC;
+    const int ai = i0 + ar, aj = j0 + ac;
+    const bool alane = lane < NA;
+    const bool avalid = alane && (ai < L) && (aj < L);
+    // the transform runs on the last waves: waves 0..4 hold the window sites (sincos) of this stage
+    const int kmix = wave - (NW - NMIX);                                 // mixture component of this wave
+    const bool awave = kmix >= 0 && avalid;
+    double aP[4] = {0.0, 0.0, 0.0, 0.0}, ask = 0.0, ag[2] = {0.0, 0.0}, cb = 0.0;
+    if (awave) {
+        const int iL = sWrapI[ar + 3], ipL = sWrapI[ar + 4], j = sWrapJ[ac + 3], jp = sWrapJ[ac + 4];
+        aP[0] = x0[iL + j]; aP[1] = x1[iL + j]; aP[2] = x0[iL + jp]; aP[3] = x1[ipL + j];
+        ask = sts[(size_t)kmix * n + iL + j];
+        cb = A.glogj ? A.glogj[b] : A.glogj_const;
+        if (A.up_link) {
+            ag[0] = A.up_link[(size_t)b * 2 * n + (size_t)mu * n + iL + j];
+        } else {
+            const double* gp = A.up_gp + (size_t)b * n;
+            ag[0] = gp[iL + j];
+            ag[1] = mu == 0 ? gp[iL + sWrapJ[ac + 2]] : gp[sWrapI[ar + 2] + j];
+        }
+    }
+    // stash windows: a thread owns one window column (32 lanes per plane-row, R1C / R2C of them
+    // active) and walks plane-rows (channel, row) in steps of NT / 32: the address is
+    // plane-row base + its fixed wrapped column, no per-element index arithmetic
+    constexpr int G32 = NT / 32;                                         // plane-rows per pass
+    constexpr int PR1 = 8 * R1R, PR2 = 8 * R2R;                          // plane-rows of the two windows
+    constexpr int NP1 = (PR1 + G32 - 1) / G32, NP2 = (PR2 + G32 - 1) / G32;
+    const int lc = tid & 31, lg = tid >> 5;
+    const int wj1 = sWrapJ[(lc < R1C ? lc : 0) + 1], wj2 = sWrapJ[(lc < R2C ? lc : 0) + 2];
+    double v1[NP1], v2[NP2];
+#pragma unroll
+    for (int k = 0; k < NP1; ++k) {
+        const int pr = lg + k * G32, ch = pr / R1R, r = pr - ch * R1R;
+        v1[k] = (lc < R1C && pr < PR1) ? st1[(size_t)ch * n + sWrapI[r + 1] + wj1] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < NP2; ++k) {
+        const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
+        v2[k] = (lc < R2C && pr < PR2) ? st2[(size_t)ch * n + sWrapI[r + 2] + wj2] : 0.0;
+    }
+    static_assert(N0 <= NT, "one window site per thread");
+    const int wr = tid / R0C, wc = tid - wr * R0C;
+    const bool wfrozen = tid < N0 && ((((mu == 0 ? j0 + wc : i0 + wr) - 3 - off) & 3) == 1 ||
+                                      (((mu == 0 ? j0 + wc : i0 + wr) - 3 - off) & 3) == 2);
+    double wP[4] = {0.0, 0.0, 0.0, 0.0};
+    if (wfrozen) {
+        const int iL = sWrapI[wr], ipL = sWrapI[wr + 1], j = sWrapJ[wc], jp = sWrapJ[wc + 1];
+        wP[0] = x0[iL + j]; wP[1] = x1[iL + j]; wP[2] = x0[iL + jp]; wP[3] = x1[ipL + j];
+    }
+    double wsw[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wsw[k] = (tid + k * NT < SW_SIZE) ? w[WCAN + tid + k * NT] : 0.0;
+    static_assert(SW_SIZE <= 2 * NT, "weight copy");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- consume: LDS clears and stores first (no dependence on the loads' values order) ------
+    for (int t = tid; t < 8 * PS0; t += NT) sGZ2[t] = 0.0;
+    for (int t = tid; t < 3 * N3; t += NT) sGO[t] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) if (tid + k * NT < SW_SIZE) sW[tid + k * NT] = wsw[k];
+    double es = 0.0, ems = 0.0, cs2 = 0.0, sn2 = 0.0, sincs = 0.0, invD = 1.0, gdelta = 0.0;
+    if (awave) {
+        const double Pa = aP[0] - aP[1] - aP[2] + aP[3];
+        gdelta = A.up_link ? (mu == 0 ? ag[0] : -ag[0]) : ag[0] - ag[1];
+        double sn, cs;
+        ft_sincos(Pa / 2, &sn, &cs);
+        es = ft_exp(ask); ems = ft_exp(-ask);
+        cs2 = cs * cs; sn2 = sn * sn; sincs = sn * cs;
+        invD = 1.0 / (ems * cs2 + es * sn2);
+        sT2[(kmix * 4 + 1) * NAS + lane] = invD;
+    }
+    if (tid < N0) {
+        double sn = 0.0, cs = 1.0;
+        if (wfrozen) ft_sincos(wP[0] - wP[1] - wP[2] + wP[3], &sn, &cs);
+        sIn[tid] = cs; sIn[PS0 + tid] = sn; sGP[tid] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < NP1; ++k) {
+        const int pr = lg + k * G32, ch = pr / R1R, r = pr - ch * R1R;
+        if (lc < R1C && pr < PR1) sD1[ch * PS1 + r * R1C + lc] = v1[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NP2; ++k) {
+        const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
+        if (lc < R2C && pr < PR2) sD2[ch * PS2 + r * R2C + lc] = v2[k];
+    }
+    __syncthreads();
+    STAMP(1);
+
+    // ---- adjoint of the tan-mixture transform at the tile's own active sites -----------------
+    if (awave) {
+        double si = 0.0;
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) si += sT2[(k * 4 + 1) * NAS + lane];
+        const double wk = invD / si;                               // softmax_k(-log D_k)
+        const double sinP = 2.0 * sincs;
+        sGO[kmix * N3 + ar * TC + ac] = gdelta * (sinP * invD / NMIX) + cb * wk * (ems * cs2 - es * sn2) * invD;
+        sT2[(kmix * 4 + 2) * NAS + lane] = gdelta * (invD / NMIX) - cb * wk * sinP * 0.5 * (es - ems) * invD;
+    }
+    __syncthreads();
+    if (kmix == 0 && avalid) {
+        double gsum = -gdelta;
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) gsum += sT2[(k * 4 + 2) * NAS + lane];
+        sGP[(ar + 3) * R0C + ac + 3] = gsum;
+        sGO[NMIX * N3 + ar * TC + ac] = gdelta;                   // dL/dt
+    }
+    __syncthreads();
+    STAMP(2);
+
+    // ---- conv3^T on the VALU (9 of 27 taps: g_out lives on the active stripe) -> padded gz2 ----
+    for (int t = tid; t < 2 * N2; t += NT) {
+        const int half = t >= N2;
+        const int s = half ? t - N2 : t;
+        const int r = s / R2C, c = s - r * R2C;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        const int ksel = ((mu == 0 ? c : r) - off) & 3;
+        if (ksel <= 2) {
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
+                const int rr = r - ky, cc = c - kx;
+                if (rr >= 0 && rr < TR && cc >= 0 && cc < TC) {
+#pragma unroll
+                    for (int co = 0; co < 3; ++co) {
+                        const double gv = sGO[co * N3 + rr * TC + cc];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            acc[k] = fma(gv, sW[CW2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx], acc[k]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = half * 4 + k;
+            sGZ2[ci * PS0 + (r + 2) * R0C + c + 2] = acc[k] * sD2[ci * PS2 + s];
+        }
+    }
+    __syncthreads();
+    STAMP(3);
+
+    // ---- conv2^T (MFMA), times act'(z1) -> gz1 in place over d1 -------------------------------
+    auto bidx4 = [](int t, int g, int cN, int dd) {
+        const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
+        return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
+    };
+    mfma_stage<24, 8, R1R, R1C, R0C, PS0>(sGZ2, sW, wave, lane, bidx4,
+        [&](int ci, const int (&o)[4], const bool (&ok)[4], double (&gh)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ok[q]) sD1[ci * PS1 + o[q]] *= gh[q];
+        });
+    __syncthreads();
+    STAMP(4);
+
+    // ---- conv1^T and the (cos, sin) adjoint at frozen plaquettes -------------------------------
+    {
+        double* sHalf = sGZ2;                                            // gz2 is consumed
+        const int nline = mu == 0 ? R0C : R0R, nother = mu == 0 ? R0R : R0C;
+        const int phase = ((mu == 0 ? j0 : i0) - 3 - off) & 3;
+        const int s1 = (1 - phase) & 3;
+        const int lead = s1 == 3 ? 1 : 0;
+        const int nfl = lead + 2 * ((nline - s1 + 3) / 4);
+        const int ntask = nfl * nother;
+        for (int t2 = tid; t2 < 2 * ntask; t2 += NT) {
+            const int half = t2 >= ntask, t = half ? t2 - ntask : t2;
+            const int k = mu == 0 ? t % nfl : t / nother;
+            const int o = mu == 0 ? t / nfl : t % nother;
+            const int kk = k - lead;
+            const int line = (lead && k == 0) ? 0 : s1 + 4 * (kk >> 1) + (kk & 1);
+            if (line >= nline) continue;
+            const int r = mu == 0 ? o : line, c = mu == 0 ? line : o;
+            const int wt = r * R0C + c;
+            int aoff[9]; double msk[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int rr = r - ky, cc = c - kx;
+                    const bool ok = (rr >= 0) && (rr < R1R) && (cc >= 0) && (cc < R1C);
+                    aoff[ky * 3 + kx] = ok ? rr * R1C + cc : 0;
+                    msk[ky * 3 + kx] = ok ? 1.0 : 0.0;
+                }
+            double gc[3] = {0.0, 0.0, 0.0}, gsn[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int co = half * 4; co < half * 4 + 4; ++co) {
+                double gv[9], w0[9], w1[9];
+                const double* gz = sD1 + co * PS1;
+                const double* wp = sW + CW0 + co * 18;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) { gv[tp] = gz[aoff[tp]]; w0[tp] = wp[tp]; w1[tp] = wp[9 + tp]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const double g_ = gv[tp] * msk[tp];
+                    gc[tp % 3] = fma(g_, w0[tp], gc[tp % 3]); gsn[tp % 3] = fma(g_, w1[tp], gsn[tp % 3]);
+                }
+            }
+            const double gct = (gc[0] + gc[1]) + gc[2];
+            const double gst = (gsn[0] + gsn[1]) + gsn[2];
+            if (half == 0) sGP[wt] = -sIn[PS0 + wt] * gct + sIn[wt] * gst;
+            else { sHalf[wt] = gct; sHalf[N0 + wt] = gst; }
+        }
+        __syncthreads();
+        double* out = A.gp_part + ((size_t)b * ntiles + tile) * N0;
+        for (int t = tid; t < N0; t += NT) {
+            const int r = t / R0C, c = t - r * R0C;
+            const int cls = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;
+            double v = sGP[t];
+            if (cls == 1 || cls == 2) v += -sIn[PS0 + t] * sHalf[t] + sIn[t] * sHalf[N0 + t];
+            out[t] = v;
+        }
+    }
+    STAMP(5);
+}
+
 int g_variant = 1;
 
 }  // namespace
@@ -478,6 +772,11 @@ int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     // forward needs half the LDS of backward: 16 x 16 tiles (less halo work) still fit twice per CU
     const dim3 grid((a.L + FLOW_TILE - 1) / FLOW_TILE, (a.L + FLOW_TILE - 1) / FLOW_TILE, a.B);
     hipLaunchKernelGGL((k_flow_mfma<0, FLOW_TILE, FLOW_TILE>), grid, dim3(NT), 0, s, a);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_flow_bwd_stash(const FlowLayerArgs& a, hipStream_t s) {
+    const dim3 grid((a.L + MF_TC - 1) / MF_TC, (a.L + MF_TR - 1) / MF_TR, a.B);
+    hipLaunchKernelGGL((k_flow_bwd_stash<MF_TR, MF_TC>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s) {

@@ -71,6 +71,7 @@ struct FlowLayerArgs {
     double* gw_part;         // bwd with wgrad: [B*ntiles][FLOW_GW_STRIDE]
     double tol;              // rev
     long long* dbg;          // optional: per-(chain,tile) stage time stamps [16] (diagnostic runs only)
+    double* stash;           // optional: this layer's activation stash (MFMA forward writes, stash backward reads)
     int B, L, mu, off, act;
 };
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);
@@ -79,6 +80,10 @@ int launch_flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s);
 // flow_mfma.hip: MFMA variants of forward / backward-wrt-x (same arguments and results)
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s);
+// backward wrt x from the activations the MFMA forward kernel stashed for this layer (a.stash)
+int launch_flow_bwd_stash(const FlowLayerArgs& a, hipStream_t s);
+// doubles per layer of the stash: act'(z1)[B][8][L][L], act'(z2)[B][8][L][L], s[B][2][L][L]
+inline size_t flow_stash_doubles(int B, int L) { return (size_t)B * 18 * L * L; }
 // 0: VALU kernels everywhere; 1 (default): MFMA kernels for forward and backward-wrt-x
 void set_flow_variant(int v);
 int get_flow_variant();

@@ -283,11 +283,12 @@ def ft_leapfrog(x, v, w, n_layers: int, beta: float, dt: float, nstep: int, act=
 
 
 def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', mode='md',
-                  out: Optional[dict] = None):
-    """One ftHMC trajectory per chain -> dict(x_new, dH, acc, H0, H1, plaq, Q).
+                  out: Optional[dict] = None, state_in: Optional[torch.Tensor] = None):
+    """One ftHMC trajectory per chain -> dict(x_new, dH, acc, H0, H1, plaq, Q, state).
 
-    `out` may carry preallocated output tensors (same keys) so that a caller can
-    replay the call inside a captured graph."""
+    `out` may carry preallocated output tensors (same keys) so that a caller can replay the call
+    inside a captured graph.  `state` is [3, B] = (S_eff, plaq, Q) of x_new; fed back as `state_in`
+    of the next trajectory of the same chains (x = x_new) it saves that call's H0 flow sweep."""
     x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
     if u.numel() != B:
         raise FthmcError(f'u: expected {B} uniforms, got {u.numel()}')
@@ -296,11 +297,18 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
         out = {'x_new': torch.empty_like(x)}
         for k in ('dH', 'acc', 'H0', 'H1', 'plaq', 'Q'):
             out[k] = torch.empty(B, dtype=x.dtype, device=x.device)
+    if 'state' not in out:
+        out['state'] = torch.empty(3, B, dtype=x.dtype, device=x.device)
+    if state_in is not None:
+        state_in = _dev(state_in, 'state_in')
+        if state_in.numel() != 3 * B:
+            raise FthmcError(f'state_in: expected [3, {B}]')
     m = {'md': MODE_MD, 'literal': MODE_LITERAL, 'reference_literal': MODE_LITERAL}[mode]
     ws, nb = _ws(x, B, L, n_layers)
     check(_lib.load().fthmc_ft_trajectory(_p(x), _p(v), _p(u), _p(w), n_layers, B, L, act_code(act), float(beta),
                                           float(dt), int(nstep), m, _p(out['x_new']), _p(out['dH']), _p(out['acc']),
-                                          _p(out['H0']), _p(out['H1']), _p(out['plaq']), _p(out['Q']), ws, nb,
+                                          _p(out['H0']), _p(out['H1']), _p(out['plaq']), _p(out['Q']),
+                                          _p(state_in), _p(out['state']), ws, nb,
                                           _stream(x)), 'fthmc_ft_trajectory')
     return out
 
@@ -336,7 +344,7 @@ def profile_stages(kind: str, x, w, mu=0, off=0, act='silu', beta=1.0):
     """Mean cycles per stage of one MFMA coupling-layer kernel launch ('flow_fwd' | 'flow_bwd')."""
     import ctypes
     x = _field(x); B, _, L, _ = x.shape
-    k = {'flow_fwd': 0, 'flow_bwd': 1}[kind]
+    k = {'flow_fwd': 0, 'flow_bwd': 1, 'flow_bwd_recompute': 2}[kind]
     buf = (ctypes.c_double * 16)()
     ws, nb = _ws(x, B, L, 1)
     check(_lib.load().fthmc_profile_stages(k, _p(x), _p(_w1(w, x)), B, L, int(mu), int(off), act_code(act),

@@ -154,11 +154,15 @@ int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, int n_l
  * mode FTHMC_MODE_MD: ipynb/ft_hmc.py:420-435 without the flow-inverse wrapper;
  * FTHMC_MODE_LITERAL: fthmc/ft_hmc.py:190-224 as packaged.
  * Outputs: x_new (latent), dH[B], acc[B] (0/1), and plaq[B], Q[B] of F(x_new)
- * (fthmc/ft_hmc.py:266-270, 311-313); H0/H1/plaq/Q may be NULL. */
+ * (fthmc/ft_hmc.py:266-270, 311-313); H0/H1/plaq/Q may be NULL.
+ * Chaining: state_out[3][B] (nullable) receives [S_eff, plaq, Q] of x_new; passing it back as
+ * state_in of the next call (x = this x_new) skips the H0 flow sweep, which would recompute
+ * exactly these numbers (the reference recomputes, ft_hmc.py:205).  state_in NULL = stateless. */
 int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w,
                         int n_layers, int B, int L, int act, double beta, double dt, int nstep,
                         int mode, double* x_new, double* dH, double* acc,
                         double* H0, double* H1, double* plaq, double* Q,
+                        const double* state_in, double* state_out,
                         void* ws, size_t ws_bytes, void* stream);
 
 /* ---- training ------------------------------------------------------------ */
@@ -174,14 +178,15 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
 /* ---- measurement hook (the only entry point that synchronises) ---------- */
 /* Average duration in milliseconds (host double) of `reps` back-to-back launches of one
  * coupling-layer kernel on `stream`, bracketed by HIP events recorded on that stream.
- * kind 0: forward kernel; 1: backward-wrt-x kernel (forward recompute + adjoint);
+ * kind 0: forward kernel; 1: backward-wrt-x kernel of the force path (reads the forward's
+ * activation stash with the MFMA variant, recomputes the forward with the VALU variant);
  * 2: fused plain-HMC leapfrog step (Wilson force stencil). */
 int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off,
                       int act, double beta, int reps, double* ms_avg_host,
                       void* ws, size_t ws_bytes, void* stream);
 
-/* Diagnostic (synchronises, mallocs on the host): one launch of the MFMA forward (kind 0) or
- * backward (kind 1) kernel with per-workgroup cycle stamps at every stage boundary;
+/* Diagnostic (synchronises, mallocs on the host): one launch of the MFMA forward (kind 0),
+ * stash backward (kind 1) or recompute backward (kind 2) kernel with per-workgroup cycle stamps at every stage boundary;
  * cycles_host16[k] = mean cycles spent between stamp k-1 and stamp k. */
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off,
                          int act, double beta, double* cycles_host16,

@@ -165,6 +165,27 @@ def test_traj_md_golden(name):
     close(xo, g['lf_x'], rtol=1e-7, atol=1e-7); close(vo, g['lf_p'], rtol=1e-7, atol=1e-7)
 
 
+def test_chained_trajectories_match_stateless():
+    """state_out -> state_in (skips the H0 flow sweep) must not change anything."""
+    gen = torch.Generator().manual_seed(77)
+    B, L, nl, beta, dt, nstep = 6, 16, 4, 4.0, 0.05, 4
+    flow = R.default_flow(nl, gen)
+    w = W(flow)
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    xa, xb, state = x.clone(), x.clone(), None
+    for t in range(3):
+        v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()
+        u = torch.rand(B, generator=gen, dtype=torch.float64).cuda()
+        ra = ops.ft_trajectory(xa, v, u, w, nl, beta, dt, nstep)
+        rb = ops.ft_trajectory(xb, v, u, w, nl, beta, dt, nstep, state_in=state)
+        for k in ('x_new', 'dH', 'acc', 'H0', 'H1', 'plaq', 'Q', 'state'):
+            assert torch.equal(ra[k], rb[k]), k
+        Se, _, plaq, Q = ops.ft_action(ra['x_new'], w, nl, beta)
+        close(ra['state'][0], Se, rtol=1e-13); close(ra['state'][1], plaq, rtol=1e-13); close(ra['state'][2], Q, atol=1e-9)
+        xa, xb, state = ra['x_new'].clone(), rb['x_new'].clone(), rb['state'].clone()
+    assert float(ra['acc'].sum()) > 0          # some chains moved, so the carried state was exercised
+
+
 def test_traj_literal_golden():
     g = load_golden('traj_literal_L8')
     flow = golden_flow(g); nl = len(flow)

@@ -79,7 +79,7 @@ def pmc_traffic():
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
             k = json.load(f)['kernels']
-        k = next(v for n, v in k.items() if 'k_flow_mfma<1' in n)
+        k = next(v for n, v in k.items() if 'k_flow_bwd_stash' in n)
         return round((k['FETCH_SIZE']['mean_per_launch'] + k['WRITE_SIZE']['mean_per_launch']) * 1024)
     except Exception:
         return None
@@ -216,7 +216,7 @@ def main():
     achieved = flops_launch / (ms_bwd * 1e-3) / 1e12
     step_flops = 2 * CONV_FLOPS_PER_SITE * L * L * N_LAYERS * B    # fwd + dgrad, per batched leapfrog step
     roofline = {
-        'bound': 'mfma', 'kernel': 'k_flow_mfma<1,8,16> (coupling-layer backward wrt x)',
+        'bound': 'mfma', 'kernel': 'k_flow_bwd_stash<8,16> (coupling-layer backward wrt x)',
         'achieved': round(achieved, 3), 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(achieved / FP64_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(),
         'avg_launch_ms': round(ms_bwd, 4),

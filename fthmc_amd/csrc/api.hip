@@ -101,11 +101,11 @@ int eval_action(const double* x, const WS& w, int nl, int B, int L, int act, dou
 // Plaquette-gradient field of sum_b S_eff (scaled): gp = scale*beta*sin P(F(x)) + sum_l gP_l,
 // with dL/dlogJ = glogj.  gw != null also accumulates weight gradients (training).
 int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double beta_scaled,
-             double glogj, double* gw, hipStream_t s) {
+             double glogj, double* gw, hipStream_t s, bool have_forward = false) {
     // MFMA path without weight gradients: the forward sweep stashes act'(z1), act'(z2), s per site
     // and the backward kernels read them back instead of recomputing the network
-    const bool stash = (gw == nullptr) && get_flow_variant() == 1;
-    if (nl > 0) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s, stash));
+    const bool stash = (gw == nullptr) && get_flow_variant() == 1 && !have_forward;
+    if (nl > 0 && !have_forward) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s, stash));
     FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, w.gp, s));
     for (int l = nl - 1; l >= 0; --l) {
         FlowLayerArgs a{};
@@ -426,18 +426,19 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
     double* ld = W.scal + (size_t)SC_LOGDET * B;
     double* S = W.scal + (size_t)SC_S * B;
-    if (gw) {
-        // d mean_b(S_W - logdet) / dw : seed beta/B on the Wilson term, -1/B on every logJ
-        FT_TRY(force_gp(xi, W, n_layers, B, L, act, beta / B, -1.0 / B, gw, s));
-    }
+    // one forward sweep serves both the outputs (x, logq, logp) and the backward pass
+    FT_TRY(sweep_forward(xi, W, n_layers, B, L, act, ld, s));
     if (x || logq || logp) {
-        FT_TRY(sweep_forward(xi, W, n_layers, B, L, act, ld, s));
         FT_TRY(launch_action_charge(phys_field(xi, W, n_layers), B, L, beta, S, nullptr, nullptr, s));
         const double lp0 = -(double)(2 * L * L) * log(FT_TWO_PI);
         if (logq) FT_TRY(launch_lincomb(ld, -1.0, nullptr, 0.0, lp0, logq, B, s));
         if (logp) FT_TRY(launch_lincomb(S, -1.0, nullptr, 0.0, 0.0, logp, B, s));
         if (x && hipMemcpyAsync(x, phys_field(xi, W, n_layers), W.n2 * sizeof(double),
                                 hipMemcpyDeviceToDevice, s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    }
+    if (gw) {
+        // d mean_b(S_W - logdet) / dw : seed beta/B on the Wilson term, -1/B on every logJ
+        FT_TRY(force_gp(xi, W, n_layers, B, L, act, beta / B, -1.0 / B, gw, s, /*have_forward=*/true));
     }
     return FTHMC_OK;
 }

@@ -31,6 +31,7 @@ using namespace fthmc;
 using namespace fthmc_flow;
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double4u_t __attribute__((ext_vector_type(4), aligned(8)));   // 8-byte aligned 32-byte piece
 
 constexpr int NT = 512;                 // threads per workgroup (8 waves)
 constexpr int NW = NT / 64;
@@ -101,7 +102,10 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
 #pragma unroll
     for (int t = 0; t < NSTEP; ++t) boff[t] = bidx(t, g, cN, dd);
     for (int tile = wave; tile < NTILE; tile += NW) {
-        int p = tile * 16 + i;
+        // A row i holds pair site 4 (i & 3) + (i >> 2) of the tile, so that the four D rows of a lane
+        // (g + 4 q, q = 0..3) are the four CONSECUTIVE pair sites 4 g + q: epilogue stores can go out
+        // as one 32-byte piece per lane instead of four strided doubles
+        int p = tile * 16 + 4 * (i & 3) + (i >> 2);
         if (p >= NPAIR) p = NPAIR - 1;                       // padding lanes: any valid address
         const int pr = p / WOUT, pc = p - pr * WOUT;
         const double* a0 = A + (2 * pr) * RSA + pc + (KC == 8 ? g * PSA : 0);
@@ -120,11 +124,11 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
         double4_t acc = accs[0];
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
-        // D[row = g + 4 q][col = i]: row = pair site, col = (channel, row of the pair)
+        // D[row = g + 4 q][col = i]: row -> pair site 4 g + q, col = (channel, row of the pair)
         int off4[4]; bool ok4[4]; double z4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int pp = tile * 16 + g + 4 * q;
+            int pp = tile * 16 + 4 * g + q;
             ok4[q] = pp < NPAIR;
             if (!ok4[q]) pp = NPAIR - 1;
             const int qr = pp / WOUT, qc = pp - qr * WOUT;
@@ -134,6 +138,24 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
         epi(cN, off4, ok4, z4);
     }
 }
+
+
+// XCD-aware block -> (chain, tile) map.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8
+// share one), and each XCD has its own L2: all tiles of a chain go to the same XCD, consecutively,
+// so the halo re-reads of neighbouring tiles (links, stashed activations) hit that XCD's L2
+// instead of going out to the fabric once per XCD.  Speed only: any placement is correct.
+struct BlockTile { int b, tile, ti, tj; };
+__device__ __forceinline__ bool block_tile(int B, int nti, int ntj, BlockTile& t) {
+    const int ntiles = nti * ntj;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int cl = slot / ntiles;
+    t.tile = slot - cl * ntiles;
+    t.b = cl * 8 + xcd;
+    t.ti = t.tile / ntj;
+    t.tj = t.tile - t.ti * ntj;
+    return t.b < B;
+}
+inline dim3 xcd_grid(int B, int nti, int ntj) { return dim3(8 * ((B + 7) / 8) * nti * ntj); }
 
 // MODE 0 forward, 1 backward wrt x
 template <int MODE, int TR, int TC>
@@ -156,10 +178,11 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = A.L, mu = A.mu, off = A.off, act = A.act;
     const int n = L * L;
-    const int b = blockIdx.z;
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    const int ntiles = gridDim.x * gridDim.y;
-    const int i0 = blockIdx.y * TR, j0 = blockIdx.x * TC;
+    const int nti_ = (A.L + TR - 1) / TR, ntj_ = (A.L + TC - 1) / TC;
+    BlockTile bt;
+    if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
+    const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
+    const int i0 = bt.ti * TR, j0 = bt.tj * TC;
     const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
     const double* __restrict__ x1 = x0 + n;
     const double* __restrict__ w = A.wint;
@@ -202,11 +225,17 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
             for (int q = 0; q < 4; ++q)
                 if (ok[q]) { sH1[co * PS1 + o[q]] = h[q]; if (BWD) sD1[co * PS1 + o[q]] = d[q]; }
             if (MODE == 0 && A.stash) {                                  // act'(z1) of the tile's own sites
+                const int r0 = o[0] / R1C - 2, c0 = o[0] % R1C - 2, ia = i0 + r0, ja = j0 + c0;
+                if (ok[3] && o[3] == o[0] + 3 && r0 >= 0 && r0 < TR && c0 >= 0 && c0 + 3 < TC && ia < L && ja + 3 < L) {
+                    *reinterpret_cast<double4u_t*>(A.stash + (((size_t)b * 8 + co) * L + ia) * L + ja) =
+                        double4u_t{d[0], d[1], d[2], d[3]};
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = o[q] / R1C - 2, c = o[q] % R1C - 2, i = i0 + r, j = j0 + c;
-                    if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L)
-                        A.stash[(((size_t)b * 8 + co) * L + i) * L + j] = d[q];
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = o[q] / R1C - 2, c = o[q] % R1C - 2, i = i0 + r, j = j0 + c;
+                        if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L)
+                            A.stash[(((size_t)b * 8 + co) * L + i) * L + j] = d[q];
+                    }
                 }
             }
         });
@@ -230,11 +259,17 @@ __global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
             for (int q = 0; q < 4; ++q)
                 if (ok[q]) { sH2[co * PS2 + o[q]] = h[q]; if (BWD) sD2[co * PS2 + o[q]] = d[q]; }
             if (MODE == 0 && A.stash) {                                  // act'(z2) of the tile's own sites
+                const int r0 = o[0] / R2C - 1, c0 = o[0] % R2C - 1, ia = i0 + r0, ja = j0 + c0;
+                if (ok[3] && o[3] == o[0] + 3 && r0 >= 0 && r0 < TR && c0 >= 0 && c0 + 3 < TC && ia < L && ja + 3 < L) {
+                    *reinterpret_cast<double4u_t*>(A.stash + (((size_t)(A.B + b) * 8 + co) * L + ia) * L + ja) =
+                        double4u_t{d[0], d[1], d[2], d[3]};
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = o[q] / R2C - 1, c = o[q] % R2C - 1, i = i0 + r, j = j0 + c;
-                    if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L)
-                        A.stash[(((size_t)(A.B + b) * 8 + co) * L + i) * L + j] = d[q];
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = o[q] / R2C - 1, c = o[q] % R2C - 1, i = i0 + r, j = j0 + c;
+                        if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L)
+                            A.stash[(((size_t)(A.B + b) * 8 + co) * L + i) * L + j] = d[q];
+                    }
                 }
             }
         });
@@ -519,10 +554,11 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_stash(FlowLayerArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = A.L, mu = A.mu, off = A.off;
     const int n = L * L;
-    const int b = blockIdx.z;
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-    const int ntiles = gridDim.x * gridDim.y;
-    const int i0 = blockIdx.y * TR, j0 = blockIdx.x * TC;
+    const int nti_ = (A.L + TR - 1) / TR, ntj_ = (A.L + TC - 1) / TC;
+    BlockTile bt;
+    if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
+    const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
+    const int i0 = bt.ti * TR, j0 = bt.tj * TC;
     const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
     const double* __restrict__ x1 = x0 + n;
     const double* __restrict__ w = A.wint;
@@ -770,17 +806,17 @@ int get_flow_variant() { return g_variant; }
 
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     // forward needs half the LDS of backward: 16 x 16 tiles (less halo work) still fit twice per CU
-    const dim3 grid((a.L + FLOW_TILE - 1) / FLOW_TILE, (a.L + FLOW_TILE - 1) / FLOW_TILE, a.B);
+    const dim3 grid = xcd_grid(a.B, (a.L + FLOW_TILE - 1) / FLOW_TILE, (a.L + FLOW_TILE - 1) / FLOW_TILE);
     hipLaunchKernelGGL((k_flow_mfma<0, FLOW_TILE, FLOW_TILE>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_bwd_stash(const FlowLayerArgs& a, hipStream_t s) {
-    const dim3 grid((a.L + MF_TC - 1) / MF_TC, (a.L + MF_TR - 1) / MF_TR, a.B);
+    const dim3 grid = xcd_grid(a.B, (a.L + MF_TR - 1) / MF_TR, (a.L + MF_TC - 1) / MF_TC);
     hipLaunchKernelGGL((k_flow_bwd_stash<MF_TR, MF_TC>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
-    const dim3 grid((a.L + MF_TC - 1) / MF_TC, (a.L + MF_TR - 1) / MF_TR, a.B);
+    const dim3 grid = xcd_grid(a.B, (a.L + MF_TR - 1) / MF_TR, (a.L + MF_TC - 1) / MF_TC);
     hipLaunchKernelGGL((k_flow_mfma<1, MF_TR, MF_TC>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }

@@ -78,7 +78,7 @@ int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, d
         a.logj_part = logdet ? w.lj_part : nullptr;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
         FT_TRY(flow_fwd(a, s));
-        if (logdet) FT_TRY(launch_sum_parts(w.lj_part, B, flow_geom(false).ntiles(L), 1.0, l > 0, logdet, s));
+        if (logdet) FT_TRY(launch_sum_parts(w.lj_part, B, flow_fwd_geom(fwd_is_mfma()).ntiles(L), 1.0, l > 0, logdet, s));
     }
     return FTHMC_OK;
 }
@@ -264,7 +264,7 @@ int fthmc_flow_layer_fwd(const double* x, const double* w, int B, int L, int mu,
     a.x = x; a.wint = W.wint; a.y = y; a.logj_part = W.lj_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
     FT_TRY(flow_fwd(a, s));
-    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(false).ntiles(L), 1.0, 0, logJ, s));
+    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_fwd_geom(fwd_is_mfma()).ntiles(L), 1.0, 0, logJ, s));
     return FTHMC_OK;
 }
 
@@ -466,16 +466,16 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     }
     int rc = FTHMC_OK;
     for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
-        if (it == 0) hipEventRecord(e0, s);
+        if (it == 0) (void)hipEventRecord(e0, s);
         if (kind == 0) rc = flow_fwd(a, s);
         else if (kind == 1) rc = a.stash ? launch_flow_bwd_stash(a, s) : flow_bwd(a, false, s);
         else rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
     }
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms_avg_host = (double)ms / reps;
     return rc;
 }
@@ -484,7 +484,7 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
     FT_WS(1);
-    const size_t nrec = (size_t)B * flow_geom(kind >= 1).ntiles(L);   // forward runs on 16 x 16 tiles
+    const size_t nrec = (size_t)B * (kind >= 1 ? flow_geom(true) : flow_fwd_geom(true)).ntiles(L);
     long long* dbg = reinterpret_cast<long long*>(W.gw_part);      // B*ntiles*960 doubles >> 16 stamps each
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FT_TRY(launch_pack_weights(w, 1, W.wint, s));

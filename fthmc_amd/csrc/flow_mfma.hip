@@ -159,7 +159,7 @@ inline dim3 xcd_grid(int B, int nti, int ntj) { return dim3(8 * ((B + 7) / 8) * 
 
 // MODE 0 forward, 1 backward wrt x
 template <int MODE, int TR, int TC>
-__global__ __launch_bounds__(NT, 4) void k_flow_mfma(FlowLayerArgs A) {
+__global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_flow_mfma(FlowLayerArgs A) {
     using S = SmemM<MODE, TR, TC>;
     using G = Geom<TR, TC>;
     constexpr bool BWD = S::BWD;
@@ -806,8 +806,8 @@ int get_flow_variant() { return g_variant; }
 
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     // forward needs half the LDS of backward: 16 x 16 tiles (less halo work) still fit twice per CU
-    const dim3 grid = xcd_grid(a.B, (a.L + FLOW_TILE - 1) / FLOW_TILE, (a.L + FLOW_TILE - 1) / FLOW_TILE);
-    hipLaunchKernelGGL((k_flow_mfma<0, FLOW_TILE, FLOW_TILE>), grid, dim3(NT), 0, s, a);
+    const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
+    hipLaunchKernelGGL((k_flow_mfma<0, MF_FWD_TR, MF_FWD_TC>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_bwd_stash(const FlowLayerArgs& a, hipStream_t s) {

@@ -212,7 +212,8 @@ def test_train_grad_golden(name):
 
 
 # ---------------------------------------------------------------- oracle at bench-like sizes
-@pytest.mark.parametrize('B,L,nl,beta', [(3, 64, 8, 6.0), (2, 32, 5, 5.0), (1, 20, 3, 2.0)])
+@pytest.mark.parametrize('B,L,nl,beta', [(3, 64, 8, 6.0), (2, 32, 5, 5.0), (1, 20, 3, 2.0), (2, 12, 4, 3.0),
+                                        (9, 8, 8, 2.0), (1, 24, 2, 4.0)])
 def test_ft_vs_oracle_random(B, L, nl, beta):
     gen = torch.Generator().manual_seed(1331 + L)
     flow = R.default_flow(nl, gen)

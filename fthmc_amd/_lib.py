@@ -32,6 +32,7 @@ SIGNATURES = {
     'fthmc_set_variant': [c_int],
     'fthmc_get_variant': [],
     'fthmc_ws_bytes': [c_int, c_int, c_int],
+    'fthmc_train_ws_bytes': [c_int, c_int, c_int],
     'fthmc_wrap': [_D, _D, c_size_t, _P],
     'fthmc_regularize': [_D, _D, c_size_t, _P],
     'fthmc_plaquettes': [_D, _D, c_int, c_int, _P],
@@ -59,7 +60,7 @@ SIGNATURES = {
     'fthmc_profile_stages': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double,
                              ctypes.POINTER(c_double), _P, c_size_t, _P],
 }
-_RESTYPE = {'fthmc_version': c_char_p, 'fthmc_last_error': c_char_p, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
+_RESTYPE = {'fthmc_version': c_char_p, 'fthmc_last_error': c_char_p, 'fthmc_train_ws_bytes': c_size_t, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
 
 _lib = None
 

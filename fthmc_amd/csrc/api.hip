@@ -24,7 +24,7 @@ constexpr size_t ALIGN = 32;   // doubles (256 B)
 inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct WS {
-    double *wint, *X, *gp, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *stash;
+    double *wint, *X, *gp, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *gw_tmp, *stash;
     size_t n2;       // doubles per field batch: B * 2 * L * L
     size_t total;    // doubles
 };
@@ -32,7 +32,7 @@ struct WS {
 // scal slots, each B doubles
 enum { SC_S = 0, SC_Q, SC_PLAQ, SC_LOGDET, SC_K, SC_H0, SC_H1, SC_OLD0, SC_OLD1, SC_OLD2, SC_NEW0, SC_NEW1, SC_NEW2, SC_SEFF, SC_N };
 
-WS ws_layout(double* base, int B, int L, int nl) {
+WS ws_layout(double* base, int B, int L, int nl, bool train = false) {
     WS w{};
     const size_t n1 = (size_t)B * L * L, n2 = 2 * n1;
     const size_t nt = flow_ntiles_max(L);
@@ -47,7 +47,8 @@ WS ws_layout(double* base, int B, int L, int nl) {
     w.scal = take((size_t)SC_N * B);
     w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
     w.gw_part = take(nl > 0 ? (size_t)B * nt * FLOW_GW_STRIDE : 0);
-    w.stash = take((size_t)nl * flow_stash_doubles(B, L));      // activation stash of a force evaluation
+    w.gw_tmp = take(nl > 0 ? (size_t)FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE : 0);
+    w.stash = take((size_t)nl * flow_stash_doubles(B, L, train));   // activation stash of a force evaluation
     w.total = o;
     return w;
 }
@@ -68,10 +69,11 @@ inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
 
 // Forward sweep x -> X[0..nl-1] (X[l] = output of layer l).  logdet (device [B]) optional.
 int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, double* logdet,
-                  hipStream_t s, bool stash = false) {
+                  hipStream_t s, bool stash = false, bool train = false) {
     for (int l = 0; l < nl; ++l) {
         FlowLayerArgs a{};
-        a.stash = stash ? w.stash + (size_t)l * flow_stash_doubles(B, L) : nullptr;
+        a.stash = stash ? w.stash + (size_t)l * flow_stash_doubles(B, L, train) : nullptr;
+        a.stash_h = train ? 1 : 0;
         a.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
         a.wint = w.wint + (size_t)l * FLOW_WINT;
         a.y = w.X + (size_t)l * w.n2;
@@ -104,7 +106,10 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
              double glogj, double* gw, hipStream_t s, bool have_forward = false) {
     // MFMA path without weight gradients: the forward sweep stashes act'(z1), act'(z2), s per site
     // and the backward kernels read them back instead of recomputing the network
-    const bool stash = (gw == nullptr) && get_flow_variant() == 1 && !have_forward;
+    // (training: the caller ran the forward with the h planes stashed too, have_forward = true)
+    const bool mfma = get_flow_variant() == 1;
+    const bool stash = mfma && (gw == nullptr ? !have_forward : have_forward);
+    const bool train = gw != nullptr && stash;
     if (nl > 0 && !have_forward) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s, stash));
     FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, w.gp, s));
     for (int l = nl - 1; l >= 0; --l) {
@@ -116,11 +121,11 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
         a.gp_part = w.gp_part;
         a.gw_part = w.gw_part;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
-        a.stash = stash ? w.stash + (size_t)l * flow_stash_doubles(B, L) : nullptr;
-        FT_TRY(stash ? launch_flow_bwd_stash(a, s) : flow_bwd(a, gw != nullptr, s));
-        if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0,
-                                        gw + (size_t)l * FTHMC_W_PER_LAYER, s));
-        FT_TRY(launch_gather_gp(w.gp_part, B, L, flow_geom(bwd_is_mfma(gw != nullptr)), 1, w.gp, s));
+        a.stash = stash ? w.stash + (size_t)l * flow_stash_doubles(B, L, train) : nullptr;
+        FT_TRY(train ? launch_flow_bwd_train(a, s) : stash ? launch_flow_bwd_stash(a, s) : flow_bwd(a, gw != nullptr, s));
+        if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_geom(train).ntiles(L), 1.0, 0,
+                                        gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
+        FT_TRY(launch_gather_gp(w.gp_part, B, L, flow_geom(stash || bwd_is_mfma(gw != nullptr)), 1, w.gp, s));
     }
     return FTHMC_OK;
 }
@@ -183,6 +188,11 @@ const char* fthmc_strerror(int code) {
 size_t fthmc_ws_bytes(int B, int L, int n_layers) {
     if (B <= 0 || L <= 0 || n_layers < 0) return 0;
     return ws_layout(nullptr, B, L, n_layers).total * sizeof(double);
+}
+
+size_t fthmc_train_ws_bytes(int B, int L, int n_layers) {
+    if (B <= 0 || L <= 0 || n_layers < 0) return 0;
+    return ws_layout(nullptr, B, L, n_layers, true).total * sizeof(double);
 }
 
 #define FT_WS(nl)                                                                   \
@@ -295,7 +305,7 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
     a.gp_part = W.gp_part; a.gw_part = W.gw_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
     FT_TRY(flow_bwd(a, gw != nullptr, s));
-    if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0, gw, s));
+    if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0, gw, W.gw_tmp, s));
     FT_TRY(launch_gather_gp(W.gp_part, B, L, flow_geom(bwd_is_mfma(gw != nullptr)), 0, W.gp, s));
     return launch_adj_add(W.gp, gy, B, L, gx, s);
 }
@@ -422,12 +432,17 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
                      void* stream) {
     if (!xi || !w || bad_shape(B, L) || n_layers < 1) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
-    FT_WS(n_layers);
+    (void)hipGetLastError();
+    if (!ws || ws_bytes < fthmc_train_ws_bytes(B, L, n_layers)) return FTHMC_ERR_WS;
+    const WS W = ws_layout(static_cast<double*>(ws), B, L, n_layers, true);
+    hipStream_t s = ft_stream(stream);
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
     double* ld = W.scal + (size_t)SC_LOGDET * B;
     double* S = W.scal + (size_t)SC_S * B;
-    // one forward sweep serves both the outputs (x, logq, logp) and the backward pass
-    FT_TRY(sweep_forward(xi, W, n_layers, B, L, act, ld, s));
+    // one forward sweep serves both the outputs (x, logq, logp) and the backward pass; with the MFMA
+    // kernels it stashes act', s and h of every layer for the weight-gradient backward
+    const bool mfma = get_flow_variant() == 1;
+    FT_TRY(sweep_forward(xi, W, n_layers, B, L, act, ld, s, mfma && gw != nullptr, mfma && gw != nullptr));
     if (x || logq || logp) {
         FT_TRY(launch_action_charge(phys_field(xi, W, n_layers), B, L, beta, S, nullptr, nullptr, s));
         const double lp0 = -(double)(2 * L * L) * log(FT_TWO_PI);

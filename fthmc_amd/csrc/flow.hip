@@ -535,20 +535,25 @@ __global__ void k_adj_add(const double* __restrict__ gp, const double* __restric
     }
 }
 
-// gw[idx] (+)= scale * sum_p part[p][idx]; 64 idx x 4 slices per block, fixed order
-__global__ void k_reduce_gw(const double* __restrict__ part, int np, double scale, int accumulate,
-                            double* __restrict__ gw) {
+// out[g][idx] = scale * sum over the g-th chunk of partials part[p][idx] (p in [g*chunk, (g+1)*chunk));
+// 64 idx x 4 slices per block, fixed order.  Run twice (partials -> REDUCE_GROUPS rows -> 1 row)
+// so that thousands of per-tile partials are summed by REDUCE_GROUPS x 15 workgroups instead of 15.
+__global__ void k_reduce_gw(const double* __restrict__ part, int np, int chunk, double scale, int accumulate,
+                            double* __restrict__ out) {
     __shared__ double red[256];
     const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + li;
+    const int g = blockIdx.y;
+    const int p0 = g * chunk, p1 = min(np, p0 + chunk);
     double a = 0.0;
     if (idx < FTHMC_W_PER_LAYER)
-        for (int p = sl; p < np; p += 4) a += part[(size_t)p * FLOW_GW_STRIDE + idx];
+        for (int p = p0 + sl; p < p1; p += 4) a += part[(size_t)p * FLOW_GW_STRIDE + idx];
     red[threadIdx.x] = a;
     __syncthreads();
     if (sl == 0 && idx < FTHMC_W_PER_LAYER) {
         const double t = ((red[li] + red[64 + li]) + red[128 + li]) + red[192 + li];
-        gw[idx] = (accumulate ? gw[idx] : 0.0) + scale * t;
+        double* o = out + (size_t)g * FLOW_GW_STRIDE + idx;
+        *o = (accumulate ? *o : 0.0) + scale * t;
     }
 }
 
@@ -592,8 +597,16 @@ int launch_adj_add(const double* gp, const double* gy, int B, int L, double* gx,
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_reduce_gw(const double* gw_part, int nparts, double scale, int accumulate, double* gw,
-                     hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce_gw, dim3((FTHMC_W_PER_LAYER + 63) / 64), dim3(256), 0, s, gw_part, nparts, scale, accumulate, gw);
+                     double* tmp, hipStream_t s) {
+    const int nb = (FTHMC_W_PER_LAYER + 63) / 64;
+    if (nparts <= 4 * FLOW_REDUCE_GROUPS || !tmp) {
+        hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1), dim3(256), 0, s, gw_part, nparts, nparts, scale, accumulate, gw);
+        FT_LAUNCH_CHECK(); return FTHMC_OK;
+    }
+    const int chunk = (nparts + FLOW_REDUCE_GROUPS - 1) / FLOW_REDUCE_GROUPS;
+    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, FLOW_REDUCE_GROUPS), dim3(256), 0, s, gw_part, nparts, chunk, 1.0, 0, tmp);
+    FT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1), dim3(256), 0, s, tmp, FLOW_REDUCE_GROUPS, FLOW_REDUCE_GROUPS, scale, accumulate, gw);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

@@ -226,15 +226,20 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
                 if (ok[q]) { sH1[co * PS1 + o[q]] = h[q]; if (BWD) sD1[co * PS1 + o[q]] = d[q]; }
             if (MODE == 0 && A.stash) {                                  // act'(z1) of the tile's own sites
                 const int r0 = o[0] / R1C - 2, c0 = o[0] % R1C - 2, ia = i0 + r0, ja = j0 + c0;
+                double* sth = A.stash_h ? A.stash + (size_t)A.B * 18 * n : nullptr;       // h1 planes
                 if (ok[3] && o[3] == o[0] + 3 && r0 >= 0 && r0 < TR && c0 >= 0 && c0 + 3 < TC && ia < L && ja + 3 < L) {
                     *reinterpret_cast<double4u_t*>(A.stash + (((size_t)b * 8 + co) * L + ia) * L + ja) =
                         double4u_t{d[0], d[1], d[2], d[3]};
+                    if (sth) *reinterpret_cast<double4u_t*>(sth + (((size_t)b * 8 + co) * L + ia) * L + ja) =
+                        double4u_t{h[0], h[1], h[2], h[3]};
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int r = o[q] / R1C - 2, c = o[q] % R1C - 2, i = i0 + r, j = j0 + c;
-                        if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L)
+                        if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L) {
                             A.stash[(((size_t)b * 8 + co) * L + i) * L + j] = d[q];
+                            if (sth) sth[(((size_t)b * 8 + co) * L + i) * L + j] = h[q];
+                        }
                     }
                 }
             }
@@ -260,15 +265,20 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
                 if (ok[q]) { sH2[co * PS2 + o[q]] = h[q]; if (BWD) sD2[co * PS2 + o[q]] = d[q]; }
             if (MODE == 0 && A.stash) {                                  // act'(z2) of the tile's own sites
                 const int r0 = o[0] / R2C - 1, c0 = o[0] % R2C - 1, ia = i0 + r0, ja = j0 + c0;
+                double* sth = A.stash_h ? A.stash + (size_t)A.B * 26 * n : nullptr;       // h2 planes
                 if (ok[3] && o[3] == o[0] + 3 && r0 >= 0 && r0 < TR && c0 >= 0 && c0 + 3 < TC && ia < L && ja + 3 < L) {
                     *reinterpret_cast<double4u_t*>(A.stash + (((size_t)(A.B + b) * 8 + co) * L + ia) * L + ja) =
                         double4u_t{d[0], d[1], d[2], d[3]};
+                    if (sth) *reinterpret_cast<double4u_t*>(sth + (((size_t)b * 8 + co) * L + ia) * L + ja) =
+                        double4u_t{h[0], h[1], h[2], h[3]};
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int r = o[q] / R2C - 1, c = o[q] % R2C - 1, i = i0 + r, j = j0 + c;
-                        if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L)
+                        if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L) {
                             A.stash[(((size_t)(A.B + b) * 8 + co) * L + i) * L + j] = d[q];
+                            if (sth) sth[(((size_t)b * 8 + co) * L + i) * L + j] = h[q];
+                        }
                     }
                 }
             }
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 // k_flow_mfma<0>), so this kernel skips conv1, conv2, both activation passes and conv3 and only
 // walks the adjoint: transform adjoint -> conv3^T -> conv2^T (MFMA) -> conv1^T.
 // HBM: 144 B/site/layer read here (+ halo re-reads out of L2) instead of ~50 % more DP work.
-template <int TR, int TC> struct SmemS {
+template <int TR, int TC, bool TRAIN> struct SmemS {
     using G = Geom<TR, TC>;
     static constexpr int IN = 0;                              // [2][PS0] cos, sin of frozen plaquettes
     static constexpr int GP = IN + 2 * G::PS0;                // [N0] partial plaquette gradient
@@ -534,12 +544,56 @@ template <int TR, int TC> struct SmemS {
     static constexpr int GO = D2 + 8 * G::PS2;                // [3][N3] g(s0, s1, t)
     static constexpr int T2 = GO + 3 * G::N3;                 // [NMIX][4][NAS]
     static constexpr int SW = T2 + NMIX * 4 * G::NAS;         // [SW_SIZE]
-    static constexpr int SIZE = SW + SW_SIZE;
+    static constexpr int H1W = SW + SW_SIZE;                  // [8][PS1] h1 window   (training)
+    static constexpr int H2W = H1W + (TRAIN ? 8 * G::PS1 : 0);   // [8][PS2] h2 window   (training)
+    static constexpr int SIZE = H2W + (TRAIN ? 8 * G::PS2 : 0);
 };
 
-template <int TR, int TC>
-__global__ __launch_bounds__(NT, 4) void k_flow_bwd_stash(FlowLayerArgs A) {
-    using S = SmemS<TR, TC>;
+// Weight gradient of a 3x3 conv as an MFMA GEMM over the sites of the tile's window:
+//   gw[co][ci][ky][kx] = sum_s gz[co][s] * hin[ci][s + (ky, kx)]
+// M = 16 = 8 co x (dy = 0, 1): A[(co, dy)][s] = gz[co][s - dy rows];  N = (ci, kx, kyb) with ky = 2 kyb:
+// D[(co, dy)][(ci, kx, kyb)] = gw[co][ci][2 kyb + dy][kx]  (row 3 of the 4 it produces is discarded).
+// That packs the 8 output channels twice into M the same way the forward packs two rows into N.
+// One wave owns one 16-column N tile and walks all sites (K); results go straight to the tile's
+// partial in global memory.  GZPAD: gz planes have a ring so row -1 is readable (zeros).
+template <int HS, int WSI, int RSG, int PSG, int RSH, int PSH, int CIN, bool GZPAD, class Store>
+__device__ __forceinline__ void wgrad_stage(const double* __restrict__ gz, const double* __restrict__ hin,
+                                            int nt, int lane, Store store) {
+    // one extra site row: the dy = 1 rows of A lag one row behind, their last term is gz[HS-1] at s = HS
+    constexpr int NS = (HS + 1) * WSI, NSTEP = (NS + 3) / 4, NCOL = CIN * 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int co = i & 7, dy = i >> 3;                      // A row m = (co, dy)
+    const int ncol = nt * 16 + i;                           // B column n = (ci, kx, kyb)
+    const int ci = ncol / 6, kx = (ncol % 6) >> 1, kyb = ncol & 1;
+    const bool ncol_ok = ncol < NCOL;
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    int r = g / WSI, c = g % WSI;                           // site of k = 4 t + g, t = 0
+#pragma unroll 2
+    for (int t = 0; t < NSTEP; ++t) {
+        const int ra = r - dy, rb = r + 2 * kyb;
+        // gz rows -1 and HS are the zero ring when GZPAD, else masked; h rows beyond the window are masked
+        const bool aok = r <= HS && (GZPAD || (ra >= 0 && ra < HS));
+        const bool bok = r <= HS && ncol_ok && rb < HS + 2;
+        const double av = aok ? gz[co * PSG + ra * RSG + c] : 0.0;
+        const double bv = bok ? hin[ci * PSH + rb * RSH + c + kx] : 0.0;
+        if (t & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc1, 0, 0, 0);
+        else       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc0, 0, 0, 0);
+        c += 4; if (c >= WSI) { c -= WSI; ++r; }            // WSI >= 4
+    }
+    const double4_t acc = acc0 + acc1;
+    // D[row = g + 4 q][col = i]: row m = (co', dy'), col n = (ci, kx, kyb) of this lane
+    if (ncol_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = g + 4 * q, co2 = m & 7, dy2 = m >> 3, ky = 2 * kyb + dy2;
+            if (ky <= 2) store(co2, ci, ky, kx, acc[q]);
+        }
+    }
+}
+
+template <int TR, int TC, bool TRAIN>
+__global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerArgs A) {
+    using S = SmemS<TR, TC, TRAIN>;
     using G = Geom<TR, TC>;
     constexpr int R0R = G::R0R, R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
     constexpr int N0 = G::N0, N1 = G::N1, N2 = G::N2, N3 = G::N3, NA = G::NA, NAS = G::NAS;
@@ -548,6 +602,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_stash(FlowLayerArgs A) {
     double* sIn = sm + S::IN;  double* sGP = sm + S::GP;  double* sGZ2 = sm + S::GZ2;
     double* sD1 = sm + S::D1;  double* sD2 = sm + S::D2;  double* sGO = sm + S::GO;
     double* sT2 = sm + S::T2;  double* sW = sm + S::SW;
+    double* sH1w = sm + S::H1W; double* sH2w = sm + S::H2W;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -562,6 +617,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_stash(FlowLayerArgs A) {
     const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
     const double* __restrict__ x1 = x0 + n;
     const double* __restrict__ w = A.wint;
+    const double* __restrict__ sh1 = A.stash + ((size_t)A.B * 18 + (size_t)b * 8) * n;   // h1[8][L][L] (training)
+    const double* __restrict__ sh2 = A.stash + ((size_t)A.B * 26 + (size_t)b * 8) * n;   // h2[8][L][L] (training)
+    double* gwp = TRAIN ? A.gw_part + ((size_t)b * ntiles + tile) * FLOW_GW_STRIDE : nullptr;
     const double* __restrict__ st1 = A.stash + (size_t)b * 8 * n;                   // act'(z1)[8][L][L]
     const double* __restrict__ st2 = A.stash + ((size_t)A.B + b) * 8 * n;           // act'(z2)[8][L][L]
     const double* __restrict__ sts = A.stash + ((size_t)A.B * 16 + (size_t)b * 2) * n;   // s[2][L][L]
@@ -618,6 +676,19 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_stash(FlowLayerArgs A) {
         const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
         v2[k] = (lc < R2C && pr < PR2) ? st2[(size_t)ch * n + sWrapI[r + 2] + wj2] : 0.0;
     }
+    double vh1[TRAIN ? NP1 : 1], vh2[TRAIN ? NP2 : 1];
+    if (TRAIN) {
+#pragma unroll
+        for (int k = 0; k < NP1; ++k) {
+            const int pr = lg + k * G32, ch = pr / R1R, r = pr - ch * R1R;
+            vh1[k] = (lc < R1C && pr < PR1) ? sh1[(size_t)ch * n + sWrapI[r + 1] + wj1] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NP2; ++k) {
+            const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
+            vh2[k] = (lc < R2C && pr < PR2) ? sh2[(size_t)ch * n + sWrapI[r + 2] + wj2] : 0.0;
+        }
+    }
     static_assert(N0 <= NT, "one window site per thread");
     const int wr = tid / R0C, wc = tid - wr * R0C;
     const bool wfrozen = tid < N0 && ((((mu == 0 ? j0 + wc : i0 + wr) - 3 - off) & 3) == 1 ||
@@ -663,6 +734,18 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_stash(FlowLayerArgs A) {
     for (int k = 0; k < NP2; ++k) {
         const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
         if (lc < R2C && pr < PR2) sD2[ch * PS2 + r * R2C + lc] = v2[k];
+    }
+    if (TRAIN) {
+#pragma unroll
+        for (int k = 0; k < NP1; ++k) {
+            const int pr = lg + k * G32, ch = pr / R1R, r = pr - ch * R1R;
+            if (lc < R1C && pr < PR1) sH1w[ch * PS1 + r * R1C + lc] = vh1[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NP2; ++k) {
+            const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
+            if (lc < R2C && pr < PR2) sH2w[ch * PS2 + r * R2C + lc] = vh2[k];
+        }
     }
     __syncthreads();
     STAMP(1);
@@ -720,6 +803,36 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_stash(FlowLayerArgs A) {
     __syncthreads();
     STAMP(3);
 
+    if (TRAIN) {
+        // ---- weight gradients of conv3 (VALU, 32 active sites) and conv2 (MFMA over the h2 window),
+        //      biases b3, b2: wave reductions in a fixed order ----------------------------------
+        for (int t = tid; t < 216; t += NT) {
+            const int co = t / 72, ci = (t / 9) % 8, tap = t % 9, ky = tap / 3, kx = tap % 3;
+            double acc = 0.0;
+            for (int a = 0; a < NA; ++a) {
+                const int r = mu == 0 ? a / (TC / 4) : off + 4 * (a / TC);
+                const int c = mu == 0 ? off + 4 * (a % (TC / 4)) : a % TC;
+                acc = fma(sGO[co * N3 + r * TC + c], sH2w[ci * PS2 + (r + ky) * R2C + c + kx], acc);
+            }
+            gwp[CW2 + t] = acc;
+        }
+        if (wave < 3) {                                              // b3[co] = sum over the tile of g_out
+            double a = 0.0;
+            for (int e = lane; e < N3; e += 64) a += sGO[wave * N3 + e];
+            a = ft_wave_sum(a);
+            if (lane == 0) gwp[CB2 + wave] = a;
+        }
+        {                                                            // b2[co = wave] = sum over the h2 window of gz2
+            double a = 0.0;
+            for (int e = lane; e < N2; e += 64) { const int r = e / R2C, c = e - r * R2C; a += sGZ2[wave * PS0 + (r + 2) * R0C + c + 2]; }
+            a = ft_wave_sum(a);
+            if (lane == 0) gwp[CB1 + wave] = a;
+        }
+        if (wave < 3)                                                // 3 N tiles of (ci, kx, kyb) = 48 columns
+            wgrad_stage<R2R, R2C, R0C, PS0, R1C, PS1, 8, true>(sGZ2 + 2 * R0C + 2, sH1w, wave, lane,
+                [&](int co, int ci, int ky, int kx, double v) { gwp[CW1 + (co * 8 + ci) * 9 + ky * 3 + kx] = v; });
+    }
+
     // ---- conv2^T (MFMA), times act'(z1) -> gz1 in place over d1 -------------------------------
     auto bidx4 = [](int t, int g, int cN, int dd) {
         const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
@@ -733,6 +846,22 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_stash(FlowLayerArgs A) {
         });
     __syncthreads();
     STAMP(4);
+
+    if (TRAIN) {
+        // ---- weight gradient of conv1 (one N tile: (ci 2, kx 3, kyb 2) = 12 columns) and b1 ------
+        if (wave == 0)
+            wgrad_stage<R1R, R1C, R1C, PS1, R0C, PS0, 2, false>(sD1, sIn, 0, lane,
+                [&](int co, int ci, int ky, int kx, double v) { gwp[CW0 + (co * 2 + ci) * 9 + ky * 3 + kx] = v; });
+        else {
+            const int co = wave;                                     // waves 1..7 -> b1[1..7]; wave 1 also b1[0]
+            for (int cc = (co == 1 ? 0 : co); cc <= co; ++cc) {
+                double a = 0.0;
+                for (int e = lane; e < N1; e += 64) a += sD1[cc * PS1 + e];
+                a = ft_wave_sum(a);
+                if (lane == 0) gwp[CB0 + cc] = a;
+            }
+        }
+    }
 
     // ---- conv1^T and the (cos, sin) adjoint at frozen plaquettes -------------------------------
     {
@@ -812,7 +941,12 @@ int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
 }
 int launch_flow_bwd_stash(const FlowLayerArgs& a, hipStream_t s) {
     const dim3 grid = xcd_grid(a.B, (a.L + MF_TR - 1) / MF_TR, (a.L + MF_TC - 1) / MF_TC);
-    hipLaunchKernelGGL((k_flow_bwd_stash<MF_TR, MF_TC>), grid, dim3(NT), 0, s, a);
+    hipLaunchKernelGGL((k_flow_bwd_stash<MF_TR, MF_TC, false>), grid, dim3(NT), 0, s, a);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s) {
+    const dim3 grid = xcd_grid(a.B, (a.L + MF_TR - 1) / MF_TR, (a.L + MF_TC - 1) / MF_TC);
+    hipLaunchKernelGGL((k_flow_bwd_stash<MF_TR, MF_TC, true>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s) {

@@ -76,6 +76,7 @@ struct FlowLayerArgs {
     double tol;              // rev
     long long* dbg;          // optional: per-(chain,tile) stage time stamps [16] (diagnostic runs only)
     double* stash;           // optional: this layer's activation stash (MFMA forward writes, stash backward reads)
+    int stash_h;             // forward: also stash h1, h2 (training: the weight gradients need them)
     int B, L, mu, off, act;
 };
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);
@@ -86,8 +87,12 @@ int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 // backward wrt x from the activations the MFMA forward kernel stashed for this layer (a.stash)
 int launch_flow_bwd_stash(const FlowLayerArgs& a, hipStream_t s);
+// backward wrt x AND the weights from the stash incl. h1, h2; partial weight gradients per tile
+// go to a.gw_part [B*ntiles][FLOW_GW_STRIDE] (ntiles of flow_geom(true))
+int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s);
 // doubles per layer of the stash: act'(z1)[B][8][L][L], act'(z2)[B][8][L][L], s[B][2][L][L]
-inline size_t flow_stash_doubles(int B, int L) { return (size_t)B * 18 * L * L; }
+// (+ h1[B][8][L][L], h2[B][8][L][L] for training)
+inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 34 : 18) * L * L; }
 // 0: VALU kernels everywhere; 1 (default): MFMA kernels for forward and backward-wrt-x
 void set_flow_variant(int v);
 int get_flow_variant();
@@ -99,7 +104,9 @@ int launch_gather_gp(const double* gp_part, int B, int L, FlowGeom g, int accumu
 // gx = gy + adj(gp)
 int launch_adj_add(const double* gp, const double* gy, int B, int L, double* gx, hipStream_t s);
 // gw[idx] (+)= scale * sum_p gw_part[p][idx], idx < 955
+// tmp: FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE doubles of scratch (two-level reduction), or null
+constexpr int FLOW_REDUCE_GROUPS = 128;
 int launch_reduce_gw(const double* gw_part, int nparts, double scale, int accumulate, double* gw,
-                     hipStream_t s);
+                     double* tmp, hipStream_t s);
 
 }  // namespace fthmc

@@ -45,8 +45,8 @@ def ws_bytes(B: int, L: int, n_layers: int) -> int:
     return int(_lib.load().fthmc_ws_bytes(B, L, n_layers))
 
 
-def _ws(t: torch.Tensor, B: int, L: int, nl: int):
-    need = ws_bytes(B, L, nl)
+def _ws(t: torch.Tensor, B: int, L: int, nl: int, train: bool = False):
+    need = int(_lib.load().fthmc_train_ws_bytes(B, L, nl)) if train else ws_bytes(B, L, nl)
     key = t.device.index
     buf = _WS.get(key)
     if buf is None or buf.numel() * 8 < need:
@@ -320,7 +320,7 @@ def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True):
     x = torch.empty_like(xi)
     logq, logp = (torch.empty(B, dtype=xi.dtype, device=xi.device) for _ in range(2))
     gw = torch.empty(n_layers * W_PER_LAYER, dtype=xi.dtype, device=xi.device) if need_gw else None
-    ws, nb = _ws(xi, B, L, n_layers)
+    ws, nb = _ws(xi, B, L, n_layers, train=True)
     check(_lib.load().fthmc_train_grad(_p(xi), _p(w), n_layers, B, L, act_code(act), float(beta), _p(x), _p(logq),
                                        _p(logp), _p(gw), ws, nb, _stream(xi)), 'fthmc_train_grad')
     return {'x': x, 'logq': logq, 'logp': logp, 'gw': gw}

@@ -59,6 +59,8 @@ int fthmc_get_variant(void);
 
 /* Bytes of scratch the flow / trajectory entry points need for (B, L, n_layers). */
 size_t fthmc_ws_bytes(int B, int L, int n_layers);
+/* Scratch for fthmc_train_grad (larger: the forward also stashes h1, h2 of every layer). */
+size_t fthmc_train_ws_bytes(int B, int L, int n_layers);
 
 /* ---- angle maps ------------------------------------------------------- */
 /* out = remainder(x + pi, 2 pi) - pi.  fthmc/utils/layers.py:41-43 (torch_mod),
@@ -170,7 +172,8 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
  * (fthmc/train.py:191-210, fthmc/utils/samplers.py:40-56):
  *   x = F(xi); logq = -2 L^2 log(2 pi) - logdet; logp = -S_W(x);
  *   loss = mean(logq - logp); gw = d loss / d w  (n_layers*955).
- * Outputs (any may be NULL): x[B][2][L][L], logq[B], logp[B], gw. */
+ * Outputs (any may be NULL): x[B][2][L][L], logq[B], logp[B], gw.
+ * ws: fthmc_train_ws_bytes(B, L, n_layers). */
 int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int L, int act,
                      double beta, double* x, double* logq, double* logp, double* gw,
                      void* ws, size_t ws_bytes, void* stream);

@@ -477,7 +477,9 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
             FT_TRY(launch_flow_fwd_mfma(a, s));
         }
     } else {
-        FT_TRY(launch_random_momenta(reinterpret_cast<const int64_t*>(x), B, 2 * L * L, W.va, nullptr, s));
+        int64_t* seeds = reinterpret_cast<int64_t*>(W.scal);             // B int64 seeds = 0 .. (any values do)
+        if (hipMemsetAsync(seeds, 0, (size_t)B * sizeof(int64_t), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+        FT_TRY(launch_random_momenta(seeds, B, 2 * L * L, W.va, nullptr, s));
     }
     int rc = FTHMC_OK;
     for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_flow_layer(FlowLayerArgs A) {
     double* sP = sm + S::P;   double* sIn = sm + S::IN;
     double* sH1 = sm + S::H1; double* sH2 = sm + S::H2;
     double* sST = sm + S::ST; double* sT2 = sm + S::T2;
-    double* sDL = sm + S::DL; double* sRed = sm + S::RED;
+    double* sDL = sm + S::DL;
     double* sD1 = sm + S::D1; double* sD2 = sm + S::D2;
     double* sGO = sm + S::GO; double* sGP = sm + S::GP;
 

@@ -15,3 +15,67 @@ def apply_flow_to_prior(prior, coupling_layers: nn.ModuleList, *, batch_size: in
         x, logJ = layer.forward(x)
         logq = logq - logJ
     return x, xi, logq
+
+
+# ---------------------------------------------------------------- independence Metropolis
+def serial_sample_generator(model, action, batch_size, N_samples):
+    """samplers.py:123-137: proposals (x, logq, logp) one at a time; every `batch_size` samples a
+    new batch is pushed through the flow on the GPU (one fused forward sweep, no autograd)."""
+    from .. import ops
+    from . import qed_helpers as qed
+    from .layers import flow_activation, flow_weights
+    layers, prior = (model['layers'], model['prior']) if isinstance(model, dict) else (model.layers, model.prior)
+    layers.eval()
+    x = logq = logp = q = None
+    for i in range(N_samples):
+        bi = i % batch_size
+        if bi == 0:
+            with torch.no_grad():
+                xi = prior.sample_n(batch_size)
+                x, logdet = ops.flow_forward(xi, flow_weights(layers, xi.device), len(layers), flow_activation(layers))
+                logq = (prior.log_prob(xi) - logdet).cpu()
+                logp = (-action(x)).cpu()
+                q = qed.batch_charges(x).cpu()
+        yield x[bi], logq[bi], logp[bi], q[bi]
+
+
+def make_mcmc_ensemble(model, action_fn, batch_size, num_samples, writer=None, keep_x: bool = False):
+    """samplers.py:182-259: flow-proposal independence Metropolis.  Proposals are generated and
+    scored in batches on the GPU; the accept chain is inherently serial and runs on the host.
+    Returns numpy histories q, dqsq, logq, logp, acc (and the configurations with keep_x)."""
+    import numpy as np
+    history = {k: [] for k in ('q', 'dqsq', 'logq', 'logp', 'acc')}
+    xarr = []
+    x_old = q_old = None
+    for x_new, logq_new, logp_new, q_new in serial_sample_generator(model, action_fn, batch_size, num_samples):
+        if not history['logp']:
+            accepted = True                                   # the chain has to start somewhere
+            q_prev = q_new
+        else:
+            q_prev = q_old
+            logp_old, logq_old = history['logp'][-1], history['logq'][-1]
+            p_accept = min(1.0, float(torch.exp((logp_new - logq_new) - (logp_old - logq_old))))
+            accepted = bool(torch.rand(1) < p_accept)
+            if not accepted:
+                x_new, q_new, logp_new, logq_new = x_old, q_old, logp_old, logq_old
+        x_old, q_old = x_new, q_new
+        if keep_x:
+            xarr.append(x_new)
+        history['q'].append(q_new)
+        history['dqsq'].append((q_new - q_prev) ** 2)
+        history['logp'].append(logp_new)
+        history['logq'].append(logq_new)
+        history['acc'].append(float(accepted))
+    out = {k: np.array([float(v) for v in vals]) for k, vals in history.items()}
+    if keep_x:
+        out['x'] = torch.stack(xarr) if xarr else None
+    return out
+
+
+def generate_ensemble(model, action, ensemble_size: int = 1024, batch_size: int = 64, nboot: int = 100,
+                      binsize: int = 16):
+    """samplers.py:80-104: topological susceptibility <Q^2> of a flow-proposal ensemble (bootstrap)."""
+    from .distributions import bootstrap
+    history = make_mcmc_ensemble(model, action, batch_size, ensemble_size)
+    qsq_mean, qsq_err = bootstrap(history['q'] ** 2, nboot=nboot, binsize=binsize)
+    return {'history': history, 'suscept_mean': qsq_mean, 'suscept_err': qsq_err}

@@ -207,3 +207,27 @@ def test_run_hmc_statistics():
     assert acc.mean() > 0.6
     assert abs(plaq.mean() - PLAQ_EXACT[2.0]) < 0.03
     assert all(abs(float(q) - round(float(q))) < 1e-6 for q in h['q'])
+
+
+def test_independence_sampler():
+    """samplers.make_mcmc_ensemble: serial accept chain over GPU-generated proposals."""
+    from fthmc_amd.config import TrainConfig
+    from fthmc_amd.train import get_model
+    from fthmc_amd.utils import qed_helpers as qed
+    from fthmc_amd.utils.samplers import generate_ensemble, make_mcmc_ensemble
+    torch.manual_seed(3)
+    cfg = TrainConfig(L=8, beta=1.0, n_layers=4, batch_size=16)
+    model = get_model(cfg)
+    action = qed.BatchAction(cfg.beta)
+    h = make_mcmc_ensemble(model, action, 16, 80, keep_x=True)
+    assert h['acc'][0] == 1.0 and 0.0 < h['acc'].mean() <= 1.0
+    assert all(len(h[k]) == 80 for k in ('q', 'dqsq', 'logq', 'logp', 'acc'))
+    assert np.abs(h['q'] - np.round(h['q'])).max() < 1e-6
+    # the recorded logp / q belong to the configuration the chain sits on
+    close(-action(h['x']), h['logp'], rtol=1e-12)
+    close(qed.batch_charges(h['x']), h['q'], atol=1e-8)
+    # rejected steps repeat the previous state
+    rej = np.where(h['acc'] == 0.0)[0]
+    assert all(h['logp'][i] == h['logp'][i - 1] and h['dqsq'][i] == 0.0 for i in rej)
+    out = generate_ensemble(model, action, ensemble_size=64, batch_size=16, nboot=10, binsize=8)
+    assert np.isfinite(out['suscept_mean']) and out['suscept_err'] >= 0

@@ -248,6 +248,9 @@ int fthmc_hmc_trajectory(const double* x, const double* v, const double* u, int 
                          double dt, int nstep, double* x_new, double* dH, double* acc, double* H0,
                          double* H1, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !v || !u || !x_new || bad_shape(B, L) || nstep < 1) return FTHMC_ERR_ARG;
+    // L <= 64 (x_new must not alias x): one persistent launch per trajectory, state in LDS / registers
+    if (L <= 64 && get_flow_variant() == 1 && x_new != x)
+        return launch_hmc_trajectory_fused(x, v, u, B, L, beta, dt, nstep, x_new, dH, acc, H0, H1, ft_stream(stream));
     FT_WS(0);
     double* S = W.scal + (size_t)SC_S * B; double* K = W.scal + (size_t)SC_K * B;
     double* h0 = H0 ? H0 : W.scal + (size_t)SC_H0 * B;
@@ -460,7 +463,7 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
 
 int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                       double beta, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
+    if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 3) return FTHMC_ERR_ARG;
     if (kind < 2 && !w) return FTHMC_ERR_ARG;
     FT_WS(1);
     hipEvent_t e0, e1;
@@ -486,7 +489,8 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
         if (it == 0) (void)hipEventRecord(e0, s);
         if (kind == 0) rc = flow_fwd(a, s);
         else if (kind == 1) rc = a.stash ? launch_flow_bwd_stash(a, s) : flow_bwd(a, false, s);
-        else rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
+        else if (kind == 2) rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
+        else rc = launch_hmc_trajectory_fused(x, W.va, W.scal + B, B, L, beta, 0.1, 10, W.xa, nullptr, nullptr, nullptr, nullptr, s);
     }
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);

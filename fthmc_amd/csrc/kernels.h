@@ -19,6 +19,10 @@ int launch_wilson_force(const double* x, int B, int L, double beta, double* F, h
 int launch_leap_step(const double* x, const double* p, double* xo, double* po, int B, int L,
                      double beta, double a, double dt, hipStream_t s);
 int launch_wilson_gp(const double* x, int B, int L, double beta, double* gp, hipStream_t s);
+// whole plain-HMC trajectory in one launch (L <= 64: links in LDS, momenta in registers)
+int launch_hmc_trajectory_fused(const double* x, const double* v, const double* u, int B, int L, double beta,
+                                double dt, int nstep, double* x_new, double* dH, double* acc, double* H0,
+                                double* H1, hipStream_t s);
 int launch_kick_from_gp(const double* gp, double* v, double* xq, double* Fout, int B, int L,
                         double dt, double a, hipStream_t s);
 int launch_metropolis(const double* x_old, const double* x_prop, const double* u, const double* H0,

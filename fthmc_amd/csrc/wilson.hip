@@ -196,6 +196,97 @@ __global__ void k_lincomb(const double* __restrict__ a, double ca, const double*
     if (b < B) out[b] = ca * a[b] + (bv ? cb * bv[b] : 0.0) + c0;
 }
 
+
+// ---------------------------------------------------------------- whole plain-HMC trajectory, one launch
+// One workgroup per chain, links in LDS, momenta in registers (every thread owns NSITE sites of
+// its chain for the whole trajectory): between H0 and the Metropolis select nothing touches HBM.
+// For L <= 64 (x: 64 KB + beta sin P plane: 32 KB of LDS).  Same arithmetic as the step kernels:
+//   x' = x + dt/2 v;  v' = v - dt F(x');  (nstep-1) x {x' += dt v'; v' -= dt F(x')};  x' += dt/2 v'
+//   xr = regularize(x');  dH = S(xr) + v'^2/2 - S(x) - v^2/2;  acc = u < exp(-dH)
+constexpr int TJ_NT = 1024, TJ_MAXL = 64, TJ_NSITE = TJ_MAXL * TJ_MAXL / TJ_NT;
+
+__global__ __launch_bounds__(TJ_NT) void k_hmc_trajectory(const double* __restrict__ x, const double* __restrict__ v,
+                                                          const double* __restrict__ u, int L, double beta, double dt,
+                                                          int nstep, double* __restrict__ x_new, double* __restrict__ dH,
+                                                          double* __restrict__ acc, double* __restrict__ H0o,
+                                                          double* __restrict__ H1o) {
+    __shared__ double sx[2 * TJ_MAXL * TJ_MAXL];        // links
+    __shared__ double sp[TJ_MAXL * TJ_MAXL];            // beta sin P
+    __shared__ double red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, n = L * L;
+    const double* xb = x + (size_t)b * 2 * n;
+    const double* vb = v + (size_t)b * 2 * n;
+    double v0[TJ_NSITE], v1[TJ_NSITE];
+    int st[TJ_NSITE], sjm[TJ_NSITE], sim[TJ_NSITE], sjp[TJ_NSITE], sip[TJ_NSITE];
+    double kin = 0.0;
+#pragma unroll
+    for (int k = 0; k < TJ_NSITE; ++k) {
+        const int s = tid + k * TJ_NT;
+        st[k] = s < n ? s : -1;
+        v0[k] = v1[k] = 0.0; sjm[k] = sim[k] = sjp[k] = sip[k] = 0;
+        if (s < n) {
+            const int i = s / L, j = s - i * L;
+            sjp[k] = i * L + (j + 1 == L ? 0 : j + 1);  sip[k] = (i + 1 == L ? 0 : i + 1) * L + j;
+            sjm[k] = i * L + (j == 0 ? L - 1 : j - 1);  sim[k] = (i == 0 ? L - 1 : i - 1) * L + j;
+            sx[s] = xb[s]; sx[n + s] = xb[n + s];
+            v0[k] = vb[s]; v1[k] = vb[n + s];
+            kin += v0[k] * v0[k] + v1[k] * v1[k];
+        }
+    }
+    __syncthreads();
+    auto action = [&]() {                                // -beta sum cos P over the chain (summation order of BatchAction)
+        double c = 0.0;
+#pragma unroll
+        for (int k = 0; k < TJ_NSITE; ++k)
+            if (st[k] >= 0) c += cos(sx[st[k]] + sx[n + sip[k]] - sx[sjp[k]] - sx[n + st[k]]);
+        return (-beta) * ft_block_sum(c, red);
+    };
+    const double h0 = action() + 0.5 * ft_block_sum(kin, red);
+    for (int step = 0; step <= nstep; ++step) {
+        const double a = (step == 0 || step == nstep) ? 0.5 * dt : dt;
+#pragma unroll
+        for (int k = 0; k < TJ_NSITE; ++k)
+            if (st[k] >= 0) { sx[st[k]] += a * v0[k]; sx[n + st[k]] += a * v1[k]; }
+        if (step == nstep) break;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TJ_NSITE; ++k)
+            if (st[k] >= 0) sp[st[k]] = beta * sin(sx[st[k]] - sx[n + st[k]] - sx[sjp[k]] + sx[n + sip[k]]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TJ_NSITE; ++k)
+            if (st[k] >= 0) {
+                const double sc = sp[st[k]];
+                v0[k] -= dt * (sc - sp[sjm[k]]);
+                v1[k] -= dt * (sp[sim[k]] - sc);
+            }
+    }
+    kin = 0.0;
+#pragma unroll
+    for (int k = 0; k < TJ_NSITE; ++k)
+        if (st[k] >= 0) {
+            sx[st[k]] = ft_regularize(sx[st[k]]); sx[n + st[k]] = ft_regularize(sx[n + st[k]]);
+            kin += v0[k] * v0[k] + v1[k] * v1[k];
+        }
+    __syncthreads();
+    const double h1 = action() + 0.5 * ft_block_sum(kin, red);
+    const double d = h1 - h0;
+    const bool ok = u[b] < exp(-d);
+    if (tid == 0) {
+        if (dH) dH[b] = d;
+        if (acc) acc[b] = ok ? 1.0 : 0.0;
+        if (H0o) H0o[b] = h0;
+        if (H1o) H1o[b] = h1;
+    }
+    double* xo = x_new + (size_t)b * 2 * n;
+#pragma unroll
+    for (int k = 0; k < TJ_NSITE; ++k)
+        if (st[k] >= 0) {
+            xo[st[k]] = ok ? sx[st[k]] : xb[st[k]];
+            xo[n + st[k]] = ok ? sx[n + st[k]] : xb[n + st[k]];
+        }
+}
+
 inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 2048 ? 2048 : (g ? g : 1)); }
 inline dim3 tile_grid(int B, int L) { return dim3((L + TS - 1) / TS, (L + TS - 1) / TS, B); }
 
@@ -242,6 +333,13 @@ int launch_wilson_force(const double* x, int B, int L, double beta, double* F, h
 int launch_leap_step(const double* x, const double* p, double* xo, double* po, int B, int L,
                      double beta, double a, double dt, hipStream_t s) {
     hipLaunchKernelGGL(k_force<1>, tile_grid(B, L), dim3(256), 0, s, x, p, xo, po, L, beta, a, dt);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_hmc_trajectory_fused(const double* x, const double* v, const double* u, int B, int L, double beta,
+                                double dt, int nstep, double* x_new, double* dH, double* acc, double* H0,
+                                double* H1, hipStream_t s) {
+    if (L > TJ_MAXL) return FTHMC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_hmc_trajectory, dim3(B), dim3(TJ_NT), 0, s, x, v, u, L, beta, dt, nstep, x_new, dH, acc, H0, H1);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_wilson_gp(const double* x, int B, int L, double beta, double* gp, hipStream_t s) {

@@ -327,11 +327,11 @@ def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True):
 
 
 def time_kernel(kind: str, x, w=None, mu=0, off=0, act='silu', beta=1.0, reps=20) -> float:
-    """Average milliseconds per launch of one kernel ('flow_fwd', 'flow_bwd', 'leap_step'),
+    """Average milliseconds per launch of one kernel ('flow_fwd', 'flow_bwd', 'leap_step', 'hmc_trajectory'),
     measured with HIP events on the current stream (synchronises)."""
     import ctypes
     x = _field(x); B, _, L, _ = x.shape
-    k = {'flow_fwd': 0, 'flow_bwd': 1, 'leap_step': 2}[kind]
+    k = {'flow_fwd': 0, 'flow_bwd': 1, 'leap_step': 2, 'hmc_trajectory': 3}[kind]
     wp = _p(_w1(w, x)) if k < 2 else None
     ms = ctypes.c_double(0.0)
     ws, nb = _ws(x, B, L, 1)

@@ -183,7 +183,8 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
  * coupling-layer kernel on `stream`, bracketed by HIP events recorded on that stream.
  * kind 0: forward kernel; 1: backward-wrt-x kernel of the force path (reads the forward's
  * activation stash with the MFMA variant, recomputes the forward with the VALU variant);
- * 2: fused plain-HMC leapfrog step (Wilson force stencil). */
+ * 2: fused plain-HMC leapfrog step (Wilson force stencil); 3: whole plain-HMC trajectory of 10
+ * steps in one launch (L <= 64). */
 int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off,
                       int act, double beta, int reps, double* ms_avg_host,
                       void* ws, size_t ws_bytes, void* stream);

@@ -124,16 +124,20 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
         double4_t acc = accs[0];
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
-        // D[row = g + 4 q][col = i]: row -> pair site 4 g + q, col = (channel, row of the pair)
+        // D[row = g + 4 q][col = i]: row -> pair site 4 g + q, col = (channel, row of the pair).
+        // One division per tile; the other three sites follow incrementally (integer VALU work in the
+        // epilogue used to outnumber the fp64 work 2:1).
         int off4[4]; bool ok4[4]; double z4[4];
+        {
+            const int pp0 = tile * 16 + 4 * g;
+            int qr = pp0 / WOUT, qc = pp0 - qr * WOUT;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int pp = tile * 16 + 4 * g + q;
-            ok4[q] = pp < NPAIR;
-            if (!ok4[q]) pp = NPAIR - 1;
-            const int qr = pp / WOUT, qc = pp - qr * WOUT;
-            off4[q] = (2 * qr + dd) * WOUT + qc;             // index inside the HOUT x WOUT plane
-            z4[q] = acc[q];
+            for (int q = 0; q < 4; ++q) {
+                ok4[q] = pp0 + q < NPAIR;
+                off4[q] = ok4[q] ? (2 * qr + dd) * WOUT + qc : 0;    // index inside the HOUT x WOUT plane
+                z4[q] = acc[q];
+                if (++qc == WOUT) { qc = 0; ++qr; }
+            }
         }
         epi(cN, off4, ok4, z4);
     }
@@ -208,6 +212,12 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
     __syncthreads();
     STAMP(1);
 
+    // stash planes of this lane's output channel (the lane -> channel map is fixed for the kernel)
+    double* const st_d1 = (MODE == 0 && A.stash) ? A.stash + ((size_t)b * 8 + (lane & 7)) * n : nullptr;
+    double* const st_d2 = st_d1 ? st_d1 + (size_t)A.B * 8 * n : nullptr;
+    double* const st_h1 = st_d1 ? st_d1 + (size_t)A.B * 18 * n : nullptr;
+    double* const st_h2 = st_d1 ? st_d1 + (size_t)A.B * 26 * n : nullptr;
+
     // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
     // B[k = (tap, ci)][n = (co, dd)] = W0[co][ci][ky4 - dd][kx]
     auto bidx1 = [](int t, int g, int cN, int dd) {
@@ -224,22 +234,14 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (ok[q]) { sH1[co * PS1 + o[q]] = h[q]; if (BWD) sD1[co * PS1 + o[q]] = d[q]; }
-            if (MODE == 0 && A.stash) {                                  // act'(z1) of the tile's own sites
-                const int r0 = o[0] / R1C - 2, c0 = o[0] % R1C - 2, ia = i0 + r0, ja = j0 + c0;
-                double* sth = A.stash_h ? A.stash + (size_t)A.B * 18 * n : nullptr;       // h1 planes
-                if (ok[3] && o[3] == o[0] + 3 && r0 >= 0 && r0 < TR && c0 >= 0 && c0 + 3 < TC && ia < L && ja + 3 < L) {
-                    *reinterpret_cast<double4u_t*>(A.stash + (((size_t)b * 8 + co) * L + ia) * L + ja) =
-                        double4u_t{d[0], d[1], d[2], d[3]};
-                    if (sth) *reinterpret_cast<double4u_t*>(sth + (((size_t)b * 8 + co) * L + ia) * L + ja) =
-                        double4u_t{h[0], h[1], h[2], h[3]};
-                } else {
+            if (MODE == 0 && A.stash) {                                  // act'(z1) (and h1) of the tile's own sites
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = o[q] / R1C - 2, c = o[q] % R1C - 2, i = i0 + r, j = j0 + c;
-                        if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L) {
-                            A.stash[(((size_t)b * 8 + co) * L + i) * L + j] = d[q];
-                            if (sth) sth[(((size_t)b * 8 + co) * L + i) * L + j] = h[q];
-                        }
+                for (int q = 0; q < 4; ++q) {
+                    const int r = o[q] / R1C - 2, c = o[q] - (r + 2) * R1C - 2;
+                    if (ok[q] && (unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC && i0 + r < L && j0 + c < L) {
+                        const int at = (i0 + r) * L + j0 + c;
+                        st_d1[at] = d[q];
+                        if (A.stash_h) st_h1[at] = h[q];
                     }
                 }
             }
@@ -263,22 +265,14 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (ok[q]) { sH2[co * PS2 + o[q]] = h[q]; if (BWD) sD2[co * PS2 + o[q]] = d[q]; }
-            if (MODE == 0 && A.stash) {                                  // act'(z2) of the tile's own sites
-                const int r0 = o[0] / R2C - 1, c0 = o[0] % R2C - 1, ia = i0 + r0, ja = j0 + c0;
-                double* sth = A.stash_h ? A.stash + (size_t)A.B * 26 * n : nullptr;       // h2 planes
-                if (ok[3] && o[3] == o[0] + 3 && r0 >= 0 && r0 < TR && c0 >= 0 && c0 + 3 < TC && ia < L && ja + 3 < L) {
-                    *reinterpret_cast<double4u_t*>(A.stash + (((size_t)(A.B + b) * 8 + co) * L + ia) * L + ja) =
-                        double4u_t{d[0], d[1], d[2], d[3]};
-                    if (sth) *reinterpret_cast<double4u_t*>(sth + (((size_t)b * 8 + co) * L + ia) * L + ja) =
-                        double4u_t{h[0], h[1], h[2], h[3]};
-                } else {
+            if (MODE == 0 && A.stash) {                                  // act'(z2) (and h2) of the tile's own sites
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int r = o[q] / R2C - 1, c = o[q] % R2C - 1, i = i0 + r, j = j0 + c;
-                        if (ok[q] && r >= 0 && r < TR && c >= 0 && c < TC && i < L && j < L) {
-                            A.stash[(((size_t)(A.B + b) * 8 + co) * L + i) * L + j] = d[q];
-                            if (sth) sth[(((size_t)b * 8 + co) * L + i) * L + j] = h[q];
-                        }
+                for (int q = 0; q < 4; ++q) {
+                    const int r = o[q] / R2C - 1, c = o[q] - (r + 1) * R2C - 1;
+                    if (ok[q] && (unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC && i0 + r < L && j0 + c < L) {
+                        const int at = (i0 + r) * L + j0 + c;
+                        st_d2[at] = d[q];
+                        if (A.stash_h) st_h2[at] = h[q];
                     }
                 }
             }

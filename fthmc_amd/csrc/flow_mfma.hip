@@ -31,7 +31,6 @@ using namespace fthmc;
 using namespace fthmc_flow;
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double double4u_t __attribute__((ext_vector_type(4), aligned(8)));   // 8-byte aligned 32-byte piece
 
 constexpr int NT = 512;                 // threads per workgroup (8 waves)
 constexpr int NW = NT / 64;
@@ -79,8 +78,9 @@ template <int MODE, int TR, int TC> struct SmemM {
 // One implicit-GEMM stage.  Output region HOUT x WOUT (HOUT even) whose input planes are one
 // site larger on every side (forward conv) or ring-2 padded (transposed conv): input index of
 // output (r, c) and window tap (ky4, kx) is (r + ky4, c + kx) for the pair's upper row r = 2q.
-// The epilogue gets the four values of a lane at once so that their chains interleave.
-// bidx(t, g, cN, dd) -> index of B[k = 4 t + g][n = cN + 8 dd] in the LDS weight copy sW.
+// The epilogue gets the four values of a lane at once so that their chains interleave:
+// epi(g, pr, pc, ok, z) with z[q] = output channel g + 4 (q & 1) at site (2 pr + (q >> 1), pc).
+// bidx(t, g, cN, dd) -> index of W[k = 4 t + g][n = cN + 8 dd] in the LDS weight copy sW.
 template <int NSTEP, int KC, int HOUT, int WOUT, int RSA, int PSA, class BIdx, class Epi>
 __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ sW,
                                            int wave, int lane, BIdx bidx, Epi epi) {
@@ -102,11 +102,14 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
 #pragma unroll
     for (int t = 0; t < NSTEP; ++t) boff[t] = bidx(t, g, cN, dd);
     for (int tile = wave; tile < NTILE; tile += NW) {
-        // A row i holds pair site 4 (i & 3) + (i >> 2) of the tile, so that the four D rows of a lane
-        // (g + 4 q, q = 0..3) are the four CONSECUTIVE pair sites 4 g + q: epilogue stores can go out
-        // as one 32-byte piece per lane instead of four strided doubles
-        int p = tile * 16 + 4 * (i & 3) + (i >> 2);
-        if (p >= NPAIR) p = NPAIR - 1;                       // padding lanes: any valid address
+        // The weights are the MFMA's A operand and the activations its B operand, so D comes out
+        // transposed: D[row = (channel, pair row)][col = pair site].  A lane then holds one pair
+        // site (col = i) and the four rows g + 4 q = (channel g | g + 4) x (pair row 0 | 1): all the
+        // site arithmetic of the epilogue (offsets, bounds, stash address) happens once per lane and
+        // tile instead of once per value (integer VALU work used to outnumber the fp64 work 2:1).
+        const int p_ = tile * 16 + i;
+        const bool ok = p_ < NPAIR;
+        const int p = ok ? p_ : NPAIR - 1;                   // padding lanes: any valid address
         const int pr = p / WOUT, pc = p - pr * WOUT;
         const double* a0 = A + (2 * pr) * RSA + pc + (KC == 8 ? g * PSA : 0);
         // independent accumulator chains keep the matrix pipe busy when a wave is alone on it
@@ -119,27 +122,14 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
             double av;
             if (KC == 8) av = a0[(t & 1) * 4 * PSA + ((t >> 1) / 3) * RSA + ((t >> 1) % 3)];
             else av = a0[koff[t]];
-            accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, sW[boff[t]], accs[t % NCH], 0, 0, 0);
+            accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(sW[boff[t]], av, accs[t % NCH], 0, 0, 0);
         }
         double4_t acc = accs[0];
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
-        // D[row = g + 4 q][col = i]: row -> pair site 4 g + q, col = (channel, row of the pair).
-        // One division per tile; the other three sites follow incrementally (integer VALU work in the
-        // epilogue used to outnumber the fp64 work 2:1).
-        int off4[4]; bool ok4[4]; double z4[4];
-        {
-            const int pp0 = tile * 16 + 4 * g;
-            int qr = pp0 / WOUT, qc = pp0 - qr * WOUT;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ok4[q] = pp0 + q < NPAIR;
-                off4[q] = ok4[q] ? (2 * qr + dd) * WOUT + qc : 0;    // index inside the HOUT x WOUT plane
-                z4[q] = acc[q];
-                if (++qc == WOUT) { qc = 0; ++qr; }
-            }
-        }
-        epi(cN, off4, ok4, z4);
+        // z[q]: q & 1 -> channel g + 4 (q & 1), q >> 1 -> row 2 pr + (q >> 1) of the pair
+        double z4[4] = {acc[0], acc[1], acc[2], acc[3]};
+        epi(g, pr, pc, ok, z4);
     }
 }
 
@@ -212,8 +202,9 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
     __syncthreads();
     STAMP(1);
 
-    // stash planes of this lane's output channel (the lane -> channel map is fixed for the kernel)
-    double* const st_d1 = (MODE == 0 && A.stash) ? A.stash + ((size_t)b * 8 + (lane & 7)) * n : nullptr;
+    // stash planes of this lane's output channels g = lane >> 4 and g + 4 (fixed for the kernel)
+    const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // tile sites inside the lattice
+    double* const st_d1 = (MODE == 0 && A.stash) ? A.stash + ((size_t)b * 8 + (lane >> 4)) * n : nullptr;
     double* const st_d2 = st_d1 ? st_d1 + (size_t)A.B * 8 * n : nullptr;
     double* const st_h1 = st_d1 ? st_d1 + (size_t)A.B * 18 * n : nullptr;
     double* const st_h2 = st_d1 ? st_d1 + (size_t)A.B * 26 * n : nullptr;
@@ -225,24 +216,29 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         return (ky >= 0 && ky <= 2) ? CW0 + (cN * 2 + ci) * 9 + ky * 3 + kx : WZERO;
     };
     mfma_stage<6, 2, R1R, R1C, R0C, PS0>(sIn, sW, wave, lane, bidx1,
-        [&](int co, const int (&o)[4], const bool (&ok)[4], double (&z)[4]) {
-            const double bias = sW[CB0 + co];
+        [&](int g, int pr, int pc, bool ok, double (&z)[4]) {
+            const double b0 = sW[CB0 + g], b1 = sW[CB0 + g + 4];
             double h[4], d[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) z[q] += bias;
+            z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
             act_eval4(z, act, h, d);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (ok[q]) { sH1[co * PS1 + o[q]] = h[q]; if (BWD) sD1[co * PS1 + o[q]] = d[q]; }
+            if (ok) {
+                double* ph = sH1 + g * PS1 + 2 * pr * R1C + pc;
+                ph[0] = h[0]; ph[4 * PS1] = h[1]; ph[R1C] = h[2]; ph[4 * PS1 + R1C] = h[3];
+                if (BWD) {
+                    double* pd = sD1 + g * PS1 + 2 * pr * R1C + pc;
+                    pd[0] = d[0]; pd[4 * PS1] = d[1]; pd[R1C] = d[2]; pd[4 * PS1 + R1C] = d[3];
+                }
+            }
             if (MODE == 0 && A.stash) {                                  // act'(z1) (and h1) of the tile's own sites
+                const int r = 2 * pr - 2, c = pc - 2;
+                if (ok && (unsigned)c < (unsigned)cmax) {
+                    const int at = (i0 + r) * L + j0 + c;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = o[q] / R1C - 2, c = o[q] - (r + 2) * R1C - 2;
-                    if (ok[q] && (unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC && i0 + r < L && j0 + c < L) {
-                        const int at = (i0 + r) * L + j0 + c;
-                        st_d1[at] = d[q];
-                        if (A.stash_h) st_h1[at] = h[q];
-                    }
+                    for (int dd = 0; dd < 2; ++dd)
+                        if ((unsigned)(r + dd) < (unsigned)rmax) {
+                            st_d1[at + dd * L] = d[2 * dd]; st_d1[at + dd * L + 4 * n] = d[2 * dd + 1];
+                            if (A.stash_h) { st_h1[at + dd * L] = h[2 * dd]; st_h1[at + dd * L + 4 * n] = h[2 * dd + 1]; }
+                        }
                 }
             }
         });
@@ -256,24 +252,29 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         return (ky >= 0 && ky <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
     };
     mfma_stage<24, 8, R2R, R2C, R1C, PS1>(sH1, sW, wave, lane, bidx2,
-        [&](int co, const int (&o)[4], const bool (&ok)[4], double (&z)[4]) {
-            const double bias = sW[CB1 + co];
+        [&](int g, int pr, int pc, bool ok, double (&z)[4]) {
+            const double b0 = sW[CB1 + g], b1 = sW[CB1 + g + 4];
             double h[4], d[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) z[q] += bias;
+            z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
             act_eval4(z, act, h, d);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (ok[q]) { sH2[co * PS2 + o[q]] = h[q]; if (BWD) sD2[co * PS2 + o[q]] = d[q]; }
+            if (ok) {
+                double* ph = sH2 + g * PS2 + 2 * pr * R2C + pc;
+                ph[0] = h[0]; ph[4 * PS2] = h[1]; ph[R2C] = h[2]; ph[4 * PS2 + R2C] = h[3];
+                if (BWD) {
+                    double* pd = sD2 + g * PS2 + 2 * pr * R2C + pc;
+                    pd[0] = d[0]; pd[4 * PS2] = d[1]; pd[R2C] = d[2]; pd[4 * PS2 + R2C] = d[3];
+                }
+            }
             if (MODE == 0 && A.stash) {                                  // act'(z2) (and h2) of the tile's own sites
+                const int r = 2 * pr - 1, c = pc - 1;
+                if (ok && (unsigned)c < (unsigned)cmax) {
+                    const int at = (i0 + r) * L + j0 + c;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = o[q] / R2C - 1, c = o[q] - (r + 1) * R2C - 1;
-                    if (ok[q] && (unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC && i0 + r < L && j0 + c < L) {
-                        const int at = (i0 + r) * L + j0 + c;
-                        st_d2[at] = d[q];
-                        if (A.stash_h) st_h2[at] = h[q];
-                    }
+                    for (int dd = 0; dd < 2; ++dd)
+                        if ((unsigned)(r + dd) < (unsigned)rmax) {
+                            st_d2[at + dd * L] = d[2 * dd]; st_d2[at + dd * L + 4 * n] = d[2 * dd + 1];
+                            if (A.stash_h) { st_h2[at + dd * L] = h[2 * dd]; st_h2[at + dd * L + 4 * n] = h[2 * dd + 1]; }
+                        }
                 }
             }
         });
@@ -443,10 +444,11 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
         };
         mfma_stage<24, 8, R1R, R1C, R0C, PS0>(sGZ2, sW, wave, lane, bidx4,
-            [&](int ci, const int (&o)[4], const bool (&ok)[4], double (&gh)[4]) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ok[q]) sD1[ci * PS1 + o[q]] *= gh[q];
+            [&](int g, int pr, int pc, bool ok, double (&gh)[4]) {
+                if (ok) {
+                    double* pd = sD1 + g * PS1 + 2 * pr * R1C + pc;
+                    pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[R1C] *= gh[2]; pd[4 * PS1 + R1C] *= gh[3];
+                }
             });
         __syncthreads();
         STAMP(8);
@@ -833,10 +835,11 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerA
         return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
     };
     mfma_stage<24, 8, R1R, R1C, R0C, PS0>(sGZ2, sW, wave, lane, bidx4,
-        [&](int ci, const int (&o)[4], const bool (&ok)[4], double (&gh)[4]) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (ok[q]) sD1[ci * PS1 + o[q]] *= gh[q];
+        [&](int g, int pr, int pc, bool ok, double (&gh)[4]) {
+            if (ok) {
+                double* pd = sD1 + g * PS1 + 2 * pr * R1C + pc;
+                pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[R1C] *= gh[2]; pd[4 * PS1 + R1C] *= gh[3];
+            }
         });
     __syncthreads();
     STAMP(4);

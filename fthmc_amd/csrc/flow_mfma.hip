@@ -653,37 +653,25 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerA
             ag[1] = mu == 0 ? gp[iL + sWrapJ[ac + 2]] : gp[sWrapI[ar + 2] + j];
         }
     }
-    // stash windows: a thread owns one window column (32 lanes per plane-row, R1C / R2C of them
-    // active) and walks plane-rows (channel, row) in steps of NT / 32: the address is
-    // plane-row base + its fixed wrapped column, no per-element index arithmetic
-    constexpr int G32 = NT / 32;                                         // plane-rows per pass
-    constexpr int PR1 = 8 * R1R, PR2 = 8 * R2R;                          // plane-rows of the two windows
-    constexpr int NP1 = (PR1 + G32 - 1) / G32, NP2 = (PR2 + G32 - 1) / G32;
+    // stash windows: a thread owns one window site (column lc = tid & 31, row lg = tid >> 5) and walks
+    // the 8 channel planes: the address is one wrapped base + ch * n, the LDS slot one base + ch * PS
+    // (immediate offsets), no per-element index arithmetic
+    static_assert(R1R <= NT / 32 && R1C <= 32, "one window site per thread");
     const int lc = tid & 31, lg = tid >> 5;
-    const int wj1 = sWrapJ[(lc < R1C ? lc : 0) + 1], wj2 = sWrapJ[(lc < R2C ? lc : 0) + 2];
-    double v1[NP1], v2[NP2];
+    const bool l1 = lc < R1C && lg < R1R, l2 = lc < R2C && lg < R2R;
+    const int go1 = sWrapI[(l1 ? lg : 0) + 1] + sWrapJ[(l1 ? lc : 0) + 1];
+    const int go2 = sWrapI[(l2 ? lg : 0) + 2] + sWrapJ[(l2 ? lc : 0) + 2];
+    double v1[8], v2[8];
 #pragma unroll
-    for (int k = 0; k < NP1; ++k) {
-        const int pr = lg + k * G32, ch = pr / R1R, r = pr - ch * R1R;
-        v1[k] = (lc < R1C && pr < PR1) ? st1[(size_t)ch * n + sWrapI[r + 1] + wj1] : 0.0;
-    }
+    for (int ch = 0; ch < 8; ++ch) v1[ch] = l1 ? st1[(size_t)ch * n + go1] : 0.0;
 #pragma unroll
-    for (int k = 0; k < NP2; ++k) {
-        const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
-        v2[k] = (lc < R2C && pr < PR2) ? st2[(size_t)ch * n + sWrapI[r + 2] + wj2] : 0.0;
-    }
-    double vh1[TRAIN ? NP1 : 1], vh2[TRAIN ? NP2 : 1];
+    for (int ch = 0; ch < 8; ++ch) v2[ch] = l2 ? st2[(size_t)ch * n + go2] : 0.0;
+    double vh1[TRAIN ? 8 : 1], vh2[TRAIN ? 8 : 1];
     if (TRAIN) {
 #pragma unroll
-        for (int k = 0; k < NP1; ++k) {
-            const int pr = lg + k * G32, ch = pr / R1R, r = pr - ch * R1R;
-            vh1[k] = (lc < R1C && pr < PR1) ? sh1[(size_t)ch * n + sWrapI[r + 1] + wj1] : 0.0;
-        }
+        for (int ch = 0; ch < 8; ++ch) vh1[ch] = l1 ? sh1[(size_t)ch * n + go1] : 0.0;
 #pragma unroll
-        for (int k = 0; k < NP2; ++k) {
-            const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
-            vh2[k] = (lc < R2C && pr < PR2) ? sh2[(size_t)ch * n + sWrapI[r + 2] + wj2] : 0.0;
-        }
+        for (int ch = 0; ch < 8; ++ch) vh2[ch] = l2 ? sh2[(size_t)ch * n + go2] : 0.0;
     }
     static_assert(N0 <= NT, "one window site per thread");
     const int wr = tid / R0C, wc = tid - wr * R0C;
@@ -721,26 +709,22 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerA
         if (wfrozen) ft_sincos(wP[0] - wP[1] - wP[2] + wP[3], &sn, &cs);
         sIn[tid] = cs; sIn[PS0 + tid] = sn; sGP[tid] = 0.0;
     }
+    if (l1) {
 #pragma unroll
-    for (int k = 0; k < NP1; ++k) {
-        const int pr = lg + k * G32, ch = pr / R1R, r = pr - ch * R1R;
-        if (lc < R1C && pr < PR1) sD1[ch * PS1 + r * R1C + lc] = v1[k];
+        for (int ch = 0; ch < 8; ++ch) sD1[ch * PS1 + lg * R1C + lc] = v1[ch];
     }
+    if (l2) {
 #pragma unroll
-    for (int k = 0; k < NP2; ++k) {
-        const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
-        if (lc < R2C && pr < PR2) sD2[ch * PS2 + r * R2C + lc] = v2[k];
+        for (int ch = 0; ch < 8; ++ch) sD2[ch * PS2 + lg * R2C + lc] = v2[ch];
     }
     if (TRAIN) {
+        if (l1) {
 #pragma unroll
-        for (int k = 0; k < NP1; ++k) {
-            const int pr = lg + k * G32, ch = pr / R1R, r = pr - ch * R1R;
-            if (lc < R1C && pr < PR1) sH1w[ch * PS1 + r * R1C + lc] = vh1[k];
+            for (int ch = 0; ch < 8; ++ch) sH1w[ch * PS1 + lg * R1C + lc] = vh1[ch];
         }
+        if (l2) {
 #pragma unroll
-        for (int k = 0; k < NP2; ++k) {
-            const int pr = lg + k * G32, ch = pr / R2R, r = pr - ch * R2R;
-            if (lc < R2C && pr < PR2) sH2w[ch * PS2 + r * R2C + lc] = vh2[k];
+            for (int ch = 0; ch < 8; ++ch) sH2w[ch * PS2 + lg * R2C + lc] = vh2[ch];
         }
     }
     __syncthreads();

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc per-dispatch CSVs (tools/collect_pmc.sh) into mean-per-launch values per kernel."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+FAMILIES = [('k_flow_bwd_stash', 'k_flow_bwd_stash<8,16> (coupling-layer backward wrt x, force path)'),
+            ('k_flow_mfma<0', 'k_flow_mfma<0,16,16> (coupling-layer forward)'),
+            ('k_flow_mfma<1', 'k_flow_mfma<1,8,16> (recompute backward)'),
+            ('k_gather_gp', 'k_gather_gp'),
+            ('k_force<1', 'k_force<1> (fused plain-HMC leapfrog step)'),
+            ('k_hmc_trajectory', 'k_hmc_trajectory (single-launch plain-HMC trajectory)')]
+
+
+def family(name):
+    for key, label in FAMILIES:
+        if key in name:
+            return label
+    return None
+
+
+def main(src, dst):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for path in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                fam = family(row.get('Kernel_Name', ''))
+                if fam is None:
+                    continue
+                a = acc[fam][row['Counter_Name']]
+                a[0] += float(row['Counter_Value']); a[1] += 1
+    out = {
+        'command': 'rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline'
+                   '  (one pass per counter group, tools/collect_pmc.sh)',
+        'units': 'FETCH_SIZE / WRITE_SIZE in KiB as reported (gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide '
+                 'streaming reads, MI355X_MICROARCH.md HBM section; our reads are 8 B/lane, uncalibrated: raw values kept); '
+                 'SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_VALU in quad-cycles summed over waves or SIMDs; '
+                 'SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; SQ_INSTS_* wave-instructions; '
+                 'GRBM_GUI_ACTIVE summed over 8 XCDs',
+        'workload': 'bench.py config: B=128 chains, L=64, 8 layers, fp64; one launch = one coupling layer over the whole '
+                    'batch (forward 2048 workgroups of 16x16 sites, backward 4096 of 8x16)',
+        'kernels': {fam: {c: {'launches': v[1], 'mean_per_launch': v[0] / v[1]} for c, v in sorted(cs.items())}
+                    for fam, cs in acc.items()},
+    }
+    with open(dst, 'w') as f:
+        json.dump(out, f, indent=1)
+    for fam, cs in out['kernels'].items():
+        print(fam)
+        for c, v in cs.items():
+            print(f'   {c:34s} {v["mean_per_launch"]:.4g}  ({v["launches"]} launches)')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])

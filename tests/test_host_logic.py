@@ -157,3 +157,21 @@ def test_two_rank_gloo_equals_single_process():
     assert one[0] == two[0] == 8.0                                   # 4 chains x 2 trajectories
     np.testing.assert_allclose(two[:7], one[:7], rtol=1e-12, atol=1e-12)
     assert one[7] == 1.0 and two[7] == 3.0                           # SUM all-reduce of "gradients"
+
+
+def test_torch_operator_library_registers_without_a_gpu():
+    """torch.ops.fthmc_hip.*: schemas exist, shapes propagate on fake tensors, and there is no CPU kernel."""
+    import fthmc_amd.torch_ops as T
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in T.__all__:
+        assert hasattr(torch.ops.fthmc_hip, name), name
+    sch = str(torch.ops.fthmc_hip.fthmc_trajectory.default._schema)
+    assert sch.startswith('fthmc_hip::fthmc_trajectory(Tensor x, Tensor v, Tensor u, Tensor w_all')
+    with FakeTensorMode():
+        x = torch.empty(3, 2, 8, 8, dtype=torch.float64)
+        y, lj = torch.ops.fthmc_hip.flow_layer_fwd(x, torch.empty(955, dtype=torch.float64), 0, 1, 2, 0)
+        assert y.shape == x.shape and lj.shape == (3,)
+        out = torch.ops.fthmc_hip.train_grad(x, torch.empty(4 * 955, dtype=torch.float64), 4, 2.0, 0)
+        assert out[3].shape == (4 * 955,)
+    with pytest.raises(NotImplementedError):
+        torch.ops.fthmc_hip.wilson_force(torch.zeros(1, 2, 8, 8, dtype=torch.float64), 1.0)

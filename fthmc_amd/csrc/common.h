@@ -16,9 +16,16 @@ namespace fthmc { void note_hip_error(hipError_t e, const char* file, int line);
          if (e_ != hipSuccess) { fthmc::note_hip_error(e_, __FILE__, __LINE__); return FTHMC_ERR_LAUNCH; } } while (0)
 
 // torch.remainder(x + pi, 2 pi) - pi   (fmod is exact; sign fix as ATen does)
+// Within three periods of the principal range the remainder is one exact subtraction (Sterbenz) or
+// the same rounded addition ATen performs, so the short path is bit-identical to fmod's.
 __device__ __forceinline__ double ft_wrap(double x) {
-    double r = fmod(x + FT_PI, FT_TWO_PI);
-    if (r < 0.0) r += FT_TWO_PI;
+    double r = x + FT_PI;
+    if (r >= -FT_TWO_PI && r < 2.0 * FT_TWO_PI) {
+        r = r >= FT_TWO_PI ? r - FT_TWO_PI : (r < 0.0 ? r + FT_TWO_PI : r);
+    } else {
+        r = fmod(r, FT_TWO_PI);
+        if (r < 0.0) r += FT_TWO_PI;
+    }
     return r - FT_PI;
 }
 

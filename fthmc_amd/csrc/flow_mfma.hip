@@ -35,6 +35,12 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int NT = 512;                 // threads per workgroup (8 waves)
 constexpr int NW = NT / 64;
 
+// Wrapped lattice coordinate of window line v (-L <= v): two selects when the lattice is wider than a
+// window (`fast`, uniform per launch), a true remainder for the small lattices of the tests.
+__device__ __forceinline__ int wrap_line(int v, int L, bool fast) {
+    return fast ? (v < 0 ? v + L : (v >= L ? v - L : v)) : ft_modL(v, L);
+}
+
 // Plane stride (doubles): smallest value >= n that is = 18 (mod 32).  The four k-lanes of an
 // A read (ds_read_b64, 64 banks) then overlap in only 2 of 32 doubles, and the eight channel
 // lanes of an epilogue ds_write_b64 (32 banks = 16 doubles) land on eight different bank pairs
@@ -184,19 +190,28 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
 
+    const bool fastw = L >= G::R0R + 1 && L >= R0C + 1;          // window lines wrap at most once
+    // the tile's own links for the final link update: issued now, consumed in the last stage
+    double xv0 = 0.0, xv1 = 0.0;
+    if (MODE == 0 && A.y && tid < N3) {
+        const int r = tid / TC, c = tid - r * TC;
+        if (i0 + r < L && j0 + c < L) { xv0 = x0[(i0 + r) * L + j0 + c]; xv1 = x1[(i0 + r) * L + j0 + c]; }
+    }
+
     // ---- plaquette window + net input; small weights -> LDS ------------------
-    for (int t = tid; t < N0; t += NT) {
-        const int r = t / R0C, c = t - r * R0C;
-        const int i = ft_modL(i0 - 3 + r, L), j = ft_modL(j0 - 3 + c, L);
-        const int ip = i + 1 == L ? 0 : i + 1, jp = j + 1 == L ? 0 : j + 1;
-        const double p = x0[i * L + j] - x1[i * L + j] - x0[i * L + jp] + x1[ip * L + j];
-        const int sel = ft_stripe(i, j, mu, off);
+    static_assert(N0 <= NT, "one window site per thread");
+    if (tid < N0) {
+        const int r = tid / R0C, c = tid - r * R0C;
+        const int iL = wrap_line(i0 - 3 + r, L, fastw) * L, ipL = wrap_line(i0 - 2 + r, L, fastw) * L;
+        const int j = wrap_line(j0 - 3 + c, L, fastw), jp = wrap_line(j0 - 2 + c, L, fastw);
+        const double p = x0[iL + j] - x1[iL + j] - x0[iL + jp] + x1[ipL + j];
+        const int sel = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;          // stripe class (L % 4 == 0)
         const bool frozen = (sel == 1 || sel == 2);
         double sn = 0.0, cs = 1.0;
         if (frozen) ft_sincos(p, &sn, &cs);
-        sP[t] = p;
-        sIn[t] = cs;
-        sIn[PS0 + t] = sn;
+        sP[tid] = p;
+        sIn[tid] = cs;
+        sIn[PS0 + tid] = sn;
     }
     for (int t = tid; t < SW_SIZE; t += NT) sW[t] = w[WCAN + t];
     __syncthreads();
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             const int r = tid / TC, c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
             if (i < L && j < L) {
-                double v0 = x0[i * L + j], v1 = x1[i * L + j];
+                double v0 = xv0, v1 = xv1;
                 if (ft_stripe(i, j, mu, off) == 0) {
                     const double d = sDL[tid];
                     if (mu == 0) v0 = ft_wrap(d + v0); else v1 = ft_wrap(-d + v1);
@@ -622,12 +637,10 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerA
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
     STAMP(0);
 
-    // Wrapped lattice coordinates of the window lines, once per workgroup (row offsets premultiplied
-    // by L): the loaders below do no integer division.
-    __shared__ int sWrapI[R0R + 1], sWrapJ[R0C + 1];
-    if (tid <= R0R) sWrapI[tid] = ft_modL(i0 - 3 + tid, L) * L;
-    else if (tid >= 64 && tid <= 64 + R0C) sWrapJ[tid - 64] = ft_modL(j0 - 3 + tid - 64, L);
-    __syncthreads();
+    // wrapped lattice coordinates of window lines (row offsets premultiplied by L)
+    const bool fastw = L >= R0R + 1 && L >= R0C + 1;
+    auto WI = [&](int k) { return wrap_line(i0 - 3 + k, L, fastw) * L; };
+    auto WJ = [&](int k) { return wrap_line(j0 - 3 + k, L, fastw); };
 
     // ---- load phase: every global load of the kernel is issued here, back to back, before any of
     //      them is consumed (three dependent round trips to L2/HBM cost ~12k cycles otherwise) ----
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerA
     const bool awave = kmix >= 0 && avalid;
     double aP[4] = {0.0, 0.0, 0.0, 0.0}, ask = 0.0, ag[2] = {0.0, 0.0}, cb = 0.0;
     if (awave) {
-        const int iL = sWrapI[ar + 3], ipL = sWrapI[ar + 4], j = sWrapJ[ac + 3], jp = sWrapJ[ac + 4];
+        const int iL = WI(ar + 3), ipL = WI(ar + 4), j = WJ(ac + 3), jp = WJ(ac + 4);
         aP[0] = x0[iL + j]; aP[1] = x1[iL + j]; aP[2] = x0[iL + jp]; aP[3] = x1[ipL + j];
         ask = sts[(size_t)kmix * n + iL + j];
         cb = A.glogj ? A.glogj[b] : A.glogj_const;
@@ -650,7 +663,7 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerA
         } else {
             const double* gp = A.up_gp + (size_t)b * n;
             ag[0] = gp[iL + j];
-            ag[1] = mu == 0 ? gp[iL + sWrapJ[ac + 2]] : gp[sWrapI[ar + 2] + j];
+            ag[1] = mu == 0 ? gp[iL + WJ(ac + 2)] : gp[WI(ar + 2) + j];
         }
     }
     // stash windows: a thread owns one window site (column lc = tid & 31, row lg = tid >> 5) and walks
@@ -659,8 +672,8 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerA
     static_assert(R1R <= NT / 32 && R1C <= 32, "one window site per thread");
     const int lc = tid & 31, lg = tid >> 5;
     const bool l1 = lc < R1C && lg < R1R, l2 = lc < R2C && lg < R2R;
-    const int go1 = sWrapI[(l1 ? lg : 0) + 1] + sWrapJ[(l1 ? lc : 0) + 1];
-    const int go2 = sWrapI[(l2 ? lg : 0) + 2] + sWrapJ[(l2 ? lc : 0) + 2];
+    const int go1 = WI((l1 ? lg : 0) + 1) + WJ((l1 ? lc : 0) + 1);
+    const int go2 = WI((l2 ? lg : 0) + 2) + WJ((l2 ? lc : 0) + 2);
     double v1[8], v2[8];
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) v1[ch] = l1 ? st1[(size_t)ch * n + go1] : 0.0;
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerA
                                       (((mu == 0 ? j0 + wc : i0 + wr) - 3 - off) & 3) == 2);
     double wP[4] = {0.0, 0.0, 0.0, 0.0};
     if (wfrozen) {
-        const int iL = sWrapI[wr], ipL = sWrapI[wr + 1], j = sWrapJ[wc], jp = sWrapJ[wc + 1];
+        const int iL = WI(wr), ipL = WI(wr + 1), j = WJ(wc), jp = WJ(wc + 1);
         wP[0] = x0[iL + j]; wP[1] = x1[iL + j]; wP[2] = x0[iL + jp]; wP[3] = x1[ipL + j];
     }
     double wsw[2];

@@ -24,7 +24,7 @@ constexpr size_t ALIGN = 32;   // doubles (256 B)
 inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct WS {
-    double *wint, *X, *gp, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *gw_tmp, *stash;
+    double *wint, *X, *gp, *gp2, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *gw_tmp, *stash;
     size_t n2;       // doubles per field batch: B * 2 * L * L
     size_t total;    // doubles
 };
@@ -42,6 +42,7 @@ WS ws_layout(double* base, int B, int L, int nl, bool train = false) {
     w.wint = take((size_t)(nl > 0 ? nl : 1) * FLOW_WINT);
     w.X = take((size_t)nl * n2);
     w.gp = take(n1);
+    w.gp2 = take(nl > 0 ? n1 : 0);                       // second plaquette-gradient field (gather-form backward)
     w.gp_part = take(nl > 0 ? (size_t)B * flow_gp_part_max(L) : 0);
     w.lj_part = take((size_t)B * nt);
     w.scal = take((size_t)SC_N * B);
@@ -111,21 +112,32 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
     const bool stash = mfma && (gw == nullptr ? !have_forward : have_forward);
     const bool train = gw != nullptr && stash;
     if (nl > 0 && !have_forward) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s, stash));
-    FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, w.gp, s));
+    // stash path: gather-form backward, gP ping-pongs between two fields and ends in w.gp
+    double* gcur = (stash && (nl & 1)) ? w.gp2 : w.gp;
+    double* galt = gcur == w.gp ? w.gp2 : w.gp;
+    FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, gcur, s));
     for (int l = nl - 1; l >= 0; --l) {
         FlowLayerArgs a{};
         a.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
         a.wint = w.wint + (size_t)l * FLOW_WINT;
-        a.up_gp = w.gp;
+        a.up_gp = gcur;
         a.glogj_const = glogj;
         a.gp_part = w.gp_part;
         a.gw_part = w.gw_part;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
-        a.stash = stash ? w.stash + (size_t)l * flow_stash_doubles(B, L, train) : nullptr;
-        FT_TRY(train ? launch_flow_bwd_train(a, s) : stash ? launch_flow_bwd_stash(a, s) : flow_bwd(a, gw != nullptr, s));
-        if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_geom(train).ntiles(L), 1.0, 0,
+        if (stash) {
+            a.stash = w.stash + (size_t)l * flow_stash_doubles(B, L, train);
+            a.gp_out = galt;
+            FT_TRY(launch_flow_bwd_gather(a, train, s));
+            if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_gather_geom().ntiles(L), 1.0, 0,
+                                            gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
+            double* t_ = gcur; gcur = galt; galt = t_;
+            continue;
+        }
+        FT_TRY(flow_bwd(a, gw != nullptr, s));
+        if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0,
                                         gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
-        FT_TRY(launch_gather_gp(w.gp_part, B, L, flow_geom(stash || bwd_is_mfma(gw != nullptr)), 1, w.gp, s));
+        FT_TRY(launch_gather_gp(w.gp_part, B, L, flow_geom(bwd_is_mfma(gw != nullptr)), 1, gcur, s));
     }
     return FTHMC_OK;
 }
@@ -463,17 +475,17 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
 
 int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                       double beta, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 3) return FTHMC_ERR_ARG;
-    if (kind < 2 && !w) return FTHMC_ERR_ARG;
+    if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 4) return FTHMC_ERR_ARG;
+    if ((kind < 2 || kind == 4) && !w) return FTHMC_ERR_ARG;
     FT_WS(1);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FlowLayerArgs a{};
-    if (kind < 2) {
+    if (kind < 2 || kind == 4) {
         FT_TRY(launch_pack_weights(w, 1, W.wint, s));
         FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
         a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
-        a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part;
+        a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.gp_out = W.gp2;
         a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
         if (get_flow_variant() == 1) {            // the hot path: forward stashes, backward reads the stash
             a.stash = W.stash;
@@ -488,7 +500,8 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
         if (it == 0) (void)hipEventRecord(e0, s);
         if (kind == 0) rc = flow_fwd(a, s);
-        else if (kind == 1) rc = a.stash ? launch_flow_bwd_stash(a, s) : flow_bwd(a, false, s);
+        else if (kind == 1) rc = a.stash ? launch_flow_bwd_gather(a, false, s) : flow_bwd(a, false, s);
+        else if (kind == 4) rc = a.stash ? launch_flow_bwd_stash(a, s) : FTHMC_ERR_UNSUPPORTED;
         else if (kind == 2) rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
         else rc = launch_hmc_trajectory_fused(x, W.va, W.scal + B, B, L, beta, 0.1, 10, W.xa, nullptr, nullptr, nullptr, nullptr, s);
     }
@@ -503,23 +516,24 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
 
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
+    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 3) return FTHMC_ERR_ARG;
     FT_WS(1);
-    const size_t nrec = (size_t)B * (kind >= 1 ? flow_geom(true) : flow_fwd_geom(true)).ntiles(L);
+    const size_t nrec = (size_t)B * (kind >= 2 ? flow_geom(true) : kind == 1 ? flow_gather_geom() : flow_fwd_geom(true)).ntiles(L);
     long long* dbg = reinterpret_cast<long long*>(W.gw_part);      // B*ntiles*960 doubles >> 16 stamps each
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FT_TRY(launch_pack_weights(w, 1, W.wint, s));
     FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
     FlowLayerArgs a{};
     a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
-    a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.dbg = dbg;
+    a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.gp_out = W.gp2; a.dbg = dbg;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    if (kind == 1) {                              // stash backward needs the forward's stash first
+    if (kind == 1 || kind == 3) {                 // stash backward needs the forward's stash first
         a.stash = W.stash; a.dbg = nullptr;
         FT_TRY(launch_flow_fwd_mfma(a, s));
         a.dbg = dbg;
     }
-    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : kind == 1 ? launch_flow_bwd_stash(a, s) : launch_flow_bwd_mfma(a, s));
+    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : kind == 1 ? launch_flow_bwd_gather(a, false, s)
+           : kind == 3 ? launch_flow_bwd_stash(a, s) : launch_flow_bwd_mfma(a, s));
     long long* h = (long long*)malloc(nrec * 16 * sizeof(long long));
     if (!h) return FTHMC_ERR_ARG;
     if (hipMemcpyAsync(h, dbg, nrec * 16 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||

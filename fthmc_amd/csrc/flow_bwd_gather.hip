@@ -1,0 +1,403 @@
+// Coupling-layer backward from stashed activations, gather form.
+//
+// A workgroup (512 threads) owns a TR x TC tile of one chain and produces the COMPLETE
+// plaquette-gradient of its own sites:  gP_out[p] = gP_in[p] + (layer's contribution at p).
+// Walking the adjoint backwards from the tile, each stage needs its input on a window one site
+// larger:  conv1^T at the tile <- gz1 on tile+1 <- conv2^T <- gz2 on tile+2 <- conv3^T <- g_out at
+// the active sites of tile+3, which is the tan-mixture adjoint evaluated there (P, s, upstream
+// gradient re-read for the halo's active sites: 1/4 of the window, ~110 DP ops each).
+// Compared with the scatter form (k_flow_bwd_stash: each tile pushes the gradient of its own
+// active sites out to a tile+3 window of partial sums that k_gather_gp adds up afterwards):
+//   * the expensive stages shrink (conv2^T runs on tile+1 instead of tile+2, conv1^T on the
+//     tile instead of tile+3), no zero-padded planes, no bounds masks in any conv stage,
+//   * no partial windows in HBM and no gather launch,
+//   * every window position is a real (wrapped) lattice site, so lattices smaller than a tile
+//     need no special case; only the final store and the weight-gradient sums look at validity,
+//   * LDS drops enough for 16 x 16 tiles at two workgroups per CU (halo factors 1.27 / 1.56
+//     instead of 1.9 / 1.4 on the two stashed windows).
+// act'(z1) is loaded while the transform adjoint and conv3^T run: the barriers in between wait
+// for LDS traffic only (s_waitcnt lgkmcnt), not for global loads in flight.
+//
+// Reference: autograd of GaugeEquivCouplingLayer.forward (fthmc/utils/layers.py:196-202,348-371)
+// as used by ft_force (qed_helpers.py:226-242) and train_step (train.py:162-228).
+#include "flow_mfma_common.h"
+
+namespace {
+
+using namespace fthmc;
+using namespace fthmc_flow;
+
+// Workgroup barrier that orders LDS traffic only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int cmax_(int a, int b) { return a > b ? a : b; }
+
+template <int TR, int TC, bool TRAIN> struct SmemG {
+    static constexpr int W3R = TR + 6, W3C = TC + 6, N3W = W3R * W3C;   // g_out window (active sites only)
+    static constexpr int W2R = TR + 4, W2C = TC + 4, N2W = W2R * W2C;   // act'(z2) -> gz2
+    static constexpr int W1R = TR + 2, W1C = TC + 2, N1W = W1R * W1C;   // act'(z1) -> gz1; cos/sin; h1, h2 (training)
+    static constexpr int N3 = TR * TC;
+    static constexpr int PS2 = ps_round(N2W), PS1 = ps_round(N1W);
+    // active lines of the g_out window: every 4th column (mu = 0) or row (mu = 1)
+    static constexpr int NLC = (W3C + 3) / 4, NLR = (W3R + 3) / 4;
+    static constexpr int NSLOT = cmax_(W3R * NLC, NLR * W3C);           // transform tasks
+    static constexpr int NTT = (NSLOT + 63) / 64 * 64;                  // threads that run them (last waves)
+    static constexpr int GO = 0;                                        // [3][N3W] g(s0, s1, t)
+    static constexpr int GZ2 = GO + 3 * N3W;                            // [8][PS2]
+    static constexpr int D1 = GZ2 + 8 * PS2;                            // [8][PS1]
+    static constexpr int IN = D1 + 8 * PS1;                             // [2][PS1] cos, sin (tile+1 coordinates)
+    static constexpr int DIR = IN + 2 * PS1;                            // [N3] layer's contribution at own sites
+    static constexpr int SW = DIR + N3;                                 // [SW_SIZE]
+    static constexpr int H1W = SW + SW_SIZE;                            // [8][PS1] h1 (training)
+    static constexpr int H2W = H1W + (TRAIN ? 8 * PS1 : 0);             // [8][PS1] h2 (training)
+    static constexpr int SIZE = H2W + (TRAIN ? 8 * PS1 : 0);
+    static_assert(W1R % 2 == 0, "row pairs");
+    static_assert(W2C <= 32 && NTT <= NT && 2 * N3 <= NT && N1W <= NT, "thread maps");
+};
+
+template <int TR, int TC, bool TRAIN>
+__global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayerArgs A) {
+    using S = SmemG<TR, TC, TRAIN>;
+    constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
+    constexpr int W1R = S::W1R, W1C = S::W1C, N1W = S::N1W, N3 = S::N3, PS1 = S::PS1, PS2 = S::PS2;
+    __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
+    double* sGO = sm + S::GO;   double* sGZ2 = sm + S::GZ2;  double* sD1 = sm + S::D1;
+    double* sIn = sm + S::IN;   double* sDir = sm + S::DIR;  double* sW = sm + S::SW;
+    double* sH1w = sm + S::H1W; double* sH2w = sm + S::H2W;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = A.L, mu = A.mu, off = A.off;
+    const int n = L * L;
+    const int nti_ = (L + TR - 1) / TR, ntj_ = (L + TC - 1) / TC;
+    BlockTile bt;
+    if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
+    const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
+    const int i0 = bt.ti * TR, j0 = bt.tj * TC;
+    const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // own sites inside the lattice
+    const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
+    const double* __restrict__ x1 = x0 + n;
+    const double* __restrict__ w = A.wint;
+    const double* __restrict__ st1 = A.stash + (size_t)b * 8 * n;                         // act'(z1)[8][L][L]
+    const double* __restrict__ st2 = A.stash + ((size_t)A.B + b) * 8 * n;                 // act'(z2)[8][L][L]
+    const double* __restrict__ sts = A.stash + ((size_t)A.B * 16 + (size_t)b * 2) * n;    // s[2][L][L]
+    const double* __restrict__ sh1 = A.stash + ((size_t)A.B * 18 + (size_t)b * 8) * n;    // h1[8][L][L] (training)
+    const double* __restrict__ sh2 = A.stash + ((size_t)A.B * 26 + (size_t)b * 8) * n;    // h2[8][L][L] (training)
+    double* gwp = TRAIN ? A.gw_part + ((size_t)b * ntiles + tile) * FLOW_GW_STRIDE : nullptr;
+    long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
+#define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+    STAMP(0);
+
+    // wrapped lattice coordinates of window lines, relative to the tile origin (rows premultiplied by L)
+    const bool fastw = L >= S::W3R + 1 && L >= W3C + 1;
+    auto WI = [&](int k) { return wrap_line(i0 + k, L, fastw) * L; };
+    auto WJ = [&](int k) { return wrap_line(j0 + k, L, fastw); };
+
+    // ---- load phase ---------------------------------------------------------------------------
+    // (1) transform tasks on the last waves: active site `a` of the tile+3 window, both mixture components
+    const int ta = tid - (NT - S::NTT);
+    const int c0 = (off - (j0 - 3)) & 3, r0 = (off - (i0 - 3)) & 3;    // first active column / row of the window
+    int tr3 = 0, tc3 = 0;
+    bool ttask = false;
+    if (ta >= 0) {
+        if (mu == 0) { tr3 = ta / S::NLC; tc3 = c0 + 4 * (ta - tr3 * S::NLC); ttask = tr3 < S::W3R && tc3 < W3C; }
+        else { const int m = ta / W3C; tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
+    }
+    double aP[4] = {0.0, 0.0, 0.0, 0.0}, as_[NMIX] = {0.0, 0.0}, ag[2] = {0.0, 0.0}, cb = 0.0;
+    if (ttask) {
+        const int iL = WI(tr3 - 3), ipL = WI(tr3 - 2), j = WJ(tc3 - 3), jp = WJ(tc3 - 2);
+        aP[0] = x0[iL + j]; aP[1] = x1[iL + j]; aP[2] = x0[iL + jp]; aP[3] = x1[ipL + j];
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) as_[k] = sts[(size_t)k * n + iL + j];
+        cb = A.glogj ? A.glogj[b] : A.glogj_const;
+        if (A.up_link) {
+            ag[0] = A.up_link[(size_t)b * 2 * n + (size_t)mu * n + iL + j];
+        } else {
+            const double* gp = A.up_gp + (size_t)b * n;
+            ag[0] = gp[iL + j];
+            ag[1] = mu == 0 ? gp[iL + WJ(tc3 - 4)] : gp[WI(tr3 - 4) + j];
+        }
+    }
+    // (2) cos / sin of the frozen plaquettes: own sites only, or the whole tile+1 window for the conv1
+    //     weight gradient (training).  Stored in tile+1 coordinates.
+    int fr1 = 0, fc1 = 0;                                                // tile+1 coordinates of this thread's site
+    bool ftask = false;
+    if (TRAIN) {
+        if (tid < N1W) {
+            fr1 = tid / W1C; fc1 = tid - fr1 * W1C;
+            const int cls = ((mu == 0 ? j0 - 1 + fc1 : i0 - 1 + fr1) - off) & 3;
+            ftask = cls == 1 || cls == 2;
+        }
+    } else if (tid < N3 / 2) {
+        int r, c;
+        if (mu == 0) { r = tid / (TC / 2); const int h = tid - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
+        else { const int hh = tid / TC; c = tid - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
+        fr1 = r + 1; fc1 = c + 1; ftask = true;
+    }
+    double wP[4] = {0.0, 0.0, 0.0, 0.0};
+    if (ftask) {
+        const int iL = WI(fr1 - 1), ipL = WI(fr1), j = WJ(fc1 - 1), jp = WJ(fc1);
+        wP[0] = x0[iL + j]; wP[1] = x1[iL + j]; wP[2] = x0[iL + jp]; wP[3] = x1[ipL + j];
+    }
+    // (3) upstream gradient of the own sites (pass-through term)
+    const int orr = tid / TC, occ = tid - orr * TC;
+    const bool ovalid = tid < N3 && orr < rmax && occ < cmax;
+    double gpin = 0.0;
+    if (ovalid && A.up_gp) gpin = A.up_gp[(size_t)b * n + (i0 + orr) * L + j0 + occ];
+    // (4) stash windows: a thread owns window column lc and rows lg, lg + 16 and walks the 8 channel planes
+    const int lc = tid & 31, lg = tid >> 5;
+    constexpr int NP2 = (W2R + 15) / 16, NP1 = (W1R + 15) / 16;
+    double v2[NP2][8];
+#pragma unroll
+    for (int p = 0; p < NP2; ++p) {
+        const int r = lg + 16 * p;
+        const bool ok = lc < W2C && r < W2R;
+        const int go = WI((ok ? r : 0) - 2) + WJ((ok ? lc : 0) - 2);
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) v2[p][ch] = ok ? st2[(size_t)ch * n + go] : 0.0;
+    }
+    double wsw[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wsw[k] = (tid + k * NT < SW_SIZE) ? w[WCAN + tid + k * NT] : 0.0;
+    static_assert(SW_SIZE <= 2 * NT, "weight copy");
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- consume ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < 2; ++k) if (tid + k * NT < SW_SIZE) sW[tid + k * NT] = wsw[k];
+    if (ttask) {
+        // adjoint of the tan-mixture transform (layers.py:66-90), everything of a site in one lane
+        const double Pa = aP[0] - aP[1] - aP[2] + aP[3];
+        const double gdelta = A.up_link ? (mu == 0 ? ag[0] : -ag[0]) : ag[0] - ag[1];
+        double sn, cs;
+        ft_sincos(Pa / 2, &sn, &cs);
+        const double cs2 = cs * cs, sn2 = sn * sn, sinP = 2.0 * (sn * cs);
+        double es[NMIX], ems[NMIX], invD[NMIX], si = 0.0;
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) { es[k] = ft_exp(as_[k]); ems[k] = ft_exp(-as_[k]); }
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) { invD[k] = 1.0 / (ems[k] * cs2 + es[k] * sn2); si += invD[k]; }
+        double gsum = -gdelta;
+        const int at = tr3 * W3C + tc3;
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) {
+            const double wk = invD[k] / si;                              // softmax_k(-log D_k)
+            sGO[k * N3W + at] = gdelta * (sinP * invD[k] / NMIX) + cb * wk * (ems[k] * cs2 - es[k] * sn2) * invD[k];
+            gsum += gdelta * (invD[k] / NMIX) - cb * wk * sinP * 0.5 * (es[k] - ems[k]) * invD[k];
+        }
+        sGO[NMIX * N3W + at] = gdelta;                                   // dL/dt
+        const int r = tr3 - 3, c = tc3 - 3;
+        if ((unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC) sDir[r * TC + c] = gsum;
+    }
+    if (TRAIN ? tid < N1W : ftask) {
+        double sn = 0.0, cs = 1.0;
+        if (ftask) ft_sincos(wP[0] - wP[1] - wP[2] + wP[3], &sn, &cs);
+        sIn[fr1 * W1C + fc1] = cs; sIn[PS1 + fr1 * W1C + fc1] = sn;
+    }
+#pragma unroll
+    for (int p = 0; p < NP2; ++p) {
+        const int r = lg + 16 * p;
+        if (lc < W2C && r < W2R) {
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) sGZ2[ch * PS2 + r * W2C + lc] = v2[p][ch];
+        }
+    }
+    // act'(z1) (and h1, h2): issued now, landing while conv3^T runs
+    double v1[NP1][8];
+    double vh1[TRAIN ? NP1 : 1][8], vh2[TRAIN ? NP1 : 1][8];
+#pragma unroll
+    for (int p = 0; p < NP1; ++p) {
+        const int r = lg + 16 * p;
+        const bool ok = lc < W1C && r < W1R;
+        const int go = WI((ok ? r : 0) - 1) + WJ((ok ? lc : 0) - 1);
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) v1[p][ch] = ok ? st1[(size_t)ch * n + go] : 0.0;
+        if (TRAIN) {
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) vh1[p][ch] = ok ? sh1[(size_t)ch * n + go] : 0.0;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) vh2[p][ch] = ok ? sh2[(size_t)ch * n + go] : 0.0;
+        }
+    }
+    lds_barrier();
+    STAMP(1);
+
+    // ---- conv3^T on the VALU: g_out lives on the active lines, so of the 9 taps of a site at most 3
+    //      (one line) contribute; times act'(z2) -> gz2 in place ------------------------------------
+    for (int t = tid; t < 2 * N2W; t += NT) {
+        const int half = t >= N2W;
+        const int s = half ? t - N2W : t;
+        const int r = s / W2C, c = s - r * W2C;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        // source = site - (ky - 1, kx - 1): window coordinates (r + 2 - ky, c + 2 - kx) of tile+3
+        const int ksel = mu == 0 ? (c + 2 - c0) & 3 : (r + 2 - r0) & 3;   // the one kx (mu=0) / ky (mu=1)
+        if (ksel <= 2) {
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
+                const int at = (r + 2 - ky) * W3C + c + 2 - kx;
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    const double gv = sGO[co * N3W + at];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc[k] = fma(gv, sW[CW2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx], acc[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sGZ2[(half * 4 + k) * PS2 + s] *= acc[k];
+    }
+#pragma unroll
+    for (int p = 0; p < NP1; ++p) {
+        const int r = lg + 16 * p;
+        if (lc < W1C && r < W1R) {
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) sD1[ch * PS1 + r * W1C + lc] = v1[p][ch];
+            if (TRAIN) {
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) sH1w[ch * PS1 + r * W1C + lc] = vh1[p][ch];
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) sH2w[ch * PS1 + r * W1C + lc] = vh2[p][ch];
+            }
+        }
+    }
+    lds_barrier();
+    STAMP(2);
+
+    if (TRAIN) {
+        // ---- weight gradient of conv3 and b3: sums over the tile's own active sites (VALU) -------
+        constexpr int NA = N3 / 4;
+        for (int t = tid; t < 216; t += NT) {
+            const int co = t / 72, ci = (t / 9) % 8, tap = t % 9, ky = tap / 3, kx = tap % 3;
+            double acc = 0.0;
+            for (int a = 0; a < NA; ++a) {
+                const int r = mu == 0 ? a / (TC / 4) : off + 4 * (a / TC);
+                const int c = mu == 0 ? off + 4 * (a % (TC / 4)) : a % TC;
+                if (r < rmax && c < cmax)
+                    acc = fma(sGO[co * N3W + (r + 3) * W3C + c + 3], sH2w[ci * PS1 + (r + ky) * W1C + c + kx], acc);
+            }
+            gwp[CW2 + t] = acc;
+        }
+        if (wave < 3) {
+            double a_ = 0.0;
+            for (int a = lane; a < NA; a += 64) {
+                const int r = mu == 0 ? a / (TC / 4) : off + 4 * (a / TC);
+                const int c = mu == 0 ? off + 4 * (a % (TC / 4)) : a % TC;
+                if (r < rmax && c < cmax) a_ += sGO[wave * N3W + (r + 3) * W3C + c + 3];
+            }
+            a_ = ft_wave_sum(a_);
+            if (lane == 0) gwp[CB2 + wave] = a_;
+        }
+    }
+
+    // ---- conv2^T (MFMA), times act'(z1) -> gz1 in place over d1 -------------------------------
+    // W[k = (tap, co)][n = (ci, dd)] = W1[co][ci][2 - (ky4 - dd)][2 - kx]
+    auto bidx4 = [](int t, int g, int cN, int dd) {
+        const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
+        return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
+    };
+    mfma_stage<24, 8, W1R, W1C, W2C, PS2>(sGZ2, sW, wave, lane, bidx4,
+        [&](int g, int pr, int pc, bool ok, double (&gh)[4]) {
+            if (ok) {
+                double* pd = sD1 + g * PS1 + 2 * pr * W1C + pc;
+                pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[W1C] *= gh[2]; pd[4 * PS1 + W1C] *= gh[3];
+            }
+        });
+    lds_barrier();
+    STAMP(3);
+
+    if (TRAIN) {
+        // ---- weight gradient of conv2 (MFMA over the tile's own sites) and b2: gz2 outside the own,
+        //      in-lattice sites is dropped first (there it belongs to other tiles), which also makes
+        //      the ring the dy trick of wgrad_stage reads ---------------------------------------------
+        for (int t = tid; t < 8 * N2W; t += NT) {
+            const int ci = t / N2W, s = t - ci * N2W, r = s / W2C - 2, c = s % W2C - 2;
+            if (!((unsigned)r < (unsigned)rmax && (unsigned)c < (unsigned)cmax)) sGZ2[ci * PS2 + s] = 0.0;
+        }
+        lds_barrier();
+        {
+            double a_ = 0.0;
+            for (int e = lane; e < N2W; e += 64) a_ += sGZ2[wave * PS2 + e];
+            a_ = ft_wave_sum(a_);
+            if (lane == 0) gwp[CB1 + wave] = a_;
+        }
+        if (wave < 3)                                                // 3 N tiles of (ci, kx, kyb) = 48 columns
+            wgrad_stage<TR, TC, W2C, PS2, W1C, PS1, 8, true>(sGZ2 + 2 * W2C + 2, sH1w, wave, lane,
+                [&](int co, int ci, int ky, int kx, double v) { gwp[CW1 + (co * 8 + ci) * 9 + ky * 3 + kx] = v; });
+    }
+
+    // ---- conv1^T and the (cos, sin) adjoint at the tile's own frozen plaquettes ------------------
+    // thread = (frozen site, quarter of the 8 channels); the four quarters of a site sit in adjacent lanes
+    if (tid < 2 * N3) {
+        const int f = tid >> 2, qq = tid & 3;
+        int r, c;
+        if (mu == 0) { r = f / (TC / 2); const int h = f - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
+        else { const int hh = f / TC; c = f - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
+        double gc[2] = {0.0, 0.0}, gsn[2] = {0.0, 0.0};
+#pragma unroll
+        for (int cq = 0; cq < 2; ++cq) {
+            const int co = 2 * qq + cq;
+            const double* gz = sD1 + co * PS1 + r * W1C + c;            // window coordinates (r + 2 - ky, c + 2 - kx)
+            const double* wp = sW + CW0 + co * 18;
+            double gv[9], w0[9], w1[9];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) { gv[tp] = gz[(2 - tp / 3) * W1C + 2 - tp % 3]; w0[tp] = wp[tp]; w1[tp] = wp[9 + tp]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) { gc[cq] = fma(gv[tp], w0[tp], gc[cq]); gsn[cq] = fma(gv[tp], w1[tp], gsn[cq]); }
+        }
+        double gct = gc[0] + gc[1], gst = gsn[0] + gsn[1];
+        gct += __shfl_xor(gct, 1, FT_WAVE); gst += __shfl_xor(gst, 1, FT_WAVE);
+        gct += __shfl_xor(gct, 2, FT_WAVE); gst += __shfl_xor(gst, 2, FT_WAVE);
+        if (qq == 0) {
+            const int at = (r + 1) * W1C + c + 1;
+            sDir[r * TC + c] = -sIn[PS1 + at] * gct + sIn[at] * gst;
+        }
+    }
+    lds_barrier();
+    STAMP(4);
+
+    if (TRAIN) {
+        // ---- weight gradient of conv1 (one N tile: (ci 2, kx 3, kyb 2) = 12 columns) and b1 ------
+        for (int t = tid; t < 8 * N1W; t += NT) {
+            const int co = t / N1W, s = t - co * N1W, r = s / W1C - 1, c = s % W1C - 1;
+            if (!((unsigned)r < (unsigned)rmax && (unsigned)c < (unsigned)cmax)) sD1[co * PS1 + s] = 0.0;
+        }
+        lds_barrier();
+        if (wave == 0)
+            wgrad_stage<TR, TC, W1C, PS1, W1C, PS1, 2, true>(sD1 + W1C + 1, sIn, 0, lane,
+                [&](int co, int ci, int ky, int kx, double v) { gwp[CW0 + (co * 2 + ci) * 9 + ky * 3 + kx] = v; });
+        else {
+            const int co = wave;                                     // waves 1..7 -> b1[1..7]; wave 1 also b1[0]
+            for (int cc = (co == 1 ? 0 : co); cc <= co; ++cc) {
+                double a_ = 0.0;
+                for (int e = lane; e < N1W; e += 64) a_ += sD1[cc * PS1 + e];
+                a_ = ft_wave_sum(a_);
+                if (lane == 0) gwp[CB0 + cc] = a_;
+            }
+        }
+    }
+
+    // ---- gP_out = gP_in + this layer's contribution at the own sites ---------------------------
+    if (ovalid) {
+        const int cls = ((mu == 0 ? j0 + occ : i0 + orr) - off) & 3;  // 0 active, 1|2 frozen, 3 passive
+        A.gp_out[(size_t)b * n + (i0 + orr) * L + j0 + occ] = gpin + (cls != 3 ? sDir[tid] : 0.0);
+    }
+    STAMP(5);
+#undef STAMP
+}
+
+}  // namespace
+
+namespace fthmc {
+
+int launch_flow_bwd_gather(const FlowLayerArgs& a, bool train, hipStream_t s) {
+    const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
+    if (train) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true>), grid, dim3(NT), 0, s, a);
+    else       hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false>), grid, dim3(NT), 0, s, a);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+
+}  // namespace fthmc

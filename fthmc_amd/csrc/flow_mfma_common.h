@@ -1,0 +1,158 @@
+// Building blocks shared by the MFMA coupling-layer kernels (flow_mfma.hip, flow_bwd_gather.hip):
+// tile geometry, the implicit-GEMM conv stage, the weight-gradient GEMM stage, the XCD-aware block map.
+#pragma once
+#include "flow_common.h"
+
+namespace fthmc_flow {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 512;                 // threads per workgroup (8 waves)
+constexpr int NW = NT / 64;
+
+// Wrapped lattice coordinate of window line v (-L <= v): two selects when the lattice is wider than a
+// window (`fast`, uniform per launch), a true remainder for the small lattices of the tests.
+__device__ __forceinline__ int wrap_line(int v, int L, bool fast) {
+    return fast ? (v < 0 ? v + L : (v >= L ? v - L : v)) : ft_modL(v, L);
+}
+
+// Plane stride (doubles): smallest value >= n that is = 18 (mod 32).  The four k-lanes of an
+// A read (ds_read_b64, 64 banks) then overlap in only 2 of 32 doubles, and the eight channel
+// lanes of an epilogue ds_write_b64 (32 banks = 16 doubles) land on eight different bank pairs
+// (with = 16 (mod 32) they would all hit the same pair: 8-way conflict on every store).
+constexpr int ps_round(int n) { return ((n - 18 + 31) / 32) * 32 + 18; }
+
+template <int TR, int TC> struct Geom {
+    static constexpr int R0R = TR + 6, R0C = TC + 6, N0 = R0R * R0C;   // plaquette / input window
+    static constexpr int R1R = TR + 4, R1C = TC + 4, N1 = R1R * R1C;   // h1 window
+    static constexpr int R2R = TR + 2, R2C = TC + 2, N2 = R2R * R2C;   // h2 window
+    static constexpr int N3 = TR * TC, NA = N3 / 4;                    // tile, active sites
+    static constexpr int NAS = NA <= 32 ? 32 : 64;                     // lane stride of per-active-site scratch
+    static constexpr int PS0 = ps_round(N0), PS1 = ps_round(N1), PS2 = ps_round(N2);
+    static_assert(PS0 % 32 == 18 && PS1 % 32 == 18 && PS2 % 32 == 18, "bank layout");
+    static_assert(PS0 >= N0 && PS1 >= N1 && PS2 >= N2, "plane size");
+    static_assert(TR % 4 == 0 && TC % 4 == 0 && NA <= 64, "tile shape");
+};
+
+// LDS copy of the layer's canonical weights (flow_common.h: CW0 CB0 CW1 CB1 CW2 CB2, WZERO)
+constexpr int SW_SIZE = WCAN_SIZE;
+
+// One implicit-GEMM stage.  Output region HOUT x WOUT (HOUT even) whose input planes are one
+// site larger on every side (forward conv) or ring-2 padded (transposed conv): input index of
+// output (r, c) and window tap (ky4, kx) is (r + ky4, c + kx) for the pair's upper row r = 2q.
+// The epilogue gets the four values of a lane at once so that their chains interleave:
+// epi(g, pr, pc, ok, z) with z[q] = output channel g + 4 (q & 1) at site (2 pr + (q >> 1), pc).
+// bidx(t, g, cN, dd) -> index of W[k = 4 t + g][n = cN + 8 dd] in the LDS weight copy sW.
+template <int NSTEP, int KC, int HOUT, int WOUT, int RSA, int PSA, class BIdx, class Epi>
+__device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ sW,
+                                           int wave, int lane, BIdx bidx, Epi epi) {
+    constexpr int NPAIR = (HOUT / 2) * WOUT;
+    constexpr int NTILE = (NPAIR + 15) / 16;
+    const int g = lane >> 4, i = lane & 15;
+    // A-operand offset of k = 4 t + g: k -> (tap = k / KC, channel = k % KC).  For KC = 8 the lane
+    // part is just g * PSA and the rest is a compile-time immediate; otherwise a small table.
+    int koff[KC == 8 ? 1 : NSTEP];
+    if (KC != 8) {
+#pragma unroll
+        for (int t = 0; t < NSTEP; ++t) {
+            const int k = 4 * t + g, tap = k / KC, cK = k - tap * KC;
+            koff[t] = cK * PSA + (tap / 3) * RSA + (tap % 3);
+        }
+    }
+    const int cN = i & 7, dd = i >> 3;
+    int boff[NSTEP];
+#pragma unroll
+    for (int t = 0; t < NSTEP; ++t) boff[t] = bidx(t, g, cN, dd);
+    for (int tile = wave; tile < NTILE; tile += NW) {
+        // The weights are the MFMA's A operand and the activations its B operand, so D comes out
+        // transposed: D[row = (channel, pair row)][col = pair site].  A lane then holds one pair
+        // site (col = i) and the four rows g + 4 q = (channel g | g + 4) x (pair row 0 | 1): all the
+        // site arithmetic of the epilogue (offsets, bounds, stash address) happens once per lane and
+        // tile instead of once per value (integer VALU work used to outnumber the fp64 work 2:1).
+        const int p_ = tile * 16 + i;
+        const bool ok = p_ < NPAIR;
+        const int p = ok ? p_ : NPAIR - 1;                   // padding lanes: any valid address
+        const int pr = p / WOUT, pc = p - pr * WOUT;
+        const double* a0 = A + (2 * pr) * RSA + pc + (KC == 8 ? g * PSA : 0);
+        // independent accumulator chains keep the matrix pipe busy when a wave is alone on it
+        constexpr int NCH = NSTEP >= 8 ? 4 : 3;
+        double4_t accs[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) accs[ch] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < NSTEP; ++t) {
+            double av;
+            if (KC == 8) av = a0[(t & 1) * 4 * PSA + ((t >> 1) / 3) * RSA + ((t >> 1) % 3)];
+            else av = a0[koff[t]];
+            accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(sW[boff[t]], av, accs[t % NCH], 0, 0, 0);
+        }
+        double4_t acc = accs[0];
+#pragma unroll
+        for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
+        // z[q]: q & 1 -> channel g + 4 (q & 1), q >> 1 -> row 2 pr + (q >> 1) of the pair
+        double z4[4] = {acc[0], acc[1], acc[2], acc[3]};
+        epi(g, pr, pc, ok, z4);
+    }
+}
+
+
+// XCD-aware block -> (chain, tile) map.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8
+// share one), and each XCD has its own L2: all tiles of a chain go to the same XCD, consecutively,
+// so the halo re-reads of neighbouring tiles (links, stashed activations) hit that XCD's L2
+// instead of going out to the fabric once per XCD.  Speed only: any placement is correct.
+struct BlockTile { int b, tile, ti, tj; };
+__device__ __forceinline__ bool block_tile(int B, int nti, int ntj, BlockTile& t) {
+    const int ntiles = nti * ntj;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int cl = slot / ntiles;
+    t.tile = slot - cl * ntiles;
+    t.b = cl * 8 + xcd;
+    t.ti = t.tile / ntj;
+    t.tj = t.tile - t.ti * ntj;
+    return t.b < B;
+}
+inline dim3 xcd_grid(int B, int nti, int ntj) { return dim3(8 * ((B + 7) / 8) * nti * ntj); }
+
+// Weight gradient of a 3x3 conv as an MFMA GEMM over the sites of the tile's window:
+//   gw[co][ci][ky][kx] = sum_s gz[co][s] * hin[ci][s + (ky, kx)]
+// M = 16 = 8 co x (dy = 0, 1): A[(co, dy)][s] = gz[co][s - dy rows];  N = (ci, kx, kyb) with ky = 2 kyb:
+// D[(co, dy)][(ci, kx, kyb)] = gw[co][ci][2 kyb + dy][kx]  (row 3 of the 4 it produces is discarded).
+// That packs the 8 output channels twice into M the same way the forward packs two rows into N.
+// One wave owns one 16-column N tile and walks all sites (K); results go straight to the tile's
+// partial in global memory.  GZPAD: gz planes have a ring so row -1 is readable (zeros).
+template <int HS, int WSI, int RSG, int PSG, int RSH, int PSH, int CIN, bool GZPAD, class Store>
+__device__ __forceinline__ void wgrad_stage(const double* __restrict__ gz, const double* __restrict__ hin,
+                                            int nt, int lane, Store store) {
+    // one extra site row: the dy = 1 rows of A lag one row behind, their last term is gz[HS-1] at s = HS
+    constexpr int NS = (HS + 1) * WSI, NSTEP = (NS + 3) / 4, NCOL = CIN * 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int co = i & 7, dy = i >> 3;                      // A row m = (co, dy)
+    const int ncol = nt * 16 + i;                           // B column n = (ci, kx, kyb)
+    const int ci = ncol / 6, kx = (ncol % 6) >> 1, kyb = ncol & 1;
+    const bool ncol_ok = ncol < NCOL;
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    int r = g / WSI, c = g % WSI;                           // site of k = 4 t + g, t = 0
+#pragma unroll 2
+    for (int t = 0; t < NSTEP; ++t) {
+        const int ra = r - dy, rb = r + 2 * kyb;
+        // gz rows -1 and HS are the zero ring when GZPAD, else masked; h rows beyond the window are masked
+        const bool aok = r <= HS && (GZPAD || (ra >= 0 && ra < HS));
+        const bool bok = r <= HS && ncol_ok && rb < HS + 2;
+        const double av = aok ? gz[co * PSG + ra * RSG + c] : 0.0;
+        const double bv = bok ? hin[ci * PSH + rb * RSH + c + kx] : 0.0;
+        if (t & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc1, 0, 0, 0);
+        else       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc0, 0, 0, 0);
+        c += 4; if (c >= WSI) { c -= WSI; ++r; }            // WSI >= 4
+    }
+    const double4_t acc = acc0 + acc1;
+    // D[row = g + 4 q][col = i]: row m = (co', dy'), col n = (ci, kx, kyb) of this lane
+    if (ncol_ok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = g + 4 * q, co2 = m & 7, dy2 = m >> 3, ky = 2 * kyb + dy2;
+            if (ky <= 2) store(co2, ci, ky, kx, acc[q]);
+        }
+    }
+}
+
+}  // namespace fthmc_flow

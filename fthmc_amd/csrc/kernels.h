@@ -75,7 +75,8 @@ struct FlowLayerArgs {
     const double* up_gp;     // bwd: upstream plaquette-gradient field [B][L][L] or null
     const double* glogj;     // bwd: [B] or null (then glogj_const)
     double glogj_const;
-    double* gp_part;         // bwd: [B][ntiles][FLOW_N0]
+    double* gp_part;         // bwd, scatter form: [B][ntiles][FLOW_N0]
+    double* gp_out;          // bwd, gather form: plaquette-gradient field after this layer [B][L][L] (not up_gp)
     double* gw_part;         // bwd with wgrad: [B*ntiles][FLOW_GW_STRIDE]
     double tol;              // rev
     long long* dbg;          // optional: per-(chain,tile) stage time stamps [16] (diagnostic runs only)
@@ -94,6 +95,12 @@ int launch_flow_bwd_stash(const FlowLayerArgs& a, hipStream_t s);
 // backward wrt x AND the weights from the stash incl. h1, h2; partial weight gradients per tile
 // go to a.gw_part [B*ntiles][FLOW_GW_STRIDE] (ntiles of flow_geom(true))
 int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s);
+// flow_bwd_gather.hip: backward from the stash in gather form: a tile produces the complete
+// gP_out = up_gp + layer contribution of its own sites (a.gp_out, out of place), no partial windows;
+// train = also per-tile weight-gradient partials to a.gw_part (ntiles of flow_gather_geom())
+constexpr int MG_TR = 16, MG_TC = 16;
+inline FlowGeom flow_gather_geom() { return FlowGeom{MG_TR, MG_TC}; }
+int launch_flow_bwd_gather(const FlowLayerArgs& a, bool train, hipStream_t s);
 // doubles per layer of the stash: act'(z1)[B][8][L][L], act'(z2)[B][8][L][L], s[B][2][L][L]
 // (+ h1[B][8][L][L], h2[B][8][L][L] for training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 34 : 18) * L * L; }

@@ -73,13 +73,13 @@ def host_threads():
     return max(1, min(n, 16))
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-    same command (profiles/r01_pmc_summary.json: FETCH_SIZE + WRITE_SIZE, KiB, raw)."""
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_summary.json: FETCH_SIZE + WRITE_SIZE, KiB, raw)."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')) as f:
             k = json.load(f)['kernels']
-        k = next(v for n, v in k.items() if 'k_flow_bwd_stash' in n)
+        k = next(v for n, v in k.items() if kernel in n)
         return round((k['FETCH_SIZE']['mean_per_launch'] + k['WRITE_SIZE']['mean_per_launch']) * 1024)
     except Exception:
         return None
@@ -205,7 +205,7 @@ def main():
     value = chain_steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- roofline of the dominant kernel (coupling-layer backward), HIP events on this stream
+    # ---- roofline of the dominant kernel, HIP events on this stream
     with torch.cuda.stream(stream):
         w0 = w[:955].contiguous()
         ms_bwd = ops.time_kernel('flow_bwd', x, w0, mu=0, off=0, beta=BETA, reps=40)
@@ -213,16 +213,27 @@ def main():
         ms_leap = ops.time_kernel('leap_step', x, beta=BETA, reps=40)
         ms_traj = ops.time_kernel('hmc_trajectory', x, beta=BETA, reps=20)
     log(f'kernel timing: bwd {ms_bwd:.4f} ms fwd {ms_fwd:.4f} ms leap {ms_leap:.5f} ms')
-    flops_launch = CONV_FLOPS_PER_SITE * L * L * B          # dense dgrad of one layer, B chains
-    achieved = flops_launch / (ms_bwd * 1e-3) / 1e12
+    flops_launch = CONV_FLOPS_PER_SITE * L * L * B          # dense conv flops of one layer (fwd = dgrad), B chains
+    # the dominant kernel = the one with the larger share of a trajectory: the forward kernel runs
+    # N_LAYERS * (NSTEP + 1) times (force sweeps + H1), the backward kernel N_LAYERS * NSTEP times
+    share = {'fwd': ms_fwd * N_LAYERS * (NSTEP + 1), 'bwd': ms_bwd * N_LAYERS * NSTEP}
+    dom = max(share, key=share.get)
+    names = {'fwd': ('k_flow_mfma<0,16,16> (coupling-layer forward: conv net + tan-mixture transform + stash)', 'k_flow_mfma<0'),
+             'bwd': ('k_flow_bwd_gather<16,16> (coupling-layer backward wrt x from the stash)', 'k_flow_bwd_gather')}
+    ms_dom = ms_fwd if dom == 'fwd' else ms_bwd
+    achieved = flops_launch / (ms_dom * 1e-3) / 1e12
     step_flops = 2 * CONV_FLOPS_PER_SITE * L * L * N_LAYERS * B    # fwd + dgrad, per batched leapfrog step
     roofline = {
-        'bound': 'mfma', 'kernel': 'k_flow_bwd_stash<8,16> (coupling-layer backward wrt x)',
+        'bound': 'mfma', 'kernel': names[dom][0],
         'achieved': round(achieved, 3), 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(achieved / FP64_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(),
-        'avg_launch_ms': round(ms_bwd, 4),
+        'frac': round(achieved / FP64_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(names[dom][1]),
+        'avg_launch_ms': round(ms_dom, 4),
         'algorithmic_flops_per_launch': flops_launch,
-        'fwd_kernel_ms': round(ms_fwd, 4),
+        'ms_per_trajectory': {k: round(v, 3) for k, v in share.items()},
+        'fwd_kernel_ms': round(ms_fwd, 4), 'bwd_kernel_ms': round(ms_bwd, 4),
+        'bwd_kernel': {'kernel': names['bwd'][0], 'achieved': round(flops_launch / (ms_bwd * 1e-3) / 1e12, 3),
+                       'frac': round(flops_launch / (ms_bwd * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                       'traffic': pmc_traffic(names['bwd'][1])},
         'whole_step_tflops': round(step_flops * (NSTEP * args.steps) / elapsed / 1e12, 3),
         'stencil': {'kernel': 'k_force<1> (fused plain-HMC leapfrog step, one launch per step)',
                     'avg_launch_ms': round(ms_leap, 5),

@@ -475,13 +475,13 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
 
 int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                       double beta, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 4) return FTHMC_ERR_ARG;
-    if ((kind < 2 || kind == 4) && !w) return FTHMC_ERR_ARG;
+    if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 3) return FTHMC_ERR_ARG;
+    if (kind < 2 && !w) return FTHMC_ERR_ARG;
     FT_WS(1);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FlowLayerArgs a{};
-    if (kind < 2 || kind == 4) {
+    if (kind < 2) {
         FT_TRY(launch_pack_weights(w, 1, W.wint, s));
         FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
         a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
@@ -501,7 +501,6 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
         if (it == 0) (void)hipEventRecord(e0, s);
         if (kind == 0) rc = flow_fwd(a, s);
         else if (kind == 1) rc = a.stash ? launch_flow_bwd_gather(a, false, s) : flow_bwd(a, false, s);
-        else if (kind == 4) rc = a.stash ? launch_flow_bwd_stash(a, s) : FTHMC_ERR_UNSUPPORTED;
         else if (kind == 2) rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
         else rc = launch_hmc_trajectory_fused(x, W.va, W.scal + B, B, L, beta, 0.1, 10, W.xa, nullptr, nullptr, nullptr, nullptr, s);
     }
@@ -516,9 +515,9 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
 
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 3) return FTHMC_ERR_ARG;
+    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
     FT_WS(1);
-    const size_t nrec = (size_t)B * (kind >= 2 ? flow_geom(true) : kind == 1 ? flow_gather_geom() : flow_fwd_geom(true)).ntiles(L);
+    const size_t nrec = (size_t)B * (kind == 2 ? flow_geom(true) : kind == 1 ? flow_gather_geom() : flow_fwd_geom(true)).ntiles(L);
     long long* dbg = reinterpret_cast<long long*>(W.gw_part);      // B*ntiles*960 doubles >> 16 stamps each
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FT_TRY(launch_pack_weights(w, 1, W.wint, s));
@@ -527,13 +526,13 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
     a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
     a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.gp_out = W.gp2; a.dbg = dbg;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    if (kind == 1 || kind == 3) {                 // stash backward needs the forward's stash first
+    if (kind == 1) {                              // stash backward needs the forward's stash first
         a.stash = W.stash; a.dbg = nullptr;
         FT_TRY(launch_flow_fwd_mfma(a, s));
         a.dbg = dbg;
     }
     FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : kind == 1 ? launch_flow_bwd_gather(a, false, s)
-           : kind == 3 ? launch_flow_bwd_stash(a, s) : launch_flow_bwd_mfma(a, s));
+                                                        : launch_flow_bwd_mfma(a, s));
     long long* h = (long long*)malloc(nrec * 16 * sizeof(long long));
     if (!h) return FTHMC_ERR_ARG;
     if (hipMemcpyAsync(h, dbg, nrec * 16 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||

@@ -27,9 +27,6 @@ namespace {
 using namespace fthmc;
 using namespace fthmc_flow;
 
-// Workgroup barrier that orders LDS traffic only.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 constexpr int cmax_(int a, int b) { return a > b ? a : b; }
 
 template <int TR, int TC, bool TRAIN> struct SmemG {

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         sIn[PS0 + tid] = sn;
     }
     for (int t = tid; t < SW_SIZE; t += NT) sW[t] = w[WCAN + t];
-    __syncthreads();
+    lds_barrier();
     STAMP(1);
 
     // stash planes of this lane's output channels g = lane >> 4 and g + 4 (fixed for the kernel)
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
                 }
             }
         });
-    __syncthreads();
+    lds_barrier();
     STAMP(2);
 
     // ---- conv2 (8 -> 8) + act on the tile+1 window ---------------------------
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
                 }
             }
         });
-    __syncthreads();
+    lds_barrier();
     STAMP(3);
 
     // ---- conv3 (8 -> 3) at the NA active sites; one input channel per wave ------
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 #pragma unroll
         for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NAS + lane] = acc[k];
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(4);
 
     // ---- tan-mixture transform: wave k evaluates mixture component k -------------
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 #pragma unroll
         for (int q = 0; q < 8; ++q) tval += sST[(q * 3 + 2) * NAS + lane];
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(5);
 
     if (MODE == 0) {
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             const double tot = ft_wave_sum(lj);
             if (lane == 0 && A.logj_part) A.logj_part[(size_t)b * ntiles + tile] = tot;
         }
-        __syncthreads();
+        lds_barrier();
         if (A.y && tid < N3) {
             const int r = tid / TC, c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
@@ -294,11 +294,11 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         }
         // h1 / h2 are dead: clear the padded gz2 planes that alias them
         for (int t = tid; t < 8 * PS0; t += NT) sGZ2[t] = 0.0;
-        __syncthreads();                                           // sST / sP / sT2[.][1] reads done
+        lds_barrier();                                           // sST / sP / sT2[.][1] reads done
         for (int t = tid; t < 3 * N3; t += NT) sGO[t] = 0.0;
         for (int t = tid; t < N0; t += NT) sGP[t] = 0.0;
         if (wave < NMIX && alane) sT2[(wave * TQ + 2) * NAS + lane] = gpk;
-        __syncthreads();
+        lds_barrier();
         if (wave < NMIX && avalid) sGO[wave * N3 + ar * TC + ac] = gs;
         if (wave == 0 && avalid) {
             double gsum = -gdelta;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             sGP[(ar + 3) * R0C + ac + 3] = gsum;
             sGO[NMIX * N3 + ar * TC + ac] = gdelta;               // dL/dt
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(6);
 
         // ---- conv3^T on the VALU: g_out lives on the active stripe only, so of the 9 taps of
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
                 sGZ2[ci * PS0 + (r + 2) * R0C + c + 2] = acc[k] * sD2[ci * PS2 + s];
             }
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(7);
 
         // ---- conv2^T, times act'(z1) -> gz1 in place over d1 ------------------------
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
                     pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[R1C] *= gh[2]; pd[4 * PS1 + R1C] *= gh[3];
                 }
             });
-        __syncthreads();
+        lds_barrier();
         STAMP(8);
 
         // ---- conv1^T and the (cos, sin) adjoint at frozen plaquettes ----------------
@@ -416,356 +416,19 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
                 if (half == 0) sGP[wt] = -sIn[PS0 + wt] * gct + sIn[wt] * gst;           // channels [0, 4)
                 else { sHalf[wt] = gct; sHalf[N0 + wt] = gst; }                           // channels [4, 8)
             }
-            __syncthreads();
+            lds_barrier();
             for (int t = tid; t < N0; t += NT) {
                 const int r = t / R0C, c = t - r * R0C;
                 const int cls = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;
                 if (cls == 1 || cls == 2) sGP[t] += -sIn[PS0 + t] * sHalf[t] + sIn[t] * sHalf[N0 + t];
             }
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(9);
         double* out = A.gp_part + ((size_t)b * ntiles + tile) * N0;
         for (int t = tid; t < N0; t += NT) out[t] = sGP[t];
         STAMP(10);
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Backward wrt x from stashed activations: the forward sweep of a force evaluation already
-// produced act'(z1), act'(z2) and s for every site (16 + 2 doubles per site and layer, written by
-// k_flow_mfma<0>), so this kernel skips conv1, conv2, both activation passes and conv3 and only
-// walks the adjoint: transform adjoint -> conv3^T -> conv2^T (MFMA) -> conv1^T.
-// HBM: 144 B/site/layer read here (+ halo re-reads out of L2) instead of ~50 % more DP work.
-template <int TR, int TC, bool TRAIN> struct SmemS {
-    using G = Geom<TR, TC>;
-    static constexpr int IN = 0;                              // [2][PS0] cos, sin of frozen plaquettes
-    static constexpr int GP = IN + 2 * G::PS0;                // [N0] partial plaquette gradient
-    static constexpr int GZ2 = GP + G::PS0;                   // [8][PS0] ring-2 padded gz2
-    static constexpr int D1 = GZ2 + 8 * G::PS0;               // [8][PS1] act'(z1) -> gz1
-    static constexpr int D2 = D1 + 8 * G::PS1;                // [8][PS2] act'(z2)
-    static constexpr int GO = D2 + 8 * G::PS2;                // [3][N3] g(s0, s1, t)
-    static constexpr int T2 = GO + 3 * G::N3;                 // [NMIX][4][NAS]
-    static constexpr int SW = T2 + NMIX * 4 * G::NAS;         // [SW_SIZE]
-    static constexpr int H1W = SW + SW_SIZE;                  // [8][PS1] h1 window   (training)
-    static constexpr int H2W = H1W + (TRAIN ? 8 * G::PS1 : 0);   // [8][PS2] h2 window   (training)
-    static constexpr int SIZE = H2W + (TRAIN ? 8 * G::PS2 : 0);
-};
-
-template <int TR, int TC, bool TRAIN>
-__global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_stash(FlowLayerArgs A) {
-    using S = SmemS<TR, TC, TRAIN>;
-    using G = Geom<TR, TC>;
-    constexpr int R0R = G::R0R, R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
-    constexpr int N0 = G::N0, N1 = G::N1, N2 = G::N2, N3 = G::N3, NA = G::NA, NAS = G::NAS;
-    constexpr int PS0 = G::PS0, PS1 = G::PS1, PS2 = G::PS2;
-    __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
-    double* sIn = sm + S::IN;  double* sGP = sm + S::GP;  double* sGZ2 = sm + S::GZ2;
-    double* sD1 = sm + S::D1;  double* sD2 = sm + S::D2;  double* sGO = sm + S::GO;
-    double* sT2 = sm + S::T2;  double* sW = sm + S::SW;
-    double* sH1w = sm + S::H1W; double* sH2w = sm + S::H2W;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L = A.L, mu = A.mu, off = A.off;
-    const int n = L * L;
-    const int nti_ = (A.L + TR - 1) / TR, ntj_ = (A.L + TC - 1) / TC;
-    BlockTile bt;
-    if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
-    const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
-    const int i0 = bt.ti * TR, j0 = bt.tj * TC;
-    const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
-    const double* __restrict__ x1 = x0 + n;
-    const double* __restrict__ w = A.wint;
-    const double* __restrict__ sh1 = A.stash + ((size_t)A.B * 18 + (size_t)b * 8) * n;   // h1[8][L][L] (training)
-    const double* __restrict__ sh2 = A.stash + ((size_t)A.B * 26 + (size_t)b * 8) * n;   // h2[8][L][L] (training)
-    double* gwp = TRAIN ? A.gw_part + ((size_t)b * ntiles + tile) * FLOW_GW_STRIDE : nullptr;
-    const double* __restrict__ st1 = A.stash + (size_t)b * 8 * n;                   // act'(z1)[8][L][L]
-    const double* __restrict__ st2 = A.stash + ((size_t)A.B + b) * 8 * n;           // act'(z2)[8][L][L]
-    const double* __restrict__ sts = A.stash + ((size_t)A.B * 16 + (size_t)b * 2) * n;   // s[2][L][L]
-    long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
-    STAMP(0);
-
-    // wrapped lattice coordinates of window lines (row offsets premultiplied by L)
-    const bool fastw = L >= R0R + 1 && L >= R0C + 1;
-    auto WI = [&](int k) { return wrap_line(i0 - 3 + k, L, fastw) * L; };
-    auto WJ = [&](int k) { return wrap_line(j0 - 3 + k, L, fastw); };
-
-    // ---- load phase: every global load of the kernel is issued here, back to back, before any of
-    //      them is consumed (three dependent round trips to L2/HBM cost ~12k cycles otherwise) ----
-    const int ar = mu == 0 ? lane / (TC / 4) : off + 4 * (lane / TC);
-    const int ac = mu == 0 ? off + 4 * (lane % (TC / 4)) : lane % TC;
-    const int ai = i0 + ar, aj = j0 + ac;
-    const bool alane = lane < NA;
-    const bool avalid = alane && (ai < L) && (aj < L);
-    // the transform runs on the last waves: waves 0..4 hold the window sites (sincos) of this stage
-    const int kmix = wave - (NW - NMIX);                                 // mixture component of this wave
-    const bool awave = kmix >= 0 && avalid;
-    double aP[4] = {0.0, 0.0, 0.0, 0.0}, ask = 0.0, ag[2] = {0.0, 0.0}, cb = 0.0;
-    if (awave) {
-        const int iL = WI(ar + 3), ipL = WI(ar + 4), j = WJ(ac + 3), jp = WJ(ac + 4);
-        aP[0] = x0[iL + j]; aP[1] = x1[iL + j]; aP[2] = x0[iL + jp]; aP[3] = x1[ipL + j];
-        ask = sts[(size_t)kmix * n + iL + j];
-        cb = A.glogj ? A.glogj[b] : A.glogj_const;
-        if (A.up_link) {
-            ag[0] = A.up_link[(size_t)b * 2 * n + (size_t)mu * n + iL + j];
-        } else {
-            const double* gp = A.up_gp + (size_t)b * n;
-            ag[0] = gp[iL + j];
-            ag[1] = mu == 0 ? gp[iL + WJ(ac + 2)] : gp[WI(ar + 2) + j];
-        }
-    }
-    // stash windows: a thread owns one window site (column lc = tid & 31, row lg = tid >> 5) and walks
-    // the 8 channel planes: the address is one wrapped base + ch * n, the LDS slot one base + ch * PS
-    // (immediate offsets), no per-element index arithmetic
-    static_assert(R1R <= NT / 32 && R1C <= 32, "one window site per thread");
-    const int lc = tid & 31, lg = tid >> 5;
-    const bool l1 = lc < R1C && lg < R1R, l2 = lc < R2C && lg < R2R;
-    const int go1 = WI((l1 ? lg : 0) + 1) + WJ((l1 ? lc : 0) + 1);
-    const int go2 = WI((l2 ? lg : 0) + 2) + WJ((l2 ? lc : 0) + 2);
-    double v1[8], v2[8];
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) v1[ch] = l1 ? st1[(size_t)ch * n + go1] : 0.0;
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch) v2[ch] = l2 ? st2[(size_t)ch * n + go2] : 0.0;
-    double vh1[TRAIN ? 8 : 1], vh2[TRAIN ? 8 : 1];
-    if (TRAIN) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) vh1[ch] = l1 ? sh1[(size_t)ch * n + go1] : 0.0;
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) vh2[ch] = l2 ? sh2[(size_t)ch * n + go2] : 0.0;
-    }
-    static_assert(N0 <= NT, "one window site per thread");
-    const int wr = tid / R0C, wc = tid - wr * R0C;
-    const bool wfrozen = tid < N0 && ((((mu == 0 ? j0 + wc : i0 + wr) - 3 - off) & 3) == 1 ||
-                                      (((mu == 0 ? j0 + wc : i0 + wr) - 3 - off) & 3) == 2);
-    double wP[4] = {0.0, 0.0, 0.0, 0.0};
-    if (wfrozen) {
-        const int iL = WI(wr), ipL = WI(wr + 1), j = WJ(wc), jp = WJ(wc + 1);
-        wP[0] = x0[iL + j]; wP[1] = x1[iL + j]; wP[2] = x0[iL + jp]; wP[3] = x1[ipL + j];
-    }
-    double wsw[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) wsw[k] = (tid + k * NT < SW_SIZE) ? w[WCAN + tid + k * NT] : 0.0;
-    static_assert(SW_SIZE <= 2 * NT, "weight copy");
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- consume: LDS clears and stores first (no dependence on the loads' values order) ------
-    for (int t = tid; t < 8 * PS0; t += NT) sGZ2[t] = 0.0;
-    for (int t = tid; t < 3 * N3; t += NT) sGO[t] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) if (tid + k * NT < SW_SIZE) sW[tid + k * NT] = wsw[k];
-    double es = 0.0, ems = 0.0, cs2 = 0.0, sn2 = 0.0, sincs = 0.0, invD = 1.0, gdelta = 0.0;
-    if (awave) {
-        const double Pa = aP[0] - aP[1] - aP[2] + aP[3];
-        gdelta = A.up_link ? (mu == 0 ? ag[0] : -ag[0]) : ag[0] - ag[1];
-        double sn, cs;
-        ft_sincos(Pa / 2, &sn, &cs);
-        es = ft_exp(ask); ems = ft_exp(-ask);
-        cs2 = cs * cs; sn2 = sn * sn; sincs = sn * cs;
-        invD = 1.0 / (ems * cs2 + es * sn2);
-        sT2[(kmix * 4 + 1) * NAS + lane] = invD;
-    }
-    if (tid < N0) {
-        double sn = 0.0, cs = 1.0;
-        if (wfrozen) ft_sincos(wP[0] - wP[1] - wP[2] + wP[3], &sn, &cs);
-        sIn[tid] = cs; sIn[PS0 + tid] = sn; sGP[tid] = 0.0;
-    }
-    if (l1) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) sD1[ch * PS1 + lg * R1C + lc] = v1[ch];
-    }
-    if (l2) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) sD2[ch * PS2 + lg * R2C + lc] = v2[ch];
-    }
-    if (TRAIN) {
-        if (l1) {
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) sH1w[ch * PS1 + lg * R1C + lc] = vh1[ch];
-        }
-        if (l2) {
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) sH2w[ch * PS2 + lg * R2C + lc] = vh2[ch];
-        }
-    }
-    __syncthreads();
-    STAMP(1);
-
-    // ---- adjoint of the tan-mixture transform at the tile's own active sites -----------------
-    if (awave) {
-        double si = 0.0;
-#pragma unroll
-        for (int k = 0; k < NMIX; ++k) si += sT2[(k * 4 + 1) * NAS + lane];
-        const double wk = invD / si;                               // softmax_k(-log D_k)
-        const double sinP = 2.0 * sincs;
-        sGO[kmix * N3 + ar * TC + ac] = gdelta * (sinP * invD / NMIX) + cb * wk * (ems * cs2 - es * sn2) * invD;
-        sT2[(kmix * 4 + 2) * NAS + lane] = gdelta * (invD / NMIX) - cb * wk * sinP * 0.5 * (es - ems) * invD;
-    }
-    __syncthreads();
-    if (kmix == 0 && avalid) {
-        double gsum = -gdelta;
-#pragma unroll
-        for (int k = 0; k < NMIX; ++k) gsum += sT2[(k * 4 + 2) * NAS + lane];
-        sGP[(ar + 3) * R0C + ac + 3] = gsum;
-        sGO[NMIX * N3 + ar * TC + ac] = gdelta;                   // dL/dt
-    }
-    __syncthreads();
-    STAMP(2);
-
-    // ---- conv3^T on the VALU (9 of 27 taps: g_out lives on the active stripe) -> padded gz2 ----
-    for (int t = tid; t < 2 * N2; t += NT) {
-        const int half = t >= N2;
-        const int s = half ? t - N2 : t;
-        const int r = s / R2C, c = s - r * R2C;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        const int ksel = ((mu == 0 ? c : r) - off) & 3;
-        if (ksel <= 2) {
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
-                const int rr = r - ky, cc = c - kx;
-                if (rr >= 0 && rr < TR && cc >= 0 && cc < TC) {
-#pragma unroll
-                    for (int co = 0; co < 3; ++co) {
-                        const double gv = sGO[co * N3 + rr * TC + cc];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            acc[k] = fma(gv, sW[CW2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx], acc[k]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int ci = half * 4 + k;
-            sGZ2[ci * PS0 + (r + 2) * R0C + c + 2] = acc[k] * sD2[ci * PS2 + s];
-        }
-    }
-    __syncthreads();
-    STAMP(3);
-
-    if (TRAIN) {
-        // ---- weight gradients of conv3 (VALU, 32 active sites) and conv2 (MFMA over the h2 window),
-        //      biases b3, b2: wave reductions in a fixed order ----------------------------------
-        for (int t = tid; t < 216; t += NT) {
-            const int co = t / 72, ci = (t / 9) % 8, tap = t % 9, ky = tap / 3, kx = tap % 3;
-            double acc = 0.0;
-            for (int a = 0; a < NA; ++a) {
-                const int r = mu == 0 ? a / (TC / 4) : off + 4 * (a / TC);
-                const int c = mu == 0 ? off + 4 * (a % (TC / 4)) : a % TC;
-                acc = fma(sGO[co * N3 + r * TC + c], sH2w[ci * PS2 + (r + ky) * R2C + c + kx], acc);
-            }
-            gwp[CW2 + t] = acc;
-        }
-        if (wave < 3) {                                              // b3[co] = sum over the tile of g_out
-            double a = 0.0;
-            for (int e = lane; e < N3; e += 64) a += sGO[wave * N3 + e];
-            a = ft_wave_sum(a);
-            if (lane == 0) gwp[CB2 + wave] = a;
-        }
-        {                                                            // b2[co = wave] = sum over the h2 window of gz2
-            double a = 0.0;
-            for (int e = lane; e < N2; e += 64) { const int r = e / R2C, c = e - r * R2C; a += sGZ2[wave * PS0 + (r + 2) * R0C + c + 2]; }
-            a = ft_wave_sum(a);
-            if (lane == 0) gwp[CB1 + wave] = a;
-        }
-        if (wave < 3)                                                // 3 N tiles of (ci, kx, kyb) = 48 columns
-            wgrad_stage<R2R, R2C, R0C, PS0, R1C, PS1, 8, true>(sGZ2 + 2 * R0C + 2, sH1w, wave, lane,
-                [&](int co, int ci, int ky, int kx, double v) { gwp[CW1 + (co * 8 + ci) * 9 + ky * 3 + kx] = v; });
-    }
-
-    // ---- conv2^T (MFMA), times act'(z1) -> gz1 in place over d1 -------------------------------
-    auto bidx4 = [](int t, int g, int cN, int dd) {
-        const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
-        return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
-    };
-    mfma_stage<24, 8, R1R, R1C, R0C, PS0>(sGZ2, sW, wave, lane, bidx4,
-        [&](int g, int pr, int pc, bool ok, double (&gh)[4]) {
-            if (ok) {
-                double* pd = sD1 + g * PS1 + 2 * pr * R1C + pc;
-                pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[R1C] *= gh[2]; pd[4 * PS1 + R1C] *= gh[3];
-            }
-        });
-    __syncthreads();
-    STAMP(4);
-
-    if (TRAIN) {
-        // ---- weight gradient of conv1 (one N tile: (ci 2, kx 3, kyb 2) = 12 columns) and b1 ------
-        if (wave == 0)
-            wgrad_stage<R1R, R1C, R1C, PS1, R0C, PS0, 2, false>(sD1, sIn, 0, lane,
-                [&](int co, int ci, int ky, int kx, double v) { gwp[CW0 + (co * 2 + ci) * 9 + ky * 3 + kx] = v; });
-        else {
-            const int co = wave;                                     // waves 1..7 -> b1[1..7]; wave 1 also b1[0]
-            for (int cc = (co == 1 ? 0 : co); cc <= co; ++cc) {
-                double a = 0.0;
-                for (int e = lane; e < N1; e += 64) a += sD1[cc * PS1 + e];
-                a = ft_wave_sum(a);
-                if (lane == 0) gwp[CB0 + cc] = a;
-            }
-        }
-    }
-
-    // ---- conv1^T and the (cos, sin) adjoint at frozen plaquettes -------------------------------
-    {
-        double* sHalf = sGZ2;                                            // gz2 is consumed
-        const int nline = mu == 0 ? R0C : R0R, nother = mu == 0 ? R0R : R0C;
-        const int phase = ((mu == 0 ? j0 : i0) - 3 - off) & 3;
-        const int s1 = (1 - phase) & 3;
-        const int lead = s1 == 3 ? 1 : 0;
-        const int nfl = lead + 2 * ((nline - s1 + 3) / 4);
-        const int ntask = nfl * nother;
-        for (int t2 = tid; t2 < 2 * ntask; t2 += NT) {
-            const int half = t2 >= ntask, t = half ? t2 - ntask : t2;
-            const int k = mu == 0 ? t % nfl : t / nother;
-            const int o = mu == 0 ? t / nfl : t % nother;
-            const int kk = k - lead;
-            const int line = (lead && k == 0) ? 0 : s1 + 4 * (kk >> 1) + (kk & 1);
-            if (line >= nline) continue;
-            const int r = mu == 0 ? o : line, c = mu == 0 ? line : o;
-            const int wt = r * R0C + c;
-            int aoff[9]; double msk[9];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int rr = r - ky, cc = c - kx;
-                    const bool ok = (rr >= 0) && (rr < R1R) && (cc >= 0) && (cc < R1C);
-                    aoff[ky * 3 + kx] = ok ? rr * R1C + cc : 0;
-                    msk[ky * 3 + kx] = ok ? 1.0 : 0.0;
-                }
-            double gc[3] = {0.0, 0.0, 0.0}, gsn[3] = {0.0, 0.0, 0.0};
-#pragma unroll 1
-            for (int co = half * 4; co < half * 4 + 4; ++co) {
-                double gv[9], w0[9], w1[9];
-                const double* gz = sD1 + co * PS1;
-                const double* wp = sW + CW0 + co * 18;
-#pragma unroll
-                for (int tp = 0; tp < 9; ++tp) { gv[tp] = gz[aoff[tp]]; w0[tp] = wp[tp]; w1[tp] = wp[9 + tp]; }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int tp = 0; tp < 9; ++tp) {
-                    const double g_ = gv[tp] * msk[tp];
-                    gc[tp % 3] = fma(g_, w0[tp], gc[tp % 3]); gsn[tp % 3] = fma(g_, w1[tp], gsn[tp % 3]);
-                }
-            }
-            const double gct = (gc[0] + gc[1]) + gc[2];
-            const double gst = (gsn[0] + gsn[1]) + gsn[2];
-            if (half == 0) sGP[wt] = -sIn[PS0 + wt] * gct + sIn[wt] * gst;
-            else { sHalf[wt] = gct; sHalf[N0 + wt] = gst; }
-        }
-        __syncthreads();
-        double* out = A.gp_part + ((size_t)b * ntiles + tile) * N0;
-        for (int t = tid; t < N0; t += NT) {
-            const int r = t / R0C, c = t - r * R0C;
-            const int cls = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;
-            double v = sGP[t];
-            if (cls == 1 || cls == 2) v += -sIn[PS0 + t] * sHalf[t] + sIn[t] * sHalf[N0 + t];
-            out[t] = v;
-        }
-    }
-    STAMP(5);
 }
 
 int g_variant = 1;
@@ -781,16 +444,6 @@ int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     // forward needs half the LDS of backward: 16 x 16 tiles (less halo work) still fit twice per CU
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
     hipLaunchKernelGGL((k_flow_mfma<0, MF_FWD_TR, MF_FWD_TC>), grid, dim3(NT), 0, s, a);
-    FT_LAUNCH_CHECK(); return FTHMC_OK;
-}
-int launch_flow_bwd_stash(const FlowLayerArgs& a, hipStream_t s) {
-    const dim3 grid = xcd_grid(a.B, (a.L + MF_TR - 1) / MF_TR, (a.L + MF_TC - 1) / MF_TC);
-    hipLaunchKernelGGL((k_flow_bwd_stash<MF_TR, MF_TC, false>), grid, dim3(NT), 0, s, a);
-    FT_LAUNCH_CHECK(); return FTHMC_OK;
-}
-int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s) {
-    const dim3 grid = xcd_grid(a.B, (a.L + MF_TR - 1) / MF_TR, (a.L + MF_TC - 1) / MF_TC);
-    hipLaunchKernelGGL((k_flow_bwd_stash<MF_TR, MF_TC, true>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s) {

@@ -10,6 +10,11 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 constexpr int NT = 512;                 // threads per workgroup (8 waves)
 constexpr int NW = NT / 64;
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the wave's global loads
+// and stores (s_waitcnt vmcnt(0)), which would stall every stage boundary on HBM round trips of the
+// stash stores / prefetched windows.  No thread of these kernels reads global data another thread wrote.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Wrapped lattice coordinate of window line v (-L <= v): two selects when the lattice is wider than a
 // window (`fast`, uniform per launch), a true remainder for the small lattices of the tests.
 __device__ __forceinline__ int wrap_line(int v, int L, bool fast) {

@@ -90,11 +90,6 @@ int launch_flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s);
 // flow_mfma.hip: MFMA variants of forward / backward-wrt-x (same arguments and results)
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s);
-// backward wrt x from the activations the MFMA forward kernel stashed for this layer (a.stash)
-int launch_flow_bwd_stash(const FlowLayerArgs& a, hipStream_t s);
-// backward wrt x AND the weights from the stash incl. h1, h2; partial weight gradients per tile
-// go to a.gw_part [B*ntiles][FLOW_GW_STRIDE] (ntiles of flow_geom(true))
-int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s);
 // flow_bwd_gather.hip: backward from the stash in gather form: a tile produces the complete
 // gP_out = up_gp + layer contribution of its own sites (a.gp_out, out of place), no partial windows;
 // train = also per-tile weight-gradient partials to a.gw_part (ntiles of flow_gather_geom())

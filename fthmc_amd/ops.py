@@ -331,8 +331,8 @@ def time_kernel(kind: str, x, w=None, mu=0, off=0, act='silu', beta=1.0, reps=20
     measured with HIP events on the current stream (synchronises)."""
     import ctypes
     x = _field(x); B, _, L, _ = x.shape
-    k = {'flow_fwd': 0, 'flow_bwd': 1, 'leap_step': 2, 'hmc_trajectory': 3, 'flow_bwd_scatter': 4}[kind]
-    wp = _p(_w1(w, x)) if k < 2 or k == 4 else None
+    k = {'flow_fwd': 0, 'flow_bwd': 1, 'leap_step': 2, 'hmc_trajectory': 3}[kind]
+    wp = _p(_w1(w, x)) if k < 2 else None
     ms = ctypes.c_double(0.0)
     ws, nb = _ws(x, B, L, 1)
     check(_lib.load().fthmc_time_kernel(k, _p(x), wp, B, L, int(mu), int(off), act_code(act), float(beta),
@@ -344,7 +344,7 @@ def profile_stages(kind: str, x, w, mu=0, off=0, act='silu', beta=1.0):
     """Mean cycles per stage of one MFMA coupling-layer kernel launch ('flow_fwd' | 'flow_bwd')."""
     import ctypes
     x = _field(x); B, _, L, _ = x.shape
-    k = {'flow_fwd': 0, 'flow_bwd': 1, 'flow_bwd_recompute': 2, 'flow_bwd_scatter': 3}[kind]
+    k = {'flow_fwd': 0, 'flow_bwd': 1, 'flow_bwd_recompute': 2}[kind]
     buf = (ctypes.c_double * 16)()
     ws, nb = _ws(x, B, L, 1)
     check(_lib.load().fthmc_profile_stages(k, _p(x), _p(_w1(w, x)), B, L, int(mu), int(off), act_code(act),

@@ -3,10 +3,9 @@
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-FAMILIES = [('k_flow_bwd_stash', 'k_flow_bwd_stash<8,16> (coupling-layer backward wrt x, force path)'),
+FAMILIES = [('k_flow_bwd_gather', 'k_flow_bwd_gather<16,16> (coupling-layer backward wrt x, force path)'),
             ('k_flow_mfma<0', 'k_flow_mfma<0,16,16> (coupling-layer forward)'),
             ('k_flow_mfma<1', 'k_flow_mfma<1,8,16> (recompute backward)'),
-            ('k_gather_gp', 'k_gather_gp'),
             ('k_force<1', 'k_force<1> (fused plain-HMC leapfrog step)'),
             ('k_hmc_trajectory', 'k_hmc_trajectory (single-launch plain-HMC trajectory)')]
 
@@ -37,7 +36,7 @@ def main(src, dst):
                  'SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; SQ_INSTS_* wave-instructions; '
                  'GRBM_GUI_ACTIVE summed over 8 XCDs',
         'workload': 'bench.py config: B=128 chains, L=64, 8 layers, fp64; one launch = one coupling layer over the whole '
-                    'batch (forward 2048 workgroups of 16x16 sites, backward 4096 of 8x16)',
+                    'batch (forward and backward: 2048 workgroups of 16x16 sites)',
         'kernels': {fam: {c: {'launches': v[1], 'mean_per_launch': v[0] / v[1]} for c, v in sorted(cs.items())}
                     for fam, cs in acc.items()},
     }

@@ -14,9 +14,8 @@ w = ops.pack_weights(flow, device='cuda')
 x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
 names = {'flow_fwd': ['', 'plaq+sincos', 'conv1', 'conv2', 'conv3', 'transform1', 'finish+store'],
          'flow_bwd': ['', 'load+xform', 'conv3T', 'conv2T', 'conv1T', 'store'],
-         'flow_bwd_scatter': ['', 'load+xform', 'adjoint', 'conv3T', 'conv2T', 'conv1T+store'],
          'flow_bwd_recompute': ['', 'plaq+sincos', 'conv1', 'conv2', 'conv3', 'transform1', 'adjoint xform', 'conv3T', 'conv2T', 'conv1T', 'store']}
-for kind in ('flow_fwd', 'flow_bwd', 'flow_bwd_scatter', 'flow_bwd_recompute'):
+for kind in ('flow_fwd', 'flow_bwd', 'flow_bwd_recompute'):
     for mu in (0, 1):
         cyc = ops.profile_stages(kind, x, w, mu=mu, off=1, beta=6.0)
         tot = sum(cyc)

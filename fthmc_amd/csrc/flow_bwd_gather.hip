@@ -171,8 +171,14 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         ft_sincos(Pa / 2, &sn, &cs);
         const double cs2 = cs * cs, sn2 = sn * sn, sinP = 2.0 * (sn * cs);
         double es[NMIX], ems[NMIX], invD[NMIX], si = 0.0;
+        {
+            double ea[2 * NMIX], eo[2 * NMIX];
 #pragma unroll
-        for (int k = 0; k < NMIX; ++k) { es[k] = ft_exp(as_[k]); ems[k] = ft_exp(-as_[k]); }
+            for (int k = 0; k < NMIX; ++k) { ea[2 * k] = as_[k]; ea[2 * k + 1] = -as_[k]; }
+            ft_expN<2 * NMIX>(ea, eo);
+#pragma unroll
+            for (int k = 0; k < NMIX; ++k) { es[k] = eo[2 * k]; ems[k] = eo[2 * k + 1]; }
+        }
 #pragma unroll
         for (int k = 0; k < NMIX; ++k) { invD[k] = 1.0 / (ems[k] * cs2 + es[k] * sn2); si += invD[k]; }
         double gsum = -gdelta;
@@ -222,29 +228,50 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
 
     // ---- conv3^T on the VALU: g_out lives on the active lines, so of the 9 taps of a site at most 3
     //      (one line) contribute; times act'(z2) -> gz2 in place ------------------------------------
-    for (int t = tid; t < 2 * N2W; t += NT) {
-        const int half = t >= N2W;
-        const int s = half ? t - N2W : t;
-        const int r = s / W2C, c = s - r * W2C;
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // task = (two sites of the same line class, half of the 8 channels): the 36 weights of a task are
+    // read once and serve both sites (the stage is bound by LDS reads per FMA, not by the FMAs)
+    static_assert(W2R % 2 == 0 && W2C % 2 == 0 && N2W <= NT, "site pairs, one round");
+    if (tid < N2W) {
+        constexpr int NPR = N2W / 2;
+        const int half = tid >= NPR;
+        const int u = half ? tid - NPR : tid;
+        int r, c, s2off;
+        if (mu == 0) { r = u / W2C; c = u - r * W2C; s2off = (W2R / 2) * W2C; }          // (r, c), (r + W2R/2, c)
+        else { r = u / (W2C / 2); c = u - r * (W2C / 2); s2off = W2C / 2; }             // (r, c), (r, c + W2C/2)
+        const int s = r * W2C + c;
         // source = site - (ky - 1, kx - 1): window coordinates (r + 2 - ky, c + 2 - kx) of tile+3
         const int ksel = mu == 0 ? (c + 2 - c0) & 3 : (r + 2 - r0) & 3;   // the one kx (mu=0) / ky (mu=1)
+        const int s3off = mu == 0 ? (W2R / 2) * W3C : W2C / 2;            // second site in tile+3 coordinates
+        double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0};
         if (ksel <= 2) {
 #pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
-                const int at = (r + 2 - ky) * W3C + c + 2 - kx;
+            for (int co = 0; co < 3; ++co) {
+                double wv[3][4], g0[3], g1[3];
 #pragma unroll
-                for (int co = 0; co < 3; ++co) {
-                    const double gv = sGO[co * N3W + at];
+                for (int kk = 0; kk < 3; ++kk) {
+                    const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
+                    const int at = (r + 2 - ky) * W3C + c + 2 - kx;
+                    g0[kk] = sGO[co * N3W + at]; g1[kk] = sGO[co * N3W + at + s3off];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        acc[k] = fma(gv, sW[CW2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx], acc[k]);
+                    for (int k = 0; k < 4; ++k) wv[kk][k] = sW[CW2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc0[k] = fma(g0[kk], wv[kk][k], acc0[k]);
+                        acc1[k] = fma(g1[kk], wv[kk][k], acc1[k]);
+                    }
             }
         }
+        // dead lines (no active site within reach) get an exact 0, whatever the stash holds there
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sGZ2[(half * 4 + k) * PS2 + s] *= acc[k];
+        for (int k = 0; k < 4; ++k) {
+            double* pz = sGZ2 + (half * 4 + k) * PS2 + s;
+            pz[0] = ksel <= 2 ? pz[0] * acc0[k] : 0.0;
+            pz[s2off] = ksel <= 2 ? pz[s2off] * acc1[k] : 0.0;
+        }
     }
 #pragma unroll
     for (int p = 0; p < NP1; ++p) {

@@ -82,6 +82,33 @@ __device__ __forceinline__ double ft_exp(double x) {
     return ldexp(p, (int)n);
 }
 
+// N independent ft_exp, written step-interleaved (the compiler keeps the source order of independent
+// instructions, and one exp is a ~22-deep dependent DP chain).  Same arithmetic as ft_exp.
+template <int N>
+__device__ __forceinline__ void ft_expN(const double (&xin)[N], double (&e)[N]) {
+    double x[N], n[N], r[N], p[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) x[q] = fmin(fmax(xin[q], -745.0), 709.0);
+#pragma unroll
+    for (int q = 0; q < N; ++q) n[q] = rint(x[q] * 1.4426950408889634074);
+#pragma unroll
+    for (int q = 0; q < N; ++q) r[q] = fma(-n[q], 6.93147180369123816490e-01, x[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) r[q] = fma(-n[q], 1.90821492927058770002e-10, r[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) p[q] = fma(1.6059043836821613e-10, r[q], 2.0876756987868100e-09);
+    constexpr double C[12] = {2.5052108385441720e-08, 2.7557319223985888e-07, 2.7557319223985893e-06,
+                              2.4801587301587302e-05, 1.9841269841269841e-04, 1.3888888888888889e-03,
+                              8.3333333333333332e-03, 4.1666666666666664e-02, 1.6666666666666666e-01,
+                              0.5, 1.0, 1.0};
+#pragma unroll
+    for (int c = 0; c < 12; ++c)
+#pragma unroll
+        for (int q = 0; q < N; ++q) p[q] = fma(p[q], r[q], C[c]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) e[q] = ldexp(p[q], (int)n[q]);
+}
+
 // sin and cos for moderate arguments (|x| up to ~1e5; plaquette angles are sums of four links):
 // Cody-Waite reduction by pi/2 in three exact-product pieces + the fdlibm kernel polynomials on
 // |r| <= pi/4.  ~35 DP ops, no slow path, < 1 ulp each (ocml's sincos carries a Payne-Hanek

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             A.stash[(((size_t)A.B * 16 + (size_t)b * 2 + wave) * L + ai) * L + aj] = sk;
         double sn, cs;
         ft_sincos(Pa / 2, &sn, &cs);
-        es = ft_exp(sk); ems = ft_exp(-sk);
+        { const double ea[2] = {sk, -sk}; double eo[2]; ft_expN<2>(ea, eo); es = eo[0]; ems = eo[1]; }
         cs2 = cs * cs; sn2 = sn * sn; sincs = sn * cs;
         invD = 1.0 / (ems * cs2 + es * sn2);
         sT2[(wave * TQ + 1) * NAS + lane] = invD;

@@ -322,9 +322,11 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
         return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
     };
-    mfma_stage<24, 8, W1R, W1C, W2C, PS2>(sGZ2, sW, wave, lane, bidx4,
-        [&](int g, int pr, int pc, bool ok, double (&gh)[4]) {
+    mfma_stage<24, 8, (W1R / 2) * W1C, W2C, PS2, false>(sGZ2, sW, wave, lane,
+        [](int p) { const int pr = p / W1C; return 2 * pr * W2C + p - pr * W1C; }, bidx4,
+        [&](int g, int p, bool ok, double (&gh)[4]) {
             if (ok) {
+                const int pr = p / W1C, pc = p - pr * W1C;
                 double* pd = sD1 + g * PS1 + 2 * pr * W1C + pc;
                 pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[W1C] *= gh[2]; pd[4 * PS1 + W1C] *= gh[3];
             }

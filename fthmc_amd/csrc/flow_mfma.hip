@@ -122,8 +122,10 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         const int k = 4 * t + g, tap = k / 2, ci = k - 2 * tap, ky = tap / 3 - dd, kx = tap % 3;
         return (ky >= 0 && ky <= 2) ? CW0 + (cN * 2 + ci) * 9 + ky * 3 + kx : WZERO;
     };
-    mfma_stage<6, 2, R1R, R1C, R0C, PS0>(sIn, sW, wave, lane, bidx1,
-        [&](int g, int pr, int pc, bool ok, double (&z)[4]) {
+    mfma_stage<6, 2, (R1R / 2) * R1C, R0C, PS0, false>(sIn, sW, wave, lane,
+        [](int p) { const int pr = p / R1C; return 2 * pr * R0C + p - pr * R1C; }, bidx1,
+        [&](int g, int p, bool ok, double (&z)[4]) {
+            const int pr = p / R1C, pc = p - pr * R1C;
             const double b0 = sW[CB0 + g], b1 = sW[CB0 + g + 4];
             double h[4], d[4];
             z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
@@ -152,39 +154,65 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
     lds_barrier();
     STAMP(2);
 
-    // ---- conv2 (8 -> 8) + act on the tile+1 window ---------------------------
-    // B[k = (tap, ci)][n = (co, dd)] = W1[co][ci][ky4 - dd][kx]
-    auto bidx2 = [](int t, int g, int cN, int dd) {
-        const int tap = t >> 1, ci = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
-        return (ky >= 0 && ky <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
-    };
-    mfma_stage<24, 8, R2R, R2C, R1C, PS1>(sH1, sW, wave, lane, bidx2,
-        [&](int g, int pr, int pc, bool ok, double (&z)[4]) {
-            const double b0 = sW[CB1 + g], b1 = sW[CB1 + g + 4];
-            double h[4], d[4];
-            z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
-            act_eval4(z, act, h, d);
-            if (ok) {
-                double* ph = sH2 + g * PS2 + 2 * pr * R2C + pc;
-                ph[0] = h[0]; ph[4 * PS2] = h[1]; ph[R2C] = h[2]; ph[4 * PS2 + R2C] = h[3];
-                if (BWD) {
-                    double* pd = sD2 + g * PS2 + 2 * pr * R2C + pc;
-                    pd[0] = d[0]; pd[4 * PS2] = d[1]; pd[R2C] = d[2]; pd[4 * PS2 + R2C] = d[3];
-                }
+    // ---- conv2 (8 -> 8) + act on the live lines of the tile+1 window -----------------------------
+    // conv3 reads h2 only within one site of an active line, so every 4th line of the window (stripe
+    // class 2, first one d0) is never used: the pair sites enumerate the (at most 14 of 18) live lines only and pair
+    // ALONG them (rows for mu = 0, columns for mu = 1): 126 pairs = 8 M tiles, one per wave, instead
+    // of 11 over the full window (16 x 16 tiles).  Dead lines of h2 / act'(z2) (LDS and stash) stay unwritten; the
+    // backward kernels write an exact 0 there instead of multiplying.
+    constexpr int NLC = R2C - R2C / 4, NLR = R2R - R2R / 4;            // live columns / rows at most
+    const int d0 = ((off + 3) - (mu == 0 ? j0 : i0)) & 3;               // first dead line of the window
+    auto conv2_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
+        // sites (r, c) and (r + dr, c + dc) in window coordinates; z[q]: channel g + 4 (q & 1), site q >> 1
+        const double b0 = sW[CB1 + g], b1 = sW[CB1 + g + 4];
+        double h[4], d[4];
+        z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
+        act_eval4(z, act, h, d);
+        const int so = dr * R2C + dc;
+        if (ok) {
+            double* ph = sH2 + g * PS2 + r * R2C + c;
+            ph[0] = h[0]; ph[4 * PS2] = h[1]; ph[so] = h[2]; ph[4 * PS2 + so] = h[3];
+            if (BWD) {
+                double* pd = sD2 + g * PS2 + r * R2C + c;
+                pd[0] = d[0]; pd[4 * PS2] = d[1]; pd[so] = d[2]; pd[4 * PS2 + so] = d[3];
             }
-            if (MODE == 0 && A.stash) {                                  // act'(z2) (and h2) of the tile's own sites
-                const int r = 2 * pr - 1, c = pc - 1;
-                if (ok && (unsigned)c < (unsigned)cmax) {
-                    const int at = (i0 + r) * L + j0 + c;
+        }
+        if (MODE == 0 && A.stash && ok) {                                // act'(z2) (and h2) of the tile's own sites
+            const int at = (i0 + r - 1) * L + j0 + c - 1;
 #pragma unroll
-                    for (int dd = 0; dd < 2; ++dd)
-                        if ((unsigned)(r + dd) < (unsigned)rmax) {
-                            st_d2[at + dd * L] = d[2 * dd]; st_d2[at + dd * L + 4 * n] = d[2 * dd + 1];
-                            if (A.stash_h) { st_h2[at + dd * L] = h[2 * dd]; st_h2[at + dd * L + 4 * n] = h[2 * dd + 1]; }
-                        }
+            for (int q = 0; q < 2; ++q)
+                if ((unsigned)(r - 1 + q * dr) < (unsigned)rmax && (unsigned)(c - 1 + q * dc) < (unsigned)cmax) {
+                    const int aq = at + q * (dr * L + dc);
+                    st_d2[aq] = d[2 * q]; st_d2[aq + 4 * n] = d[2 * q + 1];
+                    if (A.stash_h) { st_h2[aq] = h[2 * q]; st_h2[aq + 4 * n] = h[2 * q + 1]; }
                 }
-            }
-        });
+        }
+    };
+    if (mu == 0) {
+        // B[k = (tap = ky4 * 3 + kx, ci)][n = (co, dd)] = W1[co][ci][ky4 - dd][kx]; pairs = rows (2 pr, 2 pr + 1)
+        auto bidx2 = [](int t, int g, int cN, int dd) {
+            const int tap = t >> 1, ci = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
+            return (ky >= 0 && ky <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
+        };
+        mfma_stage<24, 8, (R2R / 2) * NLC, R1C, PS1, false>(sH1, sW, wave, lane,
+            [&](int p) { const int pr = p / NLC; return 2 * pr * R1C + min(live_line(p - pr * NLC, d0), R2C - 1); }, bidx2,
+            [&](int g, int p, bool ok, double (&z)[4]) {
+                const int pr = p / NLC, c = live_line(p - pr * NLC, d0);
+                conv2_epi(g, ok && c < R2C, 2 * pr, c, 1, 0, z);
+            });
+    } else {
+        // B[k = (tap = ky * 4 + kx4, ci)][n = (co, dd)] = W1[co][ci][ky][kx4 - dd]; pairs = columns (2 pc, 2 pc + 1)
+        auto bidx2 = [](int t, int g, int cN, int dd) {
+            const int tap = t >> 1, ci = (t & 1) * 4 + g, ky = tap / 4, kx = tap % 4 - dd;
+            return (kx >= 0 && kx <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
+        };
+        mfma_stage<24, 8, NLR * (R2C / 2), R1C, PS1, true>(sH1, sW, wave, lane,
+            [&](int p) { const int lr = p / (R2C / 2); return min(live_line(lr, d0), R2R - 1) * R1C + 2 * (p - lr * (R2C / 2)); }, bidx2,
+            [&](int g, int p, bool ok, double (&z)[4]) {
+                const int lr = p / (R2C / 2), r = live_line(lr, d0);
+                conv2_epi(g, ok && r < R2R, r, 2 * (p - lr * (R2C / 2)), 0, 1, z);
+            });
+    }
     lds_barrier();
     STAMP(3);
 
@@ -338,7 +366,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int ci = half * 4 + k;
-                sGZ2[ci * PS0 + (r + 2) * R0C + c + 2] = acc[k] * sD2[ci * PS2 + s];
+                sGZ2[ci * PS0 + (r + 2) * R0C + c + 2] = ksel <= 2 ? acc[k] * sD2[ci * PS2 + s] : 0.0;   // dead line: d2 unwritten
             }
         }
         lds_barrier();
@@ -350,9 +378,11 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
             return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
         };
-        mfma_stage<24, 8, R1R, R1C, R0C, PS0>(sGZ2, sW, wave, lane, bidx4,
-            [&](int g, int pr, int pc, bool ok, double (&gh)[4]) {
+        mfma_stage<24, 8, (R1R / 2) * R1C, R0C, PS0, false>(sGZ2, sW, wave, lane,
+            [](int p) { const int pr = p / R1C; return 2 * pr * R0C + p - pr * R1C; }, bidx4,
+            [&](int g, int p, bool ok, double (&gh)[4]) {
                 if (ok) {
+                    const int pr = p / R1C, pc = p - pr * R1C;
                     double* pd = sD1 + g * PS1 + 2 * pr * R1C + pc;
                     pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[R1C] *= gh[2]; pd[4 * PS1 + R1C] *= gh[3];
                 }

@@ -42,26 +42,35 @@ template <int TR, int TC> struct Geom {
 // LDS copy of the layer's canonical weights (flow_common.h: CW0 CB0 CW1 CB1 CW2 CB2, WZERO)
 constexpr int SW_SIZE = WCAN_SIZE;
 
-// One implicit-GEMM stage.  Output region HOUT x WOUT (HOUT even) whose input planes are one
-// site larger on every side (forward conv) or ring-2 padded (transposed conv): input index of
-// output (r, c) and window tap (ky4, kx) is (r + ky4, c + kx) for the pair's upper row r = 2q.
-// The epilogue gets the four values of a lane at once so that their chains interleave:
-// epi(g, pr, pc, ok, z) with z[q] = output channel g + 4 (q & 1) at site (2 pr + (q >> 1), pc).
-// bidx(t, g, cN, dd) -> index of W[k = 4 t + g][n = cN + 8 dd] in the LDS weight copy sW.
-template <int NSTEP, int KC, int HOUT, int WOUT, int RSA, int PSA, class BIdx, class Epi>
+// One implicit-GEMM stage on v_mfma_f64_16x16x4_f64 over NPAIR "pair sites": a pair is two adjacent
+// output sites (rows r, r + 1 of one column, or with PAIRCOL columns c, c + 1 of one row) that share a
+// 4 x 3 (3 x 4) input window, so N = 16 = 8 output channels x the 2 sites of the pair and
+// K = 12 window taps x KC input channels (9 of the 12 taps are non-zero for each site: 75 % useful MACs
+// instead of the 50 % of a half-empty N).
+//   amap(p)  -> offset of pair p's window origin (tap 0 of its first site) inside an input plane
+//               (row stride RSA, plane stride PSA); must be valid for every p < NPAIR
+//   bidx(t, g, cN, dd) -> index of W[k = 4 t + g][n = cN + 8 dd] in the LDS weight copy sW
+//               (tap of k: row-major over the 4 x 3 window, or 3 x 4 with PAIRCOL)
+//   epi(g, p, ok, z): z[q] = output channel g + 4 (q & 1) at site (q >> 1) of pair p; all four values
+//               of a lane at once so that their chains interleave
+// The weights are the MFMA's A operand and the activations its B operand, so D comes out transposed:
+// D[row = (channel, site of pair)][col = pair].  A lane then holds one pair (col = lane & 15) and the
+// rows g + 4 q: all site arithmetic of the epilogue (offsets, bounds, stash address) happens once per
+// lane and tile instead of once per value.
+template <int NSTEP, int KC, int NPAIR, int RSA, int PSA, bool PAIRCOL, class AMap, class BIdx, class Epi>
 __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ sW,
-                                           int wave, int lane, BIdx bidx, Epi epi) {
-    constexpr int NPAIR = (HOUT / 2) * WOUT;
+                                           int wave, int lane, AMap amap, BIdx bidx, Epi epi) {
     constexpr int NTILE = (NPAIR + 15) / 16;
     const int g = lane >> 4, i = lane & 15;
-    // A-operand offset of k = 4 t + g: k -> (tap = k / KC, channel = k % KC).  For KC = 8 the lane
-    // part is just g * PSA and the rest is a compile-time immediate; otherwise a small table.
+    auto toff = [](int tap) { return PAIRCOL ? (tap / 4) * RSA + (tap % 4) : (tap / 3) * RSA + (tap % 3); };
+    // input offset of k = 4 t + g: k -> (tap = k / KC, channel = k % KC).  For KC = 8 the lane part is
+    // just g * PSA and the rest is a compile-time immediate; otherwise a small table.
     int koff[KC == 8 ? 1 : NSTEP];
     if (KC != 8) {
 #pragma unroll
         for (int t = 0; t < NSTEP; ++t) {
             const int k = 4 * t + g, tap = k / KC, cK = k - tap * KC;
-            koff[t] = cK * PSA + (tap / 3) * RSA + (tap % 3);
+            koff[t] = cK * PSA + toff(tap);
         }
     }
     const int cN = i & 7, dd = i >> 3;
@@ -69,16 +78,10 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
 #pragma unroll
     for (int t = 0; t < NSTEP; ++t) boff[t] = bidx(t, g, cN, dd);
     for (int tile = wave; tile < NTILE; tile += NW) {
-        // The weights are the MFMA's A operand and the activations its B operand, so D comes out
-        // transposed: D[row = (channel, pair row)][col = pair site].  A lane then holds one pair
-        // site (col = i) and the four rows g + 4 q = (channel g | g + 4) x (pair row 0 | 1): all the
-        // site arithmetic of the epilogue (offsets, bounds, stash address) happens once per lane and
-        // tile instead of once per value (integer VALU work used to outnumber the fp64 work 2:1).
         const int p_ = tile * 16 + i;
         const bool ok = p_ < NPAIR;
         const int p = ok ? p_ : NPAIR - 1;                   // padding lanes: any valid address
-        const int pr = p / WOUT, pc = p - pr * WOUT;
-        const double* a0 = A + (2 * pr) * RSA + pc + (KC == 8 ? g * PSA : 0);
+        const double* a0 = A + amap(p) + (KC == 8 ? g * PSA : 0);
         // independent accumulator chains keep the matrix pipe busy when a wave is alone on it
         constexpr int NCH = NSTEP >= 8 ? 4 : 3;
         double4_t accs[NCH];
@@ -87,18 +90,20 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
 #pragma unroll
         for (int t = 0; t < NSTEP; ++t) {
             double av;
-            if (KC == 8) av = a0[(t & 1) * 4 * PSA + ((t >> 1) / 3) * RSA + ((t >> 1) % 3)];
+            if (KC == 8) av = a0[(t & 1) * 4 * PSA + toff(t >> 1)];
             else av = a0[koff[t]];
             accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(sW[boff[t]], av, accs[t % NCH], 0, 0, 0);
         }
         double4_t acc = accs[0];
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
-        // z[q]: q & 1 -> channel g + 4 (q & 1), q >> 1 -> row 2 pr + (q >> 1) of the pair
         double z4[4] = {acc[0], acc[1], acc[2], acc[3]};
-        epi(g, pr, pc, ok, z4);
+        epi(g, p, ok, z4);
     }
 }
+
+// Live-line map of a window whose every 4th line (first one d0) is dead: index of the l-th live line.
+__device__ __forceinline__ int live_line(int l, int d0) { return l < d0 ? l : l + 1 + (l - d0) / 3; }
 
 
 // XCD-aware block -> (chain, tile) map.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8

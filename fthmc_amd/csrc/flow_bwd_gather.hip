@@ -4,8 +4,8 @@
 // plaquette-gradient of its own sites:  gP_out[p] = gP_in[p] + (layer's contribution at p).
 // Walking the adjoint backwards from the tile, each stage needs its input on a window one site
 // larger:  conv1^T at the tile <- gz1 on tile+1 <- conv2^T <- gz2 on tile+2 <- conv3^T <- g_out at
-// the active sites of tile+3, which is the tan-mixture adjoint evaluated there (P, s, upstream
-// gradient re-read for the halo's active sites: 1/4 of the window, ~110 DP ops each).
+// the active sites of tile+3, which is the tan-mixture adjoint there: four FMAs per site on the
+// coefficients the forward kernel stashed (struct Stash), so this kernel never touches the links.
 // Compared with the scatter form (k_flow_bwd_stash: each tile pushes the gradient of its own
 // active sites out to a tile+3 window of partial sums that k_gather_gp adds up afterwards):
 //   * the expensive stages shrink (conv2^T runs on tile+1 instead of tile+2, conv1^T on the
@@ -73,14 +73,12 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
     const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // own sites inside the lattice
-    const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
-    const double* __restrict__ x1 = x0 + n;
     const double* __restrict__ w = A.wint;
-    const double* __restrict__ st1 = A.stash + (size_t)b * 8 * n;                         // act'(z1)[8][L][L]
-    const double* __restrict__ st2 = A.stash + ((size_t)A.B + b) * 8 * n;                 // act'(z2)[8][L][L]
-    const double* __restrict__ sts = A.stash + ((size_t)A.B * 16 + (size_t)b * 2) * n;    // s[2][L][L]
-    const double* __restrict__ sh1 = A.stash + ((size_t)A.B * 18 + (size_t)b * 8) * n;    // h1[8][L][L] (training)
-    const double* __restrict__ sh2 = A.stash + ((size_t)A.B * 26 + (size_t)b * 8) * n;    // h2[8][L][L] (training)
+    const Stash sv = stash_view(A.stash, A.B, b, n);
+    const double* __restrict__ st1 = sv.d1;
+    const double* __restrict__ st2 = sv.d2;
+    const double* __restrict__ sh1 = sv.h1;
+    const double* __restrict__ sh2 = sv.h2;
     double* gwp = TRAIN ? A.gw_part + ((size_t)b * ntiles + tile) * FLOW_GW_STRIDE : nullptr;
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -88,7 +86,8 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
 
     // wrapped lattice coordinates of window lines, relative to the tile origin (rows premultiplied by L)
     const bool fastw = L >= S::W3R + 1 && L >= W3C + 1;
-    auto WI = [&](int k) { return wrap_line(i0 + k, L, fastw) * L; };
+    auto wi = [&](int k) { return wrap_line(i0 + k, L, fastw); };
+    auto WI = [&](int k) { return wi(k) * L; };
     auto WJ = [&](int k) { return wrap_line(j0 + k, L, fastw); };
 
     // ---- load phase ---------------------------------------------------------------------------
@@ -101,19 +100,21 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         if (mu == 0) { tr3 = ta / S::NLC; tc3 = c0 + 4 * (ta - tr3 * S::NLC); ttask = tr3 < S::W3R && tc3 < W3C; }
         else { const int m = ta / W3C; tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
     }
-    double aP[4] = {0.0, 0.0, 0.0, 0.0}, as_[NMIX] = {0.0, 0.0}, ag[2] = {0.0, 0.0}, cb = 0.0;
-    if (ttask) {
-        const int iL = WI(tr3 - 3), ipL = WI(tr3 - 2), j = WJ(tc3 - 3), jp = WJ(tc3 - 2);
-        aP[0] = x0[iL + j]; aP[1] = x1[iL + j]; aP[2] = x0[iL + jp]; aP[3] = x1[ipL + j];
+    double tcv[4 * NMIX], ag[2] = {0.0, 0.0}, cb = 0.0;
 #pragma unroll
-        for (int k = 0; k < NMIX; ++k) as_[k] = sts[(size_t)k * n + iL + j];
+    for (int q = 0; q < 4 * NMIX; ++q) tcv[q] = 0.0;
+    if (ttask) {
+        const int i = wi(tr3 - 3), j = WJ(tc3 - 3);
+        const double* tc = sv.tc + stash_active_idx(i, j, L, mu);
+#pragma unroll
+        for (int q = 0; q < 4 * NMIX; ++q) tcv[q] = tc[(size_t)q * (n >> 2)];
         cb = A.glogj ? A.glogj[b] : A.glogj_const;
         if (A.up_link) {
-            ag[0] = A.up_link[(size_t)b * 2 * n + (size_t)mu * n + iL + j];
+            ag[0] = A.up_link[(size_t)b * 2 * n + (size_t)mu * n + i * L + j];
         } else {
             const double* gp = A.up_gp + (size_t)b * n;
-            ag[0] = gp[iL + j];
-            ag[1] = mu == 0 ? gp[iL + WJ(tc3 - 4)] : gp[WI(tr3 - 4) + j];
+            ag[0] = gp[i * L + j];
+            ag[1] = mu == 0 ? gp[i * L + WJ(tc3 - 4)] : gp[WI(tr3 - 4) + j];
         }
     }
     // (2) cos / sin of the frozen plaquettes: own sites only, or the whole tile+1 window for the conv1
@@ -132,10 +133,10 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         else { const int hh = tid / TC; c = tid - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
         fr1 = r + 1; fc1 = c + 1; ftask = true;
     }
-    double wP[4] = {0.0, 0.0, 0.0, 0.0};
+    double fcs = 1.0, fsn = 0.0;                                          // the net sees (1, 0) at non-frozen sites
     if (ftask) {
-        const int iL = WI(fr1 - 1), ipL = WI(fr1), j = WJ(fc1 - 1), jp = WJ(fc1);
-        wP[0] = x0[iL + j]; wP[1] = x1[iL + j]; wP[2] = x0[iL + jp]; wP[3] = x1[ipL + j];
+        const double* cs_ = sv.cs + stash_frozen_idx(wi(fr1 - 1), WJ(fc1 - 1), L, mu, off);
+        fcs = cs_[0]; fsn = cs_[n >> 1];
     }
     // (3) upstream gradient of the own sites (pass-through term)
     const int orr = tid / TC, occ = tid - orr * TC;
@@ -164,40 +165,24 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
 #pragma unroll
     for (int k = 0; k < 2; ++k) if (tid + k * NT < SW_SIZE) sW[tid + k * NT] = wsw[k];
     if (ttask) {
-        // adjoint of the tan-mixture transform (layers.py:66-90), everything of a site in one lane
-        const double Pa = aP[0] - aP[1] - aP[2] + aP[3];
+        // adjoint of the tan-mixture transform (layers.py:66-90) from the forward's coefficients
         const double gdelta = A.up_link ? (mu == 0 ? ag[0] : -ag[0]) : ag[0] - ag[1];
-        double sn, cs;
-        ft_sincos(Pa / 2, &sn, &cs);
-        const double cs2 = cs * cs, sn2 = sn * sn, sinP = 2.0 * (sn * cs);
-        double es[NMIX], ems[NMIX], invD[NMIX], si = 0.0;
-        {
-            double ea[2 * NMIX], eo[2 * NMIX];
-#pragma unroll
-            for (int k = 0; k < NMIX; ++k) { ea[2 * k] = as_[k]; ea[2 * k + 1] = -as_[k]; }
-            ft_expN<2 * NMIX>(ea, eo);
-#pragma unroll
-            for (int k = 0; k < NMIX; ++k) { es[k] = eo[2 * k]; ems[k] = eo[2 * k + 1]; }
-        }
-#pragma unroll
-        for (int k = 0; k < NMIX; ++k) { invD[k] = 1.0 / (ems[k] * cs2 + es[k] * sn2); si += invD[k]; }
-        double gsum = -gdelta;
         const int at = tr3 * W3C + tc3;
+        double csum = 0.0, esum = 0.0;
 #pragma unroll
-        for (int k = 0; k < NMIX; ++k) {
-            const double wk = invD[k] / si;                              // softmax_k(-log D_k)
-            sGO[k * N3W + at] = gdelta * (sinP * invD[k] / NMIX) + cb * wk * (ems[k] * cs2 - es[k] * sn2) * invD[k];
-            gsum += gdelta * (invD[k] / NMIX) - cb * wk * sinP * 0.5 * (es[k] - ems[k]) * invD[k];
-        }
+        for (int k = 0; k < NMIX; ++k) { csum += tcv[2 * NMIX + k]; esum += tcv[3 * NMIX + k]; }
+        const double tsum = NMIX * csum;                                 // sum_k 1 / D_k
+        double rs = __builtin_amdgcn_rcp(tsum);
+        rs = fma(fma(-tsum, rs, 1.0), rs, rs);
+        rs = fma(fma(-tsum, rs, 1.0), rs, rs);
+        const double cbr = cb * rs;
+#pragma unroll
+        for (int k = 0; k < NMIX; ++k) sGO[k * N3W + at] = gdelta * tcv[k] + cbr * tcv[NMIX + k];   // dL/ds_k
         sGO[NMIX * N3W + at] = gdelta;                                   // dL/dt
         const int r = tr3 - 3, c = tc3 - 3;
-        if ((unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC) sDir[r * TC + c] = gsum;
+        if ((unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC) sDir[r * TC + c] = gdelta * (csum - 1.0) - cbr * esum;
     }
-    if (TRAIN ? tid < N1W : ftask) {
-        double sn = 0.0, cs = 1.0;
-        if (ftask) ft_sincos(wP[0] - wP[1] - wP[2] + wP[3], &sn, &cs);
-        sIn[fr1 * W1C + fc1] = cs; sIn[PS1 + fr1 * W1C + fc1] = sn;
-    }
+    if (TRAIN ? tid < N1W : ftask) { sIn[fr1 * W1C + fc1] = fcs; sIn[PS1 + fr1 * W1C + fc1] = fsn; }
 #pragma unroll
     for (int p = 0; p < NP2; ++p) {
         const int r = lg + 16 * p;
@@ -223,6 +208,7 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
             for (int ch = 0; ch < 8; ++ch) vh2[p][ch] = ok ? sh2[(size_t)ch * n + go] : 0.0;
         }
     }
+    if (dbg && lane == 0) dbg[6 + wave] = (long long)__builtin_readcyclecounter();   // arrival at the first barrier
     lds_barrier();
     STAMP(1);
 

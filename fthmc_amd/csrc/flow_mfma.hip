@@ -104,6 +104,11 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         sP[tid] = p;
         sIn[tid] = cs;
         sIn[PS0 + tid] = sn;
+        if (MODE == 0 && A.stash && frozen && (unsigned)(r - 3) < (unsigned)min(TR, L - i0) &&
+            (unsigned)(c - 3) < (unsigned)min(TC, L - j0)) {             // the net input of the tile's own frozen sites
+            double* cs_ = A.stash + ((size_t)A.B * 18 + b) * n + stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
+            cs_[0] = cs; cs_[n >> 1] = sn;
+        }
     }
     for (int t = tid; t < SW_SIZE; t += NT) sW[t] = w[WCAN + t];
     lds_barrier();
@@ -111,10 +116,11 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 
     // stash planes of this lane's output channels g = lane >> 4 and g + 4 (fixed for the kernel)
     const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // tile sites inside the lattice
-    double* const st_d1 = (MODE == 0 && A.stash) ? A.stash + ((size_t)b * 8 + (lane >> 4)) * n : nullptr;
-    double* const st_d2 = st_d1 ? st_d1 + (size_t)A.B * 8 * n : nullptr;
-    double* const st_h1 = st_d1 ? st_d1 + (size_t)A.B * 18 * n : nullptr;
-    double* const st_h2 = st_d1 ? st_d1 + (size_t)A.B * 26 * n : nullptr;
+    const Stash sv = (MODE == 0 && A.stash) ? stash_view(A.stash, A.B, b, n) : Stash{};
+    double* const st_d1 = sv.d1 ? sv.d1 + (size_t)(lane >> 4) * n : nullptr;
+    double* const st_d2 = sv.d1 ? sv.d2 + (size_t)(lane >> 4) * n : nullptr;
+    double* const st_h1 = sv.d1 ? sv.h1 + (size_t)(lane >> 4) * n : nullptr;
+    double* const st_h2 = sv.d1 ? sv.h2 + (size_t)(lane >> 4) * n : nullptr;
 
     // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
     // B[k = (tap, ci)][n = (co, dd)] = W0[co][ci][ky4 - dd][kx]
@@ -249,8 +255,6 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         double sk = sW[CB2 + wave];
 #pragma unroll
         for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
-        if (MODE == 0 && A.stash && avalid)
-            A.stash[(((size_t)A.B * 16 + (size_t)b * 2 + wave) * L + ai) * L + aj] = sk;
         double sn, cs;
         ft_sincos(Pa / 2, &sn, &cs);
         { const double ea[2] = {sk, -sk}; double eo[2]; ft_expN<2>(ea, eo); es = eo[0]; ems = eo[1]; }
@@ -258,6 +262,16 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         invD = 1.0 / (ems * cs2 + es * sn2);
         sT2[(wave * TQ + 1) * NAS + lane] = invD;
         if (MODE == 0) sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
+        if (MODE == 0 && A.stash && avalid) {
+            // coefficients of the transform's adjoint (struct Stash): the backward kernel then needs no
+            // plaquettes, sincos or exp at the active sites of its tile+3 window
+            const double sinP = 2.0 * sincs, invD2 = invD * invD;
+            double* tc = sv.tc + stash_active_idx(ai, aj, L, mu) + (size_t)wave * (n >> 2);
+            tc[0] = sinP * invD / NMIX;                                  // A_k
+            tc[2 * (n >> 2)] = (ems * cs2 - es * sn2) * invD2;           // B_k
+            tc[4 * (n >> 2)] = invD / NMIX;                              // C_k
+            tc[6 * (n >> 2)] = sinP * 0.5 * (es - ems) * invD2;          // E_k
+        }
     }
     double tval = 0.0;
     if (MODE == 0 && wave == 0 && alane) {

@@ -42,6 +42,39 @@ template <int TR, int TC> struct Geom {
 // LDS copy of the layer's canonical weights (flow_common.h: CW0 CB0 CW1 CB1 CW2 CB2, WZERO)
 constexpr int SW_SIZE = WCAN_SIZE;
 
+// Per-layer activation stash written by the forward kernel and read back by the gather-form backward
+// (n = L * L; per chain b):
+//   d1  [8][n]     act'(z1)                       d2  [8][n]   act'(z2)  (dead lines unwritten)
+//   tc  [8][n/4]   adjoint coefficients of the tan-mixture transform at the ACTIVE sites, compact:
+//                  plane 2 q + k, q = 0..3 -> A_k, B_k, C_k, E_k.  With g = upstream dL/d delta,
+//                  cb = dL/dlogJ and the softmax normaliser rs = 1 / (K sum_k C_k)  (C_k = 1 / (K D_k)):
+//                  dL/ds_k = g A_k + cb rs B_k,   dL/dP = -g + sum_k (g C_k - cb rs E_k)
+//   cs  [2][n/2]   cos P, sin P at the FROZEN sites (the net input), compact
+//   h1, h2 [8][n]  hidden activations (training only)
+// = 16 + 2 + 1 = 19 doubles per site and layer (35 with h1, h2): kernels.h flow_stash_doubles().
+struct Stash { double *d1, *d2, *tc, *cs, *h1, *h2; };
+__device__ __forceinline__ Stash stash_view(double* base, int B, int b, int n) {
+    Stash v;
+    v.d1 = base + (size_t)b * 8 * n;
+    v.d2 = base + ((size_t)B + b) * 8 * n;
+    v.tc = base + ((size_t)B * 16 + (size_t)b * 2) * n;
+    v.cs = base + ((size_t)B * 18 + b) * n;
+    v.h1 = base + ((size_t)B * 19 + (size_t)b * 8) * n;
+    v.h2 = base + ((size_t)B * 27 + (size_t)b * 8) * n;
+    return v;
+}
+// compact index of an active site (i, j): every 4th column (mu = 0) or row (mu = 1)
+__device__ __forceinline__ int stash_active_idx(int i, int j, int L, int mu) {
+    return mu == 0 ? i * (L >> 2) + (j >> 2) : (i >> 2) * L + j;
+}
+// compact index of a frozen site (stripe classes 1, 2 of its line): two of every 4 columns / rows
+__device__ __forceinline__ int stash_frozen_idx(int i, int j, int L, int mu, int off) {
+    int u = (mu == 0 ? j : i) - off - 1;
+    if (u < 0) u += L;
+    const int f = 2 * (u >> 2) + (u & 1);
+    return mu == 0 ? i * (L >> 1) + f : f * L + j;
+}
+
 // One implicit-GEMM stage on v_mfma_f64_16x16x4_f64 over NPAIR "pair sites": a pair is two adjacent
 // output sites (rows r, r + 1 of one column, or with PAIRCOL columns c, c + 1 of one row) that share a
 // 4 x 3 (3 x 4) input window, so N = 16 = 8 output channels x the 2 sites of the pair and

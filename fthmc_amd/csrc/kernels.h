@@ -96,9 +96,8 @@ int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 constexpr int MG_TR = 16, MG_TC = 16;
 inline FlowGeom flow_gather_geom() { return FlowGeom{MG_TR, MG_TC}; }
 int launch_flow_bwd_gather(const FlowLayerArgs& a, bool train, hipStream_t s);
-// doubles per layer of the stash: act'(z1)[B][8][L][L], act'(z2)[B][8][L][L], s[B][2][L][L]
-// (+ h1[B][8][L][L], h2[B][8][L][L] for training)
-inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 34 : 18) * L * L; }
+// doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
+inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }
 // 0: VALU kernels everywhere; 1 (default): MFMA kernels for forward and backward-wrt-x
 void set_flow_variant(int v);
 int get_flow_variant();

@@ -19,6 +19,9 @@ for kind in ('flow_fwd', 'flow_bwd', 'flow_bwd_recompute'):
     for mu in (0, 1):
         cyc = ops.profile_stages(kind, x, w, mu=mu, off=1, beta=6.0)
         tot = sum(cyc)
+        tot = sum(cyc[:6])
         print(f'{kind} mu={mu}: total {tot:.0f} cycles/WG; ' + ', '.join(f'{n} {c:.0f}' for n, c in zip(names[kind][1:], cyc[1:]) if n))
+        if kind == 'flow_bwd':
+            print('    per-wave arrival at the first barrier:', ' '.join(f'{c:.0f}' for c in cyc[6:14]))
     if kind != 'flow_bwd_recompute':
         print(kind, 'ms/launch', ops.time_kernel(kind, x, w, mu=0, off=1, beta=6.0, reps=20))

@@ -49,7 +49,7 @@ template <int TR, int TC, bool TRAIN> struct SmemG {
     static constexpr int H2W = H1W + (TRAIN ? 8 * PS1 : 0);             // [8][PS1] h2 (training)
     static constexpr int SIZE = H2W + (TRAIN ? 8 * PS1 : 0);
     static_assert(W1R % 2 == 0, "row pairs");
-    static_assert(W2C <= 32 && NTT <= NT && 2 * N3 <= NT && N1W <= NT, "thread maps");
+    static_assert(NTT <= NT && 2 * N3 <= NT && N1W <= NT, "thread maps");
 };
 
 template <int TR, int TC, bool TRAIN>
@@ -143,18 +143,19 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     const bool ovalid = tid < N3 && orr < rmax && occ < cmax;
     double gpin = 0.0;
     if (ovalid && A.up_gp) gpin = A.up_gp[(size_t)b * n + (i0 + orr) * L + j0 + occ];
-    // (4) stash windows: a thread owns window column lc and rows lg, lg + 16 and walks the 8 channel planes
-    const int lc = tid & 31, lg = tid >> 5;
-    constexpr int NP2 = (W2R + 15) / 16, NP1 = (W1R + 15) / 16;
-    double v2[NP2][8];
+    // (4) stash windows, 16 bytes per lane: a thread owns the column pair (2 lq, 2 lq + 1) of window row lg
+    //     and walks the 8 channel planes.  Window columns start at j0 - 2 (even) and L is even, so a pair
+    //     never straddles the periodic wrap and is 16-byte aligned in HBM and in LDS.
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    static_assert(W2C % 2 == 0 && W2C / 2 <= 16 && W2R <= NT / 16 && (W1C + 2) / 2 <= 16 && PS2 % 2 == 0 && S::GZ2 % 2 == 0,
+                  "pair loads");
+    const int lq = tid & 15, lg = tid >> 4;
+    const bool ok2 = lq < W2C / 2 && lg < W2R;
+    const int go2 = WI((ok2 ? lg : 0) - 2) + WJ(2 * (ok2 ? lq : 0) - 2);
+    double2_t v2[8];
 #pragma unroll
-    for (int p = 0; p < NP2; ++p) {
-        const int r = lg + 16 * p;
-        const bool ok = lc < W2C && r < W2R;
-        const int go = WI((ok ? r : 0) - 2) + WJ((ok ? lc : 0) - 2);
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) v2[p][ch] = ok ? st2[(size_t)ch * n + go] : 0.0;
-    }
+    for (int ch = 0; ch < 8; ++ch)
+        v2[ch] = ok2 ? *reinterpret_cast<const double2_t*>(st2 + (size_t)ch * n + go2) : double2_t{0.0, 0.0};
     double wsw[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) wsw[k] = (tid + k * NT < SW_SIZE) ? w[WCAN + tid + k * NT] : 0.0;
@@ -183,30 +184,26 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         if ((unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC) sDir[r * TC + c] = gdelta * (csum - 1.0) - cbr * esum;
     }
     if (TRAIN ? tid < N1W : ftask) { sIn[fr1 * W1C + fc1] = fcs; sIn[PS1 + fr1 * W1C + fc1] = fsn; }
+    if (ok2) {
 #pragma unroll
-    for (int p = 0; p < NP2; ++p) {
-        const int r = lg + 16 * p;
-        if (lc < W2C && r < W2R) {
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) sGZ2[ch * PS2 + r * W2C + lc] = v2[p][ch];
-        }
+        for (int ch = 0; ch < 8; ++ch) *reinterpret_cast<double2_t*>(sGZ2 + ch * PS2 + lg * W2C + 2 * lq) = v2[ch];
     }
-    // act'(z1) (and h1, h2): issued now, landing while conv3^T runs
-    double v1[NP1][8];
-    double vh1[TRAIN ? NP1 : 1][8], vh2[TRAIN ? NP1 : 1][8];
+    // act'(z1) (and h1, h2): issued now, landing while conv3^T runs.  The tile+1 window starts at the odd
+    // column j0 - 1: pairs come from the even-aligned superset j0 - 2 .. j0 + TC + 1, its two outer
+    // columns are dropped when the pairs go to LDS.
+    const bool ok1 = lq < (W1C + 2) / 2 && lg < W1R;
+    const int go1 = WI((ok1 ? lg : 0) - 1) + WJ(2 * (ok1 ? lq : 0) - 2);
+    double2_t v1[8], vh1[TRAIN ? 8 : 1], vh2[TRAIN ? 8 : 1];
 #pragma unroll
-    for (int p = 0; p < NP1; ++p) {
-        const int r = lg + 16 * p;
-        const bool ok = lc < W1C && r < W1R;
-        const int go = WI((ok ? r : 0) - 1) + WJ((ok ? lc : 0) - 1);
+    for (int ch = 0; ch < 8; ++ch)
+        v1[ch] = ok1 ? *reinterpret_cast<const double2_t*>(st1 + (size_t)ch * n + go1) : double2_t{0.0, 0.0};
+    if (TRAIN) {
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) v1[p][ch] = ok ? st1[(size_t)ch * n + go] : 0.0;
-        if (TRAIN) {
+        for (int ch = 0; ch < 8; ++ch)
+            vh1[ch] = ok1 ? *reinterpret_cast<const double2_t*>(sh1 + (size_t)ch * n + go1) : double2_t{0.0, 0.0};
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) vh1[p][ch] = ok ? sh1[(size_t)ch * n + go] : 0.0;
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) vh2[p][ch] = ok ? sh2[(size_t)ch * n + go] : 0.0;
-        }
+        for (int ch = 0; ch < 8; ++ch)
+            vh2[ch] = ok1 ? *reinterpret_cast<const double2_t*>(sh2 + (size_t)ch * n + go1) : double2_t{0.0, 0.0};
     }
     if (dbg && lane == 0) dbg[6 + wave] = (long long)__builtin_readcyclecounter();   // arrival at the first barrier
     lds_barrier();
@@ -259,17 +256,22 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
             pz[s2off] = ksel <= 2 ? pz[s2off] * acc1[k] : 0.0;
         }
     }
+    if (ok1) {
+        const int c1 = 2 * lq - 1;                                       // tile+1 column of the pair's first value
+        const bool wa = c1 >= 0, wb = c1 + 1 < W1C;
 #pragma unroll
-    for (int p = 0; p < NP1; ++p) {
-        const int r = lg + 16 * p;
-        if (lc < W1C && r < W1R) {
+        for (int ch = 0; ch < 8; ++ch) {
+            double* pd = sD1 + ch * PS1 + lg * W1C + c1;
+            if (wa) pd[0] = v1[ch].x;
+            if (wb) pd[1] = v1[ch].y;
+        }
+        if (TRAIN) {
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch) sD1[ch * PS1 + r * W1C + lc] = v1[p][ch];
-            if (TRAIN) {
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) sH1w[ch * PS1 + r * W1C + lc] = vh1[p][ch];
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) sH2w[ch * PS1 + r * W1C + lc] = vh2[p][ch];
+            for (int ch = 0; ch < 8; ++ch) {
+                double* p1 = sH1w + ch * PS1 + lg * W1C + c1;
+                double* p2 = sH2w + ch * PS1 + lg * W1C + c1;
+                if (wa) { p1[0] = vh1[ch].x; p2[0] = vh2[ch].x; }
+                if (wb) { p1[1] = vh1[ch].y; p2[1] = vh2[ch].y; }
             }
         }
     }

@@ -15,8 +15,10 @@
 //     need no special case; only the final store and the weight-gradient sums look at validity,
 //   * LDS drops enough for 16 x 16 tiles at two workgroups per CU (halo factors 1.27 / 1.56
 //     instead of 1.9 / 1.4 on the two stashed windows).
-// act'(z1) is loaded while the transform adjoint and conv3^T run: the barriers in between wait
-// for LDS traffic only (s_waitcnt lgkmcnt), not for global loads in flight.
+// act'(z2) and act'(z1) never pass through LDS: each thread loads the values it will multiply by
+// (conv3^T task layout, conv2^T epilogue layout) at kernel start, and they land while the transform
+// adjoint, conv3^T's accumulation and the MFMA loop run: the barriers in between wait for LDS traffic
+// only (s_waitcnt lgkmcnt), not for global loads in flight.
 //
 // Reference: autograd of GaugeEquivCouplingLayer.forward (fthmc/utils/layers.py:196-202,348-371)
 // as used by ft_force (qed_helpers.py:226-242) and train_step (train.py:162-228).
@@ -40,8 +42,8 @@ template <int TR, int TC, bool TRAIN> struct SmemG {
     static constexpr int NSLOT = cmax_(W3R * NLC, NLR * W3C);           // transform tasks
     static constexpr int NTT = (NSLOT + 63) / 64 * 64;                  // threads that run them (last waves)
     static constexpr int GO = 0;                                        // [3][N3W] g(s0, s1, t)
-    static constexpr int GZ2 = GO + 3 * N3W;                            // [8][PS2]
-    static constexpr int D1 = GZ2 + 8 * PS2;                            // [8][PS1]
+    static constexpr int GZ2 = GO + 3 * N3W;                            // [8][PS2] gz2
+    static constexpr int D1 = GZ2 + 8 * PS2;                            // [8][PS1] gz1
     static constexpr int IN = D1 + 8 * PS1;                             // [2][PS1] cos, sin (tile+1 coordinates)
     static constexpr int DIR = IN + 2 * PS1;                            // [N3] layer's contribution at own sites
     static constexpr int SW = DIR + N3;                                 // [SW_SIZE]
@@ -85,12 +87,19 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     STAMP(0);
 
     // wrapped lattice coordinates of window lines, relative to the tile origin (rows premultiplied by L)
-    const bool fastw = L >= S::W3R + 1 && L >= W3C + 1;
+    const unsigned fastw = wrap_magic(L);
     auto wi = [&](int k) { return wrap_line(i0 + k, L, fastw); };
     auto WI = [&](int k) { return wi(k) * L; };
     auto WJ = [&](int k) { return wrap_line(j0 + k, L, fastw); };
 
-    // ---- load phase ---------------------------------------------------------------------------
+    // ---- load phase.  Every load is unconditional, from a clamped address (idle lanes read element 0
+    //      and drop it): straight-line code lets the compiler count outstanding loads (s_waitcnt
+    //      vmcnt(N)) instead of draining them all at the first use after a branch.  Loads return in
+    //      issue order, so what the first stage consumes is issued first and the big act' operands last.
+    double wsw[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) wsw[k] = w[WCAN + min(tid + k * NT, SW_SIZE - 1)];
+    static_assert(SW_SIZE <= 2 * NT, "weight copy");
     // (1) transform tasks on the last waves: active site `a` of the tile+3 window, both mixture components
     const int ta = tid - (NT - S::NTT);
     const int c0 = (off - (j0 - 3)) & 3, r0 = (off - (i0 - 3)) & 3;    // first active column / row of the window
@@ -99,27 +108,23 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     if (ta >= 0) {
         if (mu == 0) { tr3 = ta / S::NLC; tc3 = c0 + 4 * (ta - tr3 * S::NLC); ttask = tr3 < S::W3R && tc3 < W3C; }
         else { const int m = ta / W3C; tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
-    }
-    double tcv[4 * NMIX], ag[2] = {0.0, 0.0}, cb = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4 * NMIX; ++q) tcv[q] = 0.0;
-    if (ttask) {
+        if (!ttask) { tr3 = 3; tc3 = 3; }                                // any valid site
+    } else { tr3 = 3; tc3 = 3; }
+    double tcv[4 * NMIX], ag[2];
+    const double cb = A.glogj ? A.glogj[b] : A.glogj_const;
+    {
         const int i = wi(tr3 - 3), j = WJ(tc3 - 3);
         const double* tc = sv.tc + stash_active_idx(i, j, L, mu);
 #pragma unroll
         for (int q = 0; q < 4 * NMIX; ++q) tcv[q] = tc[(size_t)q * (n >> 2)];
-        cb = A.glogj ? A.glogj[b] : A.glogj_const;
-        if (A.up_link) {
-            ag[0] = A.up_link[(size_t)b * 2 * n + (size_t)mu * n + i * L + j];
-        } else {
-            const double* gp = A.up_gp + (size_t)b * n;
-            ag[0] = gp[i * L + j];
-            ag[1] = mu == 0 ? gp[i * L + WJ(tc3 - 4)] : gp[WI(tr3 - 4) + j];
-        }
+        // upstream gradient: a link field (first layer of a standalone call) or the plaquette-gradient field
+        const double* gsrc = A.up_link ? A.up_link + (size_t)b * 2 * n + (size_t)mu * n : A.up_gp + (size_t)b * n;
+        ag[0] = gsrc[i * L + j];
+        ag[1] = gsrc[mu == 0 ? i * L + WJ(tc3 - 4) : WI(tr3 - 4) + j];   // unused with up_link
     }
     // (2) cos / sin of the frozen plaquettes: own sites only, or the whole tile+1 window for the conv1
     //     weight gradient (training).  Stored in tile+1 coordinates.
-    int fr1 = 0, fc1 = 0;                                                // tile+1 coordinates of this thread's site
+    int fr1 = 1, fc1 = 1;                                                // tile+1 coordinates of this thread's site
     bool ftask = false;
     if (TRAIN) {
         if (tid < N1W) {
@@ -133,33 +138,70 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         else { const int hh = tid / TC; c = tid - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
         fr1 = r + 1; fc1 = c + 1; ftask = true;
     }
-    double fcs = 1.0, fsn = 0.0;                                          // the net sees (1, 0) at non-frozen sites
-    if (ftask) {
-        const double* cs_ = sv.cs + stash_frozen_idx(wi(fr1 - 1), WJ(fc1 - 1), L, mu, off);
+    double fcs, fsn;                                                     // the net sees (1, 0) at non-frozen sites
+    {
+        const double* cs_ = sv.cs + (ftask ? stash_frozen_idx(wi(fr1 - 1), WJ(fc1 - 1), L, mu, off) : 0);
         fcs = cs_[0]; fsn = cs_[n >> 1];
+        if (!ftask) { fcs = 1.0; fsn = 0.0; }
     }
     // (3) upstream gradient of the own sites (pass-through term)
     const int orr = tid / TC, occ = tid - orr * TC;
     const bool ovalid = tid < N3 && orr < rmax && occ < cmax;
-    double gpin = 0.0;
-    if (ovalid && A.up_gp) gpin = A.up_gp[(size_t)b * n + (i0 + orr) * L + j0 + occ];
-    // (4) stash windows, 16 bytes per lane: a thread owns the column pair (2 lq, 2 lq + 1) of window row lg
-    //     and walks the 8 channel planes.  Window columns start at j0 - 2 (even) and L is even, so a pair
-    //     never straddles the periodic wrap and is 16-byte aligned in HBM and in LDS.
+    double gpin;
+    {
+        const double* gsrc = A.up_gp ? A.up_gp + (size_t)b * n : sv.cs;   // no pass-through without up_gp
+        gpin = gsrc[ovalid ? (i0 + orr) * L + j0 + occ : 0];
+        if (!ovalid || !A.up_gp) gpin = 0.0;
+    }
+    // (4) act'(z2) and act'(z1) go straight into the registers of the thread that multiplies by them
+    //     (conv3^T task layout / conv2^T epilogue layout), never through LDS: they are issued here with
+    //     everything else and land while the transform adjoint, conv3^T and the MFMA loop run.
+    // conv3^T task = (two sites of the same line class, half of the 8 channels)
+    static_assert(W2R % 2 == 0 && W2C % 2 == 0 && N2W <= NT, "site pairs, one round");
+    constexpr int NPR = N2W / 2;
+    const bool c3task = tid < N2W;
+    const int c3half = c3task && tid >= NPR, c3u = c3task ? (c3half ? tid - NPR : tid) : 0;
+    int c3r, c3c;
+    if (mu == 0) { c3r = c3u / W2C; c3c = c3u - c3r * W2C; }             // (r, c), (r + W2R/2, c)
+    else { c3r = c3u / (W2C / 2); c3c = c3u - c3r * (W2C / 2); }         // (r, c), (r, c + W2C/2)
+    double d2v[2][4];
+    {
+        const int goA = WI(c3r - 2) + WJ(c3c - 2);
+        const int goB = mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double* pl = st2 + (size_t)(c3half * 4 + k) * n;
+            d2v[0][k] = pl[goA]; d2v[1][k] = pl[goB];
+        }
+    }
+    // conv2^T epilogue: lane (g = lane >> 4, i = lane & 15) of tile T = wave + 8 it owns pair 16 T + i,
+    // channels g and g + 4, both rows of the pair
+    constexpr int NPAIR1 = (W1R / 2) * W1C, NTILE1 = (NPAIR1 + 15) / 16, NIT1 = (NTILE1 + NW - 1) / NW;
+    double d1v[NIT1][4];
+#pragma unroll
+    for (int it = 0; it < NIT1; ++it) {
+        const int T = wave + NW * it, p_ = T * 16 + (lane & 15);
+        const int pp = p_ < NPAIR1 ? p_ : 0, pr = pp / W1C, pc = pp - pr * W1C;
+        const int j = WJ(pc - 1), ga = WI(2 * pr - 1) + j, gb = WI(2 * pr) + j;
+        const double* pl = st1 + (size_t)(lane >> 4) * n;
+        d1v[it][0] = pl[ga]; d1v[it][1] = pl[ga + 4 * (size_t)n];
+        d1v[it][2] = pl[gb]; d1v[it][3] = pl[gb + 4 * (size_t)n];
+    }
+    // training: h1, h2 on the tile+1 window, 16 bytes per lane (they are GEMM operands and do live in LDS).
+    // The window starts at the odd column j0 - 1: pairs come from the even-aligned superset
+    // j0 - 2 .. j0 + TC + 1 (L is even, so a pair never straddles the wrap), the two outer columns are dropped.
     typedef double double2_t __attribute__((ext_vector_type(2)));
-    static_assert(W2C % 2 == 0 && W2C / 2 <= 16 && W2R <= NT / 16 && (W1C + 2) / 2 <= 16 && PS2 % 2 == 0 && S::GZ2 % 2 == 0,
-                  "pair loads");
+    static_assert((W1C + 2) / 2 <= 16 && W1R <= NT / 16, "pair loads");
     const int lq = tid & 15, lg = tid >> 4;
-    const bool ok2 = lq < W2C / 2 && lg < W2R;
-    const int go2 = WI((ok2 ? lg : 0) - 2) + WJ(2 * (ok2 ? lq : 0) - 2);
-    double2_t v2[8];
+    const bool ok1 = TRAIN && lq < (W1C + 2) / 2 && lg < W1R;
+    double2_t vh1[TRAIN ? 8 : 1], vh2[TRAIN ? 8 : 1];
+    if (TRAIN) {
+        const int go1 = WI((ok1 ? lg : 0) - 1) + WJ(2 * (ok1 ? lq : 0) - 2);
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch)
-        v2[ch] = ok2 ? *reinterpret_cast<const double2_t*>(st2 + (size_t)ch * n + go2) : double2_t{0.0, 0.0};
-    double wsw[2];
+        for (int ch = 0; ch < 8; ++ch) vh1[ch] = *reinterpret_cast<const double2_t*>(sh1 + (size_t)ch * n + go1);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) wsw[k] = (tid + k * NT < SW_SIZE) ? w[WCAN + tid + k * NT] : 0.0;
-    static_assert(SW_SIZE <= 2 * NT, "weight copy");
+        for (int ch = 0; ch < 8; ++ch) vh2[ch] = *reinterpret_cast<const double2_t*>(sh2 + (size_t)ch * n + go1);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- consume ---------------------------------------------------------------------------------
@@ -184,43 +226,16 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         if ((unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC) sDir[r * TC + c] = gdelta * (csum - 1.0) - cbr * esum;
     }
     if (TRAIN ? tid < N1W : ftask) { sIn[fr1 * W1C + fc1] = fcs; sIn[PS1 + fr1 * W1C + fc1] = fsn; }
-    if (ok2) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) *reinterpret_cast<double2_t*>(sGZ2 + ch * PS2 + lg * W2C + 2 * lq) = v2[ch];
-    }
-    // act'(z1) (and h1, h2): issued now, landing while conv3^T runs.  The tile+1 window starts at the odd
-    // column j0 - 1: pairs come from the even-aligned superset j0 - 2 .. j0 + TC + 1, its two outer
-    // columns are dropped when the pairs go to LDS.
-    const bool ok1 = lq < (W1C + 2) / 2 && lg < W1R;
-    const int go1 = WI((ok1 ? lg : 0) - 1) + WJ(2 * (ok1 ? lq : 0) - 2);
-    double2_t v1[8], vh1[TRAIN ? 8 : 1], vh2[TRAIN ? 8 : 1];
-#pragma unroll
-    for (int ch = 0; ch < 8; ++ch)
-        v1[ch] = ok1 ? *reinterpret_cast<const double2_t*>(st1 + (size_t)ch * n + go1) : double2_t{0.0, 0.0};
-    if (TRAIN) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch)
-            vh1[ch] = ok1 ? *reinterpret_cast<const double2_t*>(sh1 + (size_t)ch * n + go1) : double2_t{0.0, 0.0};
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch)
-            vh2[ch] = ok1 ? *reinterpret_cast<const double2_t*>(sh2 + (size_t)ch * n + go1) : double2_t{0.0, 0.0};
-    }
     if (dbg && lane == 0) dbg[6 + wave] = (long long)__builtin_readcyclecounter();   // arrival at the first barrier
     lds_barrier();
     STAMP(1);
 
     // ---- conv3^T on the VALU: g_out lives on the active lines, so of the 9 taps of a site at most 3
     //      (one line) contribute; times act'(z2) -> gz2 in place ------------------------------------
-    // task = (two sites of the same line class, half of the 8 channels): the 36 weights of a task are
-    // read once and serve both sites (the stage is bound by LDS reads per FMA, not by the FMAs)
-    static_assert(W2R % 2 == 0 && W2C % 2 == 0 && N2W <= NT, "site pairs, one round");
-    if (tid < N2W) {
-        constexpr int NPR = N2W / 2;
-        const int half = tid >= NPR;
-        const int u = half ? tid - NPR : tid;
-        int r, c, s2off;
-        if (mu == 0) { r = u / W2C; c = u - r * W2C; s2off = (W2R / 2) * W2C; }          // (r, c), (r + W2R/2, c)
-        else { r = u / (W2C / 2); c = u - r * (W2C / 2); s2off = W2C / 2; }             // (r, c), (r, c + W2C/2)
+    // the 36 weights of a task are read once and serve both sites (the stage is bound by LDS reads per FMA)
+    if (c3task) {
+        const int half = c3half, r = c3r, c = c3c;
+        const int s2off = mu == 0 ? (W2R / 2) * W2C : W2C / 2;
         const int s = r * W2C + c;
         // source = site - (ky - 1, kx - 1): window coordinates (r + 2 - ky, c + 2 - kx) of tile+3
         const int ksel = mu == 0 ? (c + 2 - c0) & 3 : (r + 2 - r0) & 3;   // the one kx (mu=0) / ky (mu=1)
@@ -252,27 +267,19 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             double* pz = sGZ2 + (half * 4 + k) * PS2 + s;
-            pz[0] = ksel <= 2 ? pz[0] * acc0[k] : 0.0;
-            pz[s2off] = ksel <= 2 ? pz[s2off] * acc1[k] : 0.0;
+            pz[0] = ksel <= 2 ? d2v[0][k] * acc0[k] : 0.0;
+            pz[s2off] = ksel <= 2 ? d2v[1][k] * acc1[k] : 0.0;
         }
     }
-    if (ok1) {
+    if (TRAIN && ok1) {
         const int c1 = 2 * lq - 1;                                       // tile+1 column of the pair's first value
         const bool wa = c1 >= 0, wb = c1 + 1 < W1C;
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
-            double* pd = sD1 + ch * PS1 + lg * W1C + c1;
-            if (wa) pd[0] = v1[ch].x;
-            if (wb) pd[1] = v1[ch].y;
-        }
-        if (TRAIN) {
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                double* p1 = sH1w + ch * PS1 + lg * W1C + c1;
-                double* p2 = sH2w + ch * PS1 + lg * W1C + c1;
-                if (wa) { p1[0] = vh1[ch].x; p2[0] = vh2[ch].x; }
-                if (wb) { p1[1] = vh1[ch].y; p2[1] = vh2[ch].y; }
-            }
+            double* p1 = sH1w + ch * PS1 + lg * W1C + c1;
+            double* p2 = sH2w + ch * PS1 + lg * W1C + c1;
+            if (wa) { p1[0] = vh1[ch].x; p2[0] = vh2[ch].x; }
+            if (wb) { p1[1] = vh1[ch].y; p2[1] = vh2[ch].y; }
         }
     }
     lds_barrier();
@@ -310,13 +317,14 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
         return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
     };
-    mfma_stage<24, 8, (W1R / 2) * W1C, W2C, PS2, false>(sGZ2, sW, wave, lane,
+    mfma_stage<24, 8, NPAIR1, W2C, PS2, false, true>(sGZ2, sW, wave, lane,
         [](int p) { const int pr = p / W1C; return 2 * pr * W2C + p - pr * W1C; }, bidx4,
-        [&](int g, int p, bool ok, double (&gh)[4]) {
+        [&](int g, int p, bool ok, double (&gh)[4], int it) {
             if (ok) {
                 const int pr = p / W1C, pc = p - pr * W1C;
                 double* pd = sD1 + g * PS1 + 2 * pr * W1C + pc;
-                pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[W1C] *= gh[2]; pd[4 * PS1 + W1C] *= gh[3];
+                pd[0] = gh[0] * d1v[it][0]; pd[4 * PS1] = gh[1] * d1v[it][1];
+                pd[W1C] = gh[2] * d1v[it][2]; pd[4 * PS1 + W1C] = gh[3] * d1v[it][3];
             }
         });
     lds_barrier();

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
 
-    const bool fastw = L >= G::R0R + 1 && L >= R0C + 1;          // window lines wrap at most once
+    const unsigned fastw = wrap_magic(L);
     // the tile's own links for the final link update: issued now, consumed in the last stage
     double xv0 = 0.0, xv1 = 0.0;
     if (MODE == 0 && A.y && tid < N3) {
@@ -128,9 +128,9 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         const int k = 4 * t + g, tap = k / 2, ci = k - 2 * tap, ky = tap / 3 - dd, kx = tap % 3;
         return (ky >= 0 && ky <= 2) ? CW0 + (cN * 2 + ci) * 9 + ky * 3 + kx : WZERO;
     };
-    mfma_stage<6, 2, (R1R / 2) * R1C, R0C, PS0, false>(sIn, sW, wave, lane,
+    mfma_stage<6, 2, (R1R / 2) * R1C, R0C, PS0, false, false>(sIn, sW, wave, lane,
         [](int p) { const int pr = p / R1C; return 2 * pr * R0C + p - pr * R1C; }, bidx1,
-        [&](int g, int p, bool ok, double (&z)[4]) {
+        [&](int g, int p, bool ok, double (&z)[4], int) {
             const int pr = p / R1C, pc = p - pr * R1C;
             const double b0 = sW[CB0 + g], b1 = sW[CB0 + g + 4];
             double h[4], d[4];
@@ -200,9 +200,9 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             const int tap = t >> 1, ci = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
             return (ky >= 0 && ky <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
         };
-        mfma_stage<24, 8, (R2R / 2) * NLC, R1C, PS1, false>(sH1, sW, wave, lane,
+        mfma_stage<24, 8, (R2R / 2) * NLC, R1C, PS1, false, false>(sH1, sW, wave, lane,
             [&](int p) { const int pr = p / NLC; return 2 * pr * R1C + min(live_line(p - pr * NLC, d0), R2C - 1); }, bidx2,
-            [&](int g, int p, bool ok, double (&z)[4]) {
+            [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int pr = p / NLC, c = live_line(p - pr * NLC, d0);
                 conv2_epi(g, ok && c < R2C, 2 * pr, c, 1, 0, z);
             });
@@ -212,9 +212,9 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             const int tap = t >> 1, ci = (t & 1) * 4 + g, ky = tap / 4, kx = tap % 4 - dd;
             return (kx >= 0 && kx <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
         };
-        mfma_stage<24, 8, NLR * (R2C / 2), R1C, PS1, true>(sH1, sW, wave, lane,
+        mfma_stage<24, 8, NLR * (R2C / 2), R1C, PS1, true, false>(sH1, sW, wave, lane,
             [&](int p) { const int lr = p / (R2C / 2); return min(live_line(lr, d0), R2R - 1) * R1C + 2 * (p - lr * (R2C / 2)); }, bidx2,
-            [&](int g, int p, bool ok, double (&z)[4]) {
+            [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int lr = p / (R2C / 2), r = live_line(lr, d0);
                 conv2_epi(g, ok && r < R2R, r, 2 * (p - lr * (R2C / 2)), 0, 1, z);
             });
@@ -392,9 +392,9 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
             return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
         };
-        mfma_stage<24, 8, (R1R / 2) * R1C, R0C, PS0, false>(sGZ2, sW, wave, lane,
+        mfma_stage<24, 8, (R1R / 2) * R1C, R0C, PS0, false, false>(sGZ2, sW, wave, lane,
             [](int p) { const int pr = p / R1C; return 2 * pr * R0C + p - pr * R1C; }, bidx4,
-            [&](int g, int p, bool ok, double (&gh)[4]) {
+            [&](int g, int p, bool ok, double (&gh)[4], int) {
                 if (ok) {
                     const int pr = p / R1C, pc = p - pr * R1C;
                     double* pd = sD1 + g * PS1 + 2 * pr * R1C + pc;

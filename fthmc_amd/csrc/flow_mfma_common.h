@@ -15,10 +15,13 @@ constexpr int NW = NT / 64;
 // stash stores / prefetched windows.  No thread of these kernels reads global data another thread wrote.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Wrapped lattice coordinate of window line v (-L <= v): two selects when the lattice is wider than a
-// window (`fast`, uniform per launch), a true remainder for the small lattices of the tests.
-__device__ __forceinline__ int wrap_line(int v, int L, bool fast) {
-    return fast ? (v < 0 ? v + L : (v >= L ? v - L : v)) : ft_modL(v, L);
+// Wrapped lattice coordinate (v mod L) of window line v, -L <= v < 2^16 - L, branch-free: division by
+// the launch-uniform L through its 32-bit reciprocal (wrap_magic, one real division per kernel).
+// Exact: n M >> 32 = floor(n / L) for n, L < 2^16 with M = floor(2^32 / L) + 1.
+__device__ __forceinline__ unsigned wrap_magic(int L) { return 0xFFFFFFFFu / (unsigned)L + 1u; }
+__device__ __forceinline__ int wrap_line(int v, int L, unsigned magic) {
+    const unsigned nn = (unsigned)(v + L);
+    return (int)(nn - (unsigned)L * __umulhi(nn, magic));
 }
 
 // Plane stride (doubles): smallest value >= n that is = 18 (mod 32).  The four k-lanes of an
@@ -84,13 +87,14 @@ __device__ __forceinline__ int stash_frozen_idx(int i, int j, int L, int mu, int
 //               (row stride RSA, plane stride PSA); must be valid for every p < NPAIR
 //   bidx(t, g, cN, dd) -> index of W[k = 4 t + g][n = cN + 8 dd] in the LDS weight copy sW
 //               (tap of k: row-major over the 4 x 3 window, or 3 x 4 with PAIRCOL)
-//   epi(g, p, ok, z): z[q] = output channel g + 4 (q & 1) at site (q >> 1) of pair p; all four values
-//               of a lane at once so that their chains interleave
+//   epi(g, p, ok, z, it): z[q] = output channel g + 4 (q & 1) at site (q >> 1) of pair p; all four values
+//               of a lane at once so that their chains interleave; it = which of the wave's tiles (a
+//               compile-time constant with UNROLL, so the caller can keep per-tile operands in registers)
 // The weights are the MFMA's A operand and the activations its B operand, so D comes out transposed:
 // D[row = (channel, site of pair)][col = pair].  A lane then holds one pair (col = lane & 15) and the
 // rows g + 4 q: all site arithmetic of the epilogue (offsets, bounds, stash address) happens once per
 // lane and tile instead of once per value.
-template <int NSTEP, int KC, int NPAIR, int RSA, int PSA, bool PAIRCOL, class AMap, class BIdx, class Epi>
+template <int NSTEP, int KC, int NPAIR, int RSA, int PSA, bool PAIRCOL, bool UNROLL, class AMap, class BIdx, class Epi>
 __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ sW,
                                            int wave, int lane, AMap amap, BIdx bidx, Epi epi) {
     constexpr int NTILE = (NPAIR + 15) / 16;
@@ -110,7 +114,11 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
     int boff[NSTEP];
 #pragma unroll
     for (int t = 0; t < NSTEP; ++t) boff[t] = bidx(t, g, cN, dd);
-    for (int tile = wave; tile < NTILE; tile += NW) {
+    constexpr int NIT = (NTILE + NW - 1) / NW, NUNR = UNROLL ? NIT : 1;
+#pragma unroll NUNR
+    for (int it = 0; it < NIT; ++it) {
+        const int tile = wave + it * NW;
+        if (tile >= NTILE) break;
         const int p_ = tile * 16 + i;
         const bool ok = p_ < NPAIR;
         const int p = ok ? p_ : NPAIR - 1;                   // padding lanes: any valid address
@@ -131,7 +139,7 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
         double z4[4] = {acc[0], acc[1], acc[2], acc[3]};
-        epi(g, p, ok, z4);
+        epi(g, p, ok, z4, it);
     }
 }
 

@@ -54,7 +54,7 @@ template <int TR, int TC, bool TRAIN> struct SmemG {
     static_assert(NTT <= NT && 2 * N3 <= NT && N1W <= NT, "thread maps");
 };
 
-template <int TR, int TC, bool TRAIN>
+template <int TR, int TC, bool TRAIN, bool FASTW>
 __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     using S = SmemG<TR, TC, TRAIN>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
@@ -77,20 +77,23 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // own sites inside the lattice
     const double* __restrict__ w = A.wint;
     const Stash sv = stash_view(A.stash, A.B, b, n);
-    const double* __restrict__ st1 = sv.d1;
-    const double* __restrict__ st2 = sv.d2;
-    const double* __restrict__ sh1 = sv.h1;
-    const double* __restrict__ sh2 = sv.h2;
+    // stash planes of this chain (struct Stash), as kernel-argument base + uniform offset
+    const double* __restrict__ st1 = uniform_ptr(A.stash, (size_t)b * 8 * n);
+    const double* __restrict__ stc = uniform_ptr(A.stash, ((size_t)A.B * 16 + (size_t)b * 2) * n);
+    const double* __restrict__ scs = uniform_ptr(A.stash, ((size_t)A.B * 18 + b) * n);
+    const double* __restrict__ sh1 = uniform_ptr(A.stash, ((size_t)A.B * 19 + (size_t)b * 8) * n);
+    const double* __restrict__ sh2 = uniform_ptr(A.stash, ((size_t)A.B * 27 + (size_t)b * 8) * n);
+    (void)sv;
     double* gwp = TRAIN ? A.gw_part + ((size_t)b * ntiles + tile) * FLOW_GW_STRIDE : nullptr;
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
 
     // wrapped lattice coordinates of window lines, relative to the tile origin (rows premultiplied by L)
-    const unsigned fastw = wrap_magic(L);
-    auto wi = [&](int k) { return wrap_line(i0 + k, L, fastw); };
-    auto WI = [&](int k) { return wi(k) * L; };
-    auto WJ = [&](int k) { return wrap_line(j0 + k, L, fastw); };
+    const unsigned wmagic = FASTW ? 0u : wrap_magic(L);
+    auto wi = [&](int k) { return wrap_line<FASTW>(i0 + k, L, wmagic); };
+    auto WI = [&](int k) { return mul24(wi(k), L); };
+    auto WJ = [&](int k) { return wrap_line<FASTW>(j0 + k, L, wmagic); };
 
     // ---- load phase.  Every load is unconditional, from a clamped address (idle lanes read element 0
     //      and drop it): straight-line code lets the compiler count outstanding loads (s_waitcnt
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     //      issue order, so what the first stage consumes is issued first and the big act' operands last.
     double wsw[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) wsw[k] = w[WCAN + min(tid + k * NT, SW_SIZE - 1)];
+    for (int k = 0; k < 2; ++k) wsw[k] = ldu(w + WCAN, (unsigned)min(tid + k * NT, SW_SIZE - 1));
     static_assert(SW_SIZE <= 2 * NT, "weight copy");
     // (1) transform tasks on the last waves: active site `a` of the tile+3 window, both mixture components
     const int ta = tid - (NT - S::NTT);
@@ -106,21 +109,23 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     int tr3 = 0, tc3 = 0;
     bool ttask = false;
     if (ta >= 0) {
-        if (mu == 0) { tr3 = ta / S::NLC; tc3 = c0 + 4 * (ta - tr3 * S::NLC); ttask = tr3 < S::W3R && tc3 < W3C; }
-        else { const int m = ta / W3C; tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
+        if (mu == 0) { tr3 = fdiv<S::NLC>(ta); tc3 = c0 + 4 * (ta - tr3 * S::NLC); ttask = tr3 < S::W3R && tc3 < W3C; }
+        else { const int m = fdiv<W3C>(ta); tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
         if (!ttask) { tr3 = 3; tc3 = 3; }                                // any valid site
     } else { tr3 = 3; tc3 = 3; }
     double tcv[4 * NMIX], ag[2];
     const double cb = A.glogj ? A.glogj[b] : A.glogj_const;
     {
         const int i = wi(tr3 - 3), j = WJ(tc3 - 3);
-        const double* tc = sv.tc + stash_active_idx(i, j, L, mu);
+        // wave-uniform base + 32-bit per-lane offset everywhere: the address costs no VALU op per load
+        const unsigned ia = (unsigned)stash_active_idx(i, j, L, mu);
 #pragma unroll
-        for (int q = 0; q < 4 * NMIX; ++q) tcv[q] = tc[(size_t)q * (n >> 2)];
+        for (int q = 0; q < 4 * NMIX; ++q) tcv[q] = ldu(stc + (size_t)q * (n >> 2), ia);
         // upstream gradient: a link field (first layer of a standalone call) or the plaquette-gradient field
-        const double* gsrc = A.up_link ? A.up_link + (size_t)b * 2 * n + (size_t)mu * n : A.up_gp + (size_t)b * n;
-        ag[0] = gsrc[i * L + j];
-        ag[1] = gsrc[mu == 0 ? i * L + WJ(tc3 - 4) : WI(tr3 - 4) + j];   // unused with up_link
+        const double* gsrc = uniform_ptr(A.up_link ? A.up_link : A.up_gp, A.up_link ? (size_t)b * 2 * n + (size_t)mu * n : (size_t)b * n);
+        const int iL = mul24(i, L);
+        ag[0] = ldu(gsrc, (unsigned)(iL + j));
+        ag[1] = ldu(gsrc, (unsigned)(mu == 0 ? iL + WJ(tc3 - 4) : WI(tr3 - 4) + j));   // unused with up_link
     }
     // (2) cos / sin of the frozen plaquettes: own sites only, or the whole tile+1 window for the conv1
     //     weight gradient (training).  Stored in tile+1 coordinates.
@@ -128,29 +133,29 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     bool ftask = false;
     if (TRAIN) {
         if (tid < N1W) {
-            fr1 = tid / W1C; fc1 = tid - fr1 * W1C;
+            fr1 = fdiv<W1C>(tid); fc1 = tid - fr1 * W1C;
             const int cls = ((mu == 0 ? j0 - 1 + fc1 : i0 - 1 + fr1) - off) & 3;
             ftask = cls == 1 || cls == 2;
         }
     } else if (tid < N3 / 2) {
         int r, c;
-        if (mu == 0) { r = tid / (TC / 2); const int h = tid - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
-        else { const int hh = tid / TC; c = tid - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
+        if (mu == 0) { r = fdiv<TC / 2>(tid); const int h = tid - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
+        else { const int hh = fdiv<TC>(tid); c = tid - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
         fr1 = r + 1; fc1 = c + 1; ftask = true;
     }
     double fcs, fsn;                                                     // the net sees (1, 0) at non-frozen sites
     {
-        const double* cs_ = sv.cs + (ftask ? stash_frozen_idx(wi(fr1 - 1), WJ(fc1 - 1), L, mu, off) : 0);
-        fcs = cs_[0]; fsn = cs_[n >> 1];
+        const unsigned ic = ftask ? (unsigned)stash_frozen_idx(wi(fr1 - 1), WJ(fc1 - 1), L, mu, off) : 0u;
+        fcs = ldu(scs, ic); fsn = ldu(scs + (n >> 1), ic);
         if (!ftask) { fcs = 1.0; fsn = 0.0; }
     }
     // (3) upstream gradient of the own sites (pass-through term)
-    const int orr = tid / TC, occ = tid - orr * TC;
+    const int orr = fdiv<TC>(tid), occ = tid - orr * TC;
     const bool ovalid = tid < N3 && orr < rmax && occ < cmax;
     double gpin;
     {
-        const double* gsrc = A.up_gp ? A.up_gp + (size_t)b * n : sv.cs;   // no pass-through without up_gp
-        gpin = gsrc[ovalid ? (i0 + orr) * L + j0 + occ : 0];
+        const double* gsrc = A.up_gp ? uniform_ptr(A.up_gp, (size_t)b * n) : scs;   // no pass-through without up_gp
+        gpin = ldu(gsrc, ovalid ? (unsigned)(mul24(i0 + orr, L) + j0 + occ) : 0u);
         if (!ovalid || !A.up_gp) gpin = 0.0;
     }
     // (4) act'(z2) and act'(z1) go straight into the registers of the thread that multiplies by them
@@ -159,20 +164,20 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     // conv3^T task = (two sites of the same line class, half of the 8 channels)
     static_assert(W2R % 2 == 0 && W2C % 2 == 0 && N2W <= NT, "site pairs, one round");
     constexpr int NPR = N2W / 2;
-    const bool c3task = tid < N2W;
-    const int c3half = c3task && tid >= NPR, c3u = c3task ? (c3half ? tid - NPR : tid) : 0;
+    static_assert(NPR <= NT / 2, "one half of the channels per half of the workgroup");
+    const int c3half = wave >= NW / 2;                                   // wave-uniform: plane bases stay in SGPRs
+    const bool c3task = (tid & (NT / 2 - 1)) < NPR;
+    const int c3u = c3task ? (tid & (NT / 2 - 1)) : 0;
     int c3r, c3c;
-    if (mu == 0) { c3r = c3u / W2C; c3c = c3u - c3r * W2C; }             // (r, c), (r + W2R/2, c)
-    else { c3r = c3u / (W2C / 2); c3c = c3u - c3r * (W2C / 2); }         // (r, c), (r, c + W2C/2)
+    if (mu == 0) { c3r = fdiv<W2C>(c3u); c3c = c3u - c3r * W2C; }             // (r, c), (r + W2R/2, c)
+    else { c3r = fdiv<W2C / 2>(c3u); c3c = c3u - c3r * (W2C / 2); }         // (r, c), (r, c + W2C/2)
     double d2v[2][4];
     {
         const int goA = WI(c3r - 2) + WJ(c3c - 2);
         const int goB = mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
+        const double* pl = uniform_ptr(A.stash, ((size_t)A.B + b) * 8 * n + (size_t)(c3half * 4) * n);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double* pl = st2 + (size_t)(c3half * 4 + k) * n;
-            d2v[0][k] = pl[goA]; d2v[1][k] = pl[goB];
-        }
+        for (int k = 0; k < 4; ++k) { d2v[0][k] = ldu(pl + (size_t)k * n, (unsigned)goA); d2v[1][k] = ldu(pl + (size_t)k * n, (unsigned)goB); }
     }
     // conv2^T epilogue: lane (g = lane >> 4, i = lane & 15) of tile T = wave + 8 it owns pair 16 T + i,
     // channels g and g + 4, both rows of the pair
@@ -181,11 +186,12 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
 #pragma unroll
     for (int it = 0; it < NIT1; ++it) {
         const int T = wave + NW * it, p_ = T * 16 + (lane & 15);
-        const int pp = p_ < NPAIR1 ? p_ : 0, pr = pp / W1C, pc = pp - pr * W1C;
+        const int pp = p_ < NPAIR1 ? p_ : 0, pr = fdiv<W1C>(pp), pc = pp - pr * W1C;
         const int j = WJ(pc - 1), ga = WI(2 * pr - 1) + j, gb = WI(2 * pr) + j;
-        const double* pl = st1 + (size_t)(lane >> 4) * n;
-        d1v[it][0] = pl[ga]; d1v[it][1] = pl[ga + 4 * (size_t)n];
-        d1v[it][2] = pl[gb]; d1v[it][3] = pl[gb + 4 * (size_t)n];
+        const unsigned og = (unsigned)mul24(lane >> 4, n >> 4) * 16u;        // channel plane g (n % 16 == 0, n / 16 < 2^23)
+        const double* ph = st1 + 4 * (size_t)n;
+        d1v[it][0] = ldu(st1, og + ga); d1v[it][1] = ldu(ph, og + ga);
+        d1v[it][2] = ldu(st1, og + gb); d1v[it][3] = ldu(ph, og + gb);
     }
     // training: h1, h2 on the tile+1 window, 16 bytes per lane (they are GEMM operands and do live in LDS).
     // The window starts at the odd column j0 - 1: pairs come from the even-aligned superset
@@ -198,9 +204,9 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     if (TRAIN) {
         const int go1 = WI((ok1 ? lg : 0) - 1) + WJ(2 * (ok1 ? lq : 0) - 2);
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) vh1[ch] = *reinterpret_cast<const double2_t*>(sh1 + (size_t)ch * n + go1);
+        for (int ch = 0; ch < 8; ++ch) vh1[ch] = *reinterpret_cast<const double2_t*>(&(sh1 + (size_t)ch * n)[(unsigned)go1]);
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) vh2[ch] = *reinterpret_cast<const double2_t*>(sh2 + (size_t)ch * n + go1);
+        for (int ch = 0; ch < 8; ++ch) vh2[ch] = *reinterpret_cast<const double2_t*>(&(sh2 + (size_t)ch * n)[(unsigned)go1]);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -318,10 +324,10 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
     };
     mfma_stage<24, 8, NPAIR1, W2C, PS2, false, true>(sGZ2, sW, wave, lane,
-        [](int p) { const int pr = p / W1C; return 2 * pr * W2C + p - pr * W1C; }, bidx4,
+        [](int p) { const int pr = fdiv<W1C>(p); return 2 * pr * W2C + p - pr * W1C; }, bidx4,
         [&](int g, int p, bool ok, double (&gh)[4], int it) {
             if (ok) {
-                const int pr = p / W1C, pc = p - pr * W1C;
+                const int pr = fdiv<W1C>(p), pc = p - pr * W1C;
                 double* pd = sD1 + g * PS1 + 2 * pr * W1C + pc;
                 pd[0] = gh[0] * d1v[it][0]; pd[4 * PS1] = gh[1] * d1v[it][1];
                 pd[W1C] = gh[2] * d1v[it][2]; pd[4 * PS1 + W1C] = gh[3] * d1v[it][3];
@@ -355,8 +361,8 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     if (tid < 2 * N3) {
         const int f = tid >> 2, qq = tid & 3;
         int r, c;
-        if (mu == 0) { r = f / (TC / 2); const int h = f - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
-        else { const int hh = f / TC; c = f - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
+        if (mu == 0) { r = fdiv<TC / 2>(f); const int h = f - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
+        else { const int hh = fdiv<TC>(f); c = f - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
         double gc[2] = {0.0, 0.0}, gsn[2] = {0.0, 0.0};
 #pragma unroll
         for (int cq = 0; cq < 2; ++cq) {
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     // ---- gP_out = gP_in + this layer's contribution at the own sites ---------------------------
     if (ovalid) {
         const int cls = ((mu == 0 ? j0 + occ : i0 + orr) - off) & 3;  // 0 active, 1|2 frozen, 3 passive
-        A.gp_out[(size_t)b * n + (i0 + orr) * L + j0 + occ] = gpin + (cls != 3 ? sDir[tid] : 0.0);
+        A.gp_out[(size_t)b * n + mul24(i0 + orr, L) + j0 + occ] = gpin + (cls != 3 ? sDir[tid] : 0.0);
     }
     STAMP(5);
 #undef STAMP
@@ -417,8 +423,14 @@ namespace fthmc {
 
 int launch_flow_bwd_gather(const FlowLayerArgs& a, bool train, hipStream_t s) {
     const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
-    if (train) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true>), grid, dim3(NT), 0, s, a);
-    else       hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false>), grid, dim3(NT), 0, s, a);
+    const bool fast = wrap_fast_ok(a.L, MG_TR, MG_TC);
+    if (train) {
+        if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, true>), grid, dim3(NT), 0, s, a);
+        else      hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, false>), grid, dim3(NT), 0, s, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, true>), grid, dim3(NT), 0, s, a);
+        else      hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, false>), grid, dim3(NT), 0, s, a);
+    }
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

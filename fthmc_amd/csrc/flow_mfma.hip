@@ -94,8 +94,8 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
     static_assert(N0 <= NT, "one window site per thread");
     if (tid < N0) {
         const int r = tid / R0C, c = tid - r * R0C;
-        const int iL = wrap_line(i0 - 3 + r, L, fastw) * L, ipL = wrap_line(i0 - 2 + r, L, fastw) * L;
-        const int j = wrap_line(j0 - 3 + c, L, fastw), jp = wrap_line(j0 - 2 + c, L, fastw);
+        const int iL = wrap_line<false>(i0 - 3 + r, L, fastw) * L, ipL = wrap_line<false>(i0 - 2 + r, L, fastw) * L;
+        const int j = wrap_line<false>(j0 - 3 + c, L, fastw), jp = wrap_line<false>(j0 - 2 + c, L, fastw);
         const double p = x0[iL + j] - x1[iL + j] - x0[iL + jp] + x1[ipL + j];
         const int sel = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;          // stripe class (L % 4 == 0)
         const bool frozen = (sel == 1 || sel == 2);

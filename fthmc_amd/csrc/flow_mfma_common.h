@@ -15,14 +15,46 @@ constexpr int NW = NT / 64;
 // stash stores / prefetched windows.  No thread of these kernels reads global data another thread wrote.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Wrapped lattice coordinate (v mod L) of window line v, -L <= v < 2^16 - L, branch-free: division by
-// the launch-uniform L through its 32-bit reciprocal (wrap_magic, one real division per kernel).
-// Exact: n M >> 32 = floor(n / L) for n, L < 2^16 with M = floor(2^32 / L) + 1.
+// Integer index math of these kernels is written for the full-rate VALU ops: v_mul_hi_u32 / v_mul_lo_u32 /
+// v_mad_u64_u32 run at quarter rate, and the per-thread index set-up ahead of the first loads used to cost
+// more cycles than the HBM round trip it precedes.
+//   mul24: operands < 2^23 (lattice extents, window indices)
+//   fdiv<D>(u) = u / D for 0 <= u < 32768, 2 <= D <= 32, via one 24-bit multiply (exact: u (M D - 2^20) < 2^20)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+template <int D> __device__ __forceinline__ int fdiv(int u) {
+    static_assert(D >= 1 && D <= 32, "small divisors");
+    if (D == 1) return u;
+    if ((D & (D - 1)) == 0) return (int)((unsigned)u >> __builtin_ctz(D));
+    constexpr unsigned M = ((1u << 20) + D - 1) / D;
+    return (int)(__umul24((unsigned)u, M) >> 20);
+}
+// base + (a launch- or wave-uniform element offset forced into SGPRs): loads through the result take the
+// scalar-base form (global_load v, v_offset32, s[base]), their per-lane address is one 32-bit offset and
+// costs no 64-bit VALU add.  The kernel-argument base keeps the pointer's global address space.
+__device__ __forceinline__ size_t uniform_u64(size_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((size_t)hi << 32) | lo;
+}
+template <class T> __device__ __forceinline__ T* uniform_ptr(T* base, size_t off) { return base + uniform_u64(off); }
+// element `idx` (32-bit, idx * 8 < 2^32) of a uniform base: the byte offset is formed in 32 bits so that the
+// load can be base-in-SGPRs + one VGPR offset
+__device__ __forceinline__ double ldu(const double* base, unsigned idx) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + idx * 8u);
+}
+// Wrapped lattice coordinate (v mod L) of window line v, -L <= v.  FAST (L exceeds the window by a
+// margin, chosen at launch): the line wraps at most once, two selects.  Otherwise (small test lattices)
+// division by the launch-uniform L through its reciprocal (wrap_magic): n M >> 32 = floor(n / L) for
+// n, L < 2^16 with M = floor(2^32 / L) + 1.
 __device__ __forceinline__ unsigned wrap_magic(int L) { return 0xFFFFFFFFu / (unsigned)L + 1u; }
+template <bool FAST>
 __device__ __forceinline__ int wrap_line(int v, int L, unsigned magic) {
+    if (FAST) return v < 0 ? v + L : (v >= L ? v - L : v);
     const unsigned nn = (unsigned)(v + L);
     return (int)(nn - (unsigned)L * __umulhi(nn, magic));
 }
+// a lattice at least this much larger than the tile takes the FAST wrap (window lines reach 4 sites out)
+inline bool wrap_fast_ok(int L, int tr, int tc) { return L >= tr + 8 && L >= tc + 8; }
 
 // Plane stride (doubles): smallest value >= n that is = 18 (mod 32).  The four k-lanes of an
 // A read (ds_read_b64, 64 banks) then overlap in only 2 of 32 doubles, and the eight channel
@@ -68,14 +100,14 @@ __device__ __forceinline__ Stash stash_view(double* base, int B, int b, int n) {
 }
 // compact index of an active site (i, j): every 4th column (mu = 0) or row (mu = 1)
 __device__ __forceinline__ int stash_active_idx(int i, int j, int L, int mu) {
-    return mu == 0 ? i * (L >> 2) + (j >> 2) : (i >> 2) * L + j;
+    return mu == 0 ? mul24(i, L >> 2) + (j >> 2) : mul24(i >> 2, L) + j;
 }
 // compact index of a frozen site (stripe classes 1, 2 of its line): two of every 4 columns / rows
 __device__ __forceinline__ int stash_frozen_idx(int i, int j, int L, int mu, int off) {
     int u = (mu == 0 ? j : i) - off - 1;
     if (u < 0) u += L;
     const int f = 2 * (u >> 2) + (u & 1);
-    return mu == 0 ? i * (L >> 1) + f : f * L + j;
+    return mu == 0 ? mul24(i, L >> 1) + f : mul24(f, L) + j;
 }
 
 // One implicit-GEMM stage on v_mfma_f64_16x16x4_f64 over NPAIR "pair sites": a pair is two adjacent

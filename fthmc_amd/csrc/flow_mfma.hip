@@ -50,7 +50,7 @@ template <int MODE, int TR, int TC> struct SmemM {
 };
 
 // MODE 0 forward, 1 backward wrt x
-template <int MODE, int TR, int TC>
+template <int MODE, int TR, int TC, bool FASTW>
 __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_flow_mfma(FlowLayerArgs A) {
     using S = SmemM<MODE, TR, TC>;
     using G = Geom<TR, TC>;
@@ -75,28 +75,28 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
     if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
     const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
-    const double* __restrict__ x0 = A.x + (size_t)b * 2 * n;
+    const double* __restrict__ x0 = uniform_ptr(A.x, (size_t)b * 2 * n);
     const double* __restrict__ x1 = x0 + n;
     const double* __restrict__ w = A.wint;
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
 
-    const unsigned fastw = wrap_magic(L);
+    const unsigned fastw = FASTW ? 0u : wrap_magic(L);
     // the tile's own links for the final link update: issued now, consumed in the last stage
     double xv0 = 0.0, xv1 = 0.0;
     if (MODE == 0 && A.y && tid < N3) {
-        const int r = tid / TC, c = tid - r * TC;
-        if (i0 + r < L && j0 + c < L) { xv0 = x0[(i0 + r) * L + j0 + c]; xv1 = x1[(i0 + r) * L + j0 + c]; }
+        const int r = fdiv<TC>(tid), c = tid - r * TC;
+        if (i0 + r < L && j0 + c < L) { const unsigned at = (unsigned)(mul24(i0 + r, L) + j0 + c); xv0 = ldu(x0, at); xv1 = ldu(x1, at); }
     }
 
     // ---- plaquette window + net input; small weights -> LDS ------------------
     static_assert(N0 <= NT, "one window site per thread");
     if (tid < N0) {
-        const int r = tid / R0C, c = tid - r * R0C;
-        const int iL = wrap_line<false>(i0 - 3 + r, L, fastw) * L, ipL = wrap_line<false>(i0 - 2 + r, L, fastw) * L;
-        const int j = wrap_line<false>(j0 - 3 + c, L, fastw), jp = wrap_line<false>(j0 - 2 + c, L, fastw);
-        const double p = x0[iL + j] - x1[iL + j] - x0[iL + jp] + x1[ipL + j];
+        const int r = fdiv<R0C>(tid), c = tid - r * R0C;
+        const int iL = mul24(wrap_line<FASTW>(i0 - 3 + r, L, fastw), L), ipL = mul24(wrap_line<FASTW>(i0 - 2 + r, L, fastw), L);
+        const int j = wrap_line<FASTW>(j0 - 3 + c, L, fastw), jp = wrap_line<FASTW>(j0 - 2 + c, L, fastw);
+        const double p = ldu(x0, (unsigned)(iL + j)) - ldu(x1, (unsigned)(iL + j)) - ldu(x0, (unsigned)(iL + jp)) + ldu(x1, (unsigned)(ipL + j));
         const int sel = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;          // stripe class (L % 4 == 0)
         const bool frozen = (sel == 1 || sel == 2);
         double sn = 0.0, cs = 1.0;
@@ -129,9 +129,9 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         return (ky >= 0 && ky <= 2) ? CW0 + (cN * 2 + ci) * 9 + ky * 3 + kx : WZERO;
     };
     mfma_stage<6, 2, (R1R / 2) * R1C, R0C, PS0, false, false>(sIn, sW, wave, lane,
-        [](int p) { const int pr = p / R1C; return 2 * pr * R0C + p - pr * R1C; }, bidx1,
+        [](int p) { const int pr = fdiv<R1C>(p); return 2 * pr * R0C + p - pr * R1C; }, bidx1,
         [&](int g, int p, bool ok, double (&z)[4], int) {
-            const int pr = p / R1C, pc = p - pr * R1C;
+            const int pr = fdiv<R1C>(p), pc = p - pr * R1C;
             const double b0 = sW[CB0 + g], b1 = sW[CB0 + g + 4];
             double h[4], d[4];
             z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             if (MODE == 0 && A.stash) {                                  // act'(z1) (and h1) of the tile's own sites
                 const int r = 2 * pr - 2, c = pc - 2;
                 if (ok && (unsigned)c < (unsigned)cmax) {
-                    const int at = (i0 + r) * L + j0 + c;
+                    const int at = mul24(i0 + r, L) + j0 + c;
 #pragma unroll
                     for (int dd = 0; dd < 2; ++dd)
                         if ((unsigned)(r + dd) < (unsigned)rmax) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             }
         }
         if (MODE == 0 && A.stash && ok) {                                // act'(z2) (and h2) of the tile's own sites
-            const int at = (i0 + r - 1) * L + j0 + c - 1;
+            const int at = mul24(i0 + r - 1, L) + j0 + c - 1;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 if ((unsigned)(r - 1 + q * dr) < (unsigned)rmax && (unsigned)(c - 1 + q * dc) < (unsigned)cmax) {
@@ -201,9 +201,9 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             return (ky >= 0 && ky <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
         };
         mfma_stage<24, 8, (R2R / 2) * NLC, R1C, PS1, false, false>(sH1, sW, wave, lane,
-            [&](int p) { const int pr = p / NLC; return 2 * pr * R1C + min(live_line(p - pr * NLC, d0), R2C - 1); }, bidx2,
+            [&](int p) { const int pr = fdiv<NLC>(p); return 2 * pr * R1C + min(live_line(p - pr * NLC, d0), R2C - 1); }, bidx2,
             [&](int g, int p, bool ok, double (&z)[4], int) {
-                const int pr = p / NLC, c = live_line(p - pr * NLC, d0);
+                const int pr = fdiv<NLC>(p), c = live_line(p - pr * NLC, d0);
                 conv2_epi(g, ok && c < R2C, 2 * pr, c, 1, 0, z);
             });
     } else {
@@ -213,9 +213,9 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             return (kx >= 0 && kx <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
         };
         mfma_stage<24, 8, NLR * (R2C / 2), R1C, PS1, true, false>(sH1, sW, wave, lane,
-            [&](int p) { const int lr = p / (R2C / 2); return min(live_line(lr, d0), R2R - 1) * R1C + 2 * (p - lr * (R2C / 2)); }, bidx2,
+            [&](int p) { const int lr = fdiv<R2C / 2>(p); return min(live_line(lr, d0), R2R - 1) * R1C + 2 * (p - lr * (R2C / 2)); }, bidx2,
             [&](int g, int p, bool ok, double (&z)[4], int) {
-                const int lr = p / (R2C / 2), r = live_line(lr, d0);
+                const int lr = fdiv<R2C / 2>(p), r = live_line(lr, d0);
                 conv2_epi(g, ok && r < R2R, r, 2 * (p - lr * (R2C / 2)), 0, 1, z);
             });
     }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         }
         lds_barrier();
         if (A.y && tid < N3) {
-            const int r = tid / TC, c = tid - r * TC;
+            const int r = fdiv<TC>(tid), c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
             if (i < L && j < L) {
                 double v0 = xv0, v1 = xv1;
@@ -304,7 +304,8 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
                     if (mu == 0) v0 = ft_wrap(d + v0); else v1 = ft_wrap(-d + v1);
                 }
                 double* y0 = A.y + (size_t)b * 2 * n;
-                y0[i * L + j] = v0; y0[n + i * L + j] = v1;
+                const int at = mul24(i, L) + j;
+                y0[at] = v0; y0[n + at] = v1;
             }
         }
         STAMP(6);
@@ -393,10 +394,10 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
         };
         mfma_stage<24, 8, (R1R / 2) * R1C, R0C, PS0, false, false>(sGZ2, sW, wave, lane,
-            [](int p) { const int pr = p / R1C; return 2 * pr * R0C + p - pr * R1C; }, bidx4,
+            [](int p) { const int pr = fdiv<R1C>(p); return 2 * pr * R0C + p - pr * R1C; }, bidx4,
             [&](int g, int p, bool ok, double (&gh)[4], int) {
                 if (ok) {
-                    const int pr = p / R1C, pc = p - pr * R1C;
+                    const int pr = fdiv<R1C>(p), pc = p - pr * R1C;
                     double* pd = sD1 + g * PS1 + 2 * pr * R1C + pc;
                     pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[R1C] *= gh[2]; pd[4 * PS1 + R1C] *= gh[3];
                 }
@@ -487,12 +488,14 @@ int get_flow_variant() { return g_variant; }
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     // forward needs half the LDS of backward: 16 x 16 tiles (less halo work) still fit twice per CU
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
-    hipLaunchKernelGGL((k_flow_mfma<0, MF_FWD_TR, MF_FWD_TC>), grid, dim3(NT), 0, s, a);
+    if (wrap_fast_ok(a.L, MF_FWD_TR, MF_FWD_TC)) hipLaunchKernelGGL((k_flow_mfma<0, MF_FWD_TR, MF_FWD_TC, true>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((k_flow_mfma<0, MF_FWD_TR, MF_FWD_TC, false>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     const dim3 grid = xcd_grid(a.B, (a.L + MF_TR - 1) / MF_TR, (a.L + MF_TC - 1) / MF_TC);
-    hipLaunchKernelGGL((k_flow_mfma<1, MF_TR, MF_TC>), grid, dim3(NT), 0, s, a);
+    if (wrap_fast_ok(a.L, MF_TR, MF_TC)) hipLaunchKernelGGL((k_flow_mfma<1, MF_TR, MF_TC, true>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((k_flow_mfma<1, MF_TR, MF_TC, false>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

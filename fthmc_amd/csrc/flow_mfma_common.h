@@ -49,7 +49,7 @@ __device__ __forceinline__ double ldu(const double* base, unsigned idx) {
 __device__ __forceinline__ unsigned wrap_magic(int L) { return 0xFFFFFFFFu / (unsigned)L + 1u; }
 template <bool FAST>
 __device__ __forceinline__ int wrap_line(int v, int L, unsigned magic) {
-    if (FAST) return v < 0 ? v + L : (v >= L ? v - L : v);
+    if (FAST) return (int)min(min((unsigned)v, (unsigned)(v - L)), (unsigned)(v + L));   // -L <= v < 2 L: one v_min3_u32
     const unsigned nn = (unsigned)(v + L);
     return (int)(nn - (unsigned)L * __umulhi(nn, magic));
 }
@@ -179,22 +179,23 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
 __device__ __forceinline__ int live_line(int l, int d0) { return l < d0 ? l : l + 1 + (l - d0) / 3; }
 
 
-// XCD-aware block -> (chain, tile) map.  Blocks are dealt round-robin over the 8 XCDs (b and b + 8
+// XCD-aware block -> (chain, tile) map.  Blocks are dealt round-robin over the 8 XCDs (chains b and b + 8
 // share one), and each XCD has its own L2: all tiles of a chain go to the same XCD, consecutively,
 // so the halo re-reads of neighbouring tiles (links, stashed activations) hit that XCD's L2
 // instead of going out to the fabric once per XCD.  Speed only: any placement is correct.
 struct BlockTile { int b, tile, ti, tj; };
+// grid = (8 * ntj, nti, ceil(B / 8)): the linear block id the dispatcher deals round-robin over the 8 XCDs is
+// x + gridDim.x * (y + gridDim.y * z) and gridDim.x is a multiple of 8, so XCD = blockIdx.x & 7; the rest
+// of the coordinates come out of the block index without a division.
 __device__ __forceinline__ bool block_tile(int B, int nti, int ntj, BlockTile& t) {
-    const int ntiles = nti * ntj;
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-    const int cl = slot / ntiles;
-    t.tile = slot - cl * ntiles;
-    t.b = cl * 8 + xcd;
-    t.ti = t.tile / ntj;
-    t.tj = t.tile - t.ti * ntj;
+    const int xcd = blockIdx.x & 7;
+    t.tj = blockIdx.x >> 3;
+    t.ti = blockIdx.y;
+    t.tile = t.ti * ntj + t.tj;
+    t.b = blockIdx.z * 8 + xcd;
     return t.b < B;
 }
-inline dim3 xcd_grid(int B, int nti, int ntj) { return dim3(8 * ((B + 7) / 8) * nti * ntj); }
+inline dim3 xcd_grid(int B, int nti, int ntj) { return dim3(8 * ntj, nti, (B + 7) / 8); }
 
 // Weight gradient of a 3x3 conv as an MFMA GEMM over the sites of the tile's window:
 //   gw[co][ci][ky][kx] = sum_s gz[co][s] * hin[ci][s + (ky, kx)]

@@ -129,7 +129,7 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
             a.stash = w.stash + (size_t)l * flow_stash_doubles(B, L, train);
             a.gp_out = galt;
             FT_TRY(launch_flow_bwd_gather(a, train, s));
-            if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_gather_geom().ntiles(L), 1.0, 0,
+            if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_gather_geom(true).ntiles(L), 1.0, 0,
                                             gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
             double* t_ = gcur; gcur = galt; galt = t_;
             continue;

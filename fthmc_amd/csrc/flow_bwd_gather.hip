@@ -55,7 +55,7 @@ template <int TR, int TC, bool TRAIN> struct SmemG {
 };
 
 template <int TR, int TC, bool TRAIN, bool FASTW>
-__global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayerArgs A) {
+__global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     using S = SmemG<TR, TC, TRAIN>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
     constexpr int W1R = S::W1R, W1C = S::W1C, N1W = S::N1W, N3 = S::N3, PS1 = S::PS1, PS2 = S::PS2;
@@ -200,13 +200,12 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
     static_assert((W1C + 2) / 2 <= 16 && W1R <= NT / 16, "pair loads");
     const int lq = tid & 15, lg = tid >> 4;
     const bool ok1 = TRAIN && lq < (W1C + 2) / 2 && lg < W1R;
-    double2_t vh1[TRAIN ? 8 : 1], vh2[TRAIN ? 8 : 1];
+    // one register set for both: h2 (needed first, by the conv3 weight gradient) now, h1 once h2 is in LDS
+    double2_t vh[TRAIN ? 8 : 1];
+    const int go1 = TRAIN ? WI((ok1 ? lg : 0) - 1) + WJ(2 * (ok1 ? lq : 0) - 2) : 0;
     if (TRAIN) {
-        const int go1 = WI((ok1 ? lg : 0) - 1) + WJ(2 * (ok1 ? lq : 0) - 2);
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) vh1[ch] = *reinterpret_cast<const double2_t*>(&(sh1 + (size_t)ch * n)[(unsigned)go1]);
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) vh2[ch] = *reinterpret_cast<const double2_t*>(&(sh2 + (size_t)ch * n)[(unsigned)go1]);
+        for (int ch = 0; ch < 8; ++ch) vh[ch] = *reinterpret_cast<const double2_t*>(&(sh2 + (size_t)ch * n)[(unsigned)go1]);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -282,11 +281,14 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         const bool wa = c1 >= 0, wb = c1 + 1 < W1C;
 #pragma unroll
         for (int ch = 0; ch < 8; ++ch) {
-            double* p1 = sH1w + ch * PS1 + lg * W1C + c1;
             double* p2 = sH2w + ch * PS1 + lg * W1C + c1;
-            if (wa) { p1[0] = vh1[ch].x; p2[0] = vh2[ch].x; }
-            if (wb) { p1[1] = vh1[ch].y; p2[1] = vh2[ch].y; }
+            if (wa) p2[0] = vh[ch].x;
+            if (wb) p2[1] = vh[ch].y;
         }
+    }
+    if (TRAIN) {
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) vh[ch] = *reinterpret_cast<const double2_t*>(&(sh1 + (size_t)ch * n)[(unsigned)go1]);
     }
     lds_barrier();
     STAMP(2);
@@ -340,6 +342,16 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
         // ---- weight gradient of conv2 (MFMA over the tile's own sites) and b2: gz2 outside the own,
         //      in-lattice sites is dropped first (there it belongs to other tiles), which also makes
         //      the ring the dy trick of wgrad_stage reads ---------------------------------------------
+        if (ok1) {                                                   // h1 window -> LDS (loaded under conv3^T / conv2^T)
+            const int c1 = 2 * lq - 1;
+            const bool wa = c1 >= 0, wb = c1 + 1 < W1C;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                double* p1 = sH1w + ch * PS1 + lg * W1C + c1;
+                if (wa) p1[0] = vh[ch].x;
+                if (wb) p1[1] = vh[ch].y;
+            }
+        }
         for (int t = tid; t < 8 * N2W; t += NT) {
             const int ci = t / N2W, s = t - ci * N2W, r = s / W2C - 2, c = s % W2C - 2;
             if (!((unsigned)r < (unsigned)rmax && (unsigned)c < (unsigned)cmax)) sGZ2[ci * PS2 + s] = 0.0;
@@ -422,14 +434,14 @@ __global__ __launch_bounds__(NT, TRAIN ? 2 : 4) void k_flow_bwd_gather(FlowLayer
 namespace fthmc {
 
 int launch_flow_bwd_gather(const FlowLayerArgs& a, bool train, hipStream_t s) {
-    const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
-    const bool fast = wrap_fast_ok(a.L, MG_TR, MG_TC);
     if (train) {
-        if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, true>), grid, dim3(NT), 0, s, a);
-        else      hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, false>), grid, dim3(NT), 0, s, a);
+        const dim3 grid = xcd_grid(a.B, (a.L + MGT_TR - 1) / MGT_TR, (a.L + MGT_TC - 1) / MGT_TC);
+        if (wrap_fast_ok(a.L, MGT_TR, MGT_TC)) hipLaunchKernelGGL((k_flow_bwd_gather<MGT_TR, MGT_TC, true, true>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_bwd_gather<MGT_TR, MGT_TC, true, false>), grid, dim3(NT), 0, s, a);
     } else {
-        if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, true>), grid, dim3(NT), 0, s, a);
-        else      hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, false>), grid, dim3(NT), 0, s, a);
+        const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
+        if (wrap_fast_ok(a.L, MG_TR, MG_TC)) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, true>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, false>), grid, dim3(NT), 0, s, a);
     }
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }

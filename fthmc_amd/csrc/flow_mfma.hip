@@ -287,11 +287,13 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             double ysum = 0.0, si = 0.0;
 #pragma unroll
             for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * TQ) * NAS + (lane & (NAS - 1))]; si += sT2[(k * TQ + 1) * NAS + (lane & (NAS - 1))]; }
-            const double lj = avalid ? log(si) - log((double)NMIX) : 0.0;
             const double newP = ft_wrap(ysum / NMIX + tval);
             if (avalid) sDL[ar * TC + ac] = newP - Pa;
-            const double tot = ft_wave_sum(lj);
-            if (lane == 0 && A.logj_part) A.logj_part[(size_t)b * ntiles + tile] = tot;
+            if (A.logj_part) {                                       // force sweeps do not ask for log J
+                const double lj = avalid ? log(si) - log((double)NMIX) : 0.0;
+                const double tot = ft_wave_sum(lj);
+                if (lane == 0) A.logj_part[(size_t)b * ntiles + tile] = tot;
+            }
         }
         lds_barrier();
         if (A.y && tid < N3) {

@@ -92,9 +92,11 @@ int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 // flow_bwd_gather.hip: backward from the stash in gather form: a tile produces the complete
 // gP_out = up_gp + layer contribution of its own sites (a.gp_out, out of place), no partial windows;
-// train = also per-tile weight-gradient partials to a.gw_part (ntiles of flow_gather_geom())
+// train = also per-tile weight-gradient partials to a.gw_part (ntiles of flow_gather_geom(true))
 constexpr int MG_TR = 16, MG_TC = 16;
-inline FlowGeom flow_gather_geom() { return FlowGeom{MG_TR, MG_TC}; }
+// training variant (h1, h2 windows also in LDS): 8 x 16 tiles keep it at two workgroups per CU
+constexpr int MGT_TR = 8, MGT_TC = 16;
+inline FlowGeom flow_gather_geom(bool train = false) { return train ? FlowGeom{MGT_TR, MGT_TC} : FlowGeom{MG_TR, MG_TC}; }
 int launch_flow_bwd_gather(const FlowLayerArgs& a, bool train, hipStream_t s);
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }

@@ -128,7 +128,12 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         const int k = 4 * t + g, tap = k / 2, ci = k - 2 * tap, ky = tap / 3 - dd, kx = tap % 3;
         return (ky >= 0 && ky <= 2) ? CW0 + (cN * 2 + ci) * 9 + ky * 3 + kx : WZERO;
     };
-    mfma_stage<6, 2, (R1R / 2) * R1C, R0C, PS0, false, false>(sIn, sW, wave, lane,
+    // The window's pairs rarely fill whole 16-pair MFMA tiles (200 pairs = 12.5 tiles at 16 x 16): the
+    // MFMA path takes the whole tiles (12 = 3 per SIMD instead of a 13th that lands on one SIMD as a
+    // 4th), the last few pairs run on the VALU (18 MACs per output) on the waves that own one tile only.
+    constexpr int NP1 = (R1R / 2) * R1C, NP1M = NP1 / 16 * 16, NREM1 = 2 * (NP1 - NP1M) * 8;   // leftover outputs
+    static_assert(NP1M / 16 <= 2 * NW && NREM1 <= NT / 2, "leftover outputs go to the upper waves");
+    mfma_stage<6, 2, NP1M, R0C, PS0, false, false>(sIn, sW, wave, lane,
         [](int p) { const int pr = fdiv<R1C>(p); return 2 * pr * R0C + p - pr * R1C; }, bidx1,
         [&](int g, int p, bool ok, double (&z)[4], int) {
             const int pr = fdiv<R1C>(p), pc = p - pr * R1C;
@@ -157,6 +162,29 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
                 }
             }
         });
+    if (NREM1 > 0 && tid >= NT / 2 && tid < NT / 2 + NREM1) {
+        const int idx = tid - NT / 2, co = idx & 7, site = idx >> 3;
+        const int p = NP1M + (site >> 1), pr = fdiv<R1C>(p), pc = p - pr * R1C, r = 2 * pr + (site & 1);
+        const double* in = sIn + r * R0C + pc;
+        const double* wp = sW + CW0 + co * 18;
+        double z = sW[CB0 + co];
+#pragma unroll
+        for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) z = fma(in[ci * PS0 + (tp / 3) * R0C + tp % 3], wp[ci * 9 + tp], z);
+        double h, d;
+        act_eval(z, act, h, d);
+        sH1[co * PS1 + r * R1C + pc] = h;
+        if (BWD) sD1[co * PS1 + r * R1C + pc] = d;
+        if (MODE == 0 && A.stash) {
+            const int rr = r - 2, cc = pc - 2;
+            if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
+                const int at = mul24(i0 + rr, L) + j0 + cc;
+                sv.d1[(size_t)co * n + at] = d;
+                if (A.stash_h) sv.h1[(size_t)co * n + at] = h;
+            }
+        }
+    }
     lds_barrier();
     STAMP(2);
 

@@ -213,7 +213,7 @@ def test_train_grad_golden(name):
 
 # ---------------------------------------------------------------- oracle at bench-like sizes
 @pytest.mark.parametrize('B,L,nl,beta', [(3, 64, 8, 6.0), (2, 32, 5, 5.0), (1, 20, 3, 2.0), (2, 12, 4, 3.0),
-                                        (9, 8, 8, 2.0), (1, 24, 2, 4.0)])
+                                        (9, 8, 8, 2.0), (1, 24, 2, 4.0), (2, 40, 3, 2.5)])
 def test_ft_vs_oracle_random(B, L, nl, beta):
     gen = torch.Generator().manual_seed(1331 + L)
     flow = R.default_flow(nl, gen)
@@ -228,6 +228,55 @@ def test_ft_vs_oracle_random(B, L, nl, beta):
     close(plaq, R.plaq_mean(y, beta), rtol=1e-11); close(Q, R.charge(y), atol=1e-8)
     F = R.ft_force(x, flow, beta)
     close(ops.ft_force(x.cuda(), w, nl, beta), F, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize('B,L,nl,beta', [(3, 20, 3, 2.0), (2, 24, 2, 3.0), (5, 12, 4, 2.0), (2, 32, 3, 4.0), (1, 40, 2, 2.5)])
+def test_train_grad_vs_oracle_random(B, L, nl, beta):
+    """Reverse-KL gradient (train.py:162-228) on lattices that do not divide into tiles: ragged 8 x 16 and
+    16 x 16 tiles, windows that wrap onto themselves, chains that do not fill a block group."""
+    gen = torch.Generator().manual_seed(77 + L)
+    flow = R.default_flow(nl, gen)
+    xi = (torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+    out, grads = R.train_grads(xi, flow, beta)
+    r = ops.train_grad(xi.cuda(), W(flow), nl, beta)
+    close(r['logq'], out['logq'], rtol=1e-11); close(r['logp'], out['logp'], rtol=1e-11)
+    angle_close(r['x'], out['x'], atol=1e-10)
+    gws = ops.unpack_weight_grads(r['gw'], nl)
+    for li in range(nl):
+        for pi in range(6):
+            close(gws[li][pi], grads[li][pi], rtol=1e-8, atol=1e-11)
+
+
+def test_config5_shape_properties():
+    """BASELINE config 5 shard shape (L=256, 16 layers; 2 chains here): size-independent properties of the
+    force and training paths."""
+    gen = torch.Generator().manual_seed(4242)
+    B, L, nl, beta = 2, 256, 16, 7.0
+    flow = R.default_flow(nl, gen)
+    w = W(flow)
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    y, ld = ops.flow_forward(x, w, nl)
+    xb, ldb = ops.flow_reverse(y, w, nl, tol=1e-13)
+    angle_close(xb, x, atol=1e-8); close(ldb, -ld, atol=1e-6)
+    Q = ops.wilson_action_charge(y, beta)[1]
+    assert float((Q - Q.round()).abs().max()) < 1e-7
+    F = ops.ft_force(x, w, nl, beta)
+    d = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()
+    eps = 1e-5
+    fd = (ops.ft_action(x + eps * d, w, nl, beta)[0] - ops.ft_action(x - eps * d, w, nl, beta)[0]) / (2 * eps)
+    close((F * d).flatten(1).sum(1), fd, rtol=5e-5, atol=1e-3)
+    assert torch.equal(F, ops.ft_force(x, w, nl, beta))
+    # training gradient: directional derivative of the reverse-KL loss along a random weight direction
+    r = ops.train_grad(x, w, nl, beta)
+    dw = torch.randn(w.numel(), generator=gen, dtype=torch.float64).cuda() * 1e-2
+    flat = w.reshape(-1)
+
+    def loss(wv):
+        t = ops.train_grad(x, wv.reshape(w.shape), nl, beta, need_gw=False)
+        return (t['logq'] - t['logp']).mean()
+    eps = 1e-4
+    fdw = (loss(flat + eps * dw) - loss(flat - eps * dw)) / (2 * eps)
+    close((r['gw'] * dw).sum(), fdw, rtol=1e-5, atol=1e-6)
 
 
 def test_full_size_properties():

@@ -247,7 +247,7 @@ def main():
 
     # ---- CPU baseline (oracle = "port") on a bounded sample + parity of the HIP path on it
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
         from oracle import ref_cpu as R
         nb = min(args.cpu_chains, B)
         torch.set_num_threads(host_threads())

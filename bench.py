@@ -218,7 +218,7 @@ def main():
     # N_LAYERS * (NSTEP + 1) times (force sweeps + H1), the backward kernel N_LAYERS * NSTEP times
     share = {'fwd': ms_fwd * N_LAYERS * (NSTEP + 1), 'bwd': ms_bwd * N_LAYERS * NSTEP}
     dom = max(share, key=share.get)
-    names = {'fwd': ('k_flow_mfma<0,16,16> (coupling-layer forward: conv net + tan-mixture transform + stash)', 'k_flow_mfma<0'),
+    names = {'fwd': ('k_flow_fwd<16,16> (coupling-layer forward: conv net + tan-mixture transform + stash)', 'k_flow_fwd'),
              'bwd': ('k_flow_bwd_gather<16,16> (coupling-layer backward wrt x from the stash)', 'k_flow_bwd_gather')}
     ms_dom = ms_fwd if dom == 'fwd' else ms_bwd
     achieved = flops_launch / (ms_dom * 1e-3) / 1e12

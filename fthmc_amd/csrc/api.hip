@@ -56,12 +56,8 @@ WS ws_layout(double* base, int B, int L, int nl, bool train = false) {
 
 // which kernel family serves a call, and with it the tile geometry of its partial buffers
 inline bool fwd_is_mfma() { return get_flow_variant() == 1; }
-inline bool bwd_is_mfma(bool wgrad) { return !wgrad && get_flow_variant() == 1; }
 inline int flow_fwd(const FlowLayerArgs& a, hipStream_t s) {
     return fwd_is_mfma() ? launch_flow_fwd_mfma(a, s) : launch_flow_fwd(a, s);
-}
-inline int flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s) {
-    return bwd_is_mfma(wgrad) ? launch_flow_bwd_mfma(a, s) : launch_flow_bwd(a, wgrad, s);
 }
 
 inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
@@ -134,10 +130,10 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
             double* t_ = gcur; gcur = galt; galt = t_;
             continue;
         }
-        FT_TRY(flow_bwd(a, gw != nullptr, s));
+        FT_TRY(launch_flow_bwd(a, gw != nullptr, s));                // VALU variant: scatter form + gather
         if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0,
                                         gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
-        FT_TRY(launch_gather_gp(w.gp_part, B, L, flow_geom(bwd_is_mfma(gw != nullptr)), 1, gcur, s));
+        FT_TRY(launch_gather_gp(w.gp_part, B, L, flow_geom(false), 1, gcur, s));
     }
     return FTHMC_OK;
 }
@@ -313,15 +309,29 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
     if (!x || !w || !gy || !glogJ || !gx || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3)
         return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
-    FT_WS(1);
+    const bool mfma = get_flow_variant() == 1;
+    (void)hipGetLastError();
+    if (!ws || ws_bytes < (gw && mfma ? fthmc_train_ws_bytes(B, L, 1) : fthmc_ws_bytes(B, L, 1))) return FTHMC_ERR_WS;
+    const WS W = ws_layout(static_cast<double*>(ws), B, L, 1, gw != nullptr && mfma);
+    hipStream_t s = ft_stream(stream);
     FT_TRY(launch_pack_weights(w, 1, W.wint, s));
     FlowLayerArgs a{};
     a.x = x; a.wint = W.wint; a.up_link = gy; a.glogj = glogJ;
     a.gp_part = W.gp_part; a.gw_part = W.gw_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    FT_TRY(flow_bwd(a, gw != nullptr, s));
+    if (mfma) {
+        // forward once with the stash (no link update, no log J), then the gather-form backward seeded
+        // by the link gradient; gP_out holds the layer's plaquette gradient alone (no upstream gP field)
+        a.stash = W.stash; a.stash_h = gw ? 1 : 0;
+        FT_TRY(launch_flow_fwd_mfma(a, s));
+        a.gp_out = W.gp;
+        FT_TRY(launch_flow_bwd_gather(a, gw != nullptr, s));
+        if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_gather_geom(true).ntiles(L), 1.0, 0, gw, W.gw_tmp, s));
+        return launch_adj_add(W.gp, gy, B, L, gx, s);
+    }
+    FT_TRY(launch_flow_bwd(a, gw != nullptr, s));
     if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0, gw, W.gw_tmp, s));
-    FT_TRY(launch_gather_gp(W.gp_part, B, L, flow_geom(bwd_is_mfma(gw != nullptr)), 0, W.gp, s));
+    FT_TRY(launch_gather_gp(W.gp_part, B, L, flow_geom(false), 0, W.gp, s));
     return launch_adj_add(W.gp, gy, B, L, gx, s);
 }
 
@@ -500,7 +510,7 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
         if (it == 0) (void)hipEventRecord(e0, s);
         if (kind == 0) rc = flow_fwd(a, s);
-        else if (kind == 1) rc = a.stash ? launch_flow_bwd_gather(a, false, s) : flow_bwd(a, false, s);
+        else if (kind == 1) rc = a.stash ? launch_flow_bwd_gather(a, false, s) : launch_flow_bwd(a, false, s);
         else if (kind == 2) rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
         else rc = launch_hmc_trajectory_fused(x, W.va, W.scal + B, B, L, beta, 0.1, 10, W.xa, nullptr, nullptr, nullptr, nullptr, s);
     }
@@ -515,9 +525,9 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
 
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
+    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 1) return FTHMC_ERR_ARG;
     FT_WS(1);
-    const size_t nrec = (size_t)B * (kind == 2 ? flow_geom(true) : kind == 1 ? flow_gather_geom() : flow_fwd_geom(true)).ntiles(L);
+    const size_t nrec = (size_t)B * (kind == 1 ? flow_gather_geom() : flow_fwd_geom(true)).ntiles(L);
     long long* dbg = reinterpret_cast<long long*>(W.gw_part);      // B*ntiles*960 doubles >> 16 stamps each
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FT_TRY(launch_pack_weights(w, 1, W.wint, s));
@@ -531,8 +541,7 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
         FT_TRY(launch_flow_fwd_mfma(a, s));
         a.dbg = dbg;
     }
-    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : kind == 1 ? launch_flow_bwd_gather(a, false, s)
-                                                        : launch_flow_bwd_mfma(a, s));
+    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : launch_flow_bwd_gather(a, false, s));
     long long* h = (long long*)malloc(nrec * 16 * sizeof(long long));
     if (!h) return FTHMC_ERR_ARG;
     if (hipMemcpyAsync(h, dbg, nrec * 16 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||

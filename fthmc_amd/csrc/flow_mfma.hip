@@ -1,28 +1,18 @@
-// MFMA variant of the coupling-layer forward / backward-wrt-x kernels.
+// Coupling-layer forward on the matrix cores (GaugeEquivCouplingLayer.forward, fthmc/utils/layers.py:196-202,
+// with NCPPlaqCouplingLayer.forward :348-371, the conv net :138-167 and the tan-mixture transform :58-90).
 //
-// A workgroup (512 threads) owns a TR x TC = 8 x 16 tile of one chain; everything between
-// the link field and the link update lives in LDS (see flow.hip for the scheme: plaquette
-// window = tile + 3 halo, hidden activations on tile + 2 / + 1, scatter-form adjoint whose
-// partial plaquette-gradient window is summed across tiles by k_gather_gp).
-// The tile is sized so that the backward kernel needs < 80 KB of LDS: two workgroups share
-// a CU and the serial, transcendental-heavy stages of one (plaquettes, tan-mixture
-// transform) overlap with the matrix stages of the other.
-//
-// conv1, conv2 and conv2^T run as implicit GEMMs on v_mfma_f64_16x16x4_f64:
-//   M = 16 "pair sites" (a site column c and the two rows 2q, 2q+1 it stands for),
-//   N = 16 = 8 output channels x 2 rows of the pair,
-//   K = (4 x 3 input window that covers both rows) x input channels.
-// Packing two output rows into N fills the 16-wide tile that 8 channels alone would leave
-// half empty (75 % of the issued MACs are useful instead of 50 %).  The weights are the B
-// operand and stay in VGPRs for a whole stage (one double per lane per k-step, pre-swizzled
-// by k_pack_weights, fetched before the preceding barrier); the A operand is one
-// ds_read_b64 per MFMA straight out of the activation planes (plane strides = 16 mod 32
-// doubles, so the k-lanes of one read hit disjoint banks).
-// conv3 (8 -> 3, active sites only), conv3^T (its input is non-zero on the active stripe
-// only: 9 of 27 taps) and conv1^T (2 output channels) stay on the fp64 VALU with their
-// weights cached in LDS.
-// Measured on MI355X (tools/microbench): fp64 MFMA and fp64 VALU share one DP pipe, so the
-// matrix path buys issue efficiency and register-resident weights, not extra flops.
+// A workgroup (512 threads) owns a 16 x 16 tile of one chain, two workgroups share a CU; everything
+// between the link loads and the link update lives in LDS:
+//   plaquettes + net input (cos P, sin P) on tile+3  ->  conv1 (2 -> 8) + act on tile+2  ->  conv2 (8 -> 8) + act
+//   on the live lines of tile+1  ->  conv3 (8 -> 3) at the tile's active sites  ->  tan-mixture transform,
+//   log J  ->  link update x' = wrap(x +- (P' - P)) at the active links.
+// conv1 and conv2 are implicit GEMMs on v_mfma_f64_16x16x4_f64 (flow_mfma_common.h: mfma_stage), both
+// operands one ds_read_b64 per MFMA out of LDS; conv3 (N = 3) stays on the fp64 VALU.
+// With a.stash the kernel also writes what the backward needs (struct Stash: act'(z1), act'(z2), the
+// transform's adjoint coefficients, cos/sin of the frozen plaquettes, and h1, h2 for the weight gradients),
+// so that flow_bwd_gather.hip never re-runs the network.
+// Measured on MI355X (tools/microbench): fp64 MFMA and fp64 VALU share one DP pipe, so the matrix path
+// buys issue efficiency and register-free operands, not extra flops.
 #include "flow_mfma_common.h"
 
 namespace {
@@ -30,40 +20,29 @@ namespace {
 using namespace fthmc;
 using namespace fthmc_flow;
 
-template <int MODE, int TR, int TC> struct SmemM {
+template <int TR, int TC> struct SmemF {
     using G = Geom<TR, TC>;
-    static constexpr bool BWD = (MODE == 1);
     static constexpr int IN = 0;                              // [2][PS0] cos, sin
-    static constexpr int PG = IN + 2 * G::PS0;                // [N0] plaquettes, later partial gP (bwd)
-    static constexpr int H1 = PG + G::PS0;                    // [8][PS1] | bwd: padded gz2 [8][PS0] over H1|H2
+    static constexpr int PG = IN + 2 * G::PS0;                // [N0] plaquettes
+    static constexpr int H1 = PG + G::PS0;                    // [8][PS1]
     static constexpr int H2 = H1 + 8 * G::PS1;                // [8][PS2]
-    static constexpr int ST = H2 + 8 * G::PS2;                // [8][3][NAS] conv3 partials | bwd: g_out [3][N3]
-    static constexpr int T2 = ST + 8 * 3 * G::NAS;            // [NMIX][4 (bwd) | 2 (fwd)][NAS]
-    static constexpr int T2Q = BWD ? 4 : 2;                   // slots per component: y, 1/D, (gP part, spare)
-    static constexpr int DL = ST;                             // [N3] delta (fwd): over the consumed conv3 partials
-    static constexpr int SW = T2 + NMIX * T2Q * G::NAS;       // [SW_SIZE]
-    static constexpr int D1 = SW + SW_SIZE;                   // [8][PS1] act'(z1) -> gz1   (bwd)
-    static constexpr int D2 = D1 + (BWD ? 8 * G::PS1 : 0);    // [8][PS2] act'(z2)          (bwd)
-    static constexpr int SIZE = D2 + (BWD ? 8 * G::PS2 : 0);
-    static_assert(8 * G::PS1 + 8 * G::PS2 >= 8 * G::PS0, "padded gz2 must fit over h1|h2");
-    static_assert(3 * G::N3 <= 8 * 3 * G::NAS, "g_out / delta must fit over the conv3 partials");
+    static constexpr int ST = H2 + 8 * G::PS2;                // [8][3][NAS] conv3 partials, then delta [N3]
+    static constexpr int T2 = ST + 8 * 3 * G::NAS;            // [NMIX][2][NAS] y_k, 1/D_k
+    static constexpr int SW = T2 + NMIX * 2 * G::NAS;         // [SW_SIZE]
+    static constexpr int SIZE = SW + SW_SIZE;
+    static_assert(G::N3 <= 8 * 3 * G::NAS, "delta must fit over the conv3 partials");
 };
 
-// MODE 0 forward, 1 backward wrt x
-template <int MODE, int TR, int TC, bool FASTW>
-__global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_flow_mfma(FlowLayerArgs A) {
-    using S = SmemM<MODE, TR, TC>;
+template <int TR, int TC, bool FASTW>
+__global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
+    using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
-    constexpr bool BWD = S::BWD;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
-    constexpr int N0 = G::N0, N2 = G::N2, N3 = G::N3, NA = G::NA, NAS = G::NAS, TQ = S::T2Q;
+    constexpr int N0 = G::N0, N3 = G::N3, NA = G::NA, NAS = G::NAS, TQ = 2;
     constexpr int PS0 = G::PS0, PS1 = G::PS1, PS2 = G::PS2;
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
-    double* sIn = sm + S::IN;  double* sP = sm + S::PG;   double* sGP = sm + S::PG;
-    double* sH1 = sm + S::H1;  double* sH2 = sm + S::H2;  double* sGZ2 = sm + S::H1;
-    double* sST = sm + S::ST;  double* sGO = sm + S::ST;  double* sT2 = sm + S::T2;
-    double* sDL = sm + S::DL;  double* sW = sm + S::SW;
-    double* sD1 = sm + S::D1;  double* sD2 = sm + S::D2;
+    double* sIn = sm + S::IN;  double* sP = sm + S::PG;   double* sH1 = sm + S::H1;  double* sH2 = sm + S::H2;
+    double* sST = sm + S::ST;  double* sDL = sm + S::ST;  double* sT2 = sm + S::T2;  double* sW = sm + S::SW;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -85,7 +64,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
     const unsigned fastw = FASTW ? 0u : wrap_magic(L);
     // the tile's own links for the final link update: issued now, consumed in the last stage
     double xv0 = 0.0, xv1 = 0.0;
-    if (MODE == 0 && A.y && tid < N3) {
+    if (A.y && tid < N3) {
         const int r = fdiv<TC>(tid), c = tid - r * TC;
         if (i0 + r < L && j0 + c < L) { const unsigned at = (unsigned)(mul24(i0 + r, L) + j0 + c); xv0 = ldu(x0, at); xv1 = ldu(x1, at); }
     }
@@ -104,7 +83,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         sP[tid] = p;
         sIn[tid] = cs;
         sIn[PS0 + tid] = sn;
-        if (MODE == 0 && A.stash && frozen && (unsigned)(r - 3) < (unsigned)min(TR, L - i0) &&
+        if (A.stash && frozen && (unsigned)(r - 3) < (unsigned)min(TR, L - i0) &&
             (unsigned)(c - 3) < (unsigned)min(TC, L - j0)) {             // the net input of the tile's own frozen sites
             double* cs_ = A.stash + ((size_t)A.B * 18 + b) * n + stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
             cs_[0] = cs; cs_[n >> 1] = sn;
@@ -116,7 +95,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
 
     // stash planes of this lane's output channels g = lane >> 4 and g + 4 (fixed for the kernel)
     const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // tile sites inside the lattice
-    const Stash sv = (MODE == 0 && A.stash) ? stash_view(A.stash, A.B, b, n) : Stash{};
+    const Stash sv = A.stash ? stash_view(A.stash, A.B, b, n) : Stash{};
     double* const st_d1 = sv.d1 ? sv.d1 + (size_t)(lane >> 4) * n : nullptr;
     double* const st_d2 = sv.d1 ? sv.d2 + (size_t)(lane >> 4) * n : nullptr;
     double* const st_h1 = sv.d1 ? sv.h1 + (size_t)(lane >> 4) * n : nullptr;
@@ -144,12 +123,8 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             if (ok) {
                 double* ph = sH1 + g * PS1 + 2 * pr * R1C + pc;
                 ph[0] = h[0]; ph[4 * PS1] = h[1]; ph[R1C] = h[2]; ph[4 * PS1 + R1C] = h[3];
-                if (BWD) {
-                    double* pd = sD1 + g * PS1 + 2 * pr * R1C + pc;
-                    pd[0] = d[0]; pd[4 * PS1] = d[1]; pd[R1C] = d[2]; pd[4 * PS1 + R1C] = d[3];
-                }
             }
-            if (MODE == 0 && A.stash) {                                  // act'(z1) (and h1) of the tile's own sites
+            if (A.stash) {                                  // act'(z1) (and h1) of the tile's own sites
                 const int r = 2 * pr - 2, c = pc - 2;
                 if (ok && (unsigned)c < (unsigned)cmax) {
                     const int at = mul24(i0 + r, L) + j0 + c;
@@ -175,8 +150,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         double h, d;
         act_eval(z, act, h, d);
         sH1[co * PS1 + r * R1C + pc] = h;
-        if (BWD) sD1[co * PS1 + r * R1C + pc] = d;
-        if (MODE == 0 && A.stash) {
+        if (A.stash) {
             const int rr = r - 2, cc = pc - 2;
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
                 const int at = mul24(i0 + rr, L) + j0 + cc;
@@ -206,12 +180,8 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         if (ok) {
             double* ph = sH2 + g * PS2 + r * R2C + c;
             ph[0] = h[0]; ph[4 * PS2] = h[1]; ph[so] = h[2]; ph[4 * PS2 + so] = h[3];
-            if (BWD) {
-                double* pd = sD2 + g * PS2 + r * R2C + c;
-                pd[0] = d[0]; pd[4 * PS2] = d[1]; pd[so] = d[2]; pd[4 * PS2 + so] = d[3];
-            }
         }
-        if (MODE == 0 && A.stash && ok) {                                // act'(z2) (and h2) of the tile's own sites
+        if (A.stash && ok) {                                // act'(z2) (and h2) of the tile's own sites
             const int at = mul24(i0 + r - 1, L) + j0 + c - 1;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -277,20 +247,20 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
     // ---- tan-mixture transform: wave k evaluates mixture component k -------------
     //   y_k = wrap(2 atan(e^{s_k} tan(P/2))),  D_k = e^{-s_k} cos^2(P/2) + e^{s_k} sin^2(P/2),
     //   log J = log(sum_k 1/D_k) - log K   (= logsumexp_k(-log D_k) - log K of layers.py:85-90)
-    double Pa = 0.0, es = 0.0, ems = 0.0, cs2 = 0.0, sn2 = 0.0, sincs = 0.0, invD = 1.0;
+    double Pa = 0.0;
     if (wave < NMIX && alane) {
         Pa = sP[(ar + 3) * R0C + ac + 3];
         double sk = sW[CB2 + wave];
 #pragma unroll
         for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
-        double sn, cs;
+        double sn, cs, es, ems;
         ft_sincos(Pa / 2, &sn, &cs);
         { const double ea[2] = {sk, -sk}; double eo[2]; ft_expN<2>(ea, eo); es = eo[0]; ems = eo[1]; }
-        cs2 = cs * cs; sn2 = sn * sn; sincs = sn * cs;
-        invD = 1.0 / (ems * cs2 + es * sn2);
+        const double cs2 = cs * cs, sn2 = sn * sn, sincs = sn * cs;
+        const double invD = 1.0 / (ems * cs2 + es * sn2);
         sT2[(wave * TQ + 1) * NAS + lane] = invD;
-        if (MODE == 0) sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
-        if (MODE == 0 && A.stash && avalid) {
+        sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
+        if (A.stash && avalid) {
             // coefficients of the transform's adjoint (struct Stash): the backward kernel then needs no
             // plaquettes, sincos or exp at the active sites of its tile+3 window
             const double sinP = 2.0 * sincs, invD2 = invD * invD;
@@ -302,7 +272,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
         }
     }
     double tval = 0.0;
-    if (MODE == 0 && wave == 0 && alane) {
+    if (wave == 0 && alane) {
         tval = sW[CB2 + 2];
 #pragma unroll
         for (int q = 0; q < 8; ++q) tval += sST[(q * 3 + 2) * NAS + lane];
@@ -310,7 +280,7 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
     lds_barrier();
     STAMP(5);
 
-    if (MODE == 0) {
+    {
         if (wave == 0) {
             double ysum = 0.0, si = 0.0;
 #pragma unroll
@@ -339,170 +309,6 @@ __global__ __launch_bounds__(NT, (MODE == 0 && TR * TC <= 128) ? 6 : 4) void k_f
             }
         }
         STAMP(6);
-        return;
-    }
-
-    if (BWD) {
-        // ---- adjoint of the transform at the tile's own active sites (no transcendentals) ----
-        // conv3 partials and plaquettes are consumed: g_out takes over sST, partial gP takes over sP
-        double gdelta = 0.0;
-        double gs = 0.0, gpk = 0.0;
-        if (wave < NMIX && avalid) {
-            const double cb = A.glogj ? A.glogj[b] : A.glogj_const;
-            if (A.up_link) {
-                const double gl = A.up_link[(size_t)b * 2 * n + (size_t)mu * n + ai * L + aj];
-                gdelta = mu == 0 ? gl : -gl;
-            } else {
-                const double* gp = A.up_gp + (size_t)b * n;
-                const int im = ai == 0 ? L - 1 : ai - 1, jm = aj == 0 ? L - 1 : aj - 1;
-                gdelta = gp[ai * L + aj] - (mu == 0 ? gp[ai * L + jm] : gp[im * L + aj]);
-            }
-            double si = 0.0;
-#pragma unroll
-            for (int k = 0; k < NMIX; ++k) si += sT2[(k * TQ + 1) * NAS + lane];
-            const double wk = invD / si;                           // softmax_k(-log D_k)
-            const double sinP = 2.0 * sincs;
-            gs = gdelta * (sinP * invD / NMIX) + cb * wk * (ems * cs2 - es * sn2) * invD;
-            gpk = gdelta * (invD / NMIX) - cb * wk * sinP * 0.5 * (es - ems) * invD;
-        }
-        // h1 / h2 are dead: clear the padded gz2 planes that alias them
-        for (int t = tid; t < 8 * PS0; t += NT) sGZ2[t] = 0.0;
-        lds_barrier();                                           // sST / sP / sT2[.][1] reads done
-        for (int t = tid; t < 3 * N3; t += NT) sGO[t] = 0.0;
-        for (int t = tid; t < N0; t += NT) sGP[t] = 0.0;
-        if (wave < NMIX && alane) sT2[(wave * TQ + 2) * NAS + lane] = gpk;
-        lds_barrier();
-        if (wave < NMIX && avalid) sGO[wave * N3 + ar * TC + ac] = gs;
-        if (wave == 0 && avalid) {
-            double gsum = -gdelta;
-#pragma unroll
-            for (int k = 0; k < NMIX; ++k) gsum += sT2[(k * TQ + 2) * NAS + lane];
-            sGP[(ar + 3) * R0C + ac + 3] = gsum;
-            sGO[NMIX * N3 + ar * TC + ac] = gdelta;               // dL/dt
-        }
-        lds_barrier();
-        STAMP(6);
-
-        // ---- conv3^T on the VALU: g_out lives on the active stripe only, so of the 9 taps of
-        //      an h2 site at most 3 (one stripe line) contribute; times act'(z2) -> padded gz2 ----
-        for (int t = tid; t < 2 * N2; t += NT) {
-            const int half = t >= N2;
-            const int s = half ? t - N2 : t;
-            const int r = s / R2C, c = s - r * R2C;
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            // source tile site (rr, cc) = (r - ky, c - kx); the stripe line through the window
-            const int ksel = ((mu == 0 ? c : r) - off) & 3;        // the one kx (mu=0) / ky (mu=1)
-            if (ksel <= 2) {
-#pragma unroll
-                for (int kk = 0; kk < 3; ++kk) {
-                    const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
-                    const int rr = r - ky, cc = c - kx;
-                    if (rr >= 0 && rr < TR && cc >= 0 && cc < TC) {
-#pragma unroll
-                        for (int co = 0; co < 3; ++co) {
-                            const double gv = sGO[co * N3 + rr * TC + cc];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                acc[k] = fma(gv, sW[CW2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx], acc[k]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ci = half * 4 + k;
-                sGZ2[ci * PS0 + (r + 2) * R0C + c + 2] = ksel <= 2 ? acc[k] * sD2[ci * PS2 + s] : 0.0;   // dead line: d2 unwritten
-            }
-        }
-        lds_barrier();
-        STAMP(7);
-
-        // ---- conv2^T, times act'(z1) -> gz1 in place over d1 ------------------------
-        // B[k = (tap, co)][n = (ci, dd)] = W1[co][ci][2 - (ky4 - dd)][2 - kx]
-        auto bidx4 = [](int t, int g, int cN, int dd) {
-            const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
-            return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
-        };
-        mfma_stage<24, 8, (R1R / 2) * R1C, R0C, PS0, false, false>(sGZ2, sW, wave, lane,
-            [](int p) { const int pr = fdiv<R1C>(p); return 2 * pr * R0C + p - pr * R1C; }, bidx4,
-            [&](int g, int p, bool ok, double (&gh)[4], int) {
-                if (ok) {
-                    const int pr = fdiv<R1C>(p), pc = p - pr * R1C;
-                    double* pd = sD1 + g * PS1 + 2 * pr * R1C + pc;
-                    pd[0] *= gh[0]; pd[4 * PS1] *= gh[1]; pd[R1C] *= gh[2]; pd[4 * PS1 + R1C] *= gh[3];
-                }
-            });
-        lds_barrier();
-        STAMP(8);
-
-        // ---- conv1^T and the (cos, sin) adjoint at frozen plaquettes ----------------
-        // Frozen window lines come in pairs every 4 lines (columns for mu = 0, rows for mu = 1).
-        // Tasks = (frozen site, half of the 8 output channels), enumerated compactly: one round,
-        // every task a 4-channel chain (the stage is bound by the per-lane LDS-read -> FMA chain).
-        {
-            constexpr int R0R_ = G::R0R;
-            double* sHalf = sST;                                         // [2 halves][2][N0] partial (g_cos, g_sin); g_out is dead
-            static_assert(2 * N0 <= 8 * 3 * NAS + NMIX * 4 * NAS, "half partials must fit over ST|T2");
-            const int nline = mu == 0 ? R0C : R0R_, nother = mu == 0 ? R0R_ : R0C;
-            const int phase = ((mu == 0 ? j0 : i0) - 3 - off) & 3;      // stripe class of window line 0
-            const int s1 = (1 - phase) & 3;                              // first line of class 1
-            const int lead = s1 == 3 ? 1 : 0;                            // line 0 is the 2nd half of a pair
-            const int nfl = lead + 2 * ((nline - s1 + 3) / 4);           // slots; a trailing one may fall outside
-            const int ntask = nfl * nother;
-            for (int t2 = tid; t2 < 2 * ntask; t2 += NT) {
-                const int half = t2 >= ntask, t = half ? t2 - ntask : t2;
-                // frozen-line index k fastest for mu = 0 (lanes walk along a window row), slowest for mu = 1
-                const int k = mu == 0 ? t % nfl : t / nother;
-                const int o = mu == 0 ? t / nfl : t % nother;
-                const int kk = k - lead;
-                const int line = (lead && k == 0) ? 0 : s1 + 4 * (kk >> 1) + (kk & 1);
-                if (line >= nline) continue;
-                const int r = mu == 0 ? o : line, c = mu == 0 ? line : o;
-                const int wt = r * R0C + c;
-                int aoff[9]; double msk[9];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int rr = r - ky, cc = c - kx;
-                        const bool ok = (rr >= 0) && (rr < R1R) && (cc >= 0) && (cc < R1C);
-                        aoff[ky * 3 + kx] = ok ? rr * R1C + cc : 0;
-                        msk[ky * 3 + kx] = ok ? 1.0 : 0.0;
-                    }
-                // per output channel: issue all 18 LDS reads (9 taps of gz1, 9 weight pairs) first,
-                // then the 18 FMAs; left to itself the compiler waits after every single read
-                double gc[3] = {0.0, 0.0, 0.0}, gsn[3] = {0.0, 0.0, 0.0};
-#pragma unroll 1
-                for (int co = half * 4; co < half * 4 + 4; ++co) {
-                    double gv[9], w0[9], w1[9];
-                    const double* gz = sD1 + co * PS1;
-                    const double* wp = sW + CW0 + co * 18;                     // W0[co][ci][tap]
-#pragma unroll
-                    for (int tp = 0; tp < 9; ++tp) { gv[tp] = gz[aoff[tp]]; w0[tp] = wp[tp]; w1[tp] = wp[9 + tp]; }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int tp = 0; tp < 9; ++tp) {
-                        const double g_ = gv[tp] * msk[tp];
-                        gc[tp % 3] = fma(g_, w0[tp], gc[tp % 3]); gsn[tp % 3] = fma(g_, w1[tp], gsn[tp % 3]);
-                    }
-                }
-                const double gct = (gc[0] + gc[1]) + gc[2];
-                const double gst = (gsn[0] + gsn[1]) + gsn[2];
-                if (half == 0) sGP[wt] = -sIn[PS0 + wt] * gct + sIn[wt] * gst;           // channels [0, 4)
-                else { sHalf[wt] = gct; sHalf[N0 + wt] = gst; }                           // channels [4, 8)
-            }
-            lds_barrier();
-            for (int t = tid; t < N0; t += NT) {
-                const int r = t / R0C, c = t - r * R0C;
-                const int cls = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;
-                if (cls == 1 || cls == 2) sGP[t] += -sIn[PS0 + t] * sHalf[t] + sIn[t] * sHalf[N0 + t];
-            }
-        }
-        lds_barrier();
-        STAMP(9);
-        double* out = A.gp_part + ((size_t)b * ntiles + tile) * N0;
-        for (int t = tid; t < N0; t += NT) out[t] = sGP[t];
-        STAMP(10);
     }
 }
 
@@ -518,15 +324,8 @@ int get_flow_variant() { return g_variant; }
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     // forward needs half the LDS of backward: 16 x 16 tiles (less halo work) still fit twice per CU
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
-    if (wrap_fast_ok(a.L, MF_FWD_TR, MF_FWD_TC)) hipLaunchKernelGGL((k_flow_mfma<0, MF_FWD_TR, MF_FWD_TC, true>), grid, dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((k_flow_mfma<0, MF_FWD_TR, MF_FWD_TC, false>), grid, dim3(NT), 0, s, a);
+    if (wrap_fast_ok(a.L, MF_FWD_TR, MF_FWD_TC)) hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, true>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, false>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
-int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
-    const dim3 grid = xcd_grid(a.B, (a.L + MF_TR - 1) / MF_TR, (a.L + MF_TC - 1) / MF_TC);
-    if (wrap_fast_ok(a.L, MF_TR, MF_TC)) hipLaunchKernelGGL((k_flow_mfma<1, MF_TR, MF_TC, true>), grid, dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((k_flow_mfma<1, MF_TR, MF_TC, false>), grid, dim3(NT), 0, s, a);
-    FT_LAUNCH_CHECK(); return FTHMC_OK;
-}
-
 }  // namespace fthmc

@@ -37,7 +37,6 @@ int launch_random_momenta(const int64_t* seeds, int B, int n, double* v, double*
 constexpr int FLOW_TILE = 16;                 // VALU variant (flow.hip): 16 x 16 sites per tile
 constexpr int FLOW_R0 = FLOW_TILE + 6;        // plaquette / net-input window edge
 constexpr int FLOW_N0 = FLOW_R0 * FLOW_R0;    // window size of one gP partial
-constexpr int MF_TR = 8, MF_TC = 16;          // MFMA backward kernel: 8 x 16 sites per tile (forward: 16 x 16)
 constexpr int FLOW_WINT = 2944;               // doubles per layer, kernel-side weight layout
 constexpr int FLOW_GW_STRIDE = 960;           // doubles per (chain, tile) weight-gradient partial
 
@@ -52,16 +51,13 @@ struct FlowGeom {
 // tile of the MFMA forward kernel: 16 x 16 measured faster than 8 x 16 at 3 workgroups per CU (79 vs 94 us)
 constexpr int MF_FWD_TR = 16, MF_FWD_TC = 16;
 inline FlowGeom flow_fwd_geom(bool mfma) { return mfma ? FlowGeom{MF_FWD_TR, MF_FWD_TC} : FlowGeom{FLOW_TILE, FLOW_TILE}; }
-inline FlowGeom flow_geom(bool mfma) { return mfma ? FlowGeom{MF_TR, MF_TC} : FlowGeom{FLOW_TILE, FLOW_TILE}; }
+inline FlowGeom flow_geom(bool) { return FlowGeom{FLOW_TILE, FLOW_TILE}; }          // VALU variant: partial buffers [chain][tile][window]
 // workspace sizing: the larger of the two variants
 inline size_t flow_ntiles_max(int L) {
-    size_t a = flow_geom(false).ntiles(L), b = flow_geom(true).ntiles(L), c = flow_fwd_geom(true).ntiles(L);
-    a = a > b ? a : b; return a > c ? a : c;
+    size_t a = flow_geom(false).ntiles(L), b = FlowGeom{8, 16}.ntiles(L);   // VALU / forward tiles; training backward 8 x 16
+    return a > b ? a : b;
 }
-inline size_t flow_gp_part_max(int L) {
-    size_t a = (size_t)flow_geom(false).ntiles(L) * flow_geom(false).n0();
-    size_t b = (size_t)flow_geom(true).ntiles(L) * flow_geom(true).n0(); return a > b ? a : b;
-}
+inline size_t flow_gp_part_max(int L) { return (size_t)flow_geom(false).ntiles(L) * flow_geom(false).n0(); }
 
 // canonical (955/layer, PyTorch order) -> kernel layout (FLOW_WINT/layer)
 int launch_pack_weights(const double* w, int n_layers, double* wint, hipStream_t s);
@@ -87,9 +83,8 @@ struct FlowLayerArgs {
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_rev(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s);
-// flow_mfma.hip: MFMA variants of forward / backward-wrt-x (same arguments and results)
+// flow_mfma.hip: MFMA forward (same arguments and results as launch_flow_fwd; optionally writes the stash)
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s);
-int launch_flow_bwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 // flow_bwd_gather.hip: backward from the stash in gather form: a tile produces the complete
 // gP_out = up_gp + layer contribution of its own sites (a.gp_out, out of place), no partial windows;
 // train = also per-tile weight-gradient partials to a.gw_part (ntiles of flow_gather_geom(true))

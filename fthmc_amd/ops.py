@@ -208,7 +208,7 @@ def flow_layer_bwd(x, w, gy, glogJ, mu: int, off: int, act='silu', need_gw=False
     B, _, L, _ = x.shape
     gx = torch.empty_like(x)
     gw = torch.empty(W_PER_LAYER, dtype=x.dtype, device=x.device) if need_gw else None
-    ws, nb = _ws(x, B, L, 1)
+    ws, nb = _ws(x, B, L, 1, train=need_gw)
     check(_lib.load().fthmc_flow_layer_bwd(_p(x), _p(w), _p(gy), _p(glogJ), B, L, int(mu), int(off), act_code(act),
                                            _p(gx), _p(gw), ws, nb, _stream(x)), 'fthmc_flow_layer_bwd')
     return gx, gw
@@ -344,7 +344,7 @@ def profile_stages(kind: str, x, w, mu=0, off=0, act='silu', beta=1.0):
     """Mean cycles per stage of one MFMA coupling-layer kernel launch ('flow_fwd' | 'flow_bwd')."""
     import ctypes
     x = _field(x); B, _, L, _ = x.shape
-    k = {'flow_fwd': 0, 'flow_bwd': 1, 'flow_bwd_recompute': 2}[kind]
+    k = {'flow_fwd': 0, 'flow_bwd': 1}[kind]
     buf = (ctypes.c_double * 16)()
     ws, nb = _ws(x, B, L, 1)
     check(_lib.load().fthmc_profile_stages(k, _p(x), _p(_w1(w, x)), B, L, int(mu), int(off), act_code(act),

@@ -116,7 +116,8 @@ int fthmc_flow_layer_fwd(const double* x, const double* w, int B, int L, int mu,
                          void* ws, size_t ws_bytes, void* stream);
 /* VJP of the layer wrt x: gx = d/dx [ sum(gy * y) + sum_b glogJ[b] logJ[b] ]
  * (what autograd does for fthmc/utils/qed_helpers.py:226-242 and train.py:210).
- * gw != NULL additionally returns the same VJP wrt the 955 weights. */
+ * gw != NULL additionally returns the same VJP wrt the 955 weights; the workspace must then hold
+ * fthmc_train_ws_bytes(B, L, 1). */
 int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, const double* glogJ,
                          int B, int L, int mu, int off, int act,
                          double* gx, double* gw,
@@ -190,7 +191,7 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
                       void* ws, size_t ws_bytes, void* stream);
 
 /* Diagnostic (synchronises, mallocs on the host): one launch of the MFMA forward (kind 0),
- * stash backward (kind 1) or recompute backward (kind 2) kernel with per-workgroup cycle stamps at every stage boundary;
+ * or stash backward (kind 1) kernel with per-workgroup cycle stamps at every stage boundary;
  * cycles_host16[k] = mean cycles spent between stamp k-1 and stamp k. */
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off,
                          int act, double beta, double* cycles_host16,

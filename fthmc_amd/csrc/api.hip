@@ -56,6 +56,9 @@ WS ws_layout(double* base, int B, int L, int nl, bool train = false) {
 
 // which kernel family serves a call, and with it the tile geometry of its partial buffers
 inline bool fwd_is_mfma() { return get_flow_variant() == 1; }
+inline int flow_rev(const FlowLayerArgs& a, hipStream_t s) {
+    return fwd_is_mfma() ? launch_flow_rev_mfma(a, s) : launch_flow_rev(a, s);
+}
 inline int flow_fwd(const FlowLayerArgs& a, hipStream_t s) {
     return fwd_is_mfma() ? launch_flow_fwd_mfma(a, s) : launch_flow_fwd(a, s);
 }
@@ -298,7 +301,7 @@ int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu,
     FlowLayerArgs a{};
     a.x = y; a.wint = W.wint; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    FT_TRY(launch_flow_rev(a, s));
+    FT_TRY(flow_rev(a, s));
     if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(false).ntiles(L), 1.0, 0, logJ, s));
     return FTHMC_OK;
 }
@@ -363,7 +366,7 @@ int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, in
         FlowLayerArgs a{};
         a.x = x; a.wint = W.wint + (size_t)l * FLOW_WINT; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
-        FT_TRY(launch_flow_rev(a, s));
+        FT_TRY(flow_rev(a, s));
         FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(false).ntiles(L), 1.0, 1, ld, s));
     }
     return FTHMC_OK;

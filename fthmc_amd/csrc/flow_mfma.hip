@@ -33,7 +33,9 @@ template <int TR, int TC> struct SmemF {
     static_assert(G::N3 <= 8 * 3 * G::NAS, "delta must fit over the conv3 partials");
 };
 
-template <int TR, int TC, bool FASTW>
+// REV: the inverse layer (GaugeEquivCouplingLayer.reverse, layers.py:204-210, 373-396): same net on the same
+// frozen plaquettes, then the scalar map is inverted per active site instead of applied.
+template <int TR, int TC, bool FASTW, bool REV>
 __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
@@ -244,6 +246,77 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
     lds_barrier();
     STAMP(4);
 
+    if (REV) {
+        // ---- inverse of the tan-mixture transform: solve mean_k y_k(P) = wrap(P' - t) per active site by
+        //      safeguarded Newton (the map is monotone with derivative mean_k 1/D_k; the reference bisects
+        //      to a global 1e-6, layers.py:294-320), started from the target (s ~ 0: identity) ------------
+        if (wave == 0) {
+            double dl = 0.0, lj = 0.0;
+            if (alane) {
+                const double Pn = sP[(ar + 3) * R0C + ac + 3];
+                double sk[NMIX], tval = sW[CB2 + NMIX];
+#pragma unroll
+                for (int k = 0; k < NMIX; ++k) sk[k] = sW[CB2 + k];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int k = 0; k < NMIX; ++k) sk[k] += sST[(q * 3 + k) * NAS + lane];
+                    tval += sST[(q * 3 + NMIX) * NAS + lane];
+                }
+                double ea[2 * NMIX], eo[2 * NMIX];
+#pragma unroll
+                for (int k = 0; k < NMIX; ++k) { ea[2 * k] = sk[k]; ea[2 * k + 1] = -sk[k]; }
+                ft_expN<2 * NMIX>(ea, eo);
+                const double target = ft_wrap(Pn - tval);
+                double lo = -FT_PI, hi = FT_PI, xs = target, fp = 1.0;
+                bool done = false;
+                for (int it = 0; it < 200 && !done; ++it) {
+                    double sn, cs;
+                    ft_sincos(xs / 2, &sn, &cs);
+                    const double th = sn / cs;
+                    double f = 0.0;
+                    fp = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NMIX; ++k) {
+                        f += ft_wrap(2 * atan(eo[2 * k] * th));
+                        fp += 1.0 / (eo[2 * k + 1] * cs * cs + eo[2 * k] * sn * sn);
+                    }
+                    f /= NMIX; fp /= NMIX;
+                    const double err = target - f;
+                    if (fabs(err) <= A.tol) { done = true; break; }
+                    if (err > 0) lo = xs; else hi = xs;
+                    double xn = xs + err / fp;
+                    if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+                    if (xn == xs) done = true;
+                    xs = xn;
+                }
+                dl = xs - Pn;
+                lj = -(log(fp));                                     // log J of the inverse = -log mean_k 1/D_k at the root
+            }
+            if (avalid) sDL[ar * TC + ac] = dl;
+            if (A.logj_part) {
+                const double tot = ft_wave_sum(avalid ? lj : 0.0);
+                if (lane == 0) A.logj_part[(size_t)b * ntiles + tile] = tot;
+            }
+        }
+        lds_barrier();
+        if (A.y && tid < N3) {
+            const int r = fdiv<TC>(tid), c = tid - r * TC;
+            const int i = i0 + r, j = j0 + c;
+            if (i < L && j < L) {
+                double v0 = xv0, v1 = xv1;
+                if (ft_stripe(i, j, mu, off) == 0) {
+                    const double d = sDL[tid];
+                    if (mu == 0) v0 = ft_wrap(d + v0); else v1 = ft_wrap(-d + v1);
+                }
+                double* y0 = A.y + (size_t)b * 2 * n;
+                const int at = mul24(i, L) + j;
+                y0[at] = v0; y0[n + at] = v1;
+            }
+        }
+        return;
+    }
+
     // ---- tan-mixture transform: wave k evaluates mixture component k -------------
     //   y_k = wrap(2 atan(e^{s_k} tan(P/2))),  D_k = e^{-s_k} cos^2(P/2) + e^{s_k} sin^2(P/2),
     //   log J = log(sum_k 1/D_k) - log K   (= logsumexp_k(-log D_k) - log K of layers.py:85-90)
@@ -324,8 +397,15 @@ int get_flow_variant() { return g_variant; }
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     // forward needs half the LDS of backward: 16 x 16 tiles (less halo work) still fit twice per CU
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
-    if (wrap_fast_ok(a.L, MF_FWD_TR, MF_FWD_TC)) hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, true>), grid, dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, false>), grid, dim3(NT), 0, s, a);
+    if (wrap_fast_ok(a.L, MF_FWD_TR, MF_FWD_TC)) hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, true, false>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, false, false>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
+int launch_flow_rev_mfma(const FlowLayerArgs& a, hipStream_t s) {
+    const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
+    if (wrap_fast_ok(a.L, MF_FWD_TR, MF_FWD_TC)) hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, true, true>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, false, true>), grid, dim3(NT), 0, s, a);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+
 }  // namespace fthmc

@@ -85,6 +85,8 @@ int launch_flow_rev(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s);
 // flow_mfma.hip: MFMA forward (same arguments and results as launch_flow_fwd; optionally writes the stash)
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s);
+// the inverse layer on the same kernel (conv net unchanged, scalar map inverted by safeguarded Newton)
+int launch_flow_rev_mfma(const FlowLayerArgs& a, hipStream_t s);
 // flow_bwd_gather.hip: backward from the stash in gather form: a tile produces the complete
 // gP_out = up_gp + layer contribution of its own sites (a.gp_out, out of place), no partial windows;
 // train = also per-tile weight-gradient partials to a.gw_part (ntiles of flow_gather_geom(true))

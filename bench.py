@@ -50,6 +50,10 @@ def parse():
     ap.add_argument('--cpu-chains', type=int, default=128)
     ap.add_argument('--no-graph', action='store_true', help='launch eagerly instead of replaying a hipGraph')
     ap.add_argument('--thermalize', type=int, default=60, help='untimed plain-HMC trajectories applied to x0')
+    ap.add_argument('--groups', type=int, default=2,
+                    help='split the chains of a GPU into this many groups whose trajectories run on concurrent '
+                         'streams (chains are independent: one group fills the CUs the other leaves idle while a '
+                         'kernel drains)')
     return ap.parse_args()
 
 
@@ -127,31 +131,51 @@ def main():
     out = {'x_new': torch.empty_like(x)}
     for k in ('dH', 'acc', 'H0', 'H1', 'plaq', 'Q'):
         out[k] = torch.empty(B, dtype=torch.float64, device=dev)
-    out['state'] = torch.empty(3, B, dtype=torch.float64, device=dev)
     S0, _, p0, q0 = ops.ft_action(x, w, N_LAYERS, BETA)
-    state = torch.stack([S0, p0, q0]).contiguous()      # (S_eff, plaq, Q) of the current x, carried along
-    qold = ops.ft_action(x, w, N_LAYERS, BETA)[3].clone()
+    qold = q0.clone()
     seeds = torch.empty(B, dtype=torch.int64, device=dev)
     v = torch.empty_like(x)
     u = torch.empty(B, dtype=torch.float64, device=dev)
     stream = torch.cuda.Stream(device=dev)
 
-    def enqueue(xin):
-        """momentum refresh + one trajectory of the batch, all on the current stream"""
-        vv, uu = ops.random_momenta(seeds, xin.shape)
-        v.copy_(vv); u.copy_(uu)
-        ops.ft_trajectory(xin, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=state)
+    # chain groups: contiguous blocks of this GPU's chains, each with its own (S_eff, plaq, Q) state carried
+    # from trajectory to trajectory and, beyond the first, its own stream (and workspace: ops._ws)
+    G = max(1, min(args.groups, B))
+    groups = []
+    for gi in range(G):
+        a, b_ = gi * B // G, (gi + 1) * B // G
+        groups.append({
+            'x': x[a:b_], 'v': v[a:b_], 'u': u[a:b_], 'seeds': seeds[a:b_],
+            'out': {k: t[a:b_] for k, t in out.items()},
+            'state': torch.stack([S0[a:b_], p0[a:b_], q0[a:b_]]).contiguous(),
+            'stream': stream if gi == 0 else torch.cuda.Stream(device=dev)})
+        groups[-1]['out']['state'] = torch.empty_like(groups[-1]['state'])
+
+    def enqueue_group(g):
+        """momentum refresh + one trajectory of the group's chains, all on the current stream"""
+        vv, uu = ops.random_momenta(g['seeds'], g['x'].shape)
+        g['v'].copy_(vv); g['u'].copy_(uu)
+        ops.ft_trajectory(g['x'], g['v'], g['u'], w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=g['out'], state_in=g['state'])
+
+    def enqueue():
+        for g in groups[1:]:
+            g['stream'].wait_stream(stream)
+            with torch.cuda.stream(g['stream']):
+                enqueue_group(g)
+        enqueue_group(groups[0])
+        for g in groups[1:]:
+            stream.wait_stream(g['stream'])
 
     graph = None
     if not args.no_graph:
-        # the ~300 launches of a trajectory are captured once and replayed (launch-bound otherwise)
+        # the ~200 launches of a trajectory are captured once and replayed (launch-bound otherwise)
         with torch.cuda.stream(stream):
             seeds.copy_(parallel.chain_seeds(SEED, lo, hi, 0).to(dev))
-            enqueue(x)                      # warm allocator / workspace before capture
+            enqueue()                       # warm allocator / workspaces before capture
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
-                enqueue(x)
+                enqueue()
 
     traj = [0]
     pending = [None]
@@ -161,9 +185,10 @@ def main():
         if graph is not None:
             graph.replay()
         else:
-            enqueue(x)
+            enqueue()
         x.copy_(out['x_new'])
-        state.copy_(out['state'])
+        for g in groups:
+            g['state'].copy_(g['out']['state'])
         dq = out['Q'] - qold
         stats.add(out['acc'], out['plaq'], out['Q'], dq, out['dH'])
         qold.copy_(out['Q'])
@@ -206,17 +231,22 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline of the dominant kernel, HIP events on this stream
+    # launch shape of the timed region: one launch = one layer over one chain group (B / G chains)
+    Bl = groups[0]['x'].shape[0]
     with torch.cuda.stream(stream):
         w0 = w[:955].contiguous()
-        ms_bwd = ops.time_kernel('flow_bwd', x, w0, mu=0, off=0, beta=BETA, reps=40)
-        ms_fwd = ops.time_kernel('flow_fwd', x, w0, mu=0, off=0, beta=BETA, reps=40)
+        xl = x[:Bl].contiguous()
+        ms_bwd = ops.time_kernel('flow_bwd', xl, w0, mu=0, off=0, beta=BETA, reps=40)
+        ms_fwd = ops.time_kernel('flow_fwd', xl, w0, mu=0, off=0, beta=BETA, reps=40)
+        ms_bwd_full = ops.time_kernel('flow_bwd', x, w0, mu=0, off=0, beta=BETA, reps=40) if Bl != B else ms_bwd
+        ms_fwd_full = ops.time_kernel('flow_fwd', x, w0, mu=0, off=0, beta=BETA, reps=40) if Bl != B else ms_fwd
         ms_leap = ops.time_kernel('leap_step', x, beta=BETA, reps=40)
         ms_traj = ops.time_kernel('hmc_trajectory', x, beta=BETA, reps=20)
-    log(f'kernel timing: bwd {ms_bwd:.4f} ms fwd {ms_fwd:.4f} ms leap {ms_leap:.5f} ms')
-    flops_launch = CONV_FLOPS_PER_SITE * L * L * B          # dense conv flops of one layer (fwd = dgrad), B chains
+    log(f'kernel timing ({Bl} chains per launch): bwd {ms_bwd:.4f} ms fwd {ms_fwd:.4f} ms; leap {ms_leap:.5f} ms')
+    flops_launch = CONV_FLOPS_PER_SITE * L * L * Bl         # dense conv flops of one layer (fwd = dgrad), one launch
     # the dominant kernel = the one with the larger share of a trajectory: the forward kernel runs
     # N_LAYERS * (NSTEP + 1) times (force sweeps + H1), the backward kernel N_LAYERS * NSTEP times
-    share = {'fwd': ms_fwd * N_LAYERS * (NSTEP + 1), 'bwd': ms_bwd * N_LAYERS * NSTEP}
+    share = {'fwd': ms_fwd * N_LAYERS * (NSTEP + 1) * G, 'bwd': ms_bwd * N_LAYERS * NSTEP * G}
     dom = max(share, key=share.get)
     names = {'fwd': ('k_flow_fwd<16,16> (coupling-layer forward: conv net + tan-mixture transform + stash)', 'k_flow_fwd'),
              'bwd': ('k_flow_bwd_gather<16,16> (coupling-layer backward wrt x from the stash)', 'k_flow_bwd_gather')}
@@ -229,7 +259,11 @@ def main():
         'frac': round(achieved / FP64_PEAK_TFLOPS, 4), 'traffic': pmc_traffic(names[dom][1]),
         'avg_launch_ms': round(ms_dom, 4),
         'algorithmic_flops_per_launch': flops_launch,
-        'ms_per_trajectory': {k: round(v, 3) for k, v in share.items()},
+        'chains_per_launch': Bl,
+        'kernel_ms_per_trajectory': {k: round(v, 3) for k, v in share.items()},
+        'full_batch_exclusive': {'chains_per_launch': B, 'fwd_kernel_ms': round(ms_fwd_full, 4), 'bwd_kernel_ms': round(ms_bwd_full, 4),
+                                 'fwd_frac': round(CONV_FLOPS_PER_SITE * L * L * B / (ms_fwd_full * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
+                                 'bwd_frac': round(CONV_FLOPS_PER_SITE * L * L * B / (ms_bwd_full * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)},
         'fwd_kernel_ms': round(ms_fwd, 4), 'bwd_kernel_ms': round(ms_bwd, 4),
         'bwd_kernel': {'kernel': names['bwd'][0], 'achieved': round(flops_launch / (ms_bwd * 1e-3) / 1e12, 3),
                        'frac': round(flops_launch / (ms_bwd * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4),
@@ -284,7 +318,7 @@ def main():
                                '(BASELINE.json configs[2]; configs[3] = the same per GPU on 8 GPUs)',
                    'chains_per_gpu': B, 'chains_total': B * world, 'L': L, 'beta': BETA, 'n_layers': N_LAYERS,
                    'nstep': NSTEP, 'tau': TAU, 'parallelism': f'chains sharded x{world}',
-                   'launch': 'eager' if graph is None else 'hipGraph replay'},
+                   'launch': 'eager' if graph is None else 'hipGraph replay', 'chain_groups': G},
         'batched_leapfrog_steps_per_s': round(NSTEP * args.steps / elapsed, 3),
         'acceptance': round(m['acc'], 4), 'plaq': round(m['plaq'], 6),
         'roofline': roofline, 'cpu_baseline': cpu,

@@ -47,7 +47,8 @@ def ws_bytes(B: int, L: int, n_layers: int) -> int:
 
 def _ws(t: torch.Tensor, B: int, L: int, nl: int, train: bool = False):
     need = int(_lib.load().fthmc_train_ws_bytes(B, L, nl)) if train else ws_bytes(B, L, nl)
-    key = t.device.index
+    # one workspace per (device, stream): chain groups running on concurrent streams must not share scratch
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() * 8 < need:
         buf = torch.empty((need + 7) // 8, dtype=torch.float64, device=t.device)

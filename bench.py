@@ -138,33 +138,17 @@ def main():
     u = torch.empty(B, dtype=torch.float64, device=dev)
     stream = torch.cuda.Stream(device=dev)
 
-    # chain groups: contiguous blocks of this GPU's chains, each with its own (S_eff, plaq, Q) state carried
-    # from trajectory to trajectory and, beyond the first, its own stream (and workspace: ops._ws)
+    # chain groups (ops.ft_trajectory(groups=G)): contiguous blocks of this GPU's chains whose trajectories
+    # run on concurrent streams, forked from / joined into `stream`
     G = max(1, min(args.groups, B))
-    groups = []
-    for gi in range(G):
-        a, b_ = gi * B // G, (gi + 1) * B // G
-        groups.append({
-            'x': x[a:b_], 'v': v[a:b_], 'u': u[a:b_], 'seeds': seeds[a:b_],
-            'out': {k: t[a:b_] for k, t in out.items()},
-            'state': torch.stack([S0[a:b_], p0[a:b_], q0[a:b_]]).contiguous(),
-            'stream': stream if gi == 0 else torch.cuda.Stream(device=dev)})
-        groups[-1]['out']['state'] = torch.empty_like(groups[-1]['state'])
-
-    def enqueue_group(g):
-        """momentum refresh + one trajectory of the group's chains, all on the current stream"""
-        vv, uu = ops.random_momenta(g['seeds'], g['x'].shape)
-        g['v'].copy_(vv); g['u'].copy_(uu)
-        ops.ft_trajectory(g['x'], g['v'], g['u'], w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=g['out'], state_in=g['state'])
+    state = torch.stack([S0, p0, q0]).contiguous()      # (S_eff, plaq, Q) of the current x, carried along
+    out['state'] = torch.empty_like(state)
 
     def enqueue():
-        for g in groups[1:]:
-            g['stream'].wait_stream(stream)
-            with torch.cuda.stream(g['stream']):
-                enqueue_group(g)
-        enqueue_group(groups[0])
-        for g in groups[1:]:
-            stream.wait_stream(g['stream'])
+        """momentum refresh + one trajectory of every chain of this GPU, forked from the current stream"""
+        vv, uu = ops.random_momenta(seeds, x.shape)
+        v.copy_(vv); u.copy_(uu)
+        ops.ft_trajectory(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=state, groups=G)
 
     graph = None
     if not args.no_graph:
@@ -187,8 +171,7 @@ def main():
         else:
             enqueue()
         x.copy_(out['x_new'])
-        for g in groups:
-            g['state'].copy_(g['out']['state'])
+        state.copy_(out['state'])
         dq = out['Q'] - qold
         stats.add(out['acc'], out['plaq'], out['Q'], dq, out['dH'])
         qold.copy_(out['Q'])
@@ -232,7 +215,7 @@ def main():
 
     # ---- roofline of the dominant kernel, HIP events on this stream
     # launch shape of the timed region: one launch = one layer over one chain group (B / G chains)
-    Bl = groups[0]['x'].shape[0]
+    Bl = B // G if G > 1 else B
     with torch.cuda.stream(stream):
         w0 = w[:955].contiguous()
         xl = x[:Bl].contiguous()

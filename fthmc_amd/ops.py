@@ -283,13 +283,29 @@ def ft_leapfrog(x, v, w, n_layers: int, beta: float, dt: float, nstep: int, act=
     return xo, vo
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_streams(device, n: int):
+    key = device.index
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', mode='md',
-                  out: Optional[dict] = None, state_in: Optional[torch.Tensor] = None):
+                  out: Optional[dict] = None, state_in: Optional[torch.Tensor] = None, groups: int = 1):
     """One ftHMC trajectory per chain -> dict(x_new, dH, acc, H0, H1, plaq, Q, state).
 
     `out` may carry preallocated output tensors (same keys) so that a caller can replay the call
     inside a captured graph.  `state` is [3, B] = (S_eff, plaq, Q) of x_new; fed back as `state_in`
-    of the next trajectory of the same chains (x = x_new) it saves that call's H0 flow sweep."""
+    of the next trajectory of the same chains (x = x_new) it saves that call's H0 flow sweep.
+
+    groups > 1 splits the chains into that many contiguous groups whose trajectories run on concurrent
+    streams (forked from and joined back into the current stream, each with its own workspace): chains
+    are independent, and one group's kernels fill the CUs that the other's leave idle in every kernel
+    tail and dispatch gap.  Results do not depend on `groups`."""
     x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
     if u.numel() != B:
         raise FthmcError(f'u: expected {B} uniforms, got {u.numel()}')
@@ -300,6 +316,30 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
             out[k] = torch.empty(B, dtype=x.dtype, device=x.device)
     if 'state' not in out:
         out['state'] = torch.empty(3, B, dtype=x.dtype, device=x.device)
+    G = max(1, min(int(groups), B))
+    if G > 1:
+        if state_in is not None:
+            state_in = _dev(state_in, 'state_in')
+            if state_in.numel() != 3 * B:
+                raise FthmcError(f'state_in: expected [3, {B}]')
+            state_in = state_in.reshape(3, B)
+        main = torch.cuda.current_stream(x.device)
+        sides = _side_streams(x.device, G - 1)
+        parts = []
+        for st in sides:                                                # fork before anything of this call is on `main`
+            st.wait_stream(main)
+        for gi in list(range(1, G)) + [0]:
+            a, b_ = gi * B // G, (gi + 1) * B // G
+            st = main if gi == 0 else sides[gi - 1]
+            with torch.cuda.stream(st):
+                og = {k: t[a:b_] for k, t in out.items() if k != 'state'}
+                sg = state_in[:, a:b_].contiguous() if state_in is not None else None
+                ft_trajectory(x[a:b_], v[a:b_], u[a:b_], w, n_layers, beta, dt, nstep, act, mode, og, sg)
+                out['state'][:, a:b_].copy_(og['state'])
+                parts.append(og)                                        # keep the group's temporaries alive until the join
+        for st in sides:
+            main.wait_stream(st)
+        return out
     if state_in is not None:
         state_in = _dev(state_in, 'state_in')
         if state_in.numel() != 3 * B:

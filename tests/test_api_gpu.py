@@ -231,3 +231,27 @@ def test_independence_sampler():
     assert all(h['logp'][i] == h['logp'][i - 1] and h['dqsq'][i] == 0.0 for i in rej)
     out = generate_ensemble(model, action, ensemble_size=64, batch_size=16, nboot=10, binsize=8)
     assert np.isfinite(out['suscept_mean']) and out['suscept_err'] >= 0
+
+
+def test_chain_groups_do_not_change_results():
+    """ops.ft_trajectory(groups=G): chains split over concurrent streams give the same per-chain results."""
+    from fthmc_amd import ops
+    from oracle import ref_cpu as R
+    gen = torch.Generator().manual_seed(99)
+    B, L, nl, beta = 10, 16, 4, 3.0
+    flow = R.default_flow(nl, gen)
+    w = ops.pack_weights(flow, device='cuda')
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()
+    u = torch.rand(B, generator=gen, dtype=torch.float64).cuda()
+    ref = ops.ft_trajectory(x, v, u, w, nl, beta, 0.1, 5)
+    for G in (2, 3):
+        r = ops.ft_trajectory(x, v, u, w, nl, beta, 0.1, 5, groups=G)
+        torch.cuda.synchronize()
+        for k in ('x_new', 'dH', 'acc', 'H0', 'H1', 'plaq', 'Q', 'state'):
+            assert torch.equal(r[k], ref[k]), (G, k)
+        # chained through the carried state
+        r2 = ops.ft_trajectory(r['x_new'], v, u, w, nl, beta, 0.1, 5, state_in=r['state'], groups=G)
+        ref2 = ops.ft_trajectory(ref['x_new'], v, u, w, nl, beta, 0.1, 5, state_in=ref['state'])
+        torch.cuda.synchronize()
+        assert torch.equal(r2['dH'], ref2['dH']) and torch.equal(r2['x_new'], ref2['x_new'])

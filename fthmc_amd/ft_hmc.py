@@ -133,7 +133,7 @@ class FieldTransformation(nn.Module):
             u = torch.rand(x.shape[0], dtype=torch.float64, device=x.device)
         if self.energy_mode == 'per_chain':
             r = ops.ft_trajectory(x, v, u, self.weights(x.device), len(self.flow), self.config.beta, self.dt,
-                                  self.nstep, self._act, mode=self._mode(), groups=2 if x.shape[0] >= 32 else 1)
+                                  self.nstep, self._act, mode=self._mode(), groups=ops.default_groups(x.shape[0], x.shape[-1]))
             x_, dh, acc = r['x_new'], r['dH'], r['acc']
         else:
             h = self.calc_energy(x, v)

@@ -90,7 +90,8 @@ def train_step(model: FlowModel, config: TrainConfig, action: ActionFn, optimize
         if xi is None:
             xi = model.prior.sample_n(batch_size)
         xi = xi.to(DTYPE)
-        r = ops.train_grad(xi, flow_weights(layers, xi.device), len(layers), action.beta, flow_activation(layers))
+        r = ops.train_grad(xi, flow_weights(layers, xi.device), len(layers), action.beta, flow_activation(layers),
+                           groups=ops.default_groups(xi.shape[0], xi.shape[-1]))
         x, logq, logp = r['x'], r['logq'], r['logp']
         gw = r['gw'] * (dkl_factor / world)          # kernel seeds 1/B_local; loss is the global mean
         parallel.allreduce_grads(gw)

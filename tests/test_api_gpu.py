@@ -255,3 +255,20 @@ def test_chain_groups_do_not_change_results():
         ref2 = ops.ft_trajectory(ref['x_new'], v, u, w, nl, beta, 0.1, 5, state_in=ref['state'])
         torch.cuda.synchronize()
         assert torch.equal(r2['dH'], ref2['dH']) and torch.equal(r2['x_new'], ref2['x_new'])
+
+
+def test_train_grad_chain_groups():
+    """ops.train_grad(groups=G): same loss pieces, weight gradient equal up to summation order."""
+    from fthmc_amd import ops
+    from oracle import ref_cpu as R
+    gen = torch.Generator().manual_seed(5)
+    B, L, nl, beta = 10, 16, 3, 2.0
+    w = ops.pack_weights(R.default_flow(nl, gen), device='cuda')
+    xi = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    ref = ops.train_grad(xi, w, nl, beta)
+    for G in (2, 3):
+        r = ops.train_grad(xi, w, nl, beta, groups=G)
+        torch.cuda.synchronize()
+        for k in ('x', 'logq', 'logp'):
+            assert torch.equal(r[k], ref[k]), (G, k)
+        close(r['gw'], ref['gw'], rtol=1e-12, atol=1e-14)

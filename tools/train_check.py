@@ -10,8 +10,9 @@ for (B, L, nl, beta) in [(32, 16, 4, 4.0), (128, 64, 8, 6.0), (32, 256, 16, 7.0)
     flow = R.default_flow(nl, gen)
     w = ops.pack_weights(flow, device='cuda')
     xi = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
-    r = ops.train_grad(xi, w, nl, beta); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3): r = ops.train_grad(xi, w, nl, beta)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-    print(f'train_grad B={B} L={L} layers={nl}: {dt*1e3:.2f} ms  ({5616*L*L*nl*B/dt/1e12:.2f} TFLOP/s dense-algorithmic fwd+dgrad+wgrad)', flush=True)
+    for G in (1, 2):
+        r = ops.train_grad(xi, w, nl, beta, groups=G); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5): r = ops.train_grad(xi, w, nl, beta, groups=G)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        print(f'train_grad B={B} L={L} layers={nl} groups={G}: {dt*1e3:.2f} ms  ({5616*L*L*nl*B/dt/1e12:.2f} TFLOP/s dense-algorithmic fwd+dgrad+wgrad)', flush=True)

@@ -1,5 +1,5 @@
 // Shared constants / helpers of the coupling-layer kernels (flow.hip: VALU variant,
-// flow_mfma.hip: MFMA variant).
+// flow_fwd.hip: MFMA variant).
 #pragma once
 #include "common.h"
 #include "kernels.h"

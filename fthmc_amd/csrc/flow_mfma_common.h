@@ -1,4 +1,4 @@
-// Building blocks shared by the MFMA coupling-layer kernels (flow_mfma.hip, flow_bwd_gather.hip):
+// Building blocks shared by the MFMA coupling-layer kernels (flow_fwd.hip, flow_bwd_gather.hip):
 // tile geometry, the implicit-GEMM conv stage, the weight-gradient GEMM stage, the XCD-aware block map.
 #pragma once
 #include "flow_common.h"

@@ -83,7 +83,7 @@ struct FlowLayerArgs {
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_rev(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s);
-// flow_mfma.hip: MFMA forward (same arguments and results as launch_flow_fwd; optionally writes the stash)
+// flow_fwd.hip: MFMA forward (same arguments and results as launch_flow_fwd; optionally writes the stash)
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 // the inverse layer on the same kernel (conv net unchanged, scalar map inverted by safeguarded Newton)
 int launch_flow_rev_mfma(const FlowLayerArgs& a, hipStream_t s);

@@ -109,36 +109,6 @@ __device__ __forceinline__ void ft_expN(const double (&xin)[N], double (&e)[N]) 
     for (int q = 0; q < N; ++q) e[q] = ldexp(p[q], (int)n[q]);
 }
 
-// sin and cos for moderate arguments (|x| up to ~1e5; plaquette angles are sums of four links):
-// Cody-Waite reduction by pi/2 in three exact-product pieces + the fdlibm kernel polynomials on
-// |r| <= pi/4.  ~35 DP ops, no slow path, < 1 ulp each (ocml's sincos carries a Payne-Hanek
-// branch and is ~3x longer on the critical path of the serial stages).
-__device__ __forceinline__ void ft_sincos(double x, double* sn, double* cs) {
-    const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi
-    double r = fma(-fn, 1.57079632673412561417e+00, x);              // pi/2, first 33 bits (exact product)
-    r = fma(-fn, 6.07710050630396597660e-11, r);                     // next 33 bits
-    r = fma(-fn, 2.02226624879595063154e-21, r);                     // tail
-    const double z = r * r;
-    double ps = 1.58969099521155010221e-10;
-    ps = fma(ps, z, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);
-    const double s = fma(r * z, ps, r);
-    double pc = -1.13596475577881948265e-11;
-    pc = fma(pc, z, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);
-    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
-    const int q = (int)fn & 3;
-    const double s_ = (q & 1) ? c : s, c_ = (q & 1) ? s : c;
-    *sn = (q & 2) ? -s_ : s_;
-    *cs = ((q + 1) & 2) ? -c_ : c_;
-}
-
 // sigmoid(z) = 1 / (1 + exp(-z)) without overflow or cancellation; reciprocal by v_rcp_f64 +
 // two Newton steps (no div_scale / div_fmas / div_fixup chain).
 __device__ __forceinline__ double ft_sigmoid(double z) {

@@ -175,3 +175,24 @@ def test_torch_operator_library_registers_without_a_gpu():
         assert out[3].shape == (4 * 955,)
     with pytest.raises(NotImplementedError):
         torch.ops.fthmc_hip.wilson_force(torch.zeros(1, 2, 8, 8, dtype=torch.float64), 1.0)
+
+
+def test_observables_tooling(tmp_path):
+    """delta-Q^2 versus lag and the susceptibility on a synthetic charge history with a known answer."""
+    from fthmc_amd.utils import observables as O
+    rng = np.random.default_rng(3)
+    # a random walk with unit steps with probability 1/2: <(Q(t+k) - Q(t))^2> = k / 2
+    steps = rng.integers(0, 2, size=(20000, 4)) * rng.choice([-1, 1], size=(20000, 4))
+    q = np.cumsum(steps, axis=0).astype(np.float64)
+    rows = O.change_sqr_vs_dt(q, dt_range=4)
+    for lag, mean, sig in rows:
+        assert abs(mean - lag / 2) < 5 * sig + 0.02, (lag, mean, sig)
+    assert np.isnan(O.change_sqr(q[:3], 5)[0])
+    bm = O.block_means(np.arange(35.0), 16)                   # 35 = 3 dropped + 16 blocks of 2
+    assert bm.shape == (16,) and bm[0] == 3.5 and bm[-1] == 33.5
+    # iid integer charges with variance 2 on a volume of 64: chi = 2 / 64
+    qq = rng.normal(0, np.sqrt(2.0), size=40000)
+    chi, err = O.topological_susceptibility(qq, 64, nboot=50, binsize=8)
+    assert abs(chi - 2 / 64) < 5 * err + 1e-3
+    out = O.save_topo_change_sqr(str(tmp_path / 'dq2.txt'), q[:, 0], dt_range=3)
+    assert len(out) == 3 and len(open(tmp_path / 'dq2.txt').read().splitlines()) == 3

@@ -90,8 +90,19 @@ def pmc_traffic(kernel):
 
 
 def make_flow(gen):
-    from oracle import ref_cpu as R      # only for the shared default-init recipe + cpu_baseline
-    return R.default_flow(N_LAYERS, gen)
+    """Synthetic flow weights: PyTorch's default Conv2d init (Kaiming-uniform a = sqrt(5), i.e.
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)); SURVEY Q6: the reference's set_weights is a no-op) for the s/t net
+    2 -> 8 -> 8 -> 3, k = 3, drawn from `gen`: [(w0, b0, w1, b1, w2, b2)] * N_LAYERS."""
+    sizes = [2, 8, 8, 3]
+    flow = []
+    for _ in range(N_LAYERS):
+        w = []
+        for ci, co in zip(sizes[:-1], sizes[1:]):
+            bound = 1.0 / math.sqrt(ci * 9)
+            w.append((torch.rand(co, ci, 3, 3, generator=gen, dtype=torch.float64) * 2 - 1) * bound)
+            w.append((torch.rand(co, generator=gen, dtype=torch.float64) * 2 - 1) * bound)
+        flow.append(tuple(w))
+    return flow
 
 
 def main():

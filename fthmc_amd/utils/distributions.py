@@ -9,24 +9,27 @@ import torch.nn as nn
 
 
 def bootstrap(x: np.ndarray, *, nboot: int, binsize: int):
-    """distributions.py:13-20 (host statistics)."""
-    boots = []
-    x = x.reshape(-1, binsize, *x.shape[1:])
-    for _ in range(nboot):
-        boots.append(np.mean(x[np.random.randint(len(x), size=len(x))], axis=(0, 1)))
-    return np.mean(boots), np.std(boots)
+    """Binned bootstrap of the mean -> (mean of the resampled means, their std); distributions.py:13-20.
+    Bins are averaged first, all resampling indices are drawn in one call (same draws, in the same order, as
+    one call per resample)."""
+    x = np.asarray(x)
+    bins = x.reshape(-1, binsize, *x.shape[1:]).mean(axis=1)
+    pick = np.random.randint(len(bins), size=(nboot, len(bins)))
+    means = bins[pick].mean(axis=1)                          # [nboot, *trailing dims of x]
+    return means.mean(), means.std()
 
 
 def calc_dkl(logp: torch.Tensor, logq: torch.Tensor):
-    """distributions.py:23-24."""
-    return (logq - logp).mean()
+    """Reverse KL estimate E_q[log q - log p] (distributions.py:23-24)."""
+    return torch.mean(logq - logp)
 
 
 def calc_ess(logp: torch.Tensor, logq: torch.Tensor):
-    """distributions.py:27-37."""
+    """Effective sample size per configuration, (sum w)^2 / (N sum w^2) with w = p / q, in log space
+    (distributions.py:27-37)."""
     logw = logp - logq
-    log_ess = 2 * torch.logsumexp(logw, dim=0) - torch.logsumexp(2 * logw, dim=0)
-    return torch.exp(log_ess) / len(logw)
+    n = logw.shape[0]
+    return (2 * torch.logsumexp(logw, 0) - torch.logsumexp(2 * logw, 0)).exp() / n
 
 
 class BasePrior(nn.Module):

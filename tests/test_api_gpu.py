@@ -272,3 +272,32 @@ def test_train_grad_chain_groups():
         for k in ('x', 'logq', 'logp'):
             assert torch.equal(r[k], ref[k]), (G, k)
         close(r['gw'], ref['gw'], rtol=1e-12, atol=1e-14)
+
+
+def test_batch_hmc_and_train_step_take_the_grouped_path():
+    """Shapes large enough for ops.default_groups() = 2: the Python API's batched trajectory and fused training
+    step give the results of the ungrouped ops."""
+    from fthmc_amd import ops
+    from fthmc_amd.config import TrainConfig, lfConfig
+    from fthmc_amd.ft_hmc import FieldTransformation
+    from fthmc_amd.utils import layers as Lyr
+    B, L, nl = 32, 64, 2
+    assert ops.default_groups(B, L) == 2 and ops.default_groups(4, 16) == 1
+    torch.manual_seed(11)
+    flow = Lyr.make_u1_equiv_layers(n_layers=nl, n_mixture_comps=2, lattice_shape=(L, L), hidden_sizes=[8, 8],
+                                    kernel_size=3, activation_fn='silu').cuda().double()
+    cfg = TrainConfig(L=L, beta=3.0, n_layers=nl, batch_size=B)
+    ft = FieldTransformation(flow, cfg, lfConfig(tau=0.3, nstep=3))
+    gen = torch.Generator().manual_seed(3)
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()
+    u = torch.rand(B, generator=gen, dtype=torch.float64).cuda()
+    xnew, m = ft._batch_hmc(x, v=v, u=u)
+    ref = ops.ft_trajectory(x, v, u, ft.weights(x.device), nl, cfg.beta, ft.dt, ft.nstep, groups=1)
+    torch.cuda.synchronize()
+    assert torch.equal(m['dh'], ref['dH']) and torch.equal(xnew, ref['x_new'])
+    w = Lyr.flow_weights(flow, x.device)
+    g2, g1 = ops.train_grad(x, w, nl, cfg.beta, groups=2), ops.train_grad(x, w, nl, cfg.beta, groups=1)
+    torch.cuda.synchronize()
+    assert torch.equal(g2['logq'], g1['logq'])
+    close(g2['gw'], g1['gw'], rtol=1e-12, atol=1e-14)

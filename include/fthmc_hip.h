@@ -7,7 +7,9 @@
  * synchronises: every call only enqueues kernels on `stream` (a hipStream_t
  * passed as void*; NULL = the null stream) and returns 0 or a negative
  * FTHMC_ERR_* code.  Scratch space is caller-owned (`ws`, sized by
- * fthmc_ws_bytes) so that calls can be captured into a hipGraph.
+ * fthmc_ws_bytes) so that calls can be captured into a hipGraph.  A workspace
+ * belongs to one stream at a time: calls in flight on different streams (e.g.
+ * two groups of independent chains) need a workspace each.
  *
  * Field layout: x[B][2][L][L], angle of the U(1) link in radians, mu-major
  * (the reference's [batch, Nd, Nt, Nx]).  L % 4 == 0.

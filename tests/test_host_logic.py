@@ -196,3 +196,29 @@ def test_observables_tooling(tmp_path):
     assert abs(chi - 2 / 64) < 5 * err + 1e-3
     out = O.save_topo_change_sqr(str(tmp_path / 'dq2.txt'), q[:, 0], dt_range=3)
     assert len(out) == 3 and len(open(tmp_path / 'dq2.txt').read().splitlines()) == 3
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench.json is one JSON line of bench.py: every key the driver and the judge read is there,
+    and the numbers are mutually consistent."""
+    import json
+    line = open(os.path.join(ROOT, 'profiles', 'r01_bench.json')).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['dtype'] == 'f64' and d['data'] == 'synthetic'
+    assert d['vs_baseline'] is None                       # BASELINE.md publishes no number for this metric
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert abs(r['achieved'] - r['algorithmic_flops_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12) < 0.1
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('reference', 'port') and c['unit'] == d['unit']
+    # value = chains x leapfrog steps x trajectories / time
+    cfg = d['config']
+    assert abs(d['value'] - cfg['chains_total'] * cfg['nstep'] / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3

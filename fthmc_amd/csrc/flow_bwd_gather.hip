@@ -370,8 +370,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
 
     // ---- conv1^T and the (cos, sin) adjoint at the tile's own frozen plaquettes ------------------
     // thread = (frozen site, quarter of the 8 channels); the four quarters of a site sit in adjacent lanes
-    if (tid < 2 * N3) {
-        const int f = tid >> 2, qq = tid & 3;
+    // (training on 8 x 16 tiles: the upper four waves take it while the lower three are in the conv2 weight-gradient GEMM)
+    constexpr int C1T0 = (TRAIN && 2 * N3 <= NT / 2) ? NT / 2 : 0;
+    if (tid >= C1T0 && tid < C1T0 + 2 * N3) {
+        const int f = (tid - C1T0) >> 2, qq = tid & 3;
         int r, c;
         if (mu == 0) { r = fdiv<TC / 2>(f); const int h = f - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
         else { const int hh = fdiv<TC>(f); c = f - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }

@@ -80,11 +80,17 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
         const double p = ldu(x0, (unsigned)(iL + j)) - ldu(x1, (unsigned)(iL + j)) - ldu(x0, (unsigned)(iL + jp)) + ldu(x1, (unsigned)(ipL + j));
         const int sel = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;          // stripe class (L % 4 == 0)
         const bool frozen = (sel == 1 || sel == 2);
+        // one sincos per thread: of P where the plaquette is frozen (the net input), of P / 2 at the tile's own
+        // active sites (the transform needs it; evaluated here it costs nothing, the frozen lanes of the wave
+        // run the same instructions) -- left in the plaquette plane next to P, in the two slots of the
+        // following lines (stripe classes 1, 2), whose own plaquettes nobody reads
+        const bool aown = sel == 0 && (unsigned)(r - 3) < (unsigned)TR && (unsigned)(c - 3) < (unsigned)TC && !REV;
         double sn = 0.0, cs = 1.0;
-        if (frozen) ft_sincos(p, &sn, &cs);
-        sP[tid] = p;
-        sIn[tid] = cs;
-        sIn[PS0 + tid] = sn;
+        if (frozen || aown) ft_sincos(frozen ? p : 0.5 * p, &sn, &cs);
+        if (sel == 0) sP[tid] = p;
+        if (aown) { const int st = mu == 0 ? 1 : R0C; sP[tid + st] = cs; sP[tid + 2 * st] = sn; }
+        sIn[tid] = frozen ? cs : 1.0;
+        sIn[PS0 + tid] = frozen ? sn : 0.0;
         if (A.stash && frozen && (unsigned)(r - 3) < (unsigned)min(TR, L - i0) &&
             (unsigned)(c - 3) < (unsigned)min(TC, L - j0)) {             // the net input of the tile's own frozen sites
             double* cs_ = A.stash + ((size_t)A.B * 18 + b) * n + stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
@@ -326,8 +332,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
         double sk = sW[CB2 + wave];
 #pragma unroll
         for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
-        double sn, cs, es, ems;
-        ft_sincos(Pa / 2, &sn, &cs);
+        const int pst = mu == 0 ? 1 : R0C;
+        const double cs = sP[(ar + 3) * R0C + ac + 3 + pst], sn = sP[(ar + 3) * R0C + ac + 3 + 2 * pst];   // of P / 2
+        double es, ems;
         { const double ea[2] = {sk, -sk}; double eo[2]; ft_expN<2>(ea, eo); es = eo[0]; ems = eo[1]; }
         const double cs2 = cs * cs, sn2 = sn * sn, sincs = sn * cs;
         const double invD = 1.0 / (ems * cs2 + es * sn2);
@@ -344,11 +351,11 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
             tc[6 * (n >> 2)] = sinP * 0.5 * (es - ems) * invD2;          // E_k
         }
     }
-    double tval = 0.0;
-    if (wave == 0 && alane) {
-        tval = sW[CB2 + 2];
+    if (wave == NMIX && alane) {                                 // t on an otherwise idle wave
+        double tv = sW[CB2 + NMIX];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) tval += sST[(q * 3 + 2) * NAS + lane];
+        for (int q = 0; q < 8; ++q) tv += sST[(q * 3 + NMIX) * NAS + lane];
+        sP[(ar + 3) * R0C + ac + 3 + 3 * (mu == 0 ? 1 : R0C)] = tv;
     }
     lds_barrier();
     STAMP(5);
@@ -358,6 +365,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
             double ysum = 0.0, si = 0.0;
 #pragma unroll
             for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * TQ) * NAS + (lane & (NAS - 1))]; si += sT2[(k * TQ + 1) * NAS + (lane & (NAS - 1))]; }
+            const double tval = sP[(ar + 3) * R0C + ac + 3 + 3 * (mu == 0 ? 1 : R0C)];
             const double newP = ft_wrap(ysum / NMIX + tval);
             if (avalid) sDL[ar * TC + ac] = newP - Pa;
             if (A.logj_part) {                                       // force sweeps do not ask for log J

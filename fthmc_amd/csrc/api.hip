@@ -306,6 +306,31 @@ int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu,
     return FTHMC_OK;
 }
 
+// plaquette-level map: the coupling kernel with the plaquette field as input and output (MFMA kernels only)
+static int plaq_coupling(const double* P, const double* w, int B, int L, int mu, int off, int act, double tol,
+                         bool rev, double* out, double* logJ, void* ws, size_t ws_bytes, void* stream) {
+    if (!P || !w || !out || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2 || get_flow_variant() != 1) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(1);
+    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FlowLayerArgs a{};
+    a.x = P; a.pin = P; a.pout = out; a.wint = W.wint; a.logj_part = W.lj_part; a.tol = tol;
+    a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+    FT_TRY(rev ? launch_flow_rev_mfma(a, s) : launch_flow_fwd_mfma(a, s));
+    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_fwd_geom(true).ntiles(L), 1.0, 0, logJ, s));
+    return FTHMC_OK;
+}
+
+int fthmc_plaq_coupling_fwd(const double* P, const double* w, int B, int L, int mu, int off, int act,
+                            double* fP, double* logJ, void* ws, size_t ws_bytes, void* stream) {
+    return plaq_coupling(P, w, B, L, mu, off, act, 0.0, false, fP, logJ, ws, ws_bytes, stream);
+}
+
+int fthmc_plaq_coupling_rev(const double* fP, const double* w, int B, int L, int mu, int off, int act,
+                            double tol, double* P, double* logJ, void* ws, size_t ws_bytes, void* stream) {
+    return plaq_coupling(fP, w, B, L, mu, off, act, tol, true, P, logJ, ws, ws_bytes, stream);
+}
+
 int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, const double* glogJ,
                          int B, int L, int mu, int off, int act, double* gx, double* gw, void* ws,
                          size_t ws_bytes, void* stream) {
@@ -360,15 +385,20 @@ int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, in
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
     double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
     if (hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
-    if (x != y && hipMemcpyAsync(x, y, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return FTHMC_ERR_LAUNCH;
+    // every layer runs out of place (ping-pong between two workspace fields): a workgroup reads a 3-site
+    // link halo that its neighbours' link updates would otherwise overwrite within the same launch
+    const double* src = y;
     for (int l = n_layers - 1; l >= 0; --l) {
+        double* dst = src == W.xa ? W.xb : W.xa;
         FlowLayerArgs a{};
-        a.x = x; a.wint = W.wint + (size_t)l * FLOW_WINT; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
+        a.x = src; a.wint = W.wint + (size_t)l * FLOW_WINT; a.y = dst; a.logj_part = W.lj_part; a.tol = tol;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
         FT_TRY(flow_rev(a, s));
         FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(false).ntiles(L), 1.0, 1, ld, s));
+        src = dst;
     }
+    if (src != x && hipMemcpyAsync(x, src, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return FTHMC_ERR_LAUNCH;
     return FTHMC_OK;
 }
 
@@ -491,8 +521,6 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 3) return FTHMC_ERR_ARG;
     if (kind < 2 && !w) return FTHMC_ERR_ARG;
     FT_WS(1);
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FlowLayerArgs a{};
     if (kind < 2) {
         FT_TRY(launch_pack_weights(w, 1, W.wint, s));
@@ -509,6 +537,10 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
         if (hipMemsetAsync(seeds, 0, (size_t)B * sizeof(int64_t), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
         FT_TRY(launch_random_momenta(seeds, B, 2 * L * L, W.va, nullptr, s));
     }
+    // the events are created after the last early return and destroyed on every path below
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return FTHMC_ERR_LAUNCH; }
     int rc = FTHMC_OK;
     for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
         if (it == 0) (void)hipEventRecord(e0, s);

@@ -58,6 +58,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
     const double* __restrict__ x0 = uniform_ptr(A.x, (size_t)b * 2 * n);
     const double* __restrict__ x1 = x0 + n;
+    // plaquette-level map (NCPPlaqCouplingLayer.forward / .reverse, layers.py:348-396): the plaquette field
+    // is the input (A.pin) and the output (A.pout) instead of being derived from / folded back into links
+    const double* __restrict__ pin = A.pin ? uniform_ptr(A.pin, (size_t)b * n) : nullptr;
     const double* __restrict__ w = A.wint;
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -66,9 +69,12 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
     const unsigned fastw = FASTW ? 0u : wrap_magic(L);
     // the tile's own links for the final link update: issued now, consumed in the last stage
     double xv0 = 0.0, xv1 = 0.0;
-    if (A.y && tid < N3) {
+    if ((A.y || A.pout) && tid < N3) {
         const int r = fdiv<TC>(tid), c = tid - r * TC;
-        if (i0 + r < L && j0 + c < L) { const unsigned at = (unsigned)(mul24(i0 + r, L) + j0 + c); xv0 = ldu(x0, at); xv1 = ldu(x1, at); }
+        if (i0 + r < L && j0 + c < L) {
+            const unsigned at = (unsigned)(mul24(i0 + r, L) + j0 + c);
+            if (pin) xv0 = ldu(pin, at); else { xv0 = ldu(x0, at); xv1 = ldu(x1, at); }
+        }
     }
 
     // ---- plaquette window + net input; small weights -> LDS ------------------
@@ -77,7 +83,8 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
         const int r = fdiv<R0C>(tid), c = tid - r * R0C;
         const int iL = mul24(wrap_line<FASTW>(i0 - 3 + r, L, fastw), L), ipL = mul24(wrap_line<FASTW>(i0 - 2 + r, L, fastw), L);
         const int j = wrap_line<FASTW>(j0 - 3 + c, L, fastw), jp = wrap_line<FASTW>(j0 - 2 + c, L, fastw);
-        const double p = ldu(x0, (unsigned)(iL + j)) - ldu(x1, (unsigned)(iL + j)) - ldu(x0, (unsigned)(iL + jp)) + ldu(x1, (unsigned)(ipL + j));
+        const double p = pin ? ldu(pin, (unsigned)(iL + j))
+                             : ldu(x0, (unsigned)(iL + j)) - ldu(x1, (unsigned)(iL + j)) - ldu(x0, (unsigned)(iL + jp)) + ldu(x1, (unsigned)(ipL + j));
         const int sel = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;          // stripe class (L % 4 == 0)
         const bool frozen = (sel == 1 || sel == 2);
         // one sincos per thread: of P where the plaquette is frozen (the net input), of P / 2 at the tile's own
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
         //      safeguarded Newton (the map is monotone with derivative mean_k 1/D_k; the reference bisects
         //      to a global 1e-6, layers.py:294-320), started from the target (s ~ 0: identity) ------------
         if (wave == 0) {
-            double dl = 0.0, lj = 0.0;
+            double dl = 0.0, lj = 0.0, xsol = 0.0;
             if (alane) {
                 const double Pn = sP[(ar + 3) * R0C + ac + 3];
                 double sk[NMIX], tval = sW[CB2 + NMIX];
@@ -297,9 +304,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
                     xs = xn;
                 }
                 dl = xs - Pn;
+                xsol = xs;
                 lj = -(log(fp));                                     // log J of the inverse = -log mean_k 1/D_k at the root
             }
-            if (avalid) sDL[ar * TC + ac] = dl;
+            if (avalid) sDL[ar * TC + ac] = A.pout ? xsol : dl;
             if (A.logj_part) {
                 const double tot = ft_wave_sum(avalid ? lj : 0.0);
                 if (lane == 0) A.logj_part[(size_t)b * ntiles + tile] = tot;
@@ -319,6 +327,11 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
                 const int at = mul24(i, L) + j;
                 y0[at] = v0; y0[n + at] = v1;
             }
+        }
+        if (A.pout && tid < N3) {                                    // plaquette-level inverse: x1 at the active sites, fx elsewhere
+            const int r = fdiv<TC>(tid), c = tid - r * TC;
+            const int i = i0 + r, j = j0 + c;
+            if (i < L && j < L) A.pout[(size_t)b * n + mul24(i, L) + j] = ft_stripe(i, j, mu, off) == 0 ? sDL[tid] : xv0;
         }
         return;
     }
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
             for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * TQ) * NAS + (lane & (NAS - 1))]; si += sT2[(k * TQ + 1) * NAS + (lane & (NAS - 1))]; }
             const double tval = sP[(ar + 3) * R0C + ac + 3 + 3 * (mu == 0 ? 1 : R0C)];
             const double newP = ft_wrap(ysum / NMIX + tval);
-            if (avalid) sDL[ar * TC + ac] = newP - Pa;
+            if (avalid) sDL[ar * TC + ac] = A.pout ? newP : newP - Pa;
             if (A.logj_part) {                                       // force sweeps do not ask for log J
                 const double lj = avalid ? log(si) - log((double)NMIX) : 0.0;
                 const double tot = ft_wave_sum(lj);
@@ -388,6 +401,11 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
                 const int at = mul24(i, L) + j;
                 y0[at] = v0; y0[n + at] = v1;
             }
+        }
+        if (A.pout && tid < N3) {                                    // plaquette-level map: P' at the active sites, P elsewhere
+            const int r = fdiv<TC>(tid), c = tid - r * TC;
+            const int i = i0 + r, j = j0 + c;
+            if (i < L && j < L) A.pout[(size_t)b * n + mul24(i, L) + j] = ft_stripe(i, j, mu, off) == 0 ? sDL[tid] : xv0;
         }
         STAMP(6);
     }

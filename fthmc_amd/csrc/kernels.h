@@ -66,6 +66,8 @@ struct FlowLayerArgs {
     const double* x;         // [B][2][L][L] layer input
     const double* wint;      // this layer's weights, kernel layout
     double* y;               // fwd / rev: output field (may alias x)
+    const double* pin;       // fwd / rev, plaquette-level map: input plaquette field [B][L][L] (then x is unused)
+    double* pout;            // fwd / rev, plaquette-level map: output plaquette field [B][L][L]
     double* logj_part;       // fwd / rev: [B][ntiles]
     const double* up_link;   // bwd: upstream link gradient [B][2][L][L] or null
     const double* up_gp;     // bwd: upstream plaquette-gradient field [B][L][L] or null

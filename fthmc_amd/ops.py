@@ -10,7 +10,8 @@ import torch
 from . import _lib
 from ._lib import ACT_CODES, MODE_LITERAL, MODE_MD, W_PER_LAYER, FthmcError, check
 
-_WS = {}       # (device index) -> workspace tensor (grown on demand)
+_WS = {}           # (device index, stream) -> workspace tensor (grown on demand)
+_WS_RETIRED = []   # superseded workspaces, kept alive: a captured hipGraph may still point into them
 
 
 def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -51,9 +52,24 @@ def _ws(t: torch.Tensor, B: int, L: int, nl: int, train: bool = False):
     key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() * 8 < need:
+        if torch.cuda.is_current_stream_capturing():
+            # an allocation made here would come from the graph's private pool and the pointer would be
+            # baked into the graph while later eager calls keep using (or replace) the buffer
+            raise FthmcError(f'the workspace of this stream would have to be {"allocated" if buf is None else "grown"} '
+                             f'({need} bytes) during graph capture: run the same call once eagerly on this stream '
+                             f'first (warm-up), then capture')
+        if buf is not None:
+            _WS_RETIRED.append(buf)        # a graph captured earlier on this stream replays into it
         buf = torch.empty((need + 7) // 8, dtype=torch.float64, device=t.device)
         _WS[key] = buf
     return buf.data_ptr(), buf.numel() * 8
+
+
+def release_workspaces():
+    """Drop every cached workspace (current and superseded).  Only when no captured graph that used them will
+    be replayed again."""
+    _WS.clear()
+    _WS_RETIRED.clear()
 
 
 def set_variant(v: int):
@@ -222,6 +238,35 @@ def flow_layer_rev(y, w, mu: int, off: int, act='silu', tol: float = 1e-12):
     check(_lib.load().fthmc_flow_layer_rev(_p(y), _p(w), B, L, int(mu), int(off), act_code(act), float(tol),
                                            _p(x), _p(logJ), ws, nb, _stream(y)), 'fthmc_flow_layer_rev')
     return x, logJ
+
+
+def _plaq_field(P, name='P'):
+    P = _dev(P, name)
+    if P.dim() != 3 or P.shape[1] != P.shape[2] or P.shape[1] % 4 != 0:
+        raise FthmcError(f'{name}: expected a plaquette field [B, L, L] with L % 4 == 0, got {tuple(P.shape)}')
+    return P
+
+
+def plaq_coupling_fwd(P, w, mu: int, off: int, act='silu'):
+    """NCPPlaqCouplingLayer.forward on a plaquette field [B, L, L] -> (fP, logJ[B])."""
+    P = _plaq_field(P); B, L, _ = P.shape
+    w = _w1(w, P)
+    fP = torch.empty_like(P); logJ = torch.empty(B, dtype=P.dtype, device=P.device)
+    ws, nb = _ws(P, B, L, 1)
+    check(_lib.load().fthmc_plaq_coupling_fwd(_p(P), _p(w), B, L, int(mu), int(off), act_code(act), _p(fP), _p(logJ),
+                                              ws, nb, _stream(P)), 'fthmc_plaq_coupling_fwd')
+    return fP, logJ
+
+
+def plaq_coupling_rev(fP, w, mu: int, off: int, act='silu', tol: float = 1e-12):
+    """NCPPlaqCouplingLayer.reverse on a plaquette field [B, L, L] -> (P, logJ[B])."""
+    fP = _plaq_field(fP, 'fP'); B, L, _ = fP.shape
+    w = _w1(w, fP)
+    P = torch.empty_like(fP); logJ = torch.empty(B, dtype=fP.dtype, device=fP.device)
+    ws, nb = _ws(fP, B, L, 1)
+    check(_lib.load().fthmc_plaq_coupling_rev(_p(fP), _p(w), B, L, int(mu), int(off), act_code(act), float(tol),
+                                              _p(P), _p(logJ), ws, nb, _stream(fP)), 'fthmc_plaq_coupling_rev')
+    return P, logJ
 
 
 # ---------------------------------------------------------------- whole flow

@@ -47,7 +47,9 @@ def get_model(config: TrainConfig) -> FlowModel:
 
 def restore_model_from_checkpoint(infile, train_config: TrainConfig):
     """train.py:77-92 (same checkpoint dict keys as io.save_checkpoint, io.py:148-170)."""
-    checkpoint = torch.load(infile, map_location=device())
+    # the history inside the .tar holds numpy arrays (train_step returns grab(...)): a trusted, self-written file,
+    # loaded like the reference does (torch >= 2.6 defaults to weights_only=True, which rejects numpy pickles)
+    checkpoint = torch.load(infile, map_location=device(), weights_only=False)
     model = get_model(train_config)
     optimizer = optim.AdamW(model.layers.parameters(), lr=train_config.base_lr, weight_decay=1e-5)
     model.layers.load_state_dict(checkpoint['model_state_dict'])

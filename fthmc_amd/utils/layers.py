@@ -174,8 +174,26 @@ class NCPPlaqCouplingLayer(nn.Module):
         self.net = net
         self.inv_prec, self.inv_max_iter = inv_prec, inv_max_iter
 
+    @property
+    def activation_fn(self):
+        return getattr(self.net, 'activation_fn', 'silu')
+
+    def _w(self, dev):
+        return ops.pack_weights([net_weights(self.net)], device=dev)
+
     def forward(self, x):
-        raise NotImplementedError('the plaquette-level map runs fused inside GaugeEquivCouplingLayer on the GPU')
+        """layers.py:348-371 on a plaquette field [B, L, L] -> (fx, logJ[B]).  No autograd at this level: the
+        differentiable path is GaugeEquivCouplingLayer (the only caller in the reference, layers.py:196-202)."""
+        if x.requires_grad:
+            raise NotImplementedError('autograd runs through GaugeEquivCouplingLayer.forward (link level)')
+        assert len(x.shape) == 3, f'field should be (batch_size, *lattice_shape); got {tuple(x.shape)}'
+        return ops.plaq_coupling_fwd(x, self._w(x.device), self.mask_mu, self.mask_off, self.activation_fn)
+
+    def reverse(self, fx, tol: float = 1e-12):
+        """layers.py:373-396 -> (x, logJ[B]); per-site Newton to `tol` instead of the global bisection to
+        `inv_prec` = 1e-6."""
+        return ops.plaq_coupling_rev(fx.detach(), self._w(fx.device), self.mask_mu, self.mask_off,
+                                     self.activation_fn, tol=tol)
 
 
 class GaugeEquivCouplingLayer(nn.Module):

@@ -1,5 +1,6 @@
 """fthmc/utils/qed_helpers.py on the HIP kernels: plaquettes, Wilson action, topological
-charge, plain force / leapfrog / HMC, flow drivers, ft_action, ft_force."""
+charge, plain force / leapfrog / HMC, flow drivers, ft_action, ft_force, and the notebook's
+physical-field ftHMC wrapper (ipynb/ft_hmc.py:420-513: ft_hmc, ft_run, flow_resize)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -195,3 +196,75 @@ def hmc(param, x, verbose=True, v: Optional[torch.Tensor] = None, u: Optional[to
     acc = u < exp_mdH
     newx = xr if bool(acc) else xb
     return dH, exp_mdH, acc, newx.reshape(x.shape)
+
+
+# ---------------------------------------------------------------- ftHMC on the physical field
+def ft_hmc(param, flow, field: torch.Tensor, v: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None,
+           tol: float = 1e-12):
+    """ipynb/ft_hmc.py:420-435: one ftHMC trajectory that starts and ends on the PHYSICAL field:
+    x = F^-1(field); momenta; leapfrog in the latent field with ft_force (`:394-418`); xr = regularize(x_);
+    accept on u < exp(-dH); return F(newx).  Like the notebook the whole tensor is ONE system (one H,
+    one accept; the notebook always passes [1, 2, L, L]).  -> (dH, exp_mdH, acc, newfield).
+
+    `v`, `u` may be supplied for reproducible checks (the notebook draws randn_like(x), then rand([])).
+    `tol`: tolerance of the inverse flow (the reference bisects to a global 1e-6)."""
+    fb = _batched(field)
+    w, nl, act = flow_weights(flow, fb.device), len(flow), flow_activation(flow)
+    x = ops.flow_reverse(fb, w, nl, act, tol=tol)[0]
+    if v is None:
+        v = torch.randn_like(x)
+    if u is None:
+        u = torch.rand([], dtype=torch.float64, device=x.device)
+    vb = _batched(v)
+    if x.shape[0] == 1:
+        r = ops.ft_trajectory(x, vb, u.reshape(1), w, nl, param.beta, param.dt, param.nstep, act, mode='md')
+        dH, acc, newx = r['dH'][0], r['acc'][0] > 0.5, r['x_new']
+    else:
+        h0 = ops.ft_action(x, w, nl, param.beta, act)[0].sum() + 0.5 * ops.kinetic(vb).sum()
+        x_, v_ = ops.ft_leapfrog(x, vb, w, nl, param.beta, param.dt, param.nstep, act)
+        xr = ops.regularize(x_)
+        dH = ops.ft_action(xr, w, nl, param.beta, act)[0].sum() + 0.5 * ops.kinetic(v_).sum() - h0
+        acc = u < torch.exp(-dH)
+        newx = xr if bool(acc) else x
+    exp_mdH = torch.exp(-dH)
+    newfield = ops.flow_forward(newx, w, nl, act)[0]
+    return float(dH), float(exp_mdH), acc, newfield.reshape(field.shape)
+
+
+def ft_run(param, flow, field: Optional[torch.Tensor] = None, logfile: Optional[str] = None, verbose: bool = False):
+    """ipynb/ft_hmc.py:437-487: `param.nrun` x `param.ntraj` physical-field ftHMC trajectories of one
+    configuration [2, L, L].  Returns (field, history) with per-trajectory dH, exp_mdH, acc, plaq, topo
+    (the notebook returns the field and keeps the histories in module globals); the status lines it prints
+    go to `logfile` when given."""
+    if field is None:
+        field = param.initializer()[0]
+    history = {k: [] for k in ('dH', 'exp_mdH', 'acc', 'plaq', 'topo')}
+    out = open(logfile, 'w') if logfile else None
+
+    def put(s):
+        if out is not None:
+            out.write(s)
+        if verbose:
+            print(s, end='', flush=True)
+    try:
+        S, Q, plaq = ops.wilson_action_charge(_batched(field), param.beta)
+        put(f'Initial configuration:  plaq: {float(plaq[0])}  topo: {float(Q[0])} {tuple(field.shape)}\n')
+        for n in range(param.nrun):
+            for i in range(param.ntraj):
+                dH, exp_mdH, acc, field_run = ft_hmc(param, flow, field.reshape((1,) + tuple(field.shape[-3:])))
+                field = field_run[0]
+                S, Q, plaq = ops.wilson_action_charge(field_run, param.beta)
+                for k, val in zip(history, (dH, exp_mdH, float(bool(acc)), float(plaq[0]), float(Q[0]))):
+                    history[k].append(val)
+                put(f'Traj: {n * param.ntraj + i + 1:4}  {"ACCEPT" if bool(acc) else "REJECT"}  dH: {dH:< 12.8}  '
+                    f'exp(-dH): {exp_mdH:< 12.8}  plaq: {float(plaq[0]):< 12.8}  topo: {float(Q[0]):< 3.3}\n')
+    finally:
+        if out is not None:
+            out.close()
+    return field, history
+
+
+def flow_resize(flow: nn.ModuleList, lat_new):
+    """ipynb/ft_hmc.py:489-513: the same (translation-equivariant) conv nets with masks of another lattice."""
+    from .layers import get_nets, make_net_from_layers
+    return make_net_from_layers(lattice_shape=tuple(lat_new), nets=get_nets(flow))

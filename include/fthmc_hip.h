@@ -132,6 +132,16 @@ int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu,
                          int act, double tol, double* x, double* logJ,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* Plaquette-level coupling map on a plaquette field P[B][L][L] (no links involved):
+ * (fP, logJ[B]) = NCPPlaqCouplingLayer.forward(P): fthmc/utils/layers.py:348-371 -- P' at the active
+ * plaquettes, P at the frozen and passive ones; and its inverse NCPPlaqCouplingLayer.reverse(fP):
+ * fthmc/utils/layers.py:373-396 (logJ of the inverse = -sum log dP'/dP; `tol` as fthmc_flow_layer_rev).
+ * Served by the MFMA kernels only (FTHMC_ERR_UNSUPPORTED with fthmc_set_variant(0)).  logJ may be NULL. */
+int fthmc_plaq_coupling_fwd(const double* P, const double* w, int B, int L, int mu, int off, int act,
+                            double* fP, double* logJ, void* ws, size_t ws_bytes, void* stream);
+int fthmc_plaq_coupling_rev(const double* fP, const double* w, int B, int L, int mu, int off, int act,
+                            double tol, double* P, double* logJ, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- whole flow ---------------------------------------------------------- */
 /* y = F(x), logdet[B] = sum_l logJ_l.  fthmc/ft_hmc.py:143-150 (flow_forward),
  * fthmc/utils/qed_helpers.py:191-198 (ft_flow).  y, logdet may be NULL. */

@@ -369,6 +369,51 @@ def ft_hmc(x, v, u, flow, beta, dt, nstep, act='silu', mode='md', joint=False):
     return dH, exp_mdH, acc, newx, h0, h1
 
 
+def ft_hmc_phys(field, v, u, flow, beta, dt, nstep, act='silu', tol=1e-6, max_iter=1000):
+    """One ftHMC trajectory on the PHYSICAL field (ipynb/ft_hmc.py:420-435): x = F^-1(field) by the
+    reference's bisection (`tol` = layer.inv_prec, global stop rule), momenta `v` and uniform `u` as drawn
+    there (randn_like(x), rand([])), trajectory of the whole tensor as ONE system, newfield = F(newx).
+    Returns (dH, exp(-dH), acc, newfield, x)."""
+    with torch.no_grad():
+        x = flow_reverse(field, flow, act, tol, max_iter)[0]
+    dH, exp_mdH, acc, newx, _, _ = ft_hmc(x, v, u, flow, beta, dt, nstep, act, mode='md', joint=True)
+    with torch.no_grad():
+        newfield = flow_forward(newx, flow, act)[0]
+    return dH, exp_mdH, acc, newfield, x
+
+
+# --------------------------------------------------------------------------
+# flow-proposal independence Metropolis                       (SURVEY 8f: 3)
+# --------------------------------------------------------------------------
+def mcmc_chain(proposals, uniforms):
+    """Accept chain of samplers.make_mcmc_ensemble (samplers.py:182-259) on recorded proposals
+    [(x, logq, logp)] and the uniforms of steps 1, 2, ...: the first proposal is accepted, afterwards
+    `draw < min(1, exp((logp' - logq') - (logp - logq)))`; q = topological charge of the current
+    configuration, dqsq = (q - q_previous)^2.  Returns dict of float64 lists q, dqsq, logq, logp, acc."""
+    hist = {k: [] for k in ('q', 'dqsq', 'logq', 'logp', 'acc')}
+    xarr = []
+    draws = iter(uniforms)
+    for x_new, logq_new, logp_new in proposals:
+        if not hist['logp']:
+            accepted = True
+            q_old = charge(x_new[None])
+        else:
+            q_old = charge(xarr[-1][None])
+            logp_old, logq_old = hist['logp'][-1], hist['logq'][-1]
+            p_accept = min(1, torch.exp((logp_new - logq_new) - (logp_old - logq_old)))
+            if next(draws) < p_accept:
+                accepted = True
+            else:
+                accepted = False
+                x_new, logp_new, logq_new = xarr[-1], logp_old, logq_old
+        q_new = charge(x_new[None])
+        xarr.append(x_new)
+        for k, val in (('q', q_new), ('dqsq', (q_new - q_old) ** 2), ('logp', logp_new), ('logq', logq_new),
+                       ('acc', float(accepted))):
+            hist[k].append(val)
+    return {k: [float(v) for v in vals] for k, vals in hist.items()}
+
+
 # --------------------------------------------------------------------------
 # training step math                                         (SURVEY 8a: a17)
 # --------------------------------------------------------------------------

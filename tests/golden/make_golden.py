@@ -54,6 +54,11 @@ def _stub_modules():
 
 
 def main():
+    # `--only a,b`: write only the fixtures whose name starts with one of the prefixes (the others are
+    # still computed, so every section sees the RNG state it always saw)
+    only = None
+    if '--only' in sys.argv:
+        only = tuple(sys.argv[sys.argv.index('--only') + 1].split(','))
     sys.dont_write_bytecode = True
     sys.path.insert(0, REF)
     import torch
@@ -90,6 +95,8 @@ def main():
         return d
 
     def save(name, **arrs):
+        if only is not None and not name.startswith(only):
+            return
         path = os.path.join(OUT, name + '.npz')
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
         print(f'{name}: {os.path.getsize(path)/1024:.1f} KiB')
@@ -274,6 +281,92 @@ def main():
     save('masks', **d)
     d = {f'{b}': v for b, v in cfg.PLAQ_EXACT.items()}
     save('plaq_exact', betas=np.array(list(cfg.PLAQ_EXACT.keys())), values=np.array(list(cfg.PLAQ_EXACT.values())))
+
+    # ---- 8. physical-field ftHMC (ipynb/ft_hmc.py:420-435: ft_flow_inv -> trajectory -> ft_flow), composed
+    #         from the packaged functions (the notebook module runs an experiment at import: not imported).
+    #         'ref': the reference's own inverse tolerance (bisection to a global 1e-6);
+    #         'tight': the same layers with inv_prec = 1e-14 (bisection down to floating-point resolution)
+    for (L, beta, nl, tau, nstep, seed) in [(8, 2.0, 4, 1.0, 10, 1500), (16, 4.0, 4, 0.5, 5, 1516)]:
+        for tag, inv_prec in (('ref', None), ('tight', 1e-14)):
+            flow = make_flow(nl, L, seed)
+            if inv_prec is not None:
+                for layer in flow:
+                    layer.plaq_coupling.inv_prec = inv_prec
+            param = cfg.Param(beta=beta, L=L, tau=tau, nstep=nstep)
+            torch.manual_seed(seed + 1)
+            field = torch.empty(1, 2, L, L).uniform_(-math.pi, math.pi)
+            with torch.no_grad():
+                x = qed.ft_flow_inv(flow, field)
+            torch.manual_seed(seed + 2)
+            p = torch.randn_like(x)
+            u = torch.rand([], dtype=torch.float64)                 # drawn after the leapfrog in the notebook; it
+            dt = param.dt                                            # consumes no random numbers in between
+            with torch.no_grad():
+                act0 = qed.ft_action(param, flow, x) + 0.5 * torch.sum(p * p)
+            x_ = x + 0.5 * dt * p
+            p_ = p + (-dt) * qed.ft_force(param, flow, x_)
+            for _ in range(nstep - 1):
+                x_ = x_ + dt * p_
+                p_ = p_ + (-dt) * qed.ft_force(param, flow, x_)
+            x_ = x_ + 0.5 * dt * p_
+            xr = qed.regularize(x_)
+            with torch.no_grad():
+                act = qed.ft_action(param, flow, xr) + 0.5 * torch.sum(p_ * p_)
+                dH = act - act0
+                exp_mdH = torch.exp(-dH)
+                acc = u < exp_mdH
+                newx = xr if bool(acc) else x
+                newfield = qed.ft_flow(flow, newx)
+                prop_field = qed.ft_flow(flow, xr)
+            S = qed.BatchAction(beta)(newfield)
+            save(f'fthmc_phys_L{L}_{tag}', field=npy(field), x_inv=npy(x), v=npy(p), u=npy(u), beta=beta, dt=dt,
+                 nstep=nstep, dH=npy(dH), exp_mdH=npy(exp_mdH), acc=np.bool_(bool(acc)), newx=npy(newx),
+                 newfield=npy(newfield), prop_field=npy(prop_field), plaq=npy(-S / (beta * L * L)),
+                 Q=npy(qed.batch_charges(newfield)), **flow_arrays(flow))
+
+    # ---- 9. flow-proposal independence Metropolis (samplers.make_mcmc_ensemble, samplers.py:182-259) with the
+    #         proposals and the uniforms of the accept chain recorded.  NOTE the reference's generator
+    #         (samplers.py:123-137) unpacks `_, x, logq = apply_flow_to_prior(...)` although that function
+    #         returns (x, xi, logq): its proposals are the PRIOR draws xi with logp = -S(xi).  Both are kept.
+    for (L, beta, nl, bs, nsamp, seed) in [(8, 2.0, 4, 8, 40, 1600)]:
+        tc = cfg.TrainConfig(L=L, beta=beta, debug=True, n_layers=nl, batch_size=bs)
+        torch.manual_seed(seed)
+        model = train.get_model(tc)
+        action = qed.BatchAction(beta)
+        rec = {'xi': [], 'xflow': [], 'logq': [], 'u': []}
+        real_apply, real_rand = samplers.apply_flow_to_prior, torch.rand
+
+        def rec_apply(prior, layers_, *, batch_size, xi=None):
+            x_, xi_, logq_ = real_apply(prior, layers_, batch_size=batch_size, xi=xi)
+            rec['xi'].append(npy(xi_)); rec['xflow'].append(npy(x_)); rec['logq'].append(npy(logq_))
+            return x_, xi_, logq_
+
+        def rec_rand(*a, **k):
+            out = real_rand(*a, **k)
+            if a == (1,) and not k:
+                rec['u'].append(float(out))
+            return out
+        samplers.apply_flow_to_prior = rec_apply
+        torch.rand = rec_rand
+        try:
+            torch.manual_seed(seed + 1)
+            hist = samplers.make_mcmc_ensemble(model, action, bs, nsamp)
+        finally:
+            samplers.apply_flow_to_prior = real_apply
+            torch.rand = real_rand
+        xi_all = np.concatenate(rec['xi']); xf_all = np.concatenate(rec['xflow'])
+        with torch.no_grad():
+            logp_xi = -action(torch.from_numpy(xi_all))              # what the reference's chain uses
+            logp_flow = -action(torch.from_numpy(xf_all))            # -S(F(xi)): the intended proposal weight
+            q_xi = qed.batch_charges(torch.from_numpy(xi_all))
+            q_flow = qed.batch_charges(torch.from_numpy(xf_all))
+        assert len(rec['u']) == nsamp - 1
+        save(f'sampler_L{L}', xi=xi_all[:nsamp], xflow=xf_all[:nsamp], logq=np.concatenate(rec['logq'])[:nsamp],
+             logp_xi=npy(logp_xi)[:nsamp], logp_flow=npy(logp_flow)[:nsamp], q_xi=npy(q_xi)[:nsamp],
+             q_flow=npy(q_flow)[:nsamp], u=np.array(rec['u']), beta=beta, batch_size=bs,
+             hist_q=np.asarray(hist['q'], dtype=np.float64), hist_dqsq=np.asarray(hist['dqsq'], dtype=np.float64),
+             hist_logq=np.asarray(hist['logq'], dtype=np.float64), hist_logp=np.asarray(hist['logp'], dtype=np.float64),
+             hist_acc=np.asarray(hist['acc'], dtype=np.float64), **flow_arrays(model.layers))
 
 
 if __name__ == '__main__':

@@ -222,3 +222,35 @@ def test_committed_bench_line_follows_the_contract():
     # value = chains x leapfrog steps x trajectories / time
     cfg = d['config']
     assert abs(d['value'] - cfg['chains_total'] * cfg['nstep'] / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-3
+
+
+def test_independence_sampler_accept_chain_on_recorded_reference_run():
+    """Host logic of utils.samplers.make_mcmc_ensemble: the recorded proposals and uniforms of a reference run
+    (tests/golden/make_golden.py section 9) give the reference's accept sequence and histories."""
+    from fthmc_amd.utils import samplers as S
+    g = load_golden('sampler_L8')
+    n = len(g['logq'])
+    props = [(torch.from_numpy(g['xi'][i]), torch.tensor(g['logq'][i]), torch.tensor(g['logp_xi'][i]),
+              torch.tensor(g['q_xi'][i])) for i in range(n)]
+    h = S.make_mcmc_ensemble(None, None, int(g['batch_size']), n, proposals=props, uniforms=list(g['u']), keep_x=True)
+    assert np.array_equal(h['acc'], g['hist_acc'])
+    for k in ('q', 'dqsq', 'logq', 'logp'):
+        np.testing.assert_allclose(h[k], g['hist_' + k], rtol=2e-7, atol=1e-6)     # float32 reference histories
+    assert h['x'].shape == (n, 2, 8, 8)
+    rej = np.where(g['hist_acc'] == 0)[0]
+    assert len(rej) and all(torch.equal(h['x'][i], h['x'][i - 1]) for i in rej)    # a reject repeats the configuration
+
+
+def test_bench_launch_command_and_refusal_without_gpu():
+    """bench.py --gpus N: the parent builds a one-node torchrun command with N ranks; on a box without a GPU
+    the job fails loudly instead of printing a 1-GPU number."""
+    import bench
+    cmd = bench.launch_command(4, ['--gpus', '4', '--steps', '2'], 29511)
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=4' in cmd
+    assert cmd[-4:] == ['--gpus', '4', '--steps', '2'] and '127.0.0.1' in cmd
+    assert set(bench.CONFIGS) == {1, 2, 3, 5} and bench.CONFIGS[3]['B'] == 128 and bench.CONFIGS[5]['L'] == 256
+    if not torch.cuda.is_available():
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '0'],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and 'MI355X' in (p.stderr + p.stdout)

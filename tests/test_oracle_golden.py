@@ -179,3 +179,40 @@ def test_masks():
                 assert np.array_equal(mF.numpy(), g[k + 'frozen'])
                 assert np.array_equal(mP.numpy(), g[k + 'passive'])
                 assert np.array_equal(mL.numpy(), g[k + 'link'])
+
+
+@pytest.mark.parametrize('L', [8, 16])
+@pytest.mark.parametrize('tag,tol', [('ref', 1e-6), ('tight', 1e-14)])
+def test_physical_field_fthmc(L, tag, tol):
+    """ipynb/ft_hmc.py:420-435 composed from the packaged reference functions: the oracle reproduces the
+    reference's own inverse (same bisection, same stop rule), so both tolerances agree tightly."""
+    g = load_golden(f'fthmc_phys_L{L}_{tag}')
+    flow = golden_flow(g)
+    dH, e, acc, newfield, x = R.ft_hmc_phys(T(g['field']), T(g['v']), T(g['u']), flow, float(g['beta']), float(g['dt']),
+                                            int(g['nstep']), tol=tol)
+    angle_close(x, g['x_inv'], atol=1e-12)
+    close(dH, g['dH'], rtol=1e-8, atol=1e-9)
+    close(e, g['exp_mdH'], rtol=1e-8)
+    assert bool(acc) == bool(g['acc'])
+    angle_close(newfield, g['newfield'], atol=1e-9)
+    close(R.plaq_mean(newfield, float(g['beta'])), g['plaq'], rtol=1e-10)
+    close(R.charge(newfield), g['Q'], atol=1e-9)
+
+
+def test_independence_sampler_chain():
+    """samplers.make_mcmc_ensemble (samplers.py:182-259) replayed on its recorded proposals and uniforms.
+    The reference's generator proposes the PRIOR draws (see make_golden.py section 9): proposals =
+    (xi, logq, -S(xi)); its histories are float32 (torch.Tensor(v))."""
+    g = load_golden('sampler_L8')
+    beta, flow = float(g['beta']), golden_flow(g)
+    xi = T(g['xi'])
+    xf, logdet = R.flow_forward(xi, flow)
+    angle_close(xf, g['xflow'], atol=1e-12)
+    close(R.prior_log_prob(xi) - logdet, g['logq'], rtol=1e-12)
+    close(-R.action(xi, beta), g['logp_xi'], rtol=1e-12)
+    close(-R.action(xf, beta), g['logp_flow'], rtol=1e-12)
+    h = R.mcmc_chain(list(zip(xi, T(g['logq']), T(g['logp_xi']))), list(g['u']))
+    assert np.array_equal(np.array(h['acc']), g['hist_acc'])
+    assert 0 < np.sum(g['hist_acc']) < len(g['hist_acc'])            # the fixture holds accepts and rejects
+    for k in ('q', 'dqsq', 'logq', 'logp'):
+        close(h[k], g['hist_' + k], rtol=2e-7, atol=1e-6)            # float32 histories

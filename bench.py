@@ -434,14 +434,17 @@ def main():
         gs = torch.Generator(device='cpu').manual_seed(SEED + 99)
         vs = torch.randn(nb, 2, L, L, generator=gs, dtype=torch.float64)
         us = torch.rand(nb, generator=gs, dtype=torch.float64)
-        reps = 3 if args.config in (1, 2) else 1
-        log(f'cpu baseline: {nb} chain(s) on {nthr} threads x{reps}, then {nb1} chain(s) on 1 thread ...')
-        times = []
-        for _ in range(reps):
-            tc, oc = cpu_leg(R, cfg, flow, xs, vs, us, dt, NSTEP, nthr)
-            times.append(tc)
-        tc = sorted(times)[len(times) // 2]
-        t1thr, _ = cpu_leg(R, cfg, flow, xs[:nb1], vs[:nb1], us[:nb1], TAU / NSTEP, nstep1, 1)
+        log(f'cpu baseline: {nb} chain(s) on {nthr} threads, then {nb1} chain(s) on 1 thread ...')
+
+        def timed(xs_, vs_, us_, nstep_, thr):
+            """median trajectory time over repeats that add up to ~5 s (at least 3 when a trajectory is short)"""
+            t, o = cpu_leg(R, cfg, flow, xs_, vs_, us_, dt, nstep_, thr)
+            ts = [t]
+            while sum(ts) < 5.0 and len(ts) < 400 and (t < 2.0 or len(ts) < 3):
+                ts.append(cpu_leg(R, cfg, flow, xs_, vs_, us_, dt, nstep_, thr)[0])
+            return sorted(ts)[len(ts) // 2], o, len(ts)
+        tc, oc, reps = timed(xs, vs, us, NSTEP, nthr)
+        t1thr, _, reps1 = timed(xs[:nb1], vs[:nb1], us[:nb1], nstep1, 1)
         torch.set_num_threads(nthr)
         log(f'cpu baseline done: {tc:.1f} s on {nthr} threads, {t1thr:.1f} s on 1 thread')
         # the same sample through the HIP path
@@ -475,9 +478,9 @@ def main():
             'value': round(nb * NSTEP / tc, 3), 'unit': 'chain-leapfrog-steps/s',
             'cores': nthr, 'kind': 'port',
             'sample': f'one trajectory ({NSTEP} leapfrog steps + H0/H1) of {nb} of the {B} chains, '
-                      f'oracle/ref_cpu.py (PyTorch CPU fp64 autograd), median of {reps}: {tc:.2f} s',
+                      f'oracle/ref_cpu.py (PyTorch CPU fp64 autograd), median of {reps}: {tc:.4g} s',
             'one_thread': {'value': round(nb1 * nstep1 / t1thr, 3), 'cores': 1,
-                           'sample': f'{nstep1} leapfrog steps + H0/H1 of {nb1} chain(s): {t1thr:.2f} s'},
+                           'sample': f'{nstep1} leapfrog steps + H0/H1 of {nb1} chain(s), median of {reps1}: {t1thr:.4g} s'},
             'parity': par,
         }
 

@@ -15,7 +15,8 @@ import torch  # noqa: F401  (keep before the CDLL below)
 from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfthmc_hip.so')
+# FTHMC_LIB: another build of the same library (A/B kernel measurements in one run on one device)
+LIB_PATH = os.environ.get('FTHMC_LIB') or os.path.join(_HERE, 'libfthmc_hip.so')
 
 W_PER_LAYER = 955
 ACT_CODES = {None: 0, 'silu': 0, 'swish': 0, 'relu': 1, 'leaky_relu': 2}

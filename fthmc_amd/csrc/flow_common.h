@@ -35,31 +35,8 @@ constexpr int WCAN_SIZE = 960;
 constexpr int WZERO = CB2 + 4;        // a 0.0 inside the canonical copy (index 956)
 static_assert(WCAN + WCAN_SIZE <= FLOW_WINT, "weight layout");
 
-// exp(-a) for a >= 0: range reduction by ln2 (hi/lo split) + degree-13 Taylor (|r| <= ln2/2:
-// truncation 4e-18) + v_ldexp.  ~20 dependent DP ops instead of ocml exp's ~60, < 1.5 ulp.
-__device__ __forceinline__ double ft_exp_neg(double a) {
-    a = fmin(a, 745.0);
-    const double n = rint(a * 1.4426950408889634074);
-    double r = fma(n, 6.93147180369123816490e-01, -a);
-    r = fma(n, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;               // 1/13!
-    p = fma(p, r, 2.0876756987868100e-09);           // 1/12!
-    p = fma(p, r, 2.5052108385441720e-08);           // 1/11!
-    p = fma(p, r, 2.7557319223985888e-07);           // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);           // 1/9!
-    p = fma(p, r, 2.4801587301587302e-05);           // 1/8!
-    p = fma(p, r, 1.9841269841269841e-04);           // 1/7!
-    p = fma(p, r, 1.3888888888888889e-03);           // 1/6!
-    p = fma(p, r, 8.3333333333333332e-03);           // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);           // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);           // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, -(int)n);
-}
-
-// exp(x) for either sign (|x| clamped to the finite range): same scheme as ft_exp_neg.
+// exp(x) for either sign (|x| clamped to the finite range): range reduction by ln2 (hi/lo split) + degree-13
+// Taylor (|r| <= ln2/2: truncation 4e-18) + v_ldexp.  ~20 dependent DP ops instead of ocml exp's ~60, < 1.5 ulp.
 __device__ __forceinline__ double ft_exp(double x) {
     x = fmin(fmax(x, -745.0), 709.0);
     const double n = rint(x * 1.4426950408889634074);
@@ -109,22 +86,44 @@ __device__ __forceinline__ void ft_expN(const double (&xin)[N], double (&e)[N]) 
     for (int q = 0; q < N; ++q) e[q] = ldexp(p[q], (int)n[q]);
 }
 
-// sigmoid(z) = 1 / (1 + exp(-z)) without overflow or cancellation; reciprocal by v_rcp_f64 +
-// two Newton steps (no div_scale / div_fmas / div_fixup chain).
+// exp(r) on |r| <= ln2/2: degree-11 polynomial with c0 = c1 = 1 pinned (near-minimax: Chebyshev-node fit of
+// (exp(r) - 1 - r) / r^2, tools/minimax_exp.py): relative error 1.6e-17 in exact arithmetic (degree-13 Taylor: 4e-18,
+// two FMAs more per value).
+#define FT_EXP11(p, r)                                   \
+    p = fma(2.5100375832561234e-08, r, 2.7620075879983367e-07); \
+    p = fma(p, r, 2.7557268480310024e-06);               \
+    p = fma(p, r, 2.4801521322368692e-05);               \
+    p = fma(p, r, 0.00019841269863040545);               \
+    p = fma(p, r, 0.0013888888917196719);                \
+    p = fma(p, r, 0.008333333333330065);                 \
+    p = fma(p, r, 0.041666666666624164);                 \
+    p = fma(p, r, 0.16666666666666669);                  \
+    p = fma(p, r, 0.5000000000000001);                   \
+    p = fma(p, r, 1.0);                                  \
+    p = fma(p, r, 1.0)
+
+// sigmoid(z) = 1 / (1 + e), e = exp(-z), for either sign of z with ONE code path: -z is clamped from above only
+// (e <= exp(700) stays finite, so 1 / (1 + e) is the correctly scaled tiny number; a large positive z underflows e to
+// 0 through v_ldexp).  Reciprocal: v_rcp_f64 (4.6e-8 on this chip, tools/rcp_check.hip) + ONE third-order step
+// y (1 + u + u^2), u = 1 - t y (u^3 ~ 1e-22).  27 DP operations per value together with h and act' below (was 35).
 __device__ __forceinline__ double ft_sigmoid(double z) {
-    const double e = ft_exp_neg(fabs(z));
-    const double t = 1.0 + e;
+    const double a = fmin(-z, 700.0);
+    const double n = rint(a * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, a);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p;
+    FT_EXP11(p, r);
+    const double t = 1.0 + ldexp(p, (int)n);
     double y = __builtin_amdgcn_rcp(t);
-    y = fma(fma(-t, y, 1.0), y, y);
-    y = fma(fma(-t, y, 1.0), y, y);
-    return z >= 0.0 ? y : e * y;
+    const double u = fma(-t, y, 1.0);
+    return fma(fma(u, u, u), y, y);
 }
 
 __device__ __forceinline__ void act_eval(double z, int act, double& h, double& d) {
     if (act == FTHMC_ACT_SILU) {
         const double sg = ft_sigmoid(z);
         h = z * sg;
-        d = sg * (1.0 + z * (1.0 - sg));
+        d = fma(h, 1.0 - sg, sg);                          // silu' = sg (1 + z (1 - sg))
     } else if (act == FTHMC_ACT_RELU) {
         h = z > 0.0 ? z : 0.0;  d = z > 0.0 ? 1.0 : 0.0;
     } else {
@@ -133,47 +132,38 @@ __device__ __forceinline__ void act_eval(double z, int act, double& h, double& d
 }
 
 // Four independent activations at once, written step-interleaved: the compiler keeps the
-// source order of independent instructions, and a single sigmoid is a ~35-deep dependent DP
+// source order of independent instructions, and a single sigmoid is a ~25-deep dependent DP
 // chain (each link waits ~4 issue slots), so four chains side by side run ~3x faster than
 // four sigmoids back to back.  Same arithmetic as ft_sigmoid.
 __device__ __forceinline__ void sigmoid4(const double (&z)[4], double (&sg)[4]) {
-    double a[4], n[4], r[4], p[4], e[4], t[4], y[4], u[4];
+    double a[4], n[4], r[4], p[4], t[4], y[4], u[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] = fmin(fabs(z[q]), 745.0);
+    for (int q = 0; q < 4; ++q) a[q] = fmin(-z[q], 700.0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) n[q] = rint(a[q] * 1.4426950408889634074);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = fma(n[q], 6.93147180369123816490e-01, -a[q]);
+    for (int q = 0; q < 4; ++q) r[q] = fma(-n[q], 6.93147180369123816490e-01, a[q]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = fma(n[q], 1.90821492927058770002e-10, r[q]);
+    for (int q = 0; q < 4; ++q) r[q] = fma(-n[q], 1.90821492927058770002e-10, r[q]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = fma(1.6059043836821613e-10, r[q], 2.0876756987868100e-09);
-    constexpr double C[11] = {2.5052108385441720e-08, 2.7557319223985888e-07, 2.7557319223985893e-06,
-                              2.4801587301587302e-05, 1.9841269841269841e-04, 1.3888888888888889e-03,
-                              8.3333333333333332e-03, 4.1666666666666664e-02, 1.6666666666666666e-01,
-                              0.5, 1.0};
+    for (int q = 0; q < 4; ++q) p[q] = fma(2.5100375832561234e-08, r[q], 2.7620075879983367e-07);
+    constexpr double C[10] = {2.7557268480310024e-06, 2.4801521322368692e-05, 0.00019841269863040545,
+                              0.0013888888917196719, 0.008333333333330065, 0.041666666666624164,
+                              0.16666666666666669, 0.5000000000000001, 1.0, 1.0};
 #pragma unroll
-    for (int c = 0; c < 11; ++c)
+    for (int c = 0; c < 10; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q) p[q] = fma(p[q], r[q], C[c]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = fma(p[q], r[q], 1.0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) e[q] = ldexp(p[q], -(int)n[q]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = 1.0 + e[q];
+    for (int q = 0; q < 4; ++q) t[q] = 1.0 + ldexp(p[q], (int)n[q]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) y[q] = __builtin_amdgcn_rcp(t[q]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) u[q] = fma(-t[q], y[q], 1.0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) y[q] = fma(u[q], y[q], y[q]);
+    for (int q = 0; q < 4; ++q) u[q] = fma(u[q], u[q], u[q]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) u[q] = fma(-t[q], y[q], 1.0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) y[q] = fma(u[q], y[q], y[q]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sg[q] = z[q] >= 0.0 ? y[q] : e[q] * y[q];
+    for (int q = 0; q < 4; ++q) sg[q] = fma(u[q], y[q], y[q]);
 }
 
 __device__ __forceinline__ void act_eval4(const double (&z)[4], int act, double (&h)[4], double (&d)[4]) {
@@ -181,7 +171,7 @@ __device__ __forceinline__ void act_eval4(const double (&z)[4], int act, double 
         double sg[4];
         sigmoid4(z, sg);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { h[q] = z[q] * sg[q]; d[q] = sg[q] * (1.0 + z[q] * (1.0 - sg[q])); }
+        for (int q = 0; q < 4; ++q) { h[q] = z[q] * sg[q]; d[q] = fma(h[q], 1.0 - sg[q], sg[q]); }
     } else if (act == FTHMC_ACT_RELU) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { h[q] = z[q] > 0.0 ? z[q] : 0.0; d[q] = z[q] > 0.0 ? 1.0 : 0.0; }

@@ -20,23 +20,28 @@ namespace {
 using namespace fthmc;
 using namespace fthmc_flow;
 
+// LDS plan: three workgroups share a CU (3 x 51.7 KB), so planes whose lifetimes do not overlap share memory:
+//   region A: h1 (conv1 -> conv2's MFMA reads), then h2 (conv2's epilogue, after a barrier -> conv3)
+//   region B: the net input (stage 0 -> conv1), then the conv3 partials / delta and the transform scratch
 template <int TR, int TC> struct SmemF {
     using G = Geom<TR, TC>;
-    static constexpr int IN = 0;                              // [2][PS0] cos, sin
-    static constexpr int PG = IN + 2 * G::PS0;                // [N0] plaquettes
-    static constexpr int H1 = PG + G::PS0;                    // [8][PS1]
-    static constexpr int H2 = H1 + 8 * G::PS1;                // [8][PS2]
-    static constexpr int ST = H2 + 8 * G::PS2;                // [8][3][NAS] conv3 partials, then delta [N3]
+    static constexpr int cmax2(int a, int b) { return a > b ? a : b; }
+    static constexpr int H1 = 0;                              // [8][PS1]
+    static constexpr int H2 = 0;                              // [8][PS2]   (over h1)
+    static constexpr int IN = cmax2(8 * G::PS1, 8 * G::PS2);  // [2][PS0] cos, sin
+    static constexpr int ST = IN;                             // [8][3][NAS] conv3 partials, then delta [N3]   (over the net input)
     static constexpr int T2 = ST + 8 * 3 * G::NAS;            // [NMIX][2][NAS] y_k, 1/D_k
-    static constexpr int SW = T2 + NMIX * 2 * G::NAS;         // [SW_SIZE]
+    static constexpr int PG = IN + cmax2(2 * G::PS0, 8 * 3 * G::NAS + NMIX * 2 * G::NAS);   // [N0] plaquettes
+    static constexpr int SW = PG + G::PS0;                    // [SW_SIZE]
     static constexpr int SIZE = SW + SW_SIZE;
     static_assert(G::N3 <= 8 * 3 * G::NAS, "delta must fit over the conv3 partials");
+    static_assert(3 * SIZE * 8 <= 160 * 1024, "three workgroups per CU");
 };
 
 // REV: the inverse layer (GaugeEquivCouplingLayer.reverse, layers.py:204-210, 373-396): same net on the same
 // frozen plaquettes, then the scalar map is inverted per active site instead of applied.
 template <int TR, int TC, bool FASTW, bool REV>
-__global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
+__global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
@@ -184,6 +189,8 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
     // of 11 over the full window (16 x 16 tiles).  Dead lines of h2 / act'(z2) (LDS and stash) stay unwritten; the
     // backward kernels write an exact 0 there instead of multiplying.
     constexpr int NLC = R2C - R2C / 4, NLR = R2R - R2R / 4;            // live columns / rows at most
+    static_assert(((R2R / 2) * NLC + 15) / 16 == NW && (NLR * (R2C / 2) + 15) / 16 == NW,
+                  "one conv2 tile per wave: its epilogue holds a workgroup barrier");
     const int d0 = ((off + 3) - (mu == 0 ? j0 : i0)) & 3;               // first dead line of the window
     auto conv2_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
         // sites (r, c) and (r + dr, c + dc) in window coordinates; z[q]: channel g + 4 (q & 1), site q >> 1
@@ -191,6 +198,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_fwd(FlowLayerArgs A) {
         double h[4], d[4];
         z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
         act_eval4(z, act, h, d);
+        lds_barrier();                                      // h2 overwrites h1: every wave has finished its MFMA reads
         const int so = dr * R2C + dc;
         if (ok) {
             double* ph = sH2 + g * PS2 + r * R2C + c;

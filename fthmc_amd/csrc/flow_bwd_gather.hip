@@ -46,8 +46,8 @@ template <int TR, int TC, bool TRAIN> struct SmemG {
     static constexpr int D1 = GZ2 + 8 * PS2;                            // [8][PS1] gz1
     static constexpr int IN = D1 + 8 * PS1;                             // [2][PS1] cos, sin (tile+1 coordinates)
     static constexpr int DIR = IN + 2 * PS1;                            // [N3] layer's contribution at own sites
-    static constexpr int SW = DIR + N3;                                 // [SW_SIZE]
-    static constexpr int H1W = SW + SW_SIZE;                            // [8][PS1] h1 (training)
+    static constexpr int SW = DIR + N3;                                 // [LB_SIZE] backward weight block (flow_common.h)
+    static constexpr int H1W = SW + LB_SIZE;                            // [8][PS1] h1 (training)
     static constexpr int H2W = H1W + (TRAIN ? 8 * PS1 : 0);             // [8][PS1] h2 (training)
     static constexpr int SIZE = H2W + (TRAIN ? 8 * PS1 : 0);
     static_assert(W1R % 2 == 0, "row pairs");
@@ -99,10 +99,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     //      and drop it): straight-line code lets the compiler count outstanding loads (s_waitcnt
     //      vmcnt(N)) instead of draining them all at the first use after a branch.  Loads return in
     //      issue order, so what the first stage consumes is issued first and the big act' operands last.
-    double wsw[2];
+    constexpr int NWC = (LB_SIZE + NT - 1) / NT;
+    double wsw[NWC];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) wsw[k] = ldu(w + WCAN, (unsigned)min(tid + k * NT, SW_SIZE - 1));
-    static_assert(SW_SIZE <= 2 * NT, "weight copy");
+    for (int k = 0; k < NWC; ++k) wsw[k] = ldu(w + WBWD, (unsigned)min(tid + k * NT, LB_SIZE - 1));
     // (1) transform tasks on the last waves: active site `a` of the tile+3 window, both mixture components
     const int ta = tid - (NT - S::NTT);
     const int c0 = (off - (j0 - 3)) & 3, r0 = (off - (i0 - 3)) & 3;    // first active column / row of the window
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
 
     // ---- consume ---------------------------------------------------------------------------------
 #pragma unroll
-    for (int k = 0; k < 2; ++k) if (tid + k * NT < SW_SIZE) sW[tid + k * NT] = wsw[k];
+    for (int k = 0; k < NWC; ++k) if (tid + k * NT < LB_SIZE) sW[tid + k * NT] = wsw[k];
     if (ttask) {
         // adjoint of the tan-mixture transform (layers.py:66-90) from the forward's coefficients
         const double gdelta = A.up_link ? (mu == 0 ? ag[0] : -ag[0]) : ag[0] - ag[1];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
                     const int at = (r + 2 - ky) * W3C + c + 2 - kx;
                     g0[kk] = sGO[co * N3W + at]; g1[kk] = sGO[co * N3W + at + s3off];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) wv[kk][k] = sW[CW2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx];
+                    for (int k = 0; k < 4; ++k) wv[kk][k] = sW[LB_W2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -320,13 +320,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     }
 
     // ---- conv2^T (MFMA), times act'(z1) -> gz1 in place over d1 -------------------------------
-    // W[k = (tap, co)][n = (ci, dd)] = W1[co][ci][2 - (ky4 - dd)][2 - kx]
-    auto bidx4 = [](int t, int g, int cN, int dd) {
-        const int tap = t >> 1, co = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
-        return (ky >= 0 && ky <= 2) ? CW1 + (co * 8 + cN) * 9 + (2 - ky) * 3 + (2 - kx) : WZERO;
-    };
-    mfma_stage<24, 8, NPAIR1, W2C, PS2, false, true>(sGZ2, sW, wave, lane,
-        [](int p) { const int pr = fdiv<W1C>(p); return 2 * pr * W2C + p - pr * W1C; }, bidx4,
+    // W[k = (tap, co)][n = (ci, dd)] = W1[co][ci][2 - (ky4 - dd)][2 - kx]: the flipped, transposed, padded table T2
+    mfma_stage<KConv2Row, NPAIR1, W2C, PS2, true, false, 0>(sGZ2, sW + LB_T2, wave, lane,
+        [](int p) { const int pr = fdiv<W1C>(p); return 2 * pr * W2C + p - pr * W1C; },
         [&](int g, int p, bool ok, double (&gh)[4], int it) {
             if (ok) {
                 const int pr = fdiv<W1C>(p), pc = p - pr * W1C;
@@ -382,7 +378,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         for (int cq = 0; cq < 2; ++cq) {
             const int co = 2 * qq + cq;
             const double* gz = sD1 + co * PS1 + r * W1C + c;            // window coordinates (r + 2 - ky, c + 2 - kx)
-            const double* wp = sW + CW0 + co * 18;
+            const double* wp = sW + LB_W0 + co * 18;
             double gv[9], w0[9], w1[9];
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) { gv[tp] = gz[(2 - tp / 3) * W1C + 2 - tp % 3]; w0[tp] = wp[tp]; w1[tp] = wp[9 + tp]; }

@@ -31,9 +31,10 @@ template <int TR, int TC> struct SmemF {
     static constexpr int IN = cmax2(8 * G::PS1, 8 * G::PS2);  // [2][PS0] cos, sin
     static constexpr int ST = IN;                             // [8][3][NAS] conv3 partials, then delta [N3]   (over the net input)
     static constexpr int T2 = ST + 8 * 3 * G::NAS;            // [NMIX][2][NAS] y_k, 1/D_k
-    static constexpr int PG = IN + cmax2(2 * G::PS0, 8 * 3 * G::NAS + NMIX * 2 * G::NAS);   // [N0] plaquettes
-    static constexpr int SW = PG + G::PS0;                    // [SW_SIZE]
-    static constexpr int SIZE = SW + SW_SIZE;
+    static constexpr int P1 = IN + 2 * G::PS0;                // [LF_P1_SIZE] conv1 weight table (until conv1 is done)
+    static constexpr int PG = IN + cmax2(2 * G::PS0 + LF_P1_SIZE, 8 * 3 * G::NAS + NMIX * 2 * G::NAS);   // [N0] plaquettes
+    static constexpr int SW = PG + G::PS0;                    // [LF_SIZE] resident weight block
+    static constexpr int SIZE = SW + LF_SIZE;
     static_assert(G::N3 <= 8 * 3 * G::NAS, "delta must fit over the conv3 partials");
     static_assert(3 * SIZE * 8 <= 160 * 1024, "three workgroups per CU");
 };
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
     double* sIn = sm + S::IN;  double* sP = sm + S::PG;   double* sH1 = sm + S::H1;  double* sH2 = sm + S::H2;
     double* sST = sm + S::ST;  double* sDL = sm + S::ST;  double* sT2 = sm + S::T2;  double* sW = sm + S::SW;
+    double* sP1 = sm + S::P1;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -109,7 +111,10 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             cs_[0] = cs; cs_[n >> 1] = sn;
         }
     }
-    for (int t = tid; t < SW_SIZE; t += NT) sW[t] = w[WCAN + t];
+    {   // this layer's forward weight block (the conv2 table padded along the pair direction of this mu)
+        const double* wb = w + (mu == 0 ? WFWD0 : WFWD1);
+        for (int t = tid; t < LF_BLOCK; t += NT) { const double v = wb[t]; if (t < LF_SIZE) sW[t] = v; else sP1[t - LF_SIZE] = v; }
+    }
     lds_barrier();
     STAMP(1);
 
@@ -122,21 +127,17 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     double* const st_h2 = sv.d1 ? sv.h2 + (size_t)(lane >> 4) * n : nullptr;
 
     // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
-    // B[k = (tap, ci)][n = (co, dd)] = W0[co][ci][ky4 - dd][kx]
-    auto bidx1 = [](int t, int g, int cN, int dd) {
-        const int k = 4 * t + g, tap = k / 2, ci = k - 2 * tap, ky = tap / 3 - dd, kx = tap % 3;
-        return (ky >= 0 && ky <= 2) ? CW0 + (cN * 2 + ci) * 9 + ky * 3 + kx : WZERO;
-    };
+    // B[k = (tap, ci)][n = (co, dd)] = W0[co][ci][ky4 - dd][kx] out of the padded table P1 (flow_mfma_common.h: KConv1)
     // The window's pairs rarely fill whole 16-pair MFMA tiles (200 pairs = 12.5 tiles at 16 x 16): the
     // MFMA path takes the whole tiles (12 = 3 per SIMD instead of a 13th that lands on one SIMD as a
     // 4th), the last few pairs run on the VALU (18 MACs per output) on the waves that own one tile only.
     constexpr int NP1 = (R1R / 2) * R1C, NP1M = NP1 / 16 * 16, NREM1 = 2 * (NP1 - NP1M) * 8;   // leftover outputs
     static_assert(NP1M / 16 <= 2 * NW && NREM1 <= NT / 2, "leftover outputs go to the upper waves");
-    mfma_stage<6, 2, NP1M, R0C, PS0, false, false>(sIn, sW, wave, lane,
-        [](int p) { const int pr = fdiv<R1C>(p); return 2 * pr * R0C + p - pr * R1C; }, bidx1,
+    mfma_stage<KConv1, NP1M, R0C, PS0, false, false, 0>(sIn, sP1, wave, lane,
+        [](int p) { const int pr = fdiv<R1C>(p); return 2 * pr * R0C + p - pr * R1C; },
         [&](int g, int p, bool ok, double (&z)[4], int) {
             const int pr = fdiv<R1C>(p), pc = p - pr * R1C;
-            const double b0 = sW[CB0 + g], b1 = sW[CB0 + g + 4];
+            const double b0 = sW[LF_B0 + g], b1 = sW[LF_B0 + g + 4];
             double h[4], d[4];
             z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
             act_eval4(z, act, h, d);
@@ -161,12 +162,12 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         const int idx = tid - NT / 2, co = idx & 7, site = idx >> 3;
         const int p = NP1M + (site >> 1), pr = fdiv<R1C>(p), pc = p - pr * R1C, r = 2 * pr + (site & 1);
         const double* in = sIn + r * R0C + pc;
-        const double* wp = sW + CW0 + co * 18;
-        double z = sW[CB0 + co];
+        const double* wp = sP1 + co + 8;                               // P1[kx][ci][r5 = ky + 1][co]
+        double z = sW[LF_B0 + co];
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) z = fma(in[ci * PS0 + (tp / 3) * R0C + tp % 3], wp[ci * 9 + tp], z);
+            for (int tp = 0; tp < 9; ++tp) z = fma(in[ci * PS0 + (tp / 3) * R0C + tp % 3], wp[(tp % 3) * 96 + ci * 48 + (tp / 3) * 8], z);
         double h, d;
         act_eval(z, act, h, d);
         sH1[co * PS1 + r * R1C + pc] = h;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     const int d0 = ((off + 3) - (mu == 0 ? j0 : i0)) & 3;               // first dead line of the window
     auto conv2_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
         // sites (r, c) and (r + dr, c + dc) in window coordinates; z[q]: channel g + 4 (q & 1), site q >> 1
-        const double b0 = sW[CB1 + g], b1 = sW[CB1 + g + 4];
+        const double b0 = sW[LF_B1 + g], b1 = sW[LF_B1 + g + 4];
         double h[4], d[4];
         z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
         act_eval4(z, act, h, d);
@@ -217,24 +218,16 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     };
     if (mu == 0) {
         // B[k = (tap = ky4 * 3 + kx, ci)][n = (co, dd)] = W1[co][ci][ky4 - dd][kx]; pairs = rows (2 pr, 2 pr + 1)
-        auto bidx2 = [](int t, int g, int cN, int dd) {
-            const int tap = t >> 1, ci = (t & 1) * 4 + g, ky = tap / 3 - dd, kx = tap % 3;
-            return (ky >= 0 && ky <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
-        };
-        mfma_stage<24, 8, (R2R / 2) * NLC, R1C, PS1, false, false>(sH1, sW, wave, lane,
-            [&](int p) { const int pr = fdiv<NLC>(p); return 2 * pr * R1C + min(live_line(p - pr * NLC, d0), R2C - 1); }, bidx2,
+        mfma_stage<KConv2Row, (R2R / 2) * NLC, R1C, PS1, false, false, 0>(sH1, sW + LF_P2, wave, lane,
+            [&](int p) { const int pr = fdiv<NLC>(p); return 2 * pr * R1C + min(live_line(p - pr * NLC, d0), R2C - 1); },
             [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int pr = fdiv<NLC>(p), c = live_line(p - pr * NLC, d0);
                 conv2_epi(g, ok && c < R2C, 2 * pr, c, 1, 0, z);
             });
     } else {
         // B[k = (tap = ky * 4 + kx4, ci)][n = (co, dd)] = W1[co][ci][ky][kx4 - dd]; pairs = columns (2 pc, 2 pc + 1)
-        auto bidx2 = [](int t, int g, int cN, int dd) {
-            const int tap = t >> 1, ci = (t & 1) * 4 + g, ky = tap / 4, kx = tap % 4 - dd;
-            return (kx >= 0 && kx <= 2) ? CW1 + (cN * 8 + ci) * 9 + ky * 3 + kx : WZERO;
-        };
-        mfma_stage<24, 8, NLR * (R2C / 2), R1C, PS1, true, false>(sH1, sW, wave, lane,
-            [&](int p) { const int lr = fdiv<R2C / 2>(p); return min(live_line(lr, d0), R2R - 1) * R1C + 2 * (p - lr * (R2C / 2)); }, bidx2,
+        mfma_stage<KConv2Col, NLR * (R2C / 2), R1C, PS1, false, false, 0>(sH1, sW + LF_P2, wave, lane,
+            [&](int p) { const int lr = fdiv<R2C / 2>(p); return min(live_line(lr, d0), R2R - 1) * R1C + 2 * (p - lr * (R2C / 2)); },
             [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int lr = fdiv<R2C / 2>(p), r = live_line(lr, d0);
                 conv2_epi(g, ok && r < R2R, r, 2 * (p - lr * (R2C / 2)), 0, 1, z);
@@ -259,7 +252,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             for (int kx = 0; kx < 3; ++kx) {
                 const double v = sH2[ci * PS2 + (ar + ky) * R2C + ac + kx];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc[k] = fma(v, sW[CW2 + (k * 8 + ci) * 9 + ky * 3 + kx], acc[k]);
+                for (int k = 0; k < 3; ++k) acc[k] = fma(v, sW[LF_W2 + (k * 8 + ci) * 9 + ky * 3 + kx], acc[k]);
             }
 #pragma unroll
         for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NAS + lane] = acc[k];
@@ -275,9 +268,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             double dl = 0.0, lj = 0.0, xsol = 0.0;
             if (alane) {
                 const double Pn = sP[(ar + 3) * R0C + ac + 3];
-                double sk[NMIX], tval = sW[CB2 + NMIX];
+                double sk[NMIX], tval = sW[LF_B2 + NMIX];
 #pragma unroll
-                for (int k = 0; k < NMIX; ++k) sk[k] = sW[CB2 + k];
+                for (int k = 0; k < NMIX; ++k) sk[k] = sW[LF_B2 + k];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
 #pragma unroll
@@ -350,7 +343,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     double Pa = 0.0;
     if (wave < NMIX && alane) {
         Pa = sP[(ar + 3) * R0C + ac + 3];
-        double sk = sW[CB2 + wave];
+        double sk = sW[LF_B2 + wave];
 #pragma unroll
         for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
         const int pst = mu == 0 ? 1 : R0C;
@@ -373,7 +366,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         }
     }
     if (wave == NMIX && alane) {                                 // t on an otherwise idle wave
-        double tv = sW[CB2 + NMIX];
+        double tv = sW[LF_B2 + NMIX];
 #pragma unroll
         for (int q = 0; q < 8; ++q) tv += sST[(q * 3 + NMIX) * NAS + lane];
         sP[(ar + 3) * R0C + ac + 3 + 3 * (mu == 0 ? 1 : R0C)] = tv;

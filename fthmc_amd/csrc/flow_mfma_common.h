@@ -74,8 +74,6 @@ template <int TR, int TC> struct Geom {
     static_assert(TR % 4 == 0 && TC % 4 == 0 && NA <= 64, "tile shape");
 };
 
-// LDS copy of the layer's canonical weights (flow_common.h: CW0 CB0 CW1 CB1 CW2 CB2, WZERO)
-constexpr int SW_SIZE = WCAN_SIZE;
 
 // Per-layer activation stash written by the forward kernel and read back by the gather-form backward
 // (n = L * L; per chain b):
@@ -110,43 +108,59 @@ __device__ __forceinline__ int stash_frozen_idx(int i, int j, int L, int mu, int
     return mu == 0 ? mul24(i, L >> 1) + f : mul24(f, L) + j;
 }
 
+// LDS copy of the layer's weight block (flow_common.h: LF_* forward, LB_* backward)
 // One implicit-GEMM stage on v_mfma_f64_16x16x4_f64 over NPAIR "pair sites": a pair is two adjacent
-// output sites (rows r, r + 1 of one column, or with PAIRCOL columns c, c + 1 of one row) that share a
-// 4 x 3 (3 x 4) input window, so N = 16 = 8 output channels x the 2 sites of the pair and
-// K = 12 window taps x KC input channels (9 of the 12 taps are non-zero for each site: 75 % useful MACs
-// instead of the 50 % of a half-empty N).
-//   amap(p)  -> offset of pair p's window origin (tap 0 of its first site) inside an input plane
-//               (row stride RSA, plane stride PSA); must be valid for every p < NPAIR
-//   bidx(t, g, cN, dd) -> index of W[k = 4 t + g][n = cN + 8 dd] in the LDS weight copy sW
-//               (tap of k: row-major over the 4 x 3 window, or 3 x 4 with PAIRCOL)
+// output sites (rows r, r + 1 of one column, or columns c, c + 1 of one row) that share a 4 x 3 (3 x 4)
+// input window, so N = 16 = 8 output channels x the 2 sites of the pair and K = 12 window taps x KC input
+// channels (9 of the 12 taps are non-zero for each site: 75 % useful MACs instead of the 50 % of a half-empty N).
+// The weights are the MFMA's A operand and the activations its B operand, so D comes out transposed:
+// D[row = (channel, site of pair)][col = pair].  A lane (g = lane >> 4, i = lane & 15) then holds one pair
+// (col = i) and the rows g + 4 q: all site arithmetic of the epilogue (offsets, bounds, stash address) happens
+// once per lane and tile instead of once per value.
+// Operand addressing: K step t of lane group g reads
+//     activation  A[amap(pair) + KO::alane(g) + KO::aimm(t)]      weight  W[wl + KO::bimm(t)]
+// with aimm / bimm compile-time constants (they become the offset field of the ds_read) and wl, the lane part of
+// the weight index, computed once per stage by the caller from (g, cN = i & 7, dd = i >> 3) against a zero-padded
+// weight table (flow_common.h), so the K loop holds no VALU instruction at all.
 //   epi(g, p, ok, z, it): z[q] = output channel g + 4 (q & 1) at site (q >> 1) of pair p; all four values
 //               of a lane at once so that their chains interleave; it = which of the wave's tiles (a
 //               compile-time constant with UNROLL, so the caller can keep per-tile operands in registers)
-// The weights are the MFMA's A operand and the activations its B operand, so D comes out transposed:
-// D[row = (channel, site of pair)][col = pair].  A lane then holds one pair (col = lane & 15) and the
-// rows g + 4 q: all site arithmetic of the epilogue (offsets, bounds, stash address) happens once per
-// lane and tile instead of once per value.
-template <int NSTEP, int KC, int NPAIR, int RSA, int PSA, bool PAIRCOL, bool UNROLL, class AMap, class BIdx, class Epi>
-__device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ sW,
-                                           int wave, int lane, AMap amap, BIdx bidx, Epi epi) {
-    constexpr int NTILE = (NPAIR + 15) / 16;
+// K orders (RSA / PSA: row / plane stride of the activation planes):
+struct KConv2Row {      // 8 -> 8 channels, pairs = rows (r, r + 1): k = (tap = t >> 1 of the 4 x 3 window, ci = 4 (t & 1) + g)
+    static constexpr int NSTEP = 24;
+    template <int RSA, int PSA> static __device__ __forceinline__ int alane(int g) { return g * PSA; }
+    template <int RSA, int PSA> static constexpr int aimm(int t) { return (t & 1) * 4 * PSA + ((t >> 1) / 3) * RSA + (t >> 1) % 3; }
+    // table [kx][g][h][r5][cN]: W[cN][4 h + g][ky4 - dd][kx] sits at r5 = ky4 - dd + 1
+    static constexpr int bimm(int t) { return ((t >> 1) % 3) * 320 + (t & 1) * 40 + ((t >> 1) / 3) * 8; }
+    static __device__ __forceinline__ int wlane(int g, int cN, int dd) { return cN + g * 80 + (1 - dd) * 8; }
+};
+struct KConv2Col {      // pairs = columns (c, c + 1): 3 x 4 window, table [cN][ci][ky][c5]
+    static constexpr int NSTEP = 24;
+    template <int RSA, int PSA> static __device__ __forceinline__ int alane(int g) { return g * PSA; }
+    template <int RSA, int PSA> static constexpr int aimm(int t) { return (t & 1) * 4 * PSA + ((t >> 1) / 4) * RSA + (t >> 1) % 4; }
+    static constexpr int bimm(int t) { return ((t >> 1) / 4) * 320 + (t & 1) * 40 + ((t >> 1) % 4) * 8; }
+    static __device__ __forceinline__ int wlane(int g, int cN, int dd) { return cN + g * 80 + (1 - dd) * 8; }
+};
+struct KConv1 {         // 2 -> 8 channels, pairs = rows: k = (ci = g & 1, tap = t + 6 (g >> 1)): taps 6.. are the window's rows 2, 3
+    static constexpr int NSTEP = 6;
+    template <int RSA, int PSA> static __device__ __forceinline__ int alane(int g) { return (g & 1) * PSA + (g >> 1) * 2 * RSA; }
+    template <int RSA, int PSA> static constexpr int aimm(int t) { return (t / 3) * RSA + t % 3; }
+    static constexpr int bimm(int t) { return (t % 3) * 96 + (t / 3) * 8; }       // table [kx][ci: 48][r5: 8][cN]
+    static __device__ __forceinline__ int wlane(int g, int cN, int dd) { return cN + (g & 1) * 48 + (2 * (g >> 1) + 1 - dd) * 8; }
+};
+// DEFER: the epilogues run after ALL of the workgroup's MFMA loops (results parked in registers, one workgroup
+//        barrier in between), so that an epilogue may overwrite the planes the MFMAs read (needs UNROLL)
+// NCHAIN: independent accumulator chains per tile (0: 4, or 3 for short K)
+template <class KO, int NPAIR, int RSA, int PSA, bool UNROLL, bool DEFER, int NCHAIN, class AMap, class Epi>
+__device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ Wt,
+                                           int wave, int lane, AMap amap, Epi epi) {
+    constexpr int NSTEP = KO::NSTEP, NTILE = (NPAIR + 15) / 16;
     const int g = lane >> 4, i = lane & 15;
-    auto toff = [](int tap) { return PAIRCOL ? (tap / 4) * RSA + (tap % 4) : (tap / 3) * RSA + (tap % 3); };
-    // input offset of k = 4 t + g: k -> (tap = k / KC, channel = k % KC).  For KC = 8 the lane part is
-    // just g * PSA and the rest is a compile-time immediate; otherwise a small table.
-    int koff[KC == 8 ? 1 : NSTEP];
-    if (KC != 8) {
-#pragma unroll
-        for (int t = 0; t < NSTEP; ++t) {
-            const int k = 4 * t + g, tap = k / KC, cK = k - tap * KC;
-            koff[t] = cK * PSA + toff(tap);
-        }
-    }
-    const int cN = i & 7, dd = i >> 3;
-    int boff[NSTEP];
-#pragma unroll
-    for (int t = 0; t < NSTEP; ++t) boff[t] = bidx(t, g, cN, dd);
+    const double* wp = Wt + KO::wlane(g, i & 7, i >> 3);
+    const int al = KO::template alane<RSA, PSA>(g);
     constexpr int NIT = (NTILE + NW - 1) / NW, NUNR = UNROLL ? NIT : 1;
+    static_assert(!DEFER || UNROLL, "deferred epilogues keep their tiles in registers");
+    double zs[DEFER ? NIT : 1][4];
 #pragma unroll NUNR
     for (int it = 0; it < NIT; ++it) {
         const int tile = wave + it * NW;
@@ -154,24 +168,32 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
         const int p_ = tile * 16 + i;
         const bool ok = p_ < NPAIR;
         const int p = ok ? p_ : NPAIR - 1;                   // padding lanes: any valid address
-        const double* a0 = A + amap(p) + (KC == 8 ? g * PSA : 0);
+        const double* a0 = A + amap(p) + al;
         // independent accumulator chains keep the matrix pipe busy when a wave is alone on it
-        constexpr int NCH = NSTEP >= 8 ? 4 : 3;
+        constexpr int NCH = NCHAIN > 0 ? NCHAIN : (NSTEP >= 8 ? 4 : 3);
         double4_t accs[NCH];
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) accs[ch] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int t = 0; t < NSTEP; ++t) {
-            double av;
-            if (KC == 8) av = a0[(t & 1) * 4 * PSA + toff(t >> 1)];
-            else av = a0[koff[t]];
-            accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(sW[boff[t]], av, accs[t % NCH], 0, 0, 0);
-        }
+        for (int t = 0; t < NSTEP; ++t)
+            accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[KO::bimm(t)], a0[KO::template aimm<RSA, PSA>(t)], accs[t % NCH], 0, 0, 0);
         double4_t acc = accs[0];
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
-        double z4[4] = {acc[0], acc[1], acc[2], acc[3]};
-        epi(g, p, ok, z4, it);
+        if (DEFER) { zs[it][0] = acc[0]; zs[it][1] = acc[1]; zs[it][2] = acc[2]; zs[it][3] = acc[3]; }
+        else { double z4[4] = {acc[0], acc[1], acc[2], acc[3]}; epi(g, p, ok, z4, it); }
+    }
+    if (DEFER) {
+        lds_barrier();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int tile = wave + it * NW;
+            if (tile < NTILE) {
+                const int p_ = tile * 16 + i;
+                const bool ok = p_ < NPAIR;
+                epi(g, ok ? p_ : NPAIR - 1, ok, zs[it], it);
+            }
+        }
     }
 }
 

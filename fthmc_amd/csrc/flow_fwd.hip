@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                         }
                 }
             }
-        });
+        }, dbg ? dbg + 7 : nullptr);
     if (NREM1 > 0 && tid >= NT / 2 && tid < NT / 2 + NREM1) {
         const int idx = tid - NT / 2, co = idx & 7, site = idx >> 3;
         const int p = NP1M + (site >> 1), pr = fdiv<R1C>(p), pc = p - pr * R1C, r = 2 * pr + (site & 1);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int pr = fdiv<NLC>(p), c = live_line(p - pr * NLC, d0);
                 conv2_epi(g, ok && c < R2C, 2 * pr, c, 1, 0, z);
-            });
+            }, dbg ? dbg + 11 : nullptr);
     } else {
         // B[k = (tap = ky * 4 + kx4, ci)][n = (co, dd)] = W1[co][ci][ky][kx4 - dd]; pairs = columns (2 pc, 2 pc + 1)
         mfma_stage<KConv2Col, NLR * (R2C / 2), R1C, PS1, false, false, 0>(sH1, sW + LF_P2, wave, lane,

@@ -148,12 +148,20 @@ struct KConv1 {         // 2 -> 8 channels, pairs = rows: k = (ci = g & 1, tap =
     static constexpr int bimm(int t) { return (t % 3) * 96 + (t / 3) * 8; }       // table [kx][ci: 48][r5: 8][cN]
     static __device__ __forceinline__ int wlane(int g, int cN, int dd) { return cN + (g & 1) * 48 + (2 * (g >> 1) + 1 - dd) * 8; }
 };
+// Diagnostic builds (-DFT_DIAG) only: cycle stamp of wave 0 inside a stage, after everything the wave has issued is back
+__device__ __forceinline__ void stampx(long long* slot) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t_;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0) *slot = (long long)t_;
+}
 // DEFER: the epilogues run after ALL of the workgroup's MFMA loops (results parked in registers, one workgroup
 //        barrier in between), so that an epilogue may overwrite the planes the MFMAs read (needs UNROLL)
 // NCHAIN: independent accumulator chains per tile (0: 4, or 3 for short K)
 template <class KO, int NPAIR, int RSA, int PSA, bool UNROLL, bool DEFER, int NCHAIN, class AMap, class Epi>
 __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ Wt,
-                                           int wave, int lane, AMap amap, Epi epi) {
+                                           int wave, int lane, AMap amap, Epi epi, long long* dbg = nullptr) {
     constexpr int NSTEP = KO::NSTEP, NTILE = (NPAIR + 15) / 16;
     const int g = lane >> 4, i = lane & 15;
     const double* wp = Wt + KO::wlane(g, i & 7, i >> 3);
@@ -180,8 +188,14 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
         double4_t acc = accs[0];
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
+#ifdef FT_DIAG
+        if (dbg) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); stampx(dbg + 2 * it); }
+#endif
         if (DEFER) { zs[it][0] = acc[0]; zs[it][1] = acc[1]; zs[it][2] = acc[2]; zs[it][3] = acc[3]; }
         else { double z4[4] = {acc[0], acc[1], acc[2], acc[3]}; epi(g, p, ok, z4, it); }
+#ifdef FT_DIAG
+        if (dbg) stampx(dbg + 2 * it + 1);
+#endif
     }
     if (DEFER) {
         lds_barrier();

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(TJ_NT) void k_hmc_trajectory(const double* __restri
         double c = 0.0;
 #pragma unroll
         for (int k = 0; k < TJ_NSITE; ++k)
-            if (st[k] >= 0) c += cos(sx[st[k]] + sx[n + sip[k]] - sx[sjp[k]] - sx[n + st[k]]);
+            if (st[k] >= 0) { double sn_, cs_; ft_sincos(sx[st[k]] + sx[n + sip[k]] - sx[sjp[k]] - sx[n + st[k]], &sn_, &cs_); c += cs_; }
         return (-beta) * ft_block_sum(c, red);
     };
     const double h0 = action() + 0.5 * ft_block_sum(kin, red);
@@ -273,7 +273,11 @@ __global__ __launch_bounds__(TJ_NT) void k_hmc_trajectory(const double* __restri
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < TJ_NSITE; ++k)
-            if (st[k] >= 0) sp[st[k]] = beta * sin(sx[st[k]] - sx[n + st[k]] - sx[sjp[k]] + sx[n + sip[k]]);
+            if (st[k] >= 0) {                       // own sincos (common.h): ~3x shorter than ocml's sin, same accuracy class
+                double sn_, cs_;
+                ft_sincos(sx[st[k]] - sx[n + st[k]] - sx[sjp[k]] + sx[n + sip[k]], &sn_, &cs_);
+                sp[st[k]] = beta * sn_;
+            }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < TJ_NSITE; ++k)

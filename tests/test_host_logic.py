@@ -254,3 +254,23 @@ def test_bench_launch_command_and_refusal_without_gpu():
         p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '0'],
                            env=env, capture_output=True, text=True, timeout=300)
         assert p.returncode != 0 and 'MI355X' in (p.stderr + p.stdout)
+
+
+def test_unsupported_net_shapes_fail_loudly():
+    """The HIP kernels are built for the reference-default s/t net (hidden_sizes=[8, 8], kernel_size=3,
+    n_mixture_comps=2; include/fthmc_hip.h): any other shape raises before anything is launched -- never a silent
+    fallback (fthmc/utils/layers.py:399-429 accepts any shape on its PyTorch path)."""
+    from fthmc_amd import ops
+    from fthmc_amd._lib import FthmcError
+    from fthmc_amd.utils import layers as Lyr
+    for kw in (dict(hidden_sizes=[16, 16]), dict(hidden_sizes=[8]), dict(kernel_size=5), dict(n_mixture_comps=1),
+               dict(n_mixture_comps=3)):
+        args = dict(n_layers=2, n_mixture_comps=2, lattice_shape=(8, 8), hidden_sizes=[8, 8], kernel_size=3)
+        args.update(kw)
+        with pytest.raises(NotImplementedError, match='reference default net'):
+            Lyr.make_u1_equiv_layers(**args)
+    w = [torch.zeros(8, 2, 3, 3), torch.zeros(8), torch.zeros(8, 8, 3, 3), torch.zeros(8), torch.zeros(4, 8, 3, 3), torch.zeros(4)]
+    with pytest.raises(FthmcError, match='unsupported s/t net'):
+        ops.pack_weights([w])                                  # n_mixture_comps = 3
+    header = open(os.path.join(ROOT, 'include', 'fthmc_hip.h')).read()
+    assert 'hidden_sizes=[8,8], kernel_size=3, n_mixture_comps=2' in header and 'FTHMC_ERR_UNSUPPORTED' in header

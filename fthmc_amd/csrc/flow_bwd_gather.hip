@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
 
     // ---- conv2^T (MFMA), times act'(z1) -> gz1 in place over d1 -------------------------------
     // W[k = (tap, co)][n = (ci, dd)] = W1[co][ci][2 - (ky4 - dd)][2 - kx]: the flipped, transposed, padded table T2
-    mfma_stage<KConv2Row, NPAIR1, W2C, PS2, true, false, 0>(sGZ2, sW + LB_T2, wave, lane,
+    mfma_stage<KConv2Row, NPAIR1, W2C, PS2, true, false, FT_NCH ? FT_NCH : (TRAIN ? 0 : 2)>(sGZ2, sW + LB_T2, wave, lane,
         [](int p) { const int pr = fdiv<W1C>(p); return 2 * pr * W2C + p - pr * W1C; },
         [&](int g, int p, bool ok, double (&gh)[4], int it) {
             if (ok) {

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     // 4th), the last few pairs run on the VALU (18 MACs per output) on the waves that own one tile only.
     constexpr int NP1 = (R1R / 2) * R1C, NP1M = NP1 / 16 * 16, NREM1 = 2 * (NP1 - NP1M) * 8;   // leftover outputs
     static_assert(NP1M / 16 <= 2 * NW && NREM1 <= NT / 2, "leftover outputs go to the upper waves");
-    mfma_stage<KConv1, NP1M, R0C, PS0, false, false, 0>(sIn, sP1, wave, lane,
+    mfma_stage<KConv1, NP1M, R0C, PS0, false, false, FT_NCH ? FT_NCH : 1>(sIn, sP1, wave, lane,
         [](int p) { const int pr = fdiv<R1C>(p); return 2 * pr * R0C + p - pr * R1C; },
         [&](int g, int p, bool ok, double (&z)[4], int) {
             const int pr = fdiv<R1C>(p), pc = p - pr * R1C;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     };
     if (mu == 0) {
         // B[k = (tap = ky4 * 3 + kx, ci)][n = (co, dd)] = W1[co][ci][ky4 - dd][kx]; pairs = rows (2 pr, 2 pr + 1)
-        mfma_stage<KConv2Row, (R2R / 2) * NLC, R1C, PS1, false, false, 0>(sH1, sW + LF_P2, wave, lane,
+        mfma_stage<KConv2Row, (R2R / 2) * NLC, R1C, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
             [&](int p) { const int pr = fdiv<NLC>(p); return 2 * pr * R1C + min(live_line(p - pr * NLC, d0), R2C - 1); },
             [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int pr = fdiv<NLC>(p), c = live_line(p - pr * NLC, d0);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             }, dbg ? dbg + 11 : nullptr);
     } else {
         // B[k = (tap = ky * 4 + kx4, ci)][n = (co, dd)] = W1[co][ci][ky][kx4 - dd]; pairs = columns (2 pc, 2 pc + 1)
-        mfma_stage<KConv2Col, NLR * (R2C / 2), R1C, PS1, false, false, 0>(sH1, sW + LF_P2, wave, lane,
+        mfma_stage<KConv2Col, NLR * (R2C / 2), R1C, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
             [&](int p) { const int lr = fdiv<R2C / 2>(p); return min(live_line(lr, d0), R2R - 1) * R1C + 2 * (p - lr * (R2C / 2)); },
             [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int lr = fdiv<R2C / 2>(p), r = live_line(lr, d0);

@@ -3,6 +3,11 @@
 #pragma once
 #include "flow_common.h"
 
+// accumulator chains of the MFMA stages (0 = default rule); a build-time knob for A/B runs
+#ifndef FT_NCH
+#define FT_NCH 0
+#endif
+
 namespace fthmc_flow {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));

@@ -16,6 +16,11 @@ def family(name):
     return None
 
 
+LAUNCH_SHAPE = ('bench.py config 3 with two chain groups: one launch of a coupling-layer kernel = one layer over ONE chain group = '
+                '64 chains x 16 tiles = 1024 workgroups of 16x16 sites (L=64, fp64); k_force<1> / k_hmc_trajectory: all 128 chains')
+COMMIT = None
+
+
 def main(src, dst):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for path in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
@@ -27,15 +32,15 @@ def main(src, dst):
                 a = acc[fam][row['Counter_Name']]
                 a[0] += float(row['Counter_Value']); a[1] += 1
     out = {
-        'command': 'rocprofv3 --pmc <group> --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline'
-                   '  (one pass per counter group, tools/collect_pmc.sh)',
+        'command': 'rocprofv3 --pmc <group> --output-format csv -- python3 <bench.py --steps 2 --warmup 1 --no-cpu-baseline | tools/kernel_loop.py>'
+                   '  (one pass per counter group: tools/collect_pmc.sh / tools/pmc_kernels.sh)',
         'units': 'FETCH_SIZE / WRITE_SIZE in KiB as reported (gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide '
                  'streaming reads, MI355X_MICROARCH.md HBM section; our reads are 8 B/lane, uncalibrated: raw values kept); '
                  'SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_VALU in quad-cycles summed over waves or SIMDs; '
                  'SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; SQ_INSTS_* wave-instructions; '
                  'GRBM_GUI_ACTIVE summed over 8 XCDs',
-        'workload': 'bench.py config: B=128 chains, L=64, 8 layers, fp64; one launch = one coupling layer over the whole '
-                    'batch (forward and backward: 2048 workgroups of 16x16 sites)',
+        'launch_shape': LAUNCH_SHAPE,
+        'commit': COMMIT,
         'kernels': {fam: {c: {'launches': v[1], 'mean_per_launch': v[0] / v[1]} for c, v in sorted(cs.items())}
                     for fam, cs in acc.items()},
     }
@@ -48,4 +53,8 @@ def main(src, dst):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 3:
+        LAUNCH_SHAPE = sys.argv[3]
+    if len(sys.argv) > 4:
+        COMMIT = sys.argv[4]
     main(sys.argv[1], sys.argv[2])

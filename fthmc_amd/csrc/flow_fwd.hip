@@ -348,11 +348,13 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
         const int pst = mu == 0 ? 1 : R0C;
         const double cs = sP[(ar + 3) * R0C + ac + 3 + pst], sn = sP[(ar + 3) * R0C + ac + 3 + 2 * pst];   // of P / 2
-        double es, ems;
-        { const double ea[2] = {sk, -sk}; double eo[2]; ft_expN<2>(ea, eo); es = eo[0]; ems = eo[1]; }
+        // e^{-s} = 1 / e^{s} and the two quotients by reciprocal + one correction step (ft_rcp): |s| is O(1) for any
+        // usable flow and clamped to +-700 by ft_exp, so every denominator is far from the ends of the range
+        const double es = ft_exp(sk), ems = ft_rcp(es);
         const double cs2 = cs * cs, sn2 = sn * sn, sincs = sn * cs;
-        const double invD = 1.0 / (ems * cs2 + es * sn2);
+        const double invD = ft_rcp(ems * cs2 + es * sn2);
         sT2[(wave * TQ + 1) * NAS + lane] = invD;
+        // tan(P/2) = sn / cs: |cs| can be tiny (P near +-pi) -- a true division keeps the correctly rounded quotient there
         sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
         if (A.stash && avalid) {
             // coefficients of the transform's adjoint (struct Stash): the backward kernel then needs no

@@ -528,6 +528,9 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
         a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
         a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.gp_out = W.gp2;
         a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+#ifdef FT_DIAG
+        if (const char* e = getenv("FTHMC_DBG_STOP")) a.dbg_stop = atoi(e);
+#endif
         if (get_flow_variant() == 1) {            // the hot path: forward stashes, backward reads the stash
             a.stash = W.stash;
             FT_TRY(launch_flow_fwd_mfma(a, s));

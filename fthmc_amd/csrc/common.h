@@ -35,29 +35,42 @@ __device__ __forceinline__ double ft_regularize(double f) {
     return FT_TWO_PI * (f_ - floor(f_) - 0.5);
 }
 
+// fp64 FMAs with a CONSTANT operand held in an SGPR pair.  Left to itself hipcc (kernels here run at ~100 SGPRs) builds
+// such constants in a VGPR pair with two v_mov_b32 and issues v_fmac_f64: three VALU instructions per polynomial
+// step instead of one (s_mov_b32 runs on the scalar unit, off the fp64 pipe).
+__device__ __forceinline__ double ft_fma_vvs(double a, double b, double C) {       // a * b + C
+    double d; asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(C)); return d;
+}
+__device__ __forceinline__ double ft_fma_nvsv(double a, double C, double b) {      // -a * C + b
+    double d; asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(d) : "v"(a), "s"(C), "v"(b)); return d;
+}
+__device__ __forceinline__ double ft_mul_vs(double a, double C) {
+    double d; asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(C)); return d;
+}
+
 // sin and cos for moderate arguments (|x| up to ~1e5; plaquette angles are sums of four links):
 // Cody-Waite reduction by pi/2 in three exact-product pieces + the fdlibm kernel polynomials on
 // |r| <= pi/4.  ~35 DP ops, no slow path, < 1 ulp each (ocml's sincos carries a Payne-Hanek
 // branch and is ~3x longer on the critical path of the serial stages).
 __device__ __forceinline__ void ft_sincos(double x, double* sn, double* cs) {
-    const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi
-    double r = fma(-fn, 1.57079632673412561417e+00, x);              // pi/2, first 33 bits (exact product)
-    r = fma(-fn, 6.07710050630396597660e-11, r);                     // next 33 bits
-    r = fma(-fn, 2.02226624879595063154e-21, r);                     // tail
+    const double fn = rint(ft_mul_vs(x, 6.36619772367581382433e-01));   // x * 2/pi
+    double r = ft_fma_nvsv(fn, 1.57079632673412561417e+00, x);         // pi/2, first 33 bits (exact product)
+    r = ft_fma_nvsv(fn, 6.07710050630396597660e-11, r);                // next 33 bits
+    r = ft_fma_nvsv(fn, 2.02226624879595063154e-21, r);                // tail
     const double z = r * r;
     double ps = 1.58969099521155010221e-10;
-    ps = fma(ps, z, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);
+    ps = ft_fma_vvs(ps, z, -2.50507602534068634195e-08);
+    ps = ft_fma_vvs(ps, z, 2.75573137070700676789e-06);
+    ps = ft_fma_vvs(ps, z, -1.98412698298579493134e-04);
+    ps = ft_fma_vvs(ps, z, 8.33333333332248946124e-03);
+    ps = ft_fma_vvs(ps, z, -1.66666666666666324348e-01);
     const double s = fma(r * z, ps, r);
     double pc = -1.13596475577881948265e-11;
-    pc = fma(pc, z, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);
+    pc = ft_fma_vvs(pc, z, 2.08757232129817482790e-09);
+    pc = ft_fma_vvs(pc, z, -2.75573143513906633035e-07);
+    pc = ft_fma_vvs(pc, z, 2.48015872894767294178e-05);
+    pc = ft_fma_vvs(pc, z, -1.38888888888741095749e-03);
+    pc = ft_fma_vvs(pc, z, 4.16666666666666019037e-02);
     const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
     const int q = (int)fn & 3;
     const double s_ = (q & 1) ? c : s, c_ = (q & 1) ? s : c;

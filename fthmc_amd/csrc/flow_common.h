@@ -55,20 +55,20 @@ static_assert(WBWD + LB_SIZE <= FLOW_WINT, "weight layout");
 // Taylor (|r| <= ln2/2: truncation 4e-18) + v_ldexp.  ~20 dependent DP ops instead of ocml exp's ~60, < 1.5 ulp.
 __device__ __forceinline__ double ft_exp(double x) {
     x = fmin(fmax(x, -745.0), 709.0);
-    const double n = rint(x * 1.4426950408889634074);
-    double r = fma(-n, 6.93147180369123816490e-01, x);
-    r = fma(-n, 1.90821492927058770002e-10, r);
+    const double n = rint(ft_mul_vs(x, 1.4426950408889634074));
+    double r = ft_fma_nvsv(n, 6.93147180369123816490e-01, x);
+    r = ft_fma_nvsv(n, 1.90821492927058770002e-10, r);
     double p = 1.6059043836821613e-10;
-    p = fma(p, r, 2.0876756987868100e-09);
-    p = fma(p, r, 2.5052108385441720e-08);
-    p = fma(p, r, 2.7557319223985888e-07);
-    p = fma(p, r, 2.7557319223985893e-06);
-    p = fma(p, r, 2.4801587301587302e-05);
-    p = fma(p, r, 1.9841269841269841e-04);
-    p = fma(p, r, 1.3888888888888889e-03);
-    p = fma(p, r, 8.3333333333333332e-03);
-    p = fma(p, r, 4.1666666666666664e-02);
-    p = fma(p, r, 1.6666666666666666e-01);
+    p = ft_fma_vvs(p, r, 2.0876756987868100e-09);
+    p = ft_fma_vvs(p, r, 2.5052108385441720e-08);
+    p = ft_fma_vvs(p, r, 2.7557319223985888e-07);
+    p = ft_fma_vvs(p, r, 2.7557319223985893e-06);
+    p = ft_fma_vvs(p, r, 2.4801587301587302e-05);
+    p = ft_fma_vvs(p, r, 1.9841269841269841e-04);
+    p = ft_fma_vvs(p, r, 1.3888888888888889e-03);
+    p = ft_fma_vvs(p, r, 8.3333333333333332e-03);
+    p = ft_fma_vvs(p, r, 4.1666666666666664e-02);
+    p = ft_fma_vvs(p, r, 1.6666666666666666e-01);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -114,15 +114,16 @@ __device__ __forceinline__ void ft_expN(const double (&xin)[N], double (&e)[N]) 
 // (exp(r) - 1 - r) / r^2, tools/minimax_exp.py): relative error 1.6e-17 in exact arithmetic (degree-13 Taylor: 4e-18,
 // two FMAs more per value).
 #define FT_EXP11(p, r)                                   \
-    p = fma(2.5100375832561234e-08, r, 2.7620075879983367e-07); \
-    p = fma(p, r, 2.7557268480310024e-06);               \
-    p = fma(p, r, 2.4801521322368692e-05);               \
-    p = fma(p, r, 0.00019841269863040545);               \
-    p = fma(p, r, 0.0013888888917196719);                \
-    p = fma(p, r, 0.008333333333330065);                 \
-    p = fma(p, r, 0.041666666666624164);                 \
-    p = fma(p, r, 0.16666666666666669);                  \
-    p = fma(p, r, 0.5000000000000001);                   \
+    p = 2.5100375832561234e-08;                          \
+    p = ft_fma_vvs(p, r, 2.7620075879983367e-07);        \
+    p = ft_fma_vvs(p, r, 2.7557268480310024e-06);        \
+    p = ft_fma_vvs(p, r, 2.4801521322368692e-05);        \
+    p = ft_fma_vvs(p, r, 0.00019841269863040545);        \
+    p = ft_fma_vvs(p, r, 0.0013888888917196719);         \
+    p = ft_fma_vvs(p, r, 0.008333333333330065);          \
+    p = ft_fma_vvs(p, r, 0.041666666666624164);          \
+    p = ft_fma_vvs(p, r, 0.16666666666666669);           \
+    p = ft_fma_vvs(p, r, 0.5000000000000001);            \
     p = fma(p, r, 1.0);                                  \
     p = fma(p, r, 1.0)
 
@@ -139,9 +140,9 @@ __device__ __forceinline__ double ft_min_neg(double z, double hi) {
 
 __device__ __forceinline__ double ft_sigmoid(double z) {
     const double a = ft_min_neg(z, 700.0);
-    const double n = rint(a * 1.4426950408889634074);
-    double r = fma(-n, 6.93147180369123816490e-01, a);
-    r = fma(-n, 1.90821492927058770002e-10, r);
+    const double n = rint(ft_mul_vs(a, 1.4426950408889634074));
+    double r = ft_fma_nvsv(n, 6.93147180369123816490e-01, a);
+    r = ft_fma_nvsv(n, 1.90821492927058770002e-10, r);
     double p;
     FT_EXP11(p, r);
     const double t = 1.0 + ldexp(p, (int)n);
@@ -171,20 +172,27 @@ __device__ __forceinline__ void sigmoid4(const double (&z)[4], double (&sg)[4]) 
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = ft_min_neg(z[q], 700.0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) n[q] = rint(a[q] * 1.4426950408889634074);
+    for (int q = 0; q < 4; ++q) n[q] = rint(ft_mul_vs(a[q], 1.4426950408889634074));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = fma(-n[q], 6.93147180369123816490e-01, a[q]);
+    for (int q = 0; q < 4; ++q) r[q] = ft_fma_nvsv(n[q], 6.93147180369123816490e-01, a[q]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = fma(-n[q], 1.90821492927058770002e-10, r[q]);
+    for (int q = 0; q < 4; ++q) r[q] = ft_fma_nvsv(n[q], 1.90821492927058770002e-10, r[q]);
+    {
+        const double c11 = 2.5100375832561234e-08;                     // one VGPR pair for the leading coefficient, shared by the four chains
 #pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = fma(2.5100375832561234e-08, r[q], 2.7620075879983367e-07);
-    constexpr double C[10] = {2.7557268480310024e-06, 2.4801521322368692e-05, 0.00019841269863040545,
-                              0.0013888888917196719, 0.008333333333330065, 0.041666666666624164,
-                              0.16666666666666669, 0.5000000000000001, 1.0, 1.0};
+        for (int q = 0; q < 4; ++q) p[q] = ft_fma_vvs(c11, r[q], 2.7620075879983367e-07);
+    }
+    constexpr double C[8] = {2.7557268480310024e-06, 2.4801521322368692e-05, 0.00019841269863040545,
+                             0.0013888888917196719, 0.008333333333330065, 0.041666666666624164,
+                             0.16666666666666669, 0.5000000000000001};
 #pragma unroll
-    for (int c = 0; c < 10; ++c)
+    for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) p[q] = fma(p[q], r[q], C[c]);
+        for (int q = 0; q < 4; ++q) p[q] = ft_fma_vvs(p[q], r[q], C[c]);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[q] = fma(p[q], r[q], 1.0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) t[q] = 1.0 + ldexp(p[q], (int)n[q]);
 #pragma unroll

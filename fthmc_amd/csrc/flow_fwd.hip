@@ -74,6 +74,16 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     STAMP(0);
 
     const unsigned fastw = FASTW ? 0u : wrap_magic(L);
+    // this layer's forward weight block (the conv2 table padded along the pair direction of this mu): the loads are
+    // issued FIRST and land under the plaquette loads and the sincos; issued behind them (where they are consumed) the
+    // stage pays two memory latencies in a row.  Unconditional, clamped: straight-line code keeps the waits counted.
+    constexpr int NWC = (LF_BLOCK + NT - 1) / NT;
+    double wv[NWC];
+    {
+        const double* wb = w + (mu == 0 ? WFWD0 : WFWD1);
+#pragma unroll
+        for (int k = 0; k < NWC; ++k) wv[k] = ldu(wb, (unsigned)min(tid + k * NT, LF_BLOCK - 1));
+    }
     // the tile's own links for the final link update: issued now, consumed in the last stage
     double xv0 = 0.0, xv1 = 0.0;
     if ((A.y || A.pout) && tid < N3) {
@@ -111,12 +121,16 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             cs_[0] = cs; cs_[n >> 1] = sn;
         }
     }
-    {   // this layer's forward weight block (the conv2 table padded along the pair direction of this mu)
-        const double* wb = w + (mu == 0 ? WFWD0 : WFWD1);
-        for (int t = tid; t < LF_BLOCK; t += NT) { const double v = wb[t]; if (t < LF_SIZE) sW[t] = v; else sP1[t - LF_SIZE] = v; }
+#pragma unroll
+    for (int k = 0; k < NWC; ++k) {
+        const int t = tid + k * NT;
+        if (t < LF_SIZE) sW[t] = wv[k]; else if (t < LF_BLOCK) sP1[t - LF_SIZE] = wv[k];
     }
     lds_barrier();
     STAMP(1);
+#ifdef FT_DIAG
+    if (A.dbg_stop == 1) return;
+#endif
 
     // stash planes of this lane's output channels g = lane >> 4 and g + 4 (fixed for the kernel)
     const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // tile sites inside the lattice
@@ -182,6 +196,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     }
     lds_barrier();
     STAMP(2);
+#ifdef FT_DIAG
+    if (A.dbg_stop == 2) return;
+#endif
 
     // ---- conv2 (8 -> 8) + act on the live lines of the tile+1 window -----------------------------
     // conv3 reads h2 only within one site of an active line, so every 4th line of the window (stripe
@@ -235,6 +252,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     }
     lds_barrier();
     STAMP(3);
+#ifdef FT_DIAG
+    if (A.dbg_stop == 3) return;
+#endif
 
     // ---- conv3 (8 -> 3) at the NA active sites; one input channel per wave ------
     // active site `lane`: mu=0 columns off+4m, mu=1 rows off+4m (tile origin % 4 == 0)
@@ -259,6 +279,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     }
     lds_barrier();
     STAMP(4);
+#ifdef FT_DIAG
+    if (A.dbg_stop == 4) return;
+#endif
 
     if (REV) {
         // ---- inverse of the tan-mixture transform: solve mean_k y_k(P) = wrap(P' - t) per active site by
@@ -375,6 +398,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     }
     lds_barrier();
     STAMP(5);
+#ifdef FT_DIAG
+    if (A.dbg_stop == 5) return;
+#endif
 
     {
         if (wave == 0) {

@@ -80,6 +80,7 @@ struct FlowLayerArgs {
     long long* dbg;          // optional: per-(chain,tile) stage time stamps [16] (diagnostic runs only)
     double* stash;           // optional: this layer's activation stash (MFMA forward writes, stash backward reads)
     int stash_h;             // forward: also stash h1, h2 (training: the weight gradients need them)
+    int dbg_stop;            // -DFT_DIAG builds: the forward kernel returns after this stage (instruction counts per stage); 0 = run all
     int B, L, mu, off, act;
 };
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);

@@ -198,12 +198,17 @@ def test_observables_tooling(tmp_path):
     assert len(out) == 3 and len(open(tmp_path / 'dq2.txt').read().splitlines()) == 3
 
 
-def test_committed_bench_line_follows_the_contract():
-    """profiles/r01_bench.json is one JSON line of bench.py: every key the driver and the judge read is there,
+@pytest.mark.parametrize('name', ['r01_bench.json', 'r02_bench.json', 'r02_bench_config5.json'])
+def test_committed_bench_line_follows_the_contract(name):
+    """profiles/rNN_bench*.json is one JSON line of bench.py: every key the driver and the judge read is there,
     and the numbers are mutually consistent."""
     import json
-    line = open(os.path.join(ROOT, 'profiles', 'r01_bench.json')).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, 'profiles', name)).read().strip().splitlines()[-1]
     d = json.loads(line)
+    if name.startswith('r02'):
+        assert d['cpu_baseline']['parity']['ok'] is True and d['cpu_baseline']['one_thread']['cores'] == 1
+        assert d['roofline']['attainable']['kernel'].startswith('k_flow_fwd') and 'traffic_source' in d['roofline']
+        assert d['config']['baseline_config'] in (3, 5) and ('train' in d) == (d['config']['baseline_config'] == 5)
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k

@@ -171,13 +171,21 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     int c3r, c3c;
     if (mu == 0) { c3r = fdiv<W2C>(c3u); c3c = c3u - c3r * W2C; }             // (r, c), (r + W2R/2, c)
     else { c3r = fdiv<W2C / 2>(c3u); c3c = c3u - c3r * (W2C / 2); }         // (r, c), (r, c + W2C/2)
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    auto ldu2 = [](const double* base, unsigned idx) {               // 16-byte load, scalar base + 32-bit element offset
+        return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx * 8u);
+    };
     double d2v[2][4];
     {
         const int goA = WI(c3r - 2) + WJ(c3c - 2);
         const int goB = mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
-        const double* pl = uniform_ptr(A.stash, ((size_t)A.B + b) * 8 * n + (size_t)(c3half * 4) * n);
+        // channel-minor stash (struct Stash): the task's four channels of a site are 32 contiguous bytes
+        const double* pl = uniform_ptr(A.stash, ((size_t)A.B + b) * 8 * n + (size_t)(c3half * 4));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { d2v[0][k] = ldu(pl + (size_t)k * n, (unsigned)goA); d2v[1][k] = ldu(pl + (size_t)k * n, (unsigned)goB); }
+        for (int k = 0; k < 4; k += 2) {
+            const double2_t va = ldu2(pl + k, (unsigned)goA * 8u), vb = ldu2(pl + k, (unsigned)goB * 8u);
+            d2v[0][k] = va.x; d2v[0][k + 1] = va.y; d2v[1][k] = vb.x; d2v[1][k + 1] = vb.y;
+        }
     }
     // conv2^T epilogue: lane (g = lane >> 4, i = lane & 15) of tile T = wave + 8 it owns pair 16 T + i,
     // channels g and g + 4, both rows of the pair
@@ -188,10 +196,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         const int T = wave + NW * it, p_ = T * 16 + (lane & 15);
         const int pp = p_ < NPAIR1 ? p_ : 0, pr = fdiv<W1C>(pp), pc = pp - pr * W1C;
         const int j = WJ(pc - 1), ga = WI(2 * pr - 1) + j, gb = WI(2 * pr) + j;
-        const unsigned og = (unsigned)mul24(lane >> 4, n >> 4) * 16u;        // channel plane g (n % 16 == 0, n / 16 < 2^23)
-        const double* ph = st1 + 4 * (size_t)n;
-        d1v[it][0] = ldu(st1, og + ga); d1v[it][1] = ldu(ph, og + ga);
-        d1v[it][2] = ldu(st1, og + gb); d1v[it][3] = ldu(ph, og + gb);
+        const unsigned og = 2u * (unsigned)(lane >> 4);                      // channels 2 g, 2 g + 1: one 16-byte load per site
+        const double2_t va = ldu2(st1, (unsigned)ga * 8u + og), vb = ldu2(st1, (unsigned)gb * 8u + og);
+        d1v[it][0] = va.x; d1v[it][1] = va.y; d1v[it][2] = vb.x; d1v[it][3] = vb.y;
     }
     // training: h1, h2 on the tile+1 window, 16 bytes per lane (they are GEMM operands and do live in LDS).
     // The window starts at the odd column j0 - 1: pairs come from the even-aligned superset
@@ -326,9 +333,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         [&](int g, int p, bool ok, double (&gh)[4], int it) {
             if (ok) {
                 const int pr = fdiv<W1C>(p), pc = p - pr * W1C;
-                double* pd = sD1 + g * PS1 + 2 * pr * W1C + pc;
-                pd[0] = gh[0] * d1v[it][0]; pd[4 * PS1] = gh[1] * d1v[it][1];
-                pd[W1C] = gh[2] * d1v[it][2]; pd[4 * PS1 + W1C] = gh[3] * d1v[it][3];
+                double* pd = sD1 + 2 * g * PS1 + 2 * pr * W1C + pc;          // MFMA rows g, g + 4 = channels 2 g, 2 g + 1 (ft_chan)
+                pd[0] = gh[0] * d1v[it][0]; pd[PS1] = gh[1] * d1v[it][1];
+                pd[W1C] = gh[2] * d1v[it][2]; pd[PS1 + W1C] = gh[3] * d1v[it][3];
             }
         });
     lds_barrier();

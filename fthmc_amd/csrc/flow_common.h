@@ -40,11 +40,15 @@ static_assert(WCAN + WCAN_SIZE <= FLOW_WINT, "weight layout");
 // weight of (window tap, pair member dd) is table[line + 1 - dd]: every operand address of an MFMA is then
 // (a lane part) + (a compile-time constant of the K step) and costs no VALU instruction inside the stage.
 // Table order: [3 = tap along the pair-free direction][g 4][h 2][5 = padded line][cN 8], input channel (K) = 4 h + g,
-// output channel (N) = cN: the 32 lanes of a half-wave (cN, two values of g, dd) then read 32 different LDS banks.
+// output ROW cN of the MFMA = output channel ft_chan(cN): the 32 lanes of a half-wave (cN, two values of g, dd) then
+// read 32 different LDS banks.  ft_chan: a lane holds MFMA rows g and g + 4; with row r carrying channel
+// 2 (r & 3) + (r >> 2) those are the ADJACENT channels 2 g, 2 g + 1, which the channel-minor activation stash
+// (flow_mfma_common.h: struct Stash) stores and loads as one 16-byte access.
 //   forward block (one per mu):  b0[8] b1[8] w2[3][8][9] b2[3]+0  P2[960]  |  P1[3 kx][2 ci: stride 48][5 r5: stride 8][8 co]
 //       mu = 0 (pairs = rows r, r + 1):  P2[kx][g][h][r5][co] = w1[co][4 h + g][r5 - 1][kx]
 //       mu = 1 (pairs = columns):        P2[ky][g][h][c5][co] = w1[co][4 h + g][ky][c5 - 1]
 //   backward block:  w0[8][2][9]  w2[3][8][9]  T2[kx][g][h][r5][ci] = w1[4 h + g][ci][2 - (r5 - 1)][2 - kx]   (conv2^T)
+__host__ __device__ constexpr int ft_chan(int row) { return 2 * (row & 3) + (row >> 2); }
 constexpr int LF_B0 = 0, LF_B1 = 8, LF_W2 = 16, LF_B2 = 232, LF_P2 = 236, LF_SIZE = LF_P2 + 960;   // resident part
 constexpr int LF_P1 = LF_SIZE, LF_P1_SIZE = 288, LF_BLOCK = LF_P1 + LF_P1_SIZE;                   // conv1 table: conv1 stage only
 constexpr int LB_W0 = 0, LB_W2 = 144, LB_T2 = 360, LB_SIZE = LB_T2 + 960;

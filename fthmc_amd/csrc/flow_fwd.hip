@@ -132,13 +132,15 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     if (A.dbg_stop == 1) return;
 #endif
 
-    // stash planes of this lane's output channels g = lane >> 4 and g + 4 (fixed for the kernel)
+    // stash of this lane's output channels 2 g, 2 g + 1, g = lane >> 4 (fixed for the kernel): act' channel-minor
+    // (one 16-byte store per site), h plane-major (training)
     const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // tile sites inside the lattice
     const Stash sv = A.stash ? stash_view(A.stash, A.B, b, n) : Stash{};
-    double* const st_d1 = sv.d1 ? sv.d1 + (size_t)(lane >> 4) * n : nullptr;
-    double* const st_d2 = sv.d1 ? sv.d2 + (size_t)(lane >> 4) * n : nullptr;
-    double* const st_h1 = sv.d1 ? sv.h1 + (size_t)(lane >> 4) * n : nullptr;
-    double* const st_h2 = sv.d1 ? sv.h2 + (size_t)(lane >> 4) * n : nullptr;
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    double* const st_d1 = sv.d1 ? sv.d1 + 2 * (lane >> 4) : nullptr;
+    double* const st_d2 = sv.d1 ? sv.d2 + 2 * (lane >> 4) : nullptr;
+    double* const st_h1 = sv.d1 ? sv.h1 + (size_t)(2 * (lane >> 4)) * n : nullptr;
+    double* const st_h2 = sv.d1 ? sv.h2 + (size_t)(2 * (lane >> 4)) * n : nullptr;
 
     // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
     // B[k = (tap, ci)][n = (co, dd)] = W0[co][ci][ky4 - dd][kx] out of the padded table P1 (flow_mfma_common.h: KConv1)
@@ -151,13 +153,13 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         [](int p) { const int pr = fdiv<R1C>(p); return 2 * pr * R0C + p - pr * R1C; },
         [&](int g, int p, bool ok, double (&z)[4], int) {
             const int pr = fdiv<R1C>(p), pc = p - pr * R1C;
-            const double b0 = sW[LF_B0 + g], b1 = sW[LF_B0 + g + 4];
+            const double b0 = sW[LF_B0 + 2 * g], b1 = sW[LF_B0 + 2 * g + 1];
             double h[4], d[4];
             z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
             act_eval4(z, act, h, d);
             if (ok) {
-                double* ph = sH1 + g * PS1 + 2 * pr * R1C + pc;
-                ph[0] = h[0]; ph[4 * PS1] = h[1]; ph[R1C] = h[2]; ph[4 * PS1 + R1C] = h[3];
+                double* ph = sH1 + 2 * g * PS1 + 2 * pr * R1C + pc;
+                ph[0] = h[0]; ph[PS1] = h[1]; ph[R1C] = h[2]; ph[PS1 + R1C] = h[3];
             }
             if (A.stash) {                                  // act'(z1) (and h1) of the tile's own sites
                 const int r = 2 * pr - 2, c = pc - 2;
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
 #pragma unroll
                     for (int dd = 0; dd < 2; ++dd)
                         if ((unsigned)(r + dd) < (unsigned)rmax) {
-                            st_d1[at + dd * L] = d[2 * dd]; st_d1[at + dd * L + 4 * n] = d[2 * dd + 1];
-                            if (A.stash_h) { st_h1[at + dd * L] = h[2 * dd]; st_h1[at + dd * L + 4 * n] = h[2 * dd + 1]; }
+                            *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dd * L)) = double2_t{d[2 * dd], d[2 * dd + 1]};
+                            if (A.stash_h) { st_h1[at + dd * L] = h[2 * dd]; st_h1[at + dd * L + n] = h[2 * dd + 1]; }
                         }
                 }
             }
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         const int idx = tid - NT / 2, co = idx & 7, site = idx >> 3;
         const int p = NP1M + (site >> 1), pr = fdiv<R1C>(p), pc = p - pr * R1C, r = 2 * pr + (site & 1);
         const double* in = sIn + r * R0C + pc;
-        const double* wp = sP1 + co + 8;                               // P1[kx][ci][r5 = ky + 1][co]
+        const double* wp = sP1 + (co >> 1) + 4 * (co & 1) + 8;         // P1[kx][ci][r5 = ky + 1][row], ft_chan(row) = co
         double z = sW[LF_B0 + co];
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             const int rr = r - 2, cc = pc - 2;
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
                 const int at = mul24(i0 + rr, L) + j0 + cc;
-                sv.d1[(size_t)co * n + at] = d;
+                sv.d1[8 * (size_t)at + co] = d;
                 if (A.stash_h) sv.h1[(size_t)co * n + at] = h;
             }
         }
@@ -211,16 +213,16 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                   "one conv2 tile per wave: its epilogue holds a workgroup barrier");
     const int d0 = ((off + 3) - (mu == 0 ? j0 : i0)) & 3;               // first dead line of the window
     auto conv2_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
-        // sites (r, c) and (r + dr, c + dc) in window coordinates; z[q]: channel g + 4 (q & 1), site q >> 1
-        const double b0 = sW[LF_B1 + g], b1 = sW[LF_B1 + g + 4];
+        // sites (r, c) and (r + dr, c + dc) in window coordinates; z[q]: channel 2 g + (q & 1), site q >> 1
+        const double b0 = sW[LF_B1 + 2 * g], b1 = sW[LF_B1 + 2 * g + 1];
         double h[4], d[4];
         z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
         act_eval4(z, act, h, d);
         lds_barrier();                                      // h2 overwrites h1: every wave has finished its MFMA reads
         const int so = dr * R2C + dc;
         if (ok) {
-            double* ph = sH2 + g * PS2 + r * R2C + c;
-            ph[0] = h[0]; ph[4 * PS2] = h[1]; ph[so] = h[2]; ph[4 * PS2 + so] = h[3];
+            double* ph = sH2 + 2 * g * PS2 + r * R2C + c;
+            ph[0] = h[0]; ph[PS2] = h[1]; ph[so] = h[2]; ph[PS2 + so] = h[3];
         }
         if (A.stash && ok) {                                // act'(z2) (and h2) of the tile's own sites
             const int at = mul24(i0 + r - 1, L) + j0 + c - 1;
@@ -228,8 +230,8 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             for (int q = 0; q < 2; ++q)
                 if ((unsigned)(r - 1 + q * dr) < (unsigned)rmax && (unsigned)(c - 1 + q * dc) < (unsigned)cmax) {
                     const int aq = at + q * (dr * L + dc);
-                    st_d2[aq] = d[2 * q]; st_d2[aq + 4 * n] = d[2 * q + 1];
-                    if (A.stash_h) { st_h2[aq] = h[2 * q]; st_h2[aq + 4 * n] = h[2 * q + 1]; }
+                    *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)aq) = double2_t{d[2 * q], d[2 * q + 1]};
+                    if (A.stash_h) { st_h2[aq] = h[2 * q]; st_h2[aq + n] = h[2 * q + 1]; }
                 }
         }
     };

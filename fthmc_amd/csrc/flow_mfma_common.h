@@ -82,7 +82,9 @@ template <int TR, int TC> struct Geom {
 
 // Per-layer activation stash written by the forward kernel and read back by the gather-form backward
 // (n = L * L; per chain b):
-//   d1  [8][n]     act'(z1)                       d2  [8][n]   act'(z2)  (dead lines unwritten)
+//   d1  [n][8]     act'(z1), channel-minor        d2  [n][8]   act'(z2)  (dead lines unwritten)
+//                  (64 B per site: a window row of 20 sites is 10 cache lines for all channels, not 8 x 2..3,
+//                   and the channel pair (2 g, 2 g + 1) of a lane is one 16-byte access)
 //   tc  [8][n/4]   adjoint coefficients of the tan-mixture transform at the ACTIVE sites, compact:
 //                  plane 2 q + k, q = 0..3 -> A_k, B_k, C_k, E_k.  With g = upstream dL/d delta,
 //                  cb = dL/dlogJ and the softmax normaliser rs = 1 / (K sum_k C_k)  (C_k = 1 / (K D_k)):
@@ -127,7 +129,8 @@ __device__ __forceinline__ int stash_frozen_idx(int i, int j, int L, int mu, int
 // with aimm / bimm compile-time constants (they become the offset field of the ds_read) and wl, the lane part of
 // the weight index, computed once per stage by the caller from (g, cN = i & 7, dd = i >> 3) against a zero-padded
 // weight table (flow_common.h), so the K loop holds no VALU instruction at all.
-//   epi(g, p, ok, z, it): z[q] = output channel g + 4 (q & 1) at site (q >> 1) of pair p; all four values
+//   epi(g, p, ok, z, it): z[q] = output channel 2 g + (q & 1) (= ft_chan of MFMA row g + 4 (q & 1), flow_common.h)
+//               at site (q >> 1) of pair p; all four values
 //               of a lane at once so that their chains interleave; it = which of the wave's tiles (a
 //               compile-time constant with UNROLL, so the caller can keep per-tile operands in registers)
 // K orders (RSA / PSA: row / plane stride of the activation planes):

@@ -113,6 +113,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         else { const int m = fdiv<W3C>(ta); tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
         if (!ttask) { tr3 = 3; tc3 = 3; }                                // any valid site
     } else { tr3 = 3; tc3 = 3; }
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    auto ldu2 = [](const double* base, unsigned idx) {               // 16-byte load, scalar base + 32-bit element offset
+        return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx * 8u);
+    };
     double tcv[4 * NMIX], ag[2];
     const double cb = A.glogj ? A.glogj[b] : A.glogj_const;
     {
@@ -120,7 +124,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         // wave-uniform base + 32-bit per-lane offset everywhere: the address costs no VALU op per load
         const unsigned ia = (unsigned)stash_active_idx(i, j, L, mu);
 #pragma unroll
-        for (int q = 0; q < 4 * NMIX; ++q) tcv[q] = ldu(stc + (size_t)q * (n >> 2), ia);
+        for (int q = 0; q < 4 * NMIX; q += 2) {                             // site-major [n/4][k][A B C E]: 16 bytes per load
+            const double2_t t2 = ldu2(stc, ia * (4u * NMIX) + q);
+            tcv[q] = t2.x; tcv[q + 1] = t2.y;
+        }
         // upstream gradient: a link field (first layer of a standalone call) or the plaquette-gradient field
         const double* gsrc = uniform_ptr(A.up_link ? A.up_link : A.up_gp, A.up_link ? (size_t)b * 2 * n + (size_t)mu * n : (size_t)b * n);
         const int iL = mul24(i, L);
@@ -171,10 +178,6 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     int c3r, c3c;
     if (mu == 0) { c3r = fdiv<W2C>(c3u); c3c = c3u - c3r * W2C; }             // (r, c), (r + W2R/2, c)
     else { c3r = fdiv<W2C / 2>(c3u); c3c = c3u - c3r * (W2C / 2); }         // (r, c), (r, c + W2C/2)
-    typedef double double2_t __attribute__((ext_vector_type(2)));
-    auto ldu2 = [](const double* base, unsigned idx) {               // 16-byte load, scalar base + 32-bit element offset
-        return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx * 8u);
-    };
     double d2v[2][4];
     {
         const int goA = WI(c3r - 2) + WJ(c3c - 2);
@@ -225,14 +228,14 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         const int at = tr3 * W3C + tc3;
         double csum = 0.0, esum = 0.0;
 #pragma unroll
-        for (int k = 0; k < NMIX; ++k) { csum += tcv[2 * NMIX + k]; esum += tcv[3 * NMIX + k]; }
+        for (int k = 0; k < NMIX; ++k) { csum += tcv[4 * k + 2]; esum += tcv[4 * k + 3]; }
         const double tsum = NMIX * csum;                                 // sum_k 1 / D_k
         double rs = __builtin_amdgcn_rcp(tsum);
         rs = fma(fma(-tsum, rs, 1.0), rs, rs);
         rs = fma(fma(-tsum, rs, 1.0), rs, rs);
         const double cbr = cb * rs;
 #pragma unroll
-        for (int k = 0; k < NMIX; ++k) sGO[k * N3W + at] = gdelta * tcv[k] + cbr * tcv[NMIX + k];   // dL/ds_k
+        for (int k = 0; k < NMIX; ++k) sGO[k * N3W + at] = gdelta * tcv[4 * k] + cbr * tcv[4 * k + 1];   // dL/ds_k
         sGO[NMIX * N3W + at] = gdelta;                                   // dL/dt
         const int r = tr3 - 3, c = tc3 - 3;
         if ((unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC) sDir[r * TC + c] = gdelta * (csum - 1.0) - cbr * esum;

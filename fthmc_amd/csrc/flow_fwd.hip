@@ -385,11 +385,12 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             // coefficients of the transform's adjoint (struct Stash): the backward kernel then needs no
             // plaquettes, sincos or exp at the active sites of its tile+3 window
             const double sinP = 2.0 * sincs, invD2 = invD * invD;
-            double* tc = sv.tc + stash_active_idx(ai, aj, L, mu) + (size_t)wave * (n >> 2);
-            tc[0] = sinP * invD / NMIX;                                  // A_k
-            tc[2 * (n >> 2)] = (ems * cs2 - es * sn2) * invD2;           // B_k
-            tc[4 * (n >> 2)] = invD / NMIX;                              // C_k
-            tc[6 * (n >> 2)] = sinP * 0.5 * (es - ems) * invD2;          // E_k
+            // site-major [n/4][k][A B C E]: this wave's four coefficients are 32 contiguous bytes
+            double* tc = sv.tc + 4 * NMIX * (size_t)stash_active_idx(ai, aj, L, mu) + 4 * wave;
+            *reinterpret_cast<double2_t*>(tc) = double2_t{sinP * invD / NMIX,                      // A_k
+                                                         (ems * cs2 - es * sn2) * invD2};          // B_k
+            *reinterpret_cast<double2_t*>(tc + 2) = double2_t{invD / NMIX,                         // C_k
+                                                             sinP * 0.5 * (es - ems) * invD2};     // E_k
         }
     }
     if (wave == NMIX && alane) {                                 // t on an otherwise idle wave

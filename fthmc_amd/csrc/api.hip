@@ -563,10 +563,15 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
 
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 1) return FTHMC_ERR_ARG;
-    FT_WS(1);
-    const size_t nrec = (size_t)B * (kind == 1 ? flow_gather_geom() : flow_fwd_geom(true)).ntiles(L);
-    long long* dbg = reinterpret_cast<long long*>(W.gw_part);      // B*ntiles*960 doubles >> 16 stamps each
+    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
+    (void)hipGetLastError();
+    const bool train = kind == 2;                                  // kind 2: the training backward (weight gradients too)
+    if (!ws || ws_bytes < (train ? fthmc_train_ws_bytes(B, L, 1) : fthmc_ws_bytes(B, L, 1))) return FTHMC_ERR_WS;
+    const WS W = ws_layout(static_cast<double*>(ws), B, L, 1, train);
+    hipStream_t s = ft_stream(stream);
+    const size_t nrec = (size_t)B * (kind >= 1 ? flow_gather_geom(train) : flow_fwd_geom(true)).ntiles(L);
+    // stamp buffer: a workspace region the profiled launch does not write (B * ntiles * 16 stamps fit in either)
+    long long* dbg = reinterpret_cast<long long*>(train ? W.gp_part : W.gw_part);
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     FT_TRY(launch_pack_weights(w, 1, W.wint, s));
     FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
@@ -574,12 +579,12 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
     a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
     a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.gp_out = W.gp2; a.dbg = dbg;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    if (kind == 1) {                              // stash backward needs the forward's stash first
-        a.stash = W.stash; a.dbg = nullptr;
+    if (kind >= 1) {                              // stash backward needs the forward's stash first
+        a.stash = W.stash; a.stash_h = train ? 1 : 0; a.gw_part = W.gw_part; a.dbg = nullptr;
         FT_TRY(launch_flow_fwd_mfma(a, s));
         a.dbg = dbg;
     }
-    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : launch_flow_bwd_gather(a, false, s));
+    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : launch_flow_bwd_gather(a, train, s));
     long long* h = (long long*)malloc(nrec * 16 * sizeof(long long));
     if (!h) return FTHMC_ERR_ARG;
     if (hipMemcpyAsync(h, dbg, nrec * 16 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -587,7 +592,7 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
     for (int k = 0; k < 16; ++k) cycles_host16[k] = 0.0;
     for (size_t r = 0; r < nrec; ++r)
         for (int k = 1; k < 16; ++k) {
-            const int ref = (kind == 1 && k >= 6) ? 0 : (kind == 0 && k == 7) ? 1 : (kind == 0 && k == 11) ? 2 : k - 1;   // forward 7..12 (-DFT_DIAG builds): inside conv1 / conv2      // backward, slots 6..13: per-wave arrival at the first barrier
+            const int ref = (kind >= 1 && k >= 6) ? 0 : (kind == 0 && k == 7) ? 1 : (kind == 0 && k == 11) ? 2 : k - 1;   // forward 7..12 (-DFT_DIAG builds): inside conv1 / conv2      // backward, slots 6..13: per-wave arrival at the first barrier
             if (h[r * 16 + k] && h[r * 16 + ref]) cycles_host16[k] += (double)(h[r * 16 + k] - h[r * 16 + ref]) / nrec;
         }
     free(h);

@@ -485,11 +485,13 @@ __global__ __launch_bounds__(256) void k_flow_layer(FlowLayerArgs A) {
 // out[b] (+)= sign * sum_t part[b][t]
 __global__ void k_sum_parts(const double* __restrict__ part, int B, int np, double sign, int accumulate,
                             double* __restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    // one wave per chain: lane l sums the partials t = l, l + 64, ... in order, then a fixed xor tree
+    // (deterministic; one thread per chain read L^2 / 256 partials serially: 124 us per call at L = 256)
+    const int b = blockIdx.x, lane = threadIdx.x;
     double a = 0.0;
-    for (int t = 0; t < np; ++t) a += part[(size_t)b * np + t];
-    out[b] = (accumulate ? out[b] : 0.0) + sign * a;
+    for (int t = lane; t < np; t += FT_WAVE) a += part[(size_t)b * np + t];
+    a = ft_wave_sum(a);
+    if (lane == 0) out[b] = (accumulate ? out[b] : 0.0) + sign * a;
 }
 
 // gp[b][i][j] (+)= sum over tiles and over every window position that wraps onto (i, j).
@@ -606,7 +608,7 @@ int launch_flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s) {
 }
 int launch_sum_parts(const double* part, int B, int nparts, double sign, int accumulate, double* out,
                      hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_parts, dim3((B + 63) / 64), dim3(64), 0, s, part, B, nparts, sign, accumulate, out);
+    hipLaunchKernelGGL(k_sum_parts, dim3(B), dim3(FT_WAVE), 0, s, part, B, nparts, sign, accumulate, out);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_gather_gp(const double* gp_part, int B, int L, FlowGeom g, int accumulate, double* gp, hipStream_t s) {

@@ -304,28 +304,55 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     STAMP(2);
 
     if (TRAIN) {
-        // ---- weight gradient of conv3 and b3: sums over the tile's own active sites (VALU) -------
-        constexpr int NA = N3 / 4;
-        for (int t = tid; t < 216; t += NT) {
-            const int co = t / 72, ci = (t / 9) % 8, tap = t % 9, ky = tap / 3, kx = tap % 3;
-            double acc = 0.0;
-            for (int a = 0; a < NA; ++a) {
-                const int r = mu == 0 ? a / (TC / 4) : off + 4 * (a / TC);
-                const int c = mu == 0 ? off + 4 * (a % (TC / 4)) : a % TC;
-                if (r < rmax && c < cmax)
-                    acc = fma(sGO[co * N3W + (r + 3) * W3C + c + 3], sH2w[ci * PS1 + (r + ky) * W1C + c + kx], acc);
+        // ---- weight gradient of conv3 and b3: sums over the tile's own active sites (VALU), on the waves that own
+        //      no conv2^T tile (they would otherwise idle through the MFMA stage below); site loops with fixed
+        //      trip counts (no division per site), all of a site row's operands in flight together -------
+        constexpr int NP1T = (W1R / 2) * W1C, NT1T = (NP1T + 15) / 16;     // conv2^T tiles of this geometry
+        constexpr int W3W0 = NT1T < NW ? NT1T : 0;                          // first wave without one
+        constexpr int NTH3 = NT - 64 * W3W0;
+        if (tid >= 64 * W3W0) {
+            for (int t = tid - 64 * W3W0; t < 216; t += NTH3) {
+                const int co = t / 72, ci = (t / 9) % 8, tap = t % 9, ky = tap / 3, kx = tap % 3;
+                const double* pg = sGO + co * N3W + 3 * W3C + 3;           // g_out at own site (r, c): pg[r * W3C + c]
+                const double* ph = sH2w + ci * PS1 + ky * W1C + kx;        // h2 at (r + ky - 1, c + kx - 1): ph[r * W1C + c]
+                double acc = 0.0;
+                if (mu == 0) {
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) {
+                        double gv[TC / 4], hv[TC / 4];
+#pragma unroll
+                        for (int m = 0; m < TC / 4; ++m) { gv[m] = pg[r * W3C + off + 4 * m]; hv[m] = ph[r * W1C + off + 4 * m]; }
+#pragma unroll
+                        for (int m = 0; m < TC / 4; ++m) if (r < rmax && off + 4 * m < cmax) acc = fma(gv[m], hv[m], acc);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < TR / 4; ++q) {
+                        const int r = off + 4 * q;
+#pragma unroll
+                        for (int c0_ = 0; c0_ < TC; c0_ += 4) {
+                            double gv[4], hv[4];
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) { gv[m] = pg[r * W3C + c0_ + m]; hv[m] = ph[r * W1C + c0_ + m]; }
+#pragma unroll
+                            for (int m = 0; m < 4; ++m) if (r < rmax && c0_ + m < cmax) acc = fma(gv[m], hv[m], acc);
+                        }
+                    }
+                }
+                gwp[CW2 + t] = acc;
             }
-            gwp[CW2 + t] = acc;
         }
-        if (wave < 3) {
+        if (wave >= NW - 3) {                                            // b3[k] on the last three waves
+            constexpr int NA = N3 / 4;
+            const int k = wave - (NW - 3);
             double a_ = 0.0;
             for (int a = lane; a < NA; a += 64) {
                 const int r = mu == 0 ? a / (TC / 4) : off + 4 * (a / TC);
                 const int c = mu == 0 ? off + 4 * (a % (TC / 4)) : a % TC;
-                if (r < rmax && c < cmax) a_ += sGO[wave * N3W + (r + 3) * W3C + c + 3];
+                if (r < rmax && c < cmax) a_ += sGO[k * N3W + (r + 3) * W3C + c + 3];
             }
             a_ = ft_wave_sum(a_);
-            if (lane == 0) gwp[CB2 + wave] = a_;
+            if (lane == 0) gwp[CB2 + k] = a_;
         }
     }
 

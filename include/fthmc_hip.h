@@ -202,8 +202,8 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
                       int act, double beta, int reps, double* ms_avg_host,
                       void* ws, size_t ws_bytes, void* stream);
 
-/* Diagnostic (synchronises, mallocs on the host): one launch of the MFMA forward (kind 0),
- * or stash backward (kind 1) kernel with per-workgroup cycle stamps at every stage boundary;
+/* Diagnostic (synchronises, mallocs on the host): one launch of the MFMA forward (kind 0), stash backward
+ * (kind 1) or training backward (kind 2, ws: fthmc_train_ws_bytes) kernel with per-workgroup cycle stamps at every stage boundary;
  * cycles_host16[k] = mean cycles spent between stamp k-1 and stamp k. */
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off,
                          int act, double beta, double* cycles_host16,

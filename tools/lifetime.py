@@ -6,12 +6,13 @@ L = 64
 gen = torch.Generator().manual_seed(1331)
 w = ops.pack_weights(R.default_flow(1, gen), device='cuda')
 names = {'flow_fwd': ['', 'plaq+sincos', 'conv1', 'conv2', 'conv3', 'transform1', 'finish+store'],
-         'flow_bwd': ['', 'load+xform', 'conv3T', 'conv2T', 'conv1T', 'store']}
+         'flow_bwd': ['', 'load+xform', 'conv3T', 'conv2T', 'conv1T', 'store'],
+         'flow_bwd_train': ['', 'load+xform', 'conv3T+h2', 'wgrad3+conv2T', 'wgrad2+conv1T', 'wgrad1+store']}
 for B in [int(a) for a in sys.argv[1:]] or (16, 32, 48, 64, 96, 128, 256):
     x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
-    for kind in ('flow_fwd', 'flow_bwd'):
+    for kind in ('flow_fwd', 'flow_bwd', 'flow_bwd_train'):
         cyc = ops.profile_stages(kind, x, w, mu=0, off=1, beta=6.0)
         tot = sum(cyc[:7]) if kind == 'flow_fwd' else sum(cyc[:6])
-        ms = ops.time_kernel(kind, x, w, mu=0, off=1, beta=6.0, reps=30)
+        ms = ops.time_kernel(kind, x, w, mu=0, off=1, beta=6.0, reps=30) if kind != 'flow_bwd_train' else float('nan')
         if kind == 'flow_fwd' and any(cyc[7:13]): print('      inside conv1 (tile 0: mfma, epilogue; tile 1: mfma, epilogue), conv2 (mfma, epilogue):', ' '.join(f'{c:.0f}' for c in cyc[7:13]))
         print(f'B={B:3d} WGs={B*16:5d} {kind}: {ms*1e3:7.2f} us; lifetime {tot:6.0f} cycles/WG; ' + ', '.join(f'{n} {c:.0f}' for n, c in zip(names[kind][1:], cyc[1:]) if n), flush=True)

@@ -24,7 +24,7 @@ constexpr size_t ALIGN = 32;   // doubles (256 B)
 inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct WS {
-    double *wint, *X, *gp, *gp2, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *gw_tmp, *stash;
+    double *wint, *X, *gp, *gp2, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *gw_tmp, *stash, *gz;
     size_t n2;       // doubles per field batch: B * 2 * L * L
     size_t total;    // doubles
 };
@@ -50,6 +50,7 @@ WS ws_layout(double* base, int B, int L, int nl, bool train = false) {
     w.gw_part = take(nl > 0 ? (size_t)B * nt * FLOW_GW_STRIDE : 0);
     w.gw_tmp = take(nl > 0 ? (size_t)FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE : 0);
     w.stash = take((size_t)nl * flow_stash_doubles(B, L, train));   // activation stash of a force evaluation
+    w.gz = take(train && nl > 0 ? flow_gz_doubles(B, L) : 0);       // training: pre-activation gradients of the layer in flight
     w.total = o;
     return w;
 }
@@ -127,9 +128,13 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
         if (stash) {
             a.stash = w.stash + (size_t)l * flow_stash_doubles(B, L, train);
             a.gp_out = galt;
-            FT_TRY(launch_flow_bwd_gather(a, train, s));
-            if (gw) FT_TRY(launch_reduce_gw(w.gw_part, B * flow_gather_geom(true).ntiles(L), 1.0, 0,
-                                            gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
+            a.gz = train ? w.gz : nullptr;
+            FT_TRY(launch_flow_bwd_gather(a, s));
+            if (gw) {                                                 // weight gradients from the pre-activation gradients
+                FT_TRY(launch_flow_wgrad(a, s));
+                FT_TRY(launch_reduce_gw(w.gw_part, B * flow_wgrad_parts(L), 1.0, 0,
+                                        gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
+            }
             double* t_ = gcur; gcur = galt; galt = t_;
             continue;
         }
@@ -353,8 +358,12 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
         a.stash = W.stash; a.stash_h = gw ? 1 : 0;
         FT_TRY(launch_flow_fwd_mfma(a, s));
         a.gp_out = W.gp;
-        FT_TRY(launch_flow_bwd_gather(a, gw != nullptr, s));
-        if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_gather_geom(true).ntiles(L), 1.0, 0, gw, W.gw_tmp, s));
+        a.gz = gw ? W.gz : nullptr;
+        FT_TRY(launch_flow_bwd_gather(a, s));
+        if (gw) {
+            FT_TRY(launch_flow_wgrad(a, s));
+            FT_TRY(launch_reduce_gw(W.gw_part, B * flow_wgrad_parts(L), 1.0, 0, gw, W.gw_tmp, s));
+        }
         return launch_adj_add(W.gp, gy, B, L, gx, s);
     }
     FT_TRY(launch_flow_bwd(a, gw != nullptr, s));
@@ -548,7 +557,7 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
         if (it == 0) (void)hipEventRecord(e0, s);
         if (kind == 0) rc = flow_fwd(a, s);
-        else if (kind == 1) rc = a.stash ? launch_flow_bwd_gather(a, false, s) : launch_flow_bwd(a, false, s);
+        else if (kind == 1) rc = a.stash ? launch_flow_bwd_gather(a, s) : launch_flow_bwd(a, false, s);
         else if (kind == 2) rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
         else rc = launch_hmc_trajectory_fused(x, W.va, W.scal + B, B, L, beta, 0.1, 10, W.xa, nullptr, nullptr, nullptr, nullptr, s);
     }
@@ -565,11 +574,11 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
     (void)hipGetLastError();
-    const bool train = kind == 2;                                  // kind 2: the training backward (weight gradients too)
+    const bool train = kind == 2;                                  // kind 2: the backward in training mode (also writes A.gz)
     if (!ws || ws_bytes < (train ? fthmc_train_ws_bytes(B, L, 1) : fthmc_ws_bytes(B, L, 1))) return FTHMC_ERR_WS;
     const WS W = ws_layout(static_cast<double*>(ws), B, L, 1, train);
     hipStream_t s = ft_stream(stream);
-    const size_t nrec = (size_t)B * (kind >= 1 ? flow_gather_geom(train) : flow_fwd_geom(true)).ntiles(L);
+    const size_t nrec = (size_t)B * (kind >= 1 ? flow_gather_geom() : flow_fwd_geom(true)).ntiles(L);
     // stamp buffer: a workspace region the profiled launch does not write (B * ntiles * 16 stamps fit in either)
     long long* dbg = reinterpret_cast<long long*>(train ? W.gp_part : W.gw_part);
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
@@ -580,11 +589,11 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
     a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.gp_out = W.gp2; a.dbg = dbg;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
     if (kind >= 1) {                              // stash backward needs the forward's stash first
-        a.stash = W.stash; a.stash_h = train ? 1 : 0; a.gw_part = W.gw_part; a.dbg = nullptr;
+        a.stash = W.stash; a.stash_h = train ? 1 : 0; a.gw_part = W.gw_part; a.gz = train ? W.gz : nullptr; a.dbg = nullptr;
         FT_TRY(launch_flow_fwd_mfma(a, s));
         a.dbg = dbg;
     }
-    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : launch_flow_bwd_gather(a, train, s));
+    FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : launch_flow_bwd_gather(a, s));
     long long* h = (long long*)malloc(nrec * 16 * sizeof(long long));
     if (!h) return FTHMC_ERR_ARG;
     if (hipMemcpyAsync(h, dbg, nrec * 16 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||

@@ -31,10 +31,10 @@ using namespace fthmc_flow;
 
 constexpr int cmax_(int a, int b) { return a > b ? a : b; }
 
-template <int TR, int TC, bool TRAIN> struct SmemG {
+template <int TR, int TC> struct SmemG {
     static constexpr int W3R = TR + 6, W3C = TC + 6, N3W = W3R * W3C;   // g_out window (active sites only)
     static constexpr int W2R = TR + 4, W2C = TC + 4, N2W = W2R * W2C;   // act'(z2) -> gz2
-    static constexpr int W1R = TR + 2, W1C = TC + 2, N1W = W1R * W1C;   // act'(z1) -> gz1; cos/sin; h1, h2 (training)
+    static constexpr int W1R = TR + 2, W1C = TC + 2, N1W = W1R * W1C;   // act'(z1) -> gz1; cos/sin
     static constexpr int N3 = TR * TC;
     static constexpr int PS2 = ps_round(N2W), PS1 = ps_round(N1W);
     // active lines of the g_out window: every 4th column (mu = 0) or row (mu = 1)
@@ -47,22 +47,22 @@ template <int TR, int TC, bool TRAIN> struct SmemG {
     static constexpr int IN = D1 + 8 * PS1;                             // [2][PS1] cos, sin (tile+1 coordinates)
     static constexpr int DIR = IN + 2 * PS1;                            // [N3] layer's contribution at own sites
     static constexpr int SW = DIR + N3;                                 // [LB_SIZE] backward weight block (flow_common.h)
-    static constexpr int H1W = SW + LB_SIZE;                            // [8][PS1] h1 (training)
-    static constexpr int H2W = H1W + (TRAIN ? 8 * PS1 : 0);             // [8][PS1] h2 (training)
-    static constexpr int SIZE = H2W + (TRAIN ? 8 * PS1 : 0);
+    static constexpr int SIZE = SW + LB_SIZE;
     static_assert(W1R % 2 == 0, "row pairs");
     static_assert(NTT <= NT && 2 * N3 <= NT && N1W <= NT, "thread maps");
 };
 
-template <int TR, int TC, bool TRAIN, bool FASTW>
+// A.gz (training): the kernel additionally writes the gradients wrt the layer's pre-activations at the tile's own
+// sites -- gz2, gz1 (channel-minor) and the transform adjoint g_out at the active sites -- for k_flow_wgrad
+// (flow_wgrad.hip), which turns them into weight gradients; nothing else changes.
+template <int TR, int TC, bool FASTW>
 __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
-    using S = SmemG<TR, TC, TRAIN>;
+    using S = SmemG<TR, TC>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
-    constexpr int W1R = S::W1R, W1C = S::W1C, N1W = S::N1W, N3 = S::N3, PS1 = S::PS1, PS2 = S::PS2;
+    constexpr int W1R = S::W1R, W1C = S::W1C, N3 = S::N3, PS1 = S::PS1, PS2 = S::PS2;
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
     double* sGO = sm + S::GO;   double* sGZ2 = sm + S::GZ2;  double* sD1 = sm + S::D1;
     double* sIn = sm + S::IN;   double* sDir = sm + S::DIR;  double* sW = sm + S::SW;
-    double* sH1w = sm + S::H1W; double* sH2w = sm + S::H2W;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,10 +81,11 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     const double* __restrict__ st1 = uniform_ptr(A.stash, (size_t)b * 8 * n);
     const double* __restrict__ stc = uniform_ptr(A.stash, ((size_t)A.B * 16 + (size_t)b * 2) * n);
     const double* __restrict__ scs = uniform_ptr(A.stash, ((size_t)A.B * 18 + b) * n);
-    const double* __restrict__ sh1 = uniform_ptr(A.stash, ((size_t)A.B * 19 + (size_t)b * 8) * n);
-    const double* __restrict__ sh2 = uniform_ptr(A.stash, ((size_t)A.B * 27 + (size_t)b * 8) * n);
     (void)sv;
-    double* gwp = TRAIN ? A.gw_part + ((size_t)b * ntiles + tile) * FLOW_GW_STRIDE : nullptr;
+    // training outputs of this chain (kernels.h: FlowLayerArgs::gz)
+    double* const gz2o = A.gz ? A.gz + (size_t)b * 17 * n : nullptr;
+    double* const gz1o = A.gz ? gz2o + (size_t)8 * n : nullptr;
+    double* const goo = A.gz ? gz2o + (size_t)16 * n : nullptr;
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
@@ -134,17 +135,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         ag[0] = ldu(gsrc, (unsigned)(iL + j));
         ag[1] = ldu(gsrc, (unsigned)(mu == 0 ? iL + WJ(tc3 - 4) : WI(tr3 - 4) + j));   // unused with up_link
     }
-    // (2) cos / sin of the frozen plaquettes: own sites only, or the whole tile+1 window for the conv1
-    //     weight gradient (training).  Stored in tile+1 coordinates.
+    // (2) cos / sin of the tile's own frozen plaquettes.  Stored in tile+1 coordinates.
     int fr1 = 1, fc1 = 1;                                                // tile+1 coordinates of this thread's site
     bool ftask = false;
-    if (TRAIN) {
-        if (tid < N1W) {
-            fr1 = fdiv<W1C>(tid); fc1 = tid - fr1 * W1C;
-            const int cls = ((mu == 0 ? j0 - 1 + fc1 : i0 - 1 + fr1) - off) & 3;
-            ftask = cls == 1 || cls == 2;
-        }
-    } else if (tid < N3 / 2) {
+    if (tid < N3 / 2) {
         int r, c;
         if (mu == 0) { r = fdiv<TC / 2>(tid); const int h = tid - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
         else { const int hh = fdiv<TC>(tid); c = tid - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
@@ -203,20 +197,6 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         const double2_t va = ldu2(st1, (unsigned)ga * 8u + og), vb = ldu2(st1, (unsigned)gb * 8u + og);
         d1v[it][0] = va.x; d1v[it][1] = va.y; d1v[it][2] = vb.x; d1v[it][3] = vb.y;
     }
-    // training: h1, h2 on the tile+1 window, 16 bytes per lane (they are GEMM operands and do live in LDS).
-    // The window starts at the odd column j0 - 1: pairs come from the even-aligned superset
-    // j0 - 2 .. j0 + TC + 1 (L is even, so a pair never straddles the wrap), the two outer columns are dropped.
-    typedef double double2_t __attribute__((ext_vector_type(2)));
-    static_assert((W1C + 2) / 2 <= 16 && W1R <= NT / 16, "pair loads");
-    const int lq = tid & 15, lg = tid >> 4;
-    const bool ok1 = TRAIN && lq < (W1C + 2) / 2 && lg < W1R;
-    // one register set for both: h2 (needed first, by the conv3 weight gradient) now, h1 once h2 is in LDS
-    double2_t vh[TRAIN ? 8 : 1];
-    const int go1 = TRAIN ? WI((ok1 ? lg : 0) - 1) + WJ(2 * (ok1 ? lq : 0) - 2) : 0;
-    if (TRAIN) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) vh[ch] = *reinterpret_cast<const double2_t*>(&(sh2 + (size_t)ch * n)[(unsigned)go1]);
-    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- consume ---------------------------------------------------------------------------------
@@ -238,9 +218,17 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         for (int k = 0; k < NMIX; ++k) sGO[k * N3W + at] = gdelta * tcv[4 * k] + cbr * tcv[4 * k + 1];   // dL/ds_k
         sGO[NMIX * N3W + at] = gdelta;                                   // dL/dt
         const int r = tr3 - 3, c = tc3 - 3;
-        if ((unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC) sDir[r * TC + c] = gdelta * (csum - 1.0) - cbr * esum;
+        if ((unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC) {
+            sDir[r * TC + c] = gdelta * (csum - 1.0) - cbr * esum;
+            if (goo && r < rmax && c < cmax) {                           // training: g_out of the own active sites
+                static_assert(NMIX == 2, "g_out record: dL/ds_0, dL/ds_1, dL/dt, 0");
+                double* po = goo + 4 * (size_t)stash_active_idx(i0 + r, j0 + c, L, mu);
+                *reinterpret_cast<double2_t*>(po) = double2_t{gdelta * tcv[0] + cbr * tcv[1], gdelta * tcv[4] + cbr * tcv[5]};
+                *reinterpret_cast<double2_t*>(po + 2) = double2_t{gdelta, 0.0};
+            }
+        }
     }
-    if (TRAIN ? tid < N1W : ftask) { sIn[fr1 * W1C + fc1] = fcs; sIn[PS1 + fr1 * W1C + fc1] = fsn; }
+    if (ftask) { sIn[fr1 * W1C + fc1] = fcs; sIn[PS1 + fr1 * W1C + fc1] = fsn; }
     if (dbg && lane == 0) dbg[6 + wave] = (long long)__builtin_readcyclecounter();   // arrival at the first barrier
     lds_barrier();
     STAMP(1);
@@ -282,131 +270,53 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             double* pz = sGZ2 + (half * 4 + k) * PS2 + s;
-            pz[0] = ksel <= 2 ? d2v[0][k] * acc0[k] : 0.0;
-            pz[s2off] = ksel <= 2 ? d2v[1][k] * acc1[k] : 0.0;
+            acc0[k] = ksel <= 2 ? d2v[0][k] * acc0[k] : 0.0;
+            acc1[k] = ksel <= 2 ? d2v[1][k] * acc1[k] : 0.0;
+            pz[0] = acc0[k];
+            pz[s2off] = acc1[k];
         }
-    }
-    if (TRAIN && ok1) {
-        const int c1 = 2 * lq - 1;                                       // tile+1 column of the pair's first value
-        const bool wa = c1 >= 0, wb = c1 + 1 < W1C;
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            double* p2 = sH2w + ch * PS1 + lg * W1C + c1;
-            if (wa) p2[0] = vh[ch].x;
-            if (wb) p2[1] = vh[ch].y;
+        if (gz2o) {                                                      // training: gz2 of the tile's own sites, 32 bytes per task and site
+            const int ra = r - 2, ca = c - 2, rb = mu == 0 ? ra + W2R / 2 : ra, cb_ = mu == 0 ? ca : ca + W2C / 2;
+            if ((unsigned)ra < (unsigned)rmax && (unsigned)ca < (unsigned)cmax) {
+                double* po = gz2o + 8 * (size_t)(mul24(i0 + ra, L) + j0 + ca) + 4 * half;
+                *reinterpret_cast<double2_t*>(po) = double2_t{acc0[0], acc0[1]}; *reinterpret_cast<double2_t*>(po + 2) = double2_t{acc0[2], acc0[3]};
+            }
+            if ((unsigned)rb < (unsigned)rmax && (unsigned)cb_ < (unsigned)cmax) {
+                double* po = gz2o + 8 * (size_t)(mul24(i0 + rb, L) + j0 + cb_) + 4 * half;
+                *reinterpret_cast<double2_t*>(po) = double2_t{acc1[0], acc1[1]}; *reinterpret_cast<double2_t*>(po + 2) = double2_t{acc1[2], acc1[3]};
+            }
         }
-    }
-    if (TRAIN) {
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) vh[ch] = *reinterpret_cast<const double2_t*>(&(sh1 + (size_t)ch * n)[(unsigned)go1]);
     }
     lds_barrier();
     STAMP(2);
 
-    if (TRAIN) {
-        // ---- weight gradient of conv3 and b3: sums over the tile's own active sites (VALU), on the waves that own
-        //      no conv2^T tile (they would otherwise idle through the MFMA stage below); site loops with fixed
-        //      trip counts (no division per site), all of a site row's operands in flight together -------
-        constexpr int NP1T = (W1R / 2) * W1C, NT1T = (NP1T + 15) / 16;     // conv2^T tiles of this geometry
-        constexpr int W3W0 = NT1T < NW ? NT1T : 0;                          // first wave without one
-        constexpr int NTH3 = NT - 64 * W3W0;
-        if (tid >= 64 * W3W0) {
-            for (int t = tid - 64 * W3W0; t < 216; t += NTH3) {
-                const int co = t / 72, ci = (t / 9) % 8, tap = t % 9, ky = tap / 3, kx = tap % 3;
-                const double* pg = sGO + co * N3W + 3 * W3C + 3;           // g_out at own site (r, c): pg[r * W3C + c]
-                const double* ph = sH2w + ci * PS1 + ky * W1C + kx;        // h2 at (r + ky - 1, c + kx - 1): ph[r * W1C + c]
-                double acc = 0.0;
-                if (mu == 0) {
-#pragma unroll
-                    for (int r = 0; r < TR; ++r) {
-                        double gv[TC / 4], hv[TC / 4];
-#pragma unroll
-                        for (int m = 0; m < TC / 4; ++m) { gv[m] = pg[r * W3C + off + 4 * m]; hv[m] = ph[r * W1C + off + 4 * m]; }
-#pragma unroll
-                        for (int m = 0; m < TC / 4; ++m) if (r < rmax && off + 4 * m < cmax) acc = fma(gv[m], hv[m], acc);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < TR / 4; ++q) {
-                        const int r = off + 4 * q;
-#pragma unroll
-                        for (int c0_ = 0; c0_ < TC; c0_ += 4) {
-                            double gv[4], hv[4];
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) { gv[m] = pg[r * W3C + c0_ + m]; hv[m] = ph[r * W1C + c0_ + m]; }
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) if (r < rmax && c0_ + m < cmax) acc = fma(gv[m], hv[m], acc);
-                        }
-                    }
-                }
-                gwp[CW2 + t] = acc;
-            }
-        }
-        if (wave >= NW - 3) {                                            // b3[k] on the last three waves
-            constexpr int NA = N3 / 4;
-            const int k = wave - (NW - 3);
-            double a_ = 0.0;
-            for (int a = lane; a < NA; a += 64) {
-                const int r = mu == 0 ? a / (TC / 4) : off + 4 * (a / TC);
-                const int c = mu == 0 ? off + 4 * (a % (TC / 4)) : a % TC;
-                if (r < rmax && c < cmax) a_ += sGO[k * N3W + (r + 3) * W3C + c + 3];
-            }
-            a_ = ft_wave_sum(a_);
-            if (lane == 0) gwp[CB2 + k] = a_;
-        }
-    }
-
     // ---- conv2^T (MFMA), times act'(z1) -> gz1 in place over d1 -------------------------------
     // W[k = (tap, co)][n = (ci, dd)] = W1[co][ci][2 - (ky4 - dd)][2 - kx]: the flipped, transposed, padded table T2
-    mfma_stage<KConv2Row, NPAIR1, W2C, PS2, true, false, FT_NCH ? FT_NCH : (TRAIN ? 0 : 2)>(sGZ2, sW + LB_T2, wave, lane,
+    mfma_stage<KConv2Row, NPAIR1, W2C, PS2, true, false, FT_NCH ? FT_NCH : 2>(sGZ2, sW + LB_T2, wave, lane,
         [](int p) { const int pr = fdiv<W1C>(p); return 2 * pr * W2C + p - pr * W1C; },
         [&](int g, int p, bool ok, double (&gh)[4], int it) {
             if (ok) {
                 const int pr = fdiv<W1C>(p), pc = p - pr * W1C;
                 double* pd = sD1 + 2 * g * PS1 + 2 * pr * W1C + pc;          // MFMA rows g, g + 4 = channels 2 g, 2 g + 1 (ft_chan)
-                pd[0] = gh[0] * d1v[it][0]; pd[PS1] = gh[1] * d1v[it][1];
-                pd[W1C] = gh[2] * d1v[it][2]; pd[PS1 + W1C] = gh[3] * d1v[it][3];
+                const double v0 = gh[0] * d1v[it][0], v1 = gh[1] * d1v[it][1], v2 = gh[2] * d1v[it][2], v3 = gh[3] * d1v[it][3];
+                pd[0] = v0; pd[PS1] = v1; pd[W1C] = v2; pd[PS1 + W1C] = v3;
+                if (gz1o) {                                              // training: gz1 of the tile's own sites, 16 bytes per lane and site
+                    const int ra = 2 * pr - 1, ca = pc - 1;
+                    if ((unsigned)ca < (unsigned)cmax) {
+                        double* po = gz1o + 8 * (size_t)(mul24(i0 + ra, L) + j0 + ca) + 2 * g;
+                        if ((unsigned)ra < (unsigned)rmax) *reinterpret_cast<double2_t*>(po) = double2_t{v0, v1};
+                        if ((unsigned)(ra + 1) < (unsigned)rmax) *reinterpret_cast<double2_t*>(po + 8 * (size_t)L) = double2_t{v2, v3};
+                    }
+                }
             }
         });
     lds_barrier();
     STAMP(3);
 
-    if (TRAIN) {
-        // ---- weight gradient of conv2 (MFMA over the tile's own sites) and b2: gz2 outside the own,
-        //      in-lattice sites is dropped first (there it belongs to other tiles), which also makes
-        //      the ring the dy trick of wgrad_stage reads ---------------------------------------------
-        if (ok1) {                                                   // h1 window -> LDS (loaded under conv3^T / conv2^T)
-            const int c1 = 2 * lq - 1;
-            const bool wa = c1 >= 0, wb = c1 + 1 < W1C;
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                double* p1 = sH1w + ch * PS1 + lg * W1C + c1;
-                if (wa) p1[0] = vh[ch].x;
-                if (wb) p1[1] = vh[ch].y;
-            }
-        }
-        for (int t = tid; t < 8 * N2W; t += NT) {
-            const int ci = t / N2W, s = t - ci * N2W, r = s / W2C - 2, c = s % W2C - 2;
-            if (!((unsigned)r < (unsigned)rmax && (unsigned)c < (unsigned)cmax)) sGZ2[ci * PS2 + s] = 0.0;
-        }
-        lds_barrier();
-        {
-            double a_ = 0.0;
-            for (int e = lane; e < N2W; e += 64) a_ += sGZ2[wave * PS2 + e];
-            a_ = ft_wave_sum(a_);
-            if (lane == 0) gwp[CB1 + wave] = a_;
-        }
-        if (wave < 3)                                                // 3 N tiles of (ci, kx, kyb) = 48 columns
-            wgrad_stage<TR, TC, W2C, PS2, W1C, PS1, 8, true>(sGZ2 + 2 * W2C + 2, sH1w, wave, lane,
-                [&](int co, int ci, int ky, int kx, double v) { gwp[CW1 + (co * 8 + ci) * 9 + ky * 3 + kx] = v; });
-    }
-
     // ---- conv1^T and the (cos, sin) adjoint at the tile's own frozen plaquettes ------------------
     // thread = (frozen site, quarter of the 8 channels); the four quarters of a site sit in adjacent lanes
-    // (training on 8 x 16 tiles: the upper four waves take it while the lower three are in the conv2 weight-gradient GEMM)
-    constexpr int C1T0 = (TRAIN && 2 * N3 <= NT / 2) ? NT / 2 : 0;
-    if (tid >= C1T0 && tid < C1T0 + 2 * N3) {
-        const int f = (tid - C1T0) >> 2, qq = tid & 3;
+    if (tid < 2 * N3) {
+        const int f = tid >> 2, qq = tid & 3;
         int r, c;
         if (mu == 0) { r = fdiv<TC / 2>(f); const int h = f - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
         else { const int hh = fdiv<TC>(f); c = f - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
@@ -434,27 +344,6 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     lds_barrier();
     STAMP(4);
 
-    if (TRAIN) {
-        // ---- weight gradient of conv1 (one N tile: (ci 2, kx 3, kyb 2) = 12 columns) and b1 ------
-        for (int t = tid; t < 8 * N1W; t += NT) {
-            const int co = t / N1W, s = t - co * N1W, r = s / W1C - 1, c = s % W1C - 1;
-            if (!((unsigned)r < (unsigned)rmax && (unsigned)c < (unsigned)cmax)) sD1[co * PS1 + s] = 0.0;
-        }
-        lds_barrier();
-        if (wave == 0)
-            wgrad_stage<TR, TC, W1C, PS1, W1C, PS1, 2, true>(sD1 + W1C + 1, sIn, 0, lane,
-                [&](int co, int ci, int ky, int kx, double v) { gwp[CW0 + (co * 2 + ci) * 9 + ky * 3 + kx] = v; });
-        else {
-            const int co = wave;                                     // waves 1..7 -> b1[1..7]; wave 1 also b1[0]
-            for (int cc = (co == 1 ? 0 : co); cc <= co; ++cc) {
-                double a_ = 0.0;
-                for (int e = lane; e < N1W; e += 64) a_ += sD1[cc * PS1 + e];
-                a_ = ft_wave_sum(a_);
-                if (lane == 0) gwp[CB0 + cc] = a_;
-            }
-        }
-    }
-
     // ---- gP_out = gP_in + this layer's contribution at the own sites ---------------------------
     if (ovalid) {
         const int cls = ((mu == 0 ? j0 + occ : i0 + orr) - off) & 3;  // 0 active, 1|2 frozen, 3 passive
@@ -468,16 +357,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
 
 namespace fthmc {
 
-int launch_flow_bwd_gather(const FlowLayerArgs& a, bool train, hipStream_t s) {
-    if (train) {
-        const dim3 grid = xcd_grid(a.B, (a.L + MGT_TR - 1) / MGT_TR, (a.L + MGT_TC - 1) / MGT_TC);
-        if (wrap_fast_ok(a.L, MGT_TR, MGT_TC)) hipLaunchKernelGGL((k_flow_bwd_gather<MGT_TR, MGT_TC, true, true>), grid, dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((k_flow_bwd_gather<MGT_TR, MGT_TC, true, false>), grid, dim3(NT), 0, s, a);
-    } else {
-        const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
-        if (wrap_fast_ok(a.L, MG_TR, MG_TC)) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, true>), grid, dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, false>), grid, dim3(NT), 0, s, a);
-    }
+int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s) {
+    const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
+    if (wrap_fast_ok(a.L, MG_TR, MG_TC)) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true>), grid, dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

@@ -133,14 +133,14 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
 #endif
 
     // stash of this lane's output channels 2 g, 2 g + 1, g = lane >> 4 (fixed for the kernel): act' channel-minor
-    // (one 16-byte store per site), h plane-major (training)
+    // (one 16-byte store per site), and so is h (training)
     const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // tile sites inside the lattice
     const Stash sv = A.stash ? stash_view(A.stash, A.B, b, n) : Stash{};
     typedef double double2_t __attribute__((ext_vector_type(2)));
     double* const st_d1 = sv.d1 ? sv.d1 + 2 * (lane >> 4) : nullptr;
     double* const st_d2 = sv.d1 ? sv.d2 + 2 * (lane >> 4) : nullptr;
-    double* const st_h1 = sv.d1 ? sv.h1 + (size_t)(2 * (lane >> 4)) * n : nullptr;
-    double* const st_h2 = sv.d1 ? sv.h2 + (size_t)(2 * (lane >> 4)) * n : nullptr;
+    double* const st_h1 = sv.d1 ? sv.h1 + 2 * (lane >> 4) : nullptr;
+    double* const st_h2 = sv.d1 ? sv.h2 + 2 * (lane >> 4) : nullptr;
 
     // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
     // B[k = (tap, ci)][n = (co, dd)] = W0[co][ci][ky4 - dd][kx] out of the padded table P1 (flow_mfma_common.h: KConv1)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                     for (int dd = 0; dd < 2; ++dd)
                         if ((unsigned)(r + dd) < (unsigned)rmax) {
                             *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dd * L)) = double2_t{d[2 * dd], d[2 * dd + 1]};
-                            if (A.stash_h) { st_h1[at + dd * L] = h[2 * dd]; st_h1[at + dd * L + n] = h[2 * dd + 1]; }
+                            if (A.stash_h) *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)(at + dd * L)) = double2_t{h[2 * dd], h[2 * dd + 1]};
                         }
                 }
             }
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
                 const int at = mul24(i0 + rr, L) + j0 + cc;
                 sv.d1[8 * (size_t)at + co] = d;
-                if (A.stash_h) sv.h1[(size_t)co * n + at] = h;
+                if (A.stash_h) sv.h1[8 * (size_t)at + co] = h;
             }
         }
     }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                 if ((unsigned)(r - 1 + q * dr) < (unsigned)rmax && (unsigned)(c - 1 + q * dc) < (unsigned)cmax) {
                     const int aq = at + q * (dr * L + dc);
                     *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)aq) = double2_t{d[2 * q], d[2 * q + 1]};
-                    if (A.stash_h) { st_h2[aq] = h[2 * q]; st_h2[aq + n] = h[2 * q + 1]; }
+                    if (A.stash_h) *reinterpret_cast<double2_t*>(st_h2 + 8 * (size_t)aq) = double2_t{h[2 * q], h[2 * q + 1]};
                 }
         }
     };

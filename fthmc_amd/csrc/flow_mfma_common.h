@@ -90,7 +90,7 @@ template <int TR, int TC> struct Geom {
 //                  cb = dL/dlogJ and the softmax normaliser rs = 1 / (K sum_k C_k)  (C_k = 1 / (K D_k)):
 //                  dL/ds_k = g A_k + cb rs B_k,   dL/dP = -g + sum_k (g C_k - cb rs E_k)
 //   cs  [2][n/2]   cos P, sin P at the FROZEN sites (the net input), compact
-//   h1, h2 [8][n]  hidden activations (training only)
+//   h1, h2 [n][8]  hidden activations, channel-minor (training only)
 // = 16 + 2 + 1 = 19 doubles per site and layer (35 with h1, h2): kernels.h flow_stash_doubles().
 struct Stash { double *d1, *d2, *tc, *cs, *h1, *h2; };
 __device__ __forceinline__ Stash stash_view(double* base, int B, int b, int n) {

@@ -54,7 +54,7 @@ inline FlowGeom flow_fwd_geom(bool mfma) { return mfma ? FlowGeom{MF_FWD_TR, MF_
 inline FlowGeom flow_geom(bool) { return FlowGeom{FLOW_TILE, FLOW_TILE}; }          // VALU variant: partial buffers [chain][tile][window]
 // workspace sizing: the larger of the two variants
 inline size_t flow_ntiles_max(int L) {
-    size_t a = flow_geom(false).ntiles(L), b = FlowGeom{8, 16}.ntiles(L);   // VALU / forward tiles; training backward 8 x 16
+    size_t a = flow_geom(false).ntiles(L), b = 2 * FlowGeom{16, 16}.ntiles(L);   // VALU / forward tiles; weight-gradient partials: two per 16 x 16 tile
     return a > b ? a : b;
 }
 inline size_t flow_gp_part_max(int L) { return (size_t)flow_geom(false).ntiles(L) * flow_geom(false).n0(); }
@@ -80,6 +80,9 @@ struct FlowLayerArgs {
     long long* dbg;          // optional: per-(chain,tile) stage time stamps [16] (diagnostic runs only)
     double* stash;           // optional: this layer's activation stash (MFMA forward writes, stash backward reads)
     int stash_h;             // forward: also stash h1, h2 (training: the weight gradients need them)
+    double* gz;              // training: gradients wrt the pre-activations of this layer, written by the backward kernel at
+                             // every tile's own sites and read by k_flow_wgrad: per chain gz2 [n][8], gz1 [n][8]
+                             // (channel-minor), g_out [n/4][4] (dL/ds_0, dL/ds_1, dL/dt, 0 at the active sites, compact)
     int dbg_stop;            // -DFT_DIAG builds: the forward kernel returns after this stage (instruction counts per stage); 0 = run all
     int B, L, mu, off, act;
 };
@@ -92,12 +95,15 @@ int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_rev_mfma(const FlowLayerArgs& a, hipStream_t s);
 // flow_bwd_gather.hip: backward from the stash in gather form: a tile produces the complete
 // gP_out = up_gp + layer contribution of its own sites (a.gp_out, out of place), no partial windows;
-// train = also per-tile weight-gradient partials to a.gw_part (ntiles of flow_gather_geom(true))
+// with a.gz (training) it also writes the pre-activation gradients for launch_flow_wgrad
 constexpr int MG_TR = 16, MG_TC = 16;
-// training variant (h1, h2 windows also in LDS): 8 x 16 tiles keep it at two workgroups per CU
-constexpr int MGT_TR = 8, MGT_TC = 16;
-inline FlowGeom flow_gather_geom(bool train = false) { return train ? FlowGeom{MGT_TR, MGT_TC} : FlowGeom{MG_TR, MG_TC}; }
-int launch_flow_bwd_gather(const FlowLayerArgs& a, bool train, hipStream_t s);
+inline FlowGeom flow_gather_geom() { return FlowGeom{MG_TR, MG_TC}; }
+int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s);
+// flow_wgrad.hip: weight gradients of one layer from a.gz and the stashed h1, h2, cos / sin: one workgroup per 16 x 16
+// tile writes TWO 955-entry partials (halves of its sites) to a.gw_part [B * ntiles * 2][FLOW_GW_STRIDE]
+int launch_flow_wgrad(const FlowLayerArgs& a, hipStream_t s);
+inline size_t flow_gz_doubles(int B, int L) { return (size_t)B * 17 * L * L; }
+inline int flow_wgrad_parts(int L) { return 2 * FlowGeom{MG_TR, MG_TC}.ntiles(L); }
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }
 // 0: VALU kernels everywhere; 1 (default): MFMA kernels for forward and backward-wrt-x

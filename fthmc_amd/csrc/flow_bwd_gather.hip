@@ -174,8 +174,11 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     else { c3r = fdiv<W2C / 2>(c3u); c3c = c3u - c3r * (W2C / 2); }         // (r, c), (r, c + W2C/2)
     double d2v[2][4];
     {
-        const int goA = WI(c3r - 2) + WJ(c3c - 2);
-        const int goB = mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
+        // both sites of a task sit on the same line class; on a dead line (no active site within reach, conv3^T writes an
+        // exact 0 there) the stash holds nothing: those lanes all read element 0 (one cache line) instead of a window row
+        const bool c3live = ((mu == 0 ? c3c + 2 - c0 : c3r + 2 - r0) & 3) <= 2;
+        const int goA = c3live ? WI(c3r - 2) + WJ(c3c - 2) : 0;
+        const int goB = !c3live ? 0 : mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
         // channel-minor stash (struct Stash): the task's four channels of a site are 32 contiguous bytes
         const double* pl = uniform_ptr(A.stash, ((size_t)A.B + b) * 8 * n + (size_t)(c3half * 4));
 #pragma unroll

@@ -1,5 +1,5 @@
 // Building blocks shared by the MFMA coupling-layer kernels (flow_fwd.hip, flow_bwd_gather.hip):
-// tile geometry, the implicit-GEMM conv stage, the weight-gradient GEMM stage, the XCD-aware block map.
+// tile geometry, the implicit-GEMM conv stage, the XCD-aware block map.
 #pragma once
 #include "flow_common.h"
 
@@ -240,47 +240,5 @@ __device__ __forceinline__ bool block_tile(int B, int nti, int ntj, BlockTile& t
     return t.b < B;
 }
 inline dim3 xcd_grid(int B, int nti, int ntj) { return dim3(8 * ntj, nti, (B + 7) / 8); }
-
-// Weight gradient of a 3x3 conv as an MFMA GEMM over the sites of the tile's window:
-//   gw[co][ci][ky][kx] = sum_s gz[co][s] * hin[ci][s + (ky, kx)]
-// M = 16 = 8 co x (dy = 0, 1): A[(co, dy)][s] = gz[co][s - dy rows];  N = (ci, kx, kyb) with ky = 2 kyb:
-// D[(co, dy)][(ci, kx, kyb)] = gw[co][ci][2 kyb + dy][kx]  (row 3 of the 4 it produces is discarded).
-// That packs the 8 output channels twice into M the same way the forward packs two rows into N.
-// One wave owns one 16-column N tile and walks all sites (K); results go straight to the tile's
-// partial in global memory.  GZPAD: gz planes have a ring so row -1 is readable (zeros).
-template <int HS, int WSI, int RSG, int PSG, int RSH, int PSH, int CIN, bool GZPAD, class Store>
-__device__ __forceinline__ void wgrad_stage(const double* __restrict__ gz, const double* __restrict__ hin,
-                                            int nt, int lane, Store store) {
-    // one extra site row: the dy = 1 rows of A lag one row behind, their last term is gz[HS-1] at s = HS
-    constexpr int NS = (HS + 1) * WSI, NSTEP = (NS + 3) / 4, NCOL = CIN * 6;
-    const int g = lane >> 4, i = lane & 15;
-    const int co = i & 7, dy = i >> 3;                      // A row m = (co, dy)
-    const int ncol = nt * 16 + i;                           // B column n = (ci, kx, kyb)
-    const int ci = ncol / 6, kx = (ncol % 6) >> 1, kyb = ncol & 1;
-    const bool ncol_ok = ncol < NCOL;
-    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    int r = g / WSI, c = g % WSI;                           // site of k = 4 t + g, t = 0
-#pragma unroll 2
-    for (int t = 0; t < NSTEP; ++t) {
-        const int ra = r - dy, rb = r + 2 * kyb;
-        // gz rows -1 and HS are the zero ring when GZPAD, else masked; h rows beyond the window are masked
-        const bool aok = r <= HS && (GZPAD || (ra >= 0 && ra < HS));
-        const bool bok = r <= HS && ncol_ok && rb < HS + 2;
-        const double av = aok ? gz[co * PSG + ra * RSG + c] : 0.0;
-        const double bv = bok ? hin[ci * PSH + rb * RSH + c + kx] : 0.0;
-        if (t & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc1, 0, 0, 0);
-        else       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc0, 0, 0, 0);
-        c += 4; if (c >= WSI) { c -= WSI; ++r; }            // WSI >= 4
-    }
-    const double4_t acc = acc0 + acc1;
-    // D[row = g + 4 q][col = i]: row m = (co', dy'), col n = (ci, kx, kyb) of this lane
-    if (ncol_ok) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = g + 4 * q, co2 = m & 7, dy2 = m >> 3, ky = 2 * kyb + dy2;
-            if (ky <= 2) store(co2, ci, ky, kx, acc[q]);
-        }
-    }
-}
 
 }  // namespace fthmc_flow

@@ -7,7 +7,7 @@ gen = torch.Generator().manual_seed(1331)
 w = ops.pack_weights(R.default_flow(1, gen), device='cuda')
 names = {'flow_fwd': ['', 'plaq+sincos', 'conv1', 'conv2', 'conv3', 'transform1', 'finish+store'],
          'flow_bwd': ['', 'load+xform', 'conv3T', 'conv2T', 'conv1T', 'store'],
-         'flow_bwd_train': ['', 'load+xform', 'conv3T+h2', 'wgrad3+conv2T', 'wgrad2+conv1T', 'wgrad1+store']}
+         'flow_bwd_train': ['', 'load+xform', 'conv3T', 'conv2T', 'conv1T', 'store']}     # backward with the pre-activation gradients written (training)
 for B in [int(a) for a in sys.argv[1:]] or (16, 32, 48, 64, 96, 128, 256):
     x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
     for kind in ('flow_fwd', 'flow_bwd', 'flow_bwd_train'):

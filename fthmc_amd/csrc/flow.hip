@@ -49,13 +49,14 @@ __global__ void k_pack_weights(const double* __restrict__ w, int n_layers, doubl
                 const int e = u - LF_P1, kx = e / 96, ci = (e / 48) % 2, ky = (e / 8) % 6 - 1, co = ft_chan(e % 8);
                 v = (ky >= 0 && ky <= 2) ? c[CW0 + (co * 2 + ci) * 9 + ky * 3 + kx] : 0.0;
             }
-        } else if (t >= WBWD && t < WBWD + LB_SIZE) {                      // backward block
-            const int u = t - WBWD;
+        } else if (t >= WBWD && t < WBWD1 + LB_SIZE) {                     // backward blocks (rows, columns)
+            const int col = t >= WBWD1, u = t - (col ? WBWD1 : WBWD);
             if (u < LB_W2) v = c[CW0 + u];
             else if (u < LB_T2) v = c[CW2 + u - LB_W2];
             else {
-                const int e = u - LB_T2, kx = e / 320, co = 4 * ((e / 40) % 2) + (e / 80) % 4, ky = (e / 8) % 5 - 1, ci = ft_chan(e % 8);
-                v = (ky >= 0 && ky <= 2) ? c[CW1 + (co * 8 + ci) * 9 + (2 - ky) * 3 + (2 - kx)] : 0.0;
+                const int e = u - LB_T2, a3 = e / 320, co = 4 * ((e / 40) % 2) + (e / 80) % 4, l5 = (e / 8) % 5 - 1, ci = ft_chan(e % 8);
+                const int ky = col ? a3 : l5, kx = col ? l5 : a3;
+                v = (l5 >= 0 && l5 <= 2) ? c[CW1 + (co * 8 + ci) * 9 + (2 - ky) * 3 + (2 - kx)] : 0.0;
             }
         }
         d[t] = v;

@@ -36,7 +36,10 @@ template <int TR, int TC> struct SmemG {
     static constexpr int W2R = TR + 4, W2C = TC + 4, N2W = W2R * W2C;   // act'(z2) -> gz2
     static constexpr int W1R = TR + 2, W1C = TC + 2, N1W = W1R * W1C;   // act'(z1) -> gz1; cos/sin
     static constexpr int N3 = TR * TC;
-    static constexpr int PS2 = ps_round(N2W), PS1 = ps_round(N1W);
+    // gz2 rows are RS2 apart in LDS: odd, so that the 16 lanes of a conv2^T operand read (one per window row, below)
+    // fall into 16 different banks
+    static constexpr int RS2 = W2C + 1;
+    static constexpr int PS2 = ps_round(W2R * RS2), PS1 = ps_round(N1W);
     // active lines of the g_out window: every 4th column (mu = 0) or row (mu = 1)
     static constexpr int NLC = (W3C + 3) / 4, NLR = (W3R + 3) / 4;
     static constexpr int NSLOT = cmax_(W3R * NLC, NLR * W3C);           // transform tasks
@@ -52,6 +55,23 @@ template <int TR, int TC> struct SmemG {
     static_assert(NTT <= NT && 2 * N3 <= NT && N1W <= NT, "thread maps");
 };
 
+// One conv2^T tile: the 18 live K steps of a pair window whose line KD (of its four lines across the pairing direction,
+// NL = lines per tap row of KO's window) is dead.  Straight-line code per (K order, KD): the operand reads pipeline freely.
+template <class KO, int NL, int KD, int RSA, int PSA>
+__device__ __forceinline__ double4_t conv2t_tile(const double* __restrict__ wp, const double* __restrict__ a0) {
+    double4_t accs[2] = {double4_t{0.0, 0.0, 0.0, 0.0}, double4_t{0.0, 0.0, 0.0, 0.0}};
+    int s = 0;
+#pragma unroll
+    for (int t = 0; t < KO::NSTEP; ++t) {
+        // tap t >> 1 of the window; the line across the pairing direction: its column (4-wide window) / its row (4-high window)
+        const int line = NL == 4 ? (t >> 1) % 4 : (t >> 1) / 3;
+        if (line == KD) continue;
+        accs[s & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[KO::bimm(t)], a0[KO::template aimm<RSA, PSA>(t)], accs[s & 1], 0, 0, 0);
+        ++s;
+    }
+    return accs[0] + accs[1];
+}
+
 // A.gz (training): the kernel additionally writes the gradients wrt the layer's pre-activations at the tile's own
 // sites -- gz2, gz1 (channel-minor) and the transform adjoint g_out at the active sites -- for k_flow_wgrad
 // (flow_wgrad.hip), which turns them into weight gradients; nothing else changes.
@@ -59,7 +79,7 @@ template <int TR, int TC, bool FASTW>
 __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     using S = SmemG<TR, TC>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
-    constexpr int W1R = S::W1R, W1C = S::W1C, N3 = S::N3, PS1 = S::PS1, PS2 = S::PS2;
+    constexpr int W1R = S::W1R, W1C = S::W1C, N3 = S::N3, PS1 = S::PS1, PS2 = S::PS2, RS2 = S::RS2;
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
     double* sGO = sm + S::GO;   double* sGZ2 = sm + S::GZ2;  double* sD1 = sm + S::D1;
     double* sIn = sm + S::IN;   double* sDir = sm + S::DIR;  double* sW = sm + S::SW;
@@ -103,7 +123,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     constexpr int NWC = (LB_SIZE + NT - 1) / NT;
     double wsw[NWC];
 #pragma unroll
-    for (int k = 0; k < NWC; ++k) wsw[k] = ldu(w + WBWD, (unsigned)min(tid + k * NT, LB_SIZE - 1));
+    for (int k = 0; k < NWC; ++k) wsw[k] = ldu(w + (mu == 0 ? WBWD1 : WBWD), (unsigned)min(tid + k * NT, LB_SIZE - 1));
     // (1) transform tasks on the last waves: active site `a` of the tile+3 window, both mixture components
     const int ta = tid - (NT - S::NTT);
     const int c0 = (off - (j0 - 3)) & 3, r0 = (off - (i0 - 3)) & 3;    // first active column / row of the window
@@ -187,15 +207,27 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
             d2v[0][k] = va.x; d2v[0][k + 1] = va.y; d2v[1][k] = vb.x; d2v[1][k + 1] = vb.y;
         }
     }
-    // conv2^T epilogue: lane (g = lane >> 4, i = lane & 15) of tile T = wave + 8 it owns pair 16 T + i,
-    // channels g and g + 4, both rows of the pair
-    constexpr int NPAIR1 = (W1R / 2) * W1C, NTILE1 = (NPAIR1 + 15) / 16, NIT1 = (NTILE1 + NW - 1) / NW;
+    // conv2^T pairs its output sites ACROSS the stripe lines -- columns (c, c + 1) of one row for mu = 0, rows (r, r + 1)
+    // of one column for mu = 1 -- so the pair's input window is four consecutive lines of gz2, exactly one of which is
+    // dead (conv3^T wrote zeros there): its six K steps are skipped, 18 of 24 remain.  Which of the four it is depends on
+    // the parity of the pair's position u across the lines only, so an MFMA tile holds pairs of ONE parity:
+    //     tiles 0 .. NU-1:  u = tile, positions v = 0 .. 15 along the lines        (NU = 9 pairs across, NV = 18 along)
+    //     tiles NU, NU+1:   the remaining v = 16, 17 of the even / of the odd u
+    // The epilogue's lane (g = lane >> 4, i = lane & 15) of tile T = wave + 8 it owns pair i of the tile, channels
+    // 2 g and 2 g + 1, both sites of the pair.
+    static_assert(TR == 16 && TC == 16, "conv2^T tile map: 16 positions along the lines + 2");
+    constexpr int NU = W1C / 2, NTILE1 = NU + 2, NIT1 = (NTILE1 + NW - 1) / NW;
+    static_assert(NIT1 == 2 && W1R == W1C, "two rounds of conv2^T tiles");
+    int pu[NIT1], pv[NIT1];                                              // pair position (across, along); rows / columns of site 0:
+    bool pok[NIT1];                                                      //   mu = 0: (pv, 2 pu)   mu = 1: (2 pu, pv)   in tile+1 coordinates
     double d1v[NIT1][4];
 #pragma unroll
     for (int it = 0; it < NIT1; ++it) {
-        const int T = wave + NW * it, p_ = T * 16 + (lane & 15);
-        const int pp = p_ < NPAIR1 ? p_ : 0, pr = fdiv<W1C>(pp), pc = pp - pr * W1C;
-        const int j = WJ(pc - 1), ga = WI(2 * pr - 1) + j, gb = WI(2 * pr) + j;
+        const int T = wave + NW * it, i = lane & 15;
+        if (T < NU) { pu[it] = T; pv[it] = i; pok[it] = true; }
+        else { pu[it] = 2 * (i >> 1) + (T - NU); pv[it] = 16 + (i & 1); pok[it] = T < NTILE1 && pu[it] < NU; if (!pok[it]) { pu[it] = 0; pv[it] = 0; } }
+        const int ra = mu == 0 ? pv[it] : 2 * pu[it], ca = mu == 0 ? 2 * pu[it] : pv[it];
+        const int ga = WI(ra - 1) + WJ(ca - 1), gb = mu == 0 ? WI(ra - 1) + WJ(ca) : WI(ra) + WJ(ca - 1);
         const unsigned og = 2u * (unsigned)(lane >> 4);                      // channels 2 g, 2 g + 1: one 16-byte load per site
         const double2_t va = ldu2(st1, (unsigned)ga * 8u + og), vb = ldu2(st1, (unsigned)gb * 8u + og);
         d1v[it][0] = va.x; d1v[it][1] = va.y; d1v[it][2] = vb.x; d1v[it][3] = vb.y;
@@ -235,14 +267,17 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     if (dbg && lane == 0) dbg[6 + wave] = (long long)__builtin_readcyclecounter();   // arrival at the first barrier
     lds_barrier();
     STAMP(1);
+#ifdef FT_DIAG
+    if (A.dbg_stop == 1) return;
+#endif
 
     // ---- conv3^T on the VALU: g_out lives on the active lines, so of the 9 taps of a site at most 3
     //      (one line) contribute; times act'(z2) -> gz2 in place ------------------------------------
     // the 36 weights of a task are read once and serve both sites (the stage is bound by LDS reads per FMA)
     if (c3task) {
         const int half = c3half, r = c3r, c = c3c;
-        const int s2off = mu == 0 ? (W2R / 2) * W2C : W2C / 2;
-        const int s = r * W2C + c;
+        const int s2off = mu == 0 ? (W2R / 2) * RS2 : W2C / 2;
+        const int s = r * RS2 + c;
         // source = site - (ky - 1, kx - 1): window coordinates (r + 2 - ky, c + 2 - kx) of tile+3
         const int ksel = mu == 0 ? (c + 2 - c0) & 3 : (r + 2 - r0) & 3;   // the one kx (mu=0) / ky (mu=1)
         const int s3off = mu == 0 ? (W2R / 2) * W3C : W2C / 2;            // second site in tile+3 coordinates
@@ -292,29 +327,59 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     }
     lds_barrier();
     STAMP(2);
+#ifdef FT_DIAG
+    if (A.dbg_stop == 2) return;
+#endif
 
-    // ---- conv2^T (MFMA), times act'(z1) -> gz1 in place over d1 -------------------------------
-    // W[k = (tap, co)][n = (ci, dd)] = W1[co][ci][2 - (ky4 - dd)][2 - kx]: the flipped, transposed, padded table T2
-    mfma_stage<KConv2Row, NPAIR1, W2C, PS2, true, false, FT_NCH ? FT_NCH : 2>(sGZ2, sW + LB_T2, wave, lane,
-        [](int p) { const int pr = fdiv<W1C>(p); return 2 * pr * W2C + p - pr * W1C; },
-        [&](int g, int p, bool ok, double (&gh)[4], int it) {
-            if (ok) {
-                const int pr = fdiv<W1C>(p), pc = p - pr * W1C;
-                double* pd = sD1 + 2 * g * PS1 + 2 * pr * W1C + pc;          // MFMA rows g, g + 4 = channels 2 g, 2 g + 1 (ft_chan)
-                const double v0 = gh[0] * d1v[it][0], v1 = gh[1] * d1v[it][1], v2 = gh[2] * d1v[it][2], v3 = gh[3] * d1v[it][3];
-                pd[0] = v0; pd[PS1] = v1; pd[W1C] = v2; pd[PS1 + W1C] = v3;
-                if (gz1o) {                                              // training: gz1 of the tile's own sites, 16 bytes per lane and site
-                    const int ra = 2 * pr - 1, ca = pc - 1;
-                    if ((unsigned)ca < (unsigned)cmax) {
-                        double* po = gz1o + 8 * (size_t)(mul24(i0 + ra, L) + j0 + ca) + 2 * g;
-                        if ((unsigned)ra < (unsigned)rmax) *reinterpret_cast<double2_t*>(po) = double2_t{v0, v1};
-                        if ((unsigned)(ra + 1) < (unsigned)rmax) *reinterpret_cast<double2_t*>(po + 8 * (size_t)L) = double2_t{v2, v3};
-                    }
+    // ---- conv2^T (MFMA), times act'(z1) -> gz1 -------------------------------------------------
+    // W[k = (tap, co)][n = (ci, dd)]: the flipped, transposed, padded table T2 of this mu (flow_common.h)
+    {
+        const int g = lane >> 4, i = lane & 15;
+        const double* wp = sW + LB_T2 + KConv2Row::wlane(g, i & 7, i >> 3);        // the lane part is the same for both K orders
+        const int kd0 = ((mu == 0 ? c0 : r0) + 1) & 3;                             // dead window line of the even pairs (odd: + 2)
+#pragma unroll
+        for (int it = 0; it < NIT1; ++it) {
+            const int T = wave + NW * it;
+            if (T >= NTILE1) break;
+            const int kd = (kd0 + 2 * (T < NU ? T & 1 : T - NU)) & 3;              // wave-uniform
+            const double* a0 = sGZ2 + g * PS2 + (mu == 0 ? pv[it] * RS2 + 2 * pu[it] : 2 * pu[it] * RS2 + pv[it]);
+            double4_t acc;
+            if (mu == 0) {
+                switch (kd) {
+                    case 0: acc = conv2t_tile<KConv2Col, 4, 0, RS2, PS2>(wp, a0); break;
+                    case 1: acc = conv2t_tile<KConv2Col, 4, 1, RS2, PS2>(wp, a0); break;
+                    case 2: acc = conv2t_tile<KConv2Col, 4, 2, RS2, PS2>(wp, a0); break;
+                    default: acc = conv2t_tile<KConv2Col, 4, 3, RS2, PS2>(wp, a0); break;
+                }
+            } else {
+                switch (kd) {
+                    case 0: acc = conv2t_tile<KConv2Row, 3, 0, RS2, PS2>(wp, a0); break;
+                    case 1: acc = conv2t_tile<KConv2Row, 3, 1, RS2, PS2>(wp, a0); break;
+                    case 2: acc = conv2t_tile<KConv2Row, 3, 2, RS2, PS2>(wp, a0); break;
+                    default: acc = conv2t_tile<KConv2Row, 3, 3, RS2, PS2>(wp, a0); break;
                 }
             }
-        });
+            if (pok[it]) {
+                const int ra = mu == 0 ? pv[it] : 2 * pu[it], ca = mu == 0 ? 2 * pu[it] : pv[it];   // site 0; site 1 = next column / row
+                const int ds = mu == 0 ? 1 : W1C;
+                double* pd = sD1 + 2 * g * PS1 + ra * W1C + ca;              // MFMA rows g, g + 4 = channels 2 g, 2 g + 1 (ft_chan)
+                const double v0 = acc[0] * d1v[it][0], v1 = acc[1] * d1v[it][1], v2 = acc[2] * d1v[it][2], v3 = acc[3] * d1v[it][3];
+                pd[0] = v0; pd[PS1] = v1; pd[ds] = v2; pd[PS1 + ds] = v3;
+                if (gz1o) {                                                  // training: gz1 of the tile's own sites, 16 bytes per lane and site
+                    const int r1 = ra - 1, c1 = ca - 1, r2 = mu == 0 ? r1 : r1 + 1, c2 = mu == 0 ? c1 + 1 : c1;
+                    if ((unsigned)r1 < (unsigned)rmax && (unsigned)c1 < (unsigned)cmax)
+                        *reinterpret_cast<double2_t*>(gz1o + 8 * (size_t)(mul24(i0 + r1, L) + j0 + c1) + 2 * g) = double2_t{v0, v1};
+                    if ((unsigned)r2 < (unsigned)rmax && (unsigned)c2 < (unsigned)cmax)
+                        *reinterpret_cast<double2_t*>(gz1o + 8 * (size_t)(mul24(i0 + r2, L) + j0 + c2) + 2 * g) = double2_t{v2, v3};
+                }
+            }
+        }
+    }
     lds_barrier();
     STAMP(3);
+#ifdef FT_DIAG
+    if (A.dbg_stop == 3) return;
+#endif
 
     // ---- conv1^T and the (cos, sin) adjoint at the tile's own frozen plaquettes ------------------
     // thread = (frozen site, quarter of the 8 channels); the four quarters of a site sit in adjacent lanes
@@ -346,6 +411,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     }
     lds_barrier();
     STAMP(4);
+#ifdef FT_DIAG
+    if (A.dbg_stop == 4) return;
+#endif
 
     // ---- gP_out = gP_in + this layer's contribution at the own sites ---------------------------
     if (ovalid) {

@@ -47,13 +47,16 @@ static_assert(WCAN + WCAN_SIZE <= FLOW_WINT, "weight layout");
 //   forward block (one per mu):  b0[8] b1[8] w2[3][8][9] b2[3]+0  P2[960]  |  P1[3 kx][2 ci: stride 48][5 r5: stride 8][8 co]
 //       mu = 0 (pairs = rows r, r + 1):  P2[kx][g][h][r5][co] = w1[co][4 h + g][r5 - 1][kx]
 //       mu = 1 (pairs = columns):        P2[ky][g][h][c5][co] = w1[co][4 h + g][ky][c5 - 1]
-//   backward block:  w0[8][2][9]  w2[3][8][9]  T2[kx][g][h][r5][ci] = w1[4 h + g][ci][2 - (r5 - 1)][2 - kx]   (conv2^T)
+//   backward block (one per mu; conv2^T pairs its output sites ACROSS the stripe lines, see flow_bwd_gather.hip):
+//       w0[8][2][9]  w2[3][8][9]  T2[960]
+//       mu = 1 (pairs = rows):     T2[kx][g][h][r5][ci] = w1[4 h + g][ci][2 - (r5 - 1)][2 - kx]
+//       mu = 0 (pairs = columns):  T2[ky][g][h][c5][ci] = w1[4 h + g][ci][2 - ky][2 - (c5 - 1)]
 __host__ __device__ constexpr int ft_chan(int row) { return 2 * (row & 3) + (row >> 2); }
 constexpr int LF_B0 = 0, LF_B1 = 8, LF_W2 = 16, LF_B2 = 232, LF_P2 = 236, LF_SIZE = LF_P2 + 960;   // resident part
 constexpr int LF_P1 = LF_SIZE, LF_P1_SIZE = 288, LF_BLOCK = LF_P1 + LF_P1_SIZE;                   // conv1 table: conv1 stage only
 constexpr int LB_W0 = 0, LB_W2 = 144, LB_T2 = 360, LB_SIZE = LB_T2 + 960;
-constexpr int WFWD0 = 2944, WFWD1 = WFWD0 + LF_BLOCK, WBWD = WFWD1 + LF_BLOCK;
-static_assert(WBWD + LB_SIZE <= FLOW_WINT, "weight layout");
+constexpr int WFWD0 = 2944, WFWD1 = WFWD0 + LF_BLOCK, WBWD = WFWD1 + LF_BLOCK, WBWD1 = WBWD + LB_SIZE;   // WBWD: rows, WBWD1: columns
+static_assert(WBWD1 + LB_SIZE <= FLOW_WINT, "weight layout");
 
 // exp(x) for either sign (|x| clamped to the finite range): range reduction by ln2 (hi/lo split) + degree-13
 // Taylor (|r| <= ln2/2: truncation 4e-18) + v_ldexp.  ~20 dependent DP ops instead of ocml exp's ~60, < 1.5 ulp.

@@ -11,19 +11,20 @@ python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
 out = sys.argv[1]
-rows = {}
-for stop in (1, 2, 3, 4, 5, 0):
-    acc = defaultdict(lambda: [0.0, 0])
-    for path in glob.glob(os.path.join(out, f'stop{stop}', '**', '*counter_collection.csv'), recursive=True):
-        for r in csv.DictReader(open(path)):
-            if 'k_flow_fwd' in r['Kernel_Name']:
-                a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
-    rows[stop] = {k: v[0] / v[1] / 16384 for k, v in acc.items()}          # per wave (B=128: 2048 workgroups x 8 waves)
-names = ['stage0 plaq+sincos+weights', 'conv1', 'conv2', 'conv3', 'transform', 'finish+update']
-prev = defaultdict(float)
-keys = sorted(rows[0])
-print('per wave, mean over all waves of a full-batch launch'); print('stage'.ljust(30) + ''.join(k.replace('SQ_INSTS_', '').rjust(14) for k in keys))
-for stop, nm in zip((1, 2, 3, 4, 5, 0), names):
-    print(nm.ljust(30) + ''.join(f'{rows[stop][k] - prev[k]:14.1f}' for k in keys)); prev = rows[stop]
-print('total'.ljust(30) + ''.join(f'{rows[0][k]:14.1f}' for k in keys))
+for KEY, names, stops in (('k_flow_fwd', ['stage0 plaq+sincos+weights', 'conv1', 'conv2', 'conv3', 'transform', 'finish+update'], (1, 2, 3, 4, 5, 0)),
+                          ('k_flow_bwd_gather', ['stage0 loads+transform adjoint', 'conv3T', 'conv2T', 'conv1T', 'store'], (1, 2, 3, 4, 0))):
+    rows = {}
+    for stop in stops:
+        acc = defaultdict(lambda: [0.0, 0])
+        for path in glob.glob(os.path.join(out, f'stop{stop}', '**', '*counter_collection.csv'), recursive=True):
+            for r in csv.DictReader(open(path)):
+                if KEY in r['Kernel_Name']:
+                    a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
+        rows[stop] = {k: v[0] / v[1] / 16384 for k, v in acc.items()}          # per wave (B=128: 2048 workgroups x 8 waves)
+    prev = defaultdict(float)
+    keys = sorted(rows[0])
+    print(KEY + ': per wave, mean over all waves of a full-batch launch'); print('stage'.ljust(32) + ''.join(k.replace('SQ_INSTS_', '').rjust(14) for k in keys))
+    for stop, nm in zip(stops, names):
+        print(nm.ljust(32) + ''.join(f'{rows[stop][k] - prev[k]:14.1f}' for k in keys)); prev = rows[stop]
+    print('total'.ljust(32) + ''.join(f'{rows[0][k]:14.1f}' for k in keys))
 PY

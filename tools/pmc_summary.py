@@ -53,7 +53,7 @@ def main(src, dst):
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 3:
+    if len(sys.argv) > 3 and sys.argv[3]:
         LAUNCH_SHAPE = sys.argv[3]
     if len(sys.argv) > 4:
         COMMIT = sys.argv[4]

@@ -67,8 +67,8 @@ PARITY_TOL = 1e-6              # north_star: 1e-6 relative, fp64
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='weak: --batch chains per GPU; strong: --batch chains in total, split over the GPUs')
@@ -81,6 +81,7 @@ def parse():
                     help='split the chains of a GPU into this many groups whose trajectories run on concurrent '
                          'streams (chains are independent: one group fills the CUs the other leaves idle while a '
                          'kernel drains); default: 2 for large launches, else 1')
+    ap.add_argument('--group-sizes', type=str, default=None, help='explicit chain-group sizes, e.g. 96,32 (experiments)')
     return ap.parse_args()
 
 
@@ -235,6 +236,9 @@ def main():
     # run on concurrent streams, forked from / joined into `stream`
     G = args.groups if args.groups is not None else ops.default_groups(B, L)
     G = max(1, min(G, B)) if flowed else 1
+    Gsplit = [int(t) for t in args.group_sizes.split(',')] if (args.group_sizes and flowed) else G
+    if isinstance(Gsplit, list):
+        G = len(Gsplit)
     state = torch.stack([S0, p0, q0]).contiguous()      # (S_eff, plaq, Q) of the current x, carried along
     out['state'] = torch.empty_like(state)
 
@@ -243,7 +247,7 @@ def main():
         vv, uu = ops.random_momenta(seeds, x.shape)
         v.copy_(vv); u.copy_(uu)
         if flowed:
-            ops.ft_trajectory(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=state, groups=G)
+            ops.ft_trajectory(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=state, groups=Gsplit)
         else:
             r = ops.hmc_trajectory(x, v, u, BETA, dt, NSTEP)
             for k in ('x_new', 'dH', 'acc', 'H0', 'H1'):
@@ -366,7 +370,7 @@ def main():
             'note': 'no HBM traffic between steps: the per-step HBM model is an upper bound'}
     if flowed:
         # launch shape of the timed region: one launch = one layer over one chain group (B / G chains)
-        Bl = B // G if G > 1 else B
+        Bl = (max(Gsplit) if isinstance(Gsplit, list) else B // G) if G > 1 else B
         with torch.cuda.stream(stream):
             w0 = w[:955].contiguous()
             xl = x[:Bl].contiguous()

@@ -45,9 +45,20 @@ __global__ void k_pack_weights(const double* __restrict__ w, int n_layers, doubl
                 const int e = u - LF_P2, a3 = e / 320, ci = 4 * ((e / 40) % 2) + (e / 80) % 4, l5 = (e / 8) % 5 - 1, co = ft_chan(e % 8);
                 const int ky = col ? a3 : l5, kx = col ? l5 : a3;
                 v = (l5 >= 0 && l5 <= 2) ? c[CW1 + (co * 8 + ci) * 9 + ky * 3 + kx] : 0.0;
+            } else if (u < LF_P1 + LF_BC) {                              // conv1 pairs across the lines: columns for mu = 0
+                const int e = u - LF_P1, a3 = e / 96, ci = (e / 48) % 2, l5 = (e / 8) % 6 - 1, co = ft_chan(e % 8);
+                const int ky = col ? l5 : a3, kx = col ? a3 : l5;
+                v = (l5 >= 0 && l5 <= 2) ? c[CW0 + (co * 2 + ci) * 9 + ky * 3 + kx] : 0.0;
             } else {
-                const int e = u - LF_P1, kx = e / 96, ci = (e / 48) % 2, ky = (e / 8) % 6 - 1, co = ft_chan(e % 8);
-                v = (ky >= 0 && ky <= 2) ? c[CW0 + (co * 2 + ci) * 9 + ky * 3 + kx] : 0.0;
+                // bias + the constant part of conv1: window lines k = 0..3 of stripe class (s + k) & 3, frozen = classes 1, 2;
+                // a non-frozen line carries (cos, sin) = (1, 0): site dd sees it through tap line k - dd, all three taps along
+                const int e = u - LF_P1 - LF_BC, s4 = e / 16, dd = (e / 8) % 2, co = e % 8;
+                v = c[CB0 + co];
+                for (int k = 0; k < 4; ++k) {
+                    const int cls = (s4 + k) & 3, tl = k - dd;
+                    if (cls == 1 || cls == 2 || tl < 0 || tl > 2) continue;
+                    for (int a = 0; a < 3; ++a) v += c[CW0 + (co * 2 + 0) * 9 + (col ? tl * 3 + a : a * 3 + tl)];
+                }
             }
         } else if (t >= WBWD && t < WBWD1 + LB_SIZE) {                     // backward blocks (rows, columns)
             const int col = t >= WBWD1, u = t - (col ? WBWD1 : WBWD);

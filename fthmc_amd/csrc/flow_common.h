@@ -44,7 +44,12 @@ static_assert(WCAN + WCAN_SIZE <= FLOW_WINT, "weight layout");
 // read 32 different LDS banks.  ft_chan: a lane holds MFMA rows g and g + 4; with row r carrying channel
 // 2 (r & 3) + (r >> 2) those are the ADJACENT channels 2 g, 2 g + 1, which the channel-minor activation stash
 // (flow_mfma_common.h: struct Stash) stores and loads as one 16-byte access.
-//   forward block (one per mu):  b0[8] b1[8] w2[3][8][9] b2[3]+0  P2[960]  |  P1[3 kx][2 ci: stride 48][5 r5: stride 8][8 co]
+//   forward block (one per mu):  b0[8] b1[8] w2[3][8][9] b2[3]+0  P2[960]  |  P1[3][2 ci: stride 48][5 padded lines: stride 8][8 co]  BC[4 s][2 dd][8 co]
+//       conv1 pairs its output sites ACROSS the stripe lines (flow_fwd.hip), conv2 along them:
+//       mu = 0 (conv1 pairs = columns):  P1[ky][ci][c5][co] = w0[co][ci][ky][c5 - 1]
+//       mu = 1 (conv1 pairs = rows):     P1[kx][ci][r5][co] = w0[co][ci][r5 - 1][kx]
+//       BC[s][dd][co] = b0[co] + the contribution of the constant net input (cos, sin) = (1, 0) on the two non-frozen
+//       lines of the pair's four-line window, s = stripe class of the window's first line, dd = site of the pair
 //       mu = 0 (pairs = rows r, r + 1):  P2[kx][g][h][r5][co] = w1[co][4 h + g][r5 - 1][kx]
 //       mu = 1 (pairs = columns):        P2[ky][g][h][c5][co] = w1[co][4 h + g][ky][c5 - 1]
 //   backward block (one per mu; conv2^T pairs its output sites ACROSS the stripe lines, see flow_bwd_gather.hip):
@@ -53,7 +58,7 @@ static_assert(WCAN + WCAN_SIZE <= FLOW_WINT, "weight layout");
 //       mu = 0 (pairs = columns):  T2[ky][g][h][c5][ci] = w1[4 h + g][ci][2 - ky][2 - (c5 - 1)]
 __host__ __device__ constexpr int ft_chan(int row) { return 2 * (row & 3) + (row >> 2); }
 constexpr int LF_B0 = 0, LF_B1 = 8, LF_W2 = 16, LF_B2 = 232, LF_P2 = 236, LF_SIZE = LF_P2 + 960;   // resident part
-constexpr int LF_P1 = LF_SIZE, LF_P1_SIZE = 288, LF_BLOCK = LF_P1 + LF_P1_SIZE;                   // conv1 table: conv1 stage only
+constexpr int LF_P1 = LF_SIZE, LF_BC = 288, LF_P1_SIZE = LF_BC + 64, LF_BLOCK = LF_P1 + LF_P1_SIZE;   // conv1 tables: conv1 stage only
 constexpr int LB_W0 = 0, LB_W2 = 144, LB_T2 = 360, LB_SIZE = LB_T2 + 960;
 constexpr int WFWD0 = 2944, WFWD1 = WFWD0 + LF_BLOCK, WBWD = WFWD1 + LF_BLOCK, WBWD1 = WBWD + LB_SIZE;   // WBWD: rows, WBWD1: columns
 static_assert(WBWD1 + LB_SIZE <= FLOW_WINT, "weight layout");

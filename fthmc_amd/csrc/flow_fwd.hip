@@ -143,52 +143,80 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     double* const st_h2 = sv.d1 ? sv.h2 + 2 * (lane >> 4) : nullptr;
 
     // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
-    // B[k = (tap, ci)][n = (co, dd)] = W0[co][ci][ky4 - dd][kx] out of the padded table P1 (flow_mfma_common.h: KConv1)
-    // The window's pairs rarely fill whole 16-pair MFMA tiles (200 pairs = 12.5 tiles at 16 x 16): the
-    // MFMA path takes the whole tiles (12 = 3 per SIMD instead of a 13th that lands on one SIMD as a
-    // 4th), the last few pairs run on the VALU (18 MACs per output) on the waves that own one tile only.
-    constexpr int NP1 = (R1R / 2) * R1C, NP1M = NP1 / 16 * 16, NREM1 = 2 * (NP1 - NP1M) * 8;   // leftover outputs
-    static_assert(NP1M / 16 <= 2 * NW && NREM1 <= NT / 2, "leftover outputs go to the upper waves");
-    mfma_stage<KConv1, NP1M, R0C, PS0, false, false, FT_NCH ? FT_NCH : 1>(sIn, sP1, wave, lane,
-        [](int p) { const int pr = fdiv<R1C>(p); return 2 * pr * R0C + p - pr * R1C; },
-        [&](int g, int p, bool ok, double (&z)[4], int) {
-            const int pr = fdiv<R1C>(p), pc = p - pr * R1C;
-            const double b0 = sW[LF_B0 + 2 * g], b1 = sW[LF_B0 + 2 * g + 1];
-            double h[4], d[4];
-            z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
-            act_eval4(z, act, h, d);
-            if (ok) {
-                double* ph = sH1 + 2 * g * PS1 + 2 * pr * R1C + pc;
-                ph[0] = h[0]; ph[PS1] = h[1]; ph[R1C] = h[2]; ph[PS1 + R1C] = h[3];
-            }
-            if (A.stash) {                                  // act'(z1) (and h1) of the tile's own sites
-                const int r = 2 * pr - 2, c = pc - 2;
-                if (ok && (unsigned)c < (unsigned)cmax) {
-                    const int at = mul24(i0 + r, L) + j0 + c;
+    // The net input is (cos P, sin P) on the frozen lines and the constant (1, 0) elsewhere, so only HALF of conv1's
+    // taps carry data.  Output sites are paired ACROSS the stripe lines (columns c, c + 1 of one row for mu = 0, rows for
+    // mu = 1): a pair's input window is then four consecutive lines, exactly two of them frozen -- which two depends
+    // only on the parity of the pair's position u across the lines.  K = 2 frozen lines x 3 taps along x 2 channels =
+    // 3 MFMA steps instead of 6 (lane group g: channel g & 1, frozen line g >> 1; step t: tap along the lines); the
+    // constant lines are folded into the bias (table BC, flow_common.h).  MFMA tiles hold pairs of ONE parity:
+    //     pair index inside a parity class = uu * R1 + v  (u = 2 uu + parity across, v along the lines),
+    // 6 whole tiles per class; the last few pairs (v >= R1 - 4 of the last uu: 12.5 tiles in all, a 13th would land
+    // on one SIMD as a 4th) run on the VALU, all 18 taps, on the waves that own one tile only.
+    static_assert(R1R == R1C && R1R % 2 == 0, "square window, pairs across either direction");
+    constexpr int R1 = R1C, NU1 = R1 / 2, NPC = (NU1 / 2) * R1;          // pairs per parity class (NU1 even)
+    static_assert(NU1 % 2 == 0, "as many even as odd pair positions");
+    constexpr int NTC = NPC / 16, NREMP = NPC - NTC * 16, NREM1 = 2 * (2 * NREMP) * 8;   // whole tiles per class; leftover outputs
+    static_assert(2 * NTC <= 2 * NW && NREM1 <= NT / 2 && NREMP <= R1, "tile rounds; leftover outputs go to the upper waves");
+    {
+        const int g = lane >> 4, i = lane & 15, cN = i & 7, dd = i >> 3;
+        const int sbase = ((mu == 0 ? j0 : i0) - 3 - off) & 3;           // stripe class of the input window's first line
+        const int lstep = mu == 0 ? 1 : R0C;                             // LDS step across the lines / along them
+        const int astep = mu == 0 ? R0C : 1;
 #pragma unroll
-                    for (int dd = 0; dd < 2; ++dd)
-                        if ((unsigned)(r + dd) < (unsigned)rmax) {
-                            *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dd * L)) = double2_t{d[2 * dd], d[2 * dd + 1]};
-                            if (A.stash_h) *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)(at + dd * L)) = double2_t{h[2 * dd], h[2 * dd + 1]};
-                        }
+        for (int it = 0; it < 2; ++it) {
+            const int T = wave + it * NW;
+            if (T >= 2 * NTC) break;
+            const int par = T & 1, idx = (T >> 1) * 16 + i;              // tiles alternate between the parity classes
+            const int uu = fdiv<R1>(idx), v = idx - uu * R1, u = 2 * uu + par;
+            const int s4 = (sbase + 2 * par) & 3;                        // class of the pair window's first line (wave-uniform)
+            const int fl = ((g >> 1) + 1 - s4) & 3;                      // this lane group's frozen line of the window: classes 1, 2
+            const double* a0 = sIn + (g & 1) * PS0 + (2 * u + fl) * lstep + v * astep;
+            const double* wp = sP1 + cN + (g & 1) * 48 + (fl + 1 - dd) * 8;
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[t * 96], a0[t * astep], acc, 0, 0, 0);
+            // z[q]: channel 2 g + (q & 1) at site q >> 1 of the pair; bias + constant lines from BC[s4][site][channel]
+            const double* bc = sP1 + LF_BC + s4 * 16 + 2 * g;
+            double z[4] = {acc[0] + bc[0], acc[1] + bc[1], acc[2] + bc[8], acc[3] + bc[9]};
+            double h[4], d[4];
+            act_eval4(z, act, h, d);
+            const int r = mu == 0 ? v : 2 * u, c = mu == 0 ? 2 * u : v;  // site 0 in h1-window coordinates; site 1 = next column / row
+            const int ds = mu == 0 ? 1 : R1C;
+            double* ph = sH1 + 2 * g * PS1 + r * R1C + c;
+            ph[0] = h[0]; ph[PS1] = h[1]; ph[ds] = h[2]; ph[PS1 + ds] = h[3];
+            if (A.stash) {                                  // act'(z1) (and h1) of the tile's own sites
+                const int r0 = r - 2, c0 = c - 2, r1 = mu == 0 ? r0 : r0 + 1, c1 = mu == 0 ? c0 + 1 : c0;
+                const int at = mul24(i0 + r0, L) + j0 + c0, dat = mu == 0 ? 1 : L;
+                if ((unsigned)r0 < (unsigned)rmax && (unsigned)c0 < (unsigned)cmax) {
+                    *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)at) = double2_t{d[0], d[1]};
+                    if (A.stash_h) *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)at) = double2_t{h[0], h[1]};
+                }
+                if ((unsigned)r1 < (unsigned)rmax && (unsigned)c1 < (unsigned)cmax) {
+                    *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dat)) = double2_t{d[2], d[3]};
+                    if (A.stash_h) *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)(at + dat)) = double2_t{h[2], h[3]};
                 }
             }
-        }, dbg ? dbg + 7 : nullptr);
+        }
+    }
     if (NREM1 > 0 && tid >= NT / 2 && tid < NT / 2 + NREM1) {
-        const int idx = tid - NT / 2, co = idx & 7, site = idx >> 3;
-        const int p = NP1M + (site >> 1), pr = fdiv<R1C>(p), pc = p - pr * R1C, r = 2 * pr + (site & 1);
-        const double* in = sIn + r * R0C + pc;
-        const double* wp = sP1 + (co >> 1) + 4 * (co & 1) + 8;         // P1[kx][ci][r5 = ky + 1][row], ft_chan(row) = co
+        // leftover pairs of either class: uu = NU1 / 2 - 1, v = R1 - NREMP ..; thread = (site, output channel), all 18 taps
+        const int idx = tid - NT / 2, co = idx & 7, site = idx >> 3, pair = site >> 1, sd = site & 1;
+        const int par = pair >= NREMP, v = R1 - NREMP + (pair - par * NREMP), u = NU1 - 2 + par;
+        const int r = mu == 0 ? v : 2 * u + sd, c = mu == 0 ? 2 * u + sd : v;
+        const double* in = sIn + r * R0C + c;
+        const double* wp = sP1 + (co >> 1) + 4 * (co & 1) + 8;         // P1[a][ci][line + 1][row], ft_chan(row) = co
         double z = sW[LF_B0 + co];
 #pragma unroll
         for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) z = fma(in[ci * PS0 + (tp / 3) * R0C + tp % 3], wp[(tp % 3) * 96 + ci * 48 + (tp / 3) * 8], z);
+            for (int tp = 0; tp < 9; ++tp)                              // mu = 0: P1[ky][ci][kx + 1], mu = 1: P1[kx][ci][ky + 1]
+                z = fma(in[ci * PS0 + (tp / 3) * R0C + tp % 3], wp[(mu == 0 ? tp / 3 : tp % 3) * 96 + ci * 48 + (mu == 0 ? tp % 3 : tp / 3) * 8], z);
         double h, d;
         act_eval(z, act, h, d);
-        sH1[co * PS1 + r * R1C + pc] = h;
+        sH1[co * PS1 + r * R1C + c] = h;
         if (A.stash) {
-            const int rr = r - 2, cc = pc - 2;
+            const int rr = r - 2, cc = c - 2;
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
                 const int at = mul24(i0 + rr, L) + j0 + cc;
                 sv.d1[8 * (size_t)at + co] = d;

@@ -37,7 +37,7 @@ int launch_random_momenta(const int64_t* seeds, int B, int n, double* v, double*
 constexpr int FLOW_TILE = 16;                 // VALU variant (flow.hip): 16 x 16 sites per tile
 constexpr int FLOW_R0 = FLOW_TILE + 6;        // plaquette / net-input window edge
 constexpr int FLOW_N0 = FLOW_R0 * FLOW_R0;    // window size of one gP partial
-constexpr int FLOW_WINT = 8640;               // doubles per layer, kernel-side weight layout
+constexpr int FLOW_WINT = 8768;               // doubles per layer, kernel-side weight layout
 constexpr int FLOW_GW_STRIDE = 960;           // doubles per (chain, tile) weight-gradient partial
 
 // tile geometry of a variant: partial buffers are indexed [chain][tile][window]

@@ -353,9 +353,9 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
     inside a captured graph.  `state` is [3, B] = (S_eff, plaq, Q) of x_new; fed back as `state_in`
     of the next trajectory of the same chains (x = x_new) it saves that call's H0 flow sweep.
 
-    groups > 1 splits the chains into that many contiguous groups whose trajectories run on concurrent
-    streams (forked from and joined back into the current stream, each with its own workspace): chains
-    are independent, and one group's kernels fill the CUs that the other's leave idle in every kernel
+    groups > 1 splits the chains into that many contiguous groups (a list gives the group sizes) whose trajectories
+    run on concurrent streams (forked from and joined back into the current stream, each with its own workspace):
+    chains are independent, and one group's kernels fill the CUs that the other's leave idle in every kernel
     tail and dispatch gap.  Results do not depend on `groups`."""
     x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
     if u.numel() != B:
@@ -367,7 +367,14 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
             out[k] = torch.empty(B, dtype=x.dtype, device=x.device)
     if 'state' not in out:
         out['state'] = torch.empty(3, B, dtype=x.dtype, device=x.device)
-    G = max(1, min(int(groups), B))
+    if isinstance(groups, (list, tuple)):                               # explicit group sizes (chains per group)
+        if sum(groups) != B or min(groups) < 1:
+            raise FthmcError(f'groups: sizes {tuple(groups)} do not add up to {B} chains')
+        G = len(groups)
+        edges = [sum(groups[:k]) for k in range(G + 1)]
+    else:
+        G = max(1, min(int(groups), B))
+        edges = [k * B // G for k in range(G + 1)]
     if G > 1:
         if state_in is not None:
             state_in = _dev(state_in, 'state_in')
@@ -380,7 +387,7 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
         for st in sides:                                                # fork before anything of this call is on `main`
             st.wait_stream(main)
         for gi in list(range(1, G)) + [0]:
-            a, b_ = gi * B // G, (gi + 1) * B // G
+            a, b_ = edges[gi], edges[gi + 1]
             st = main if gi == 0 else sides[gi - 1]
             with torch.cuda.stream(st):
                 og = {k: t[a:b_] for k, t in out.items() if k != 'state'}

@@ -5,7 +5,7 @@
 # launches); instructions per stage (needs experiments/lib_diag.so = the -DFT_DIAG build of HEAD); workgroup lifetimes.
 ROOT=$(pwd); OUT=$1; COMMIT=${2:-unknown}; mkdir -p "$OUT"; export TMPDIR=/tmp
 for c in 3 1 2 5; do
-  python3 bench.py --config $c --steps 20 --warmup 5 > "$OUT/bench_config$c.json" 2> "$OUT/bench_config$c.log" || echo "bench config $c failed: $?" >> "$OUT/errors.txt"
+  python3 bench.py --config $c --steps 100 --warmup 10 > "$OUT/bench_config$c.json" 2> "$OUT/bench_config$c.log" || echo "bench config $c failed: $?" >> "$OUT/errors.txt"
   echo "[refresh] bench config $c done"
 done
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/stats.log" 2>&1)

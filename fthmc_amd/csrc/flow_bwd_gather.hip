@@ -264,7 +264,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         }
     }
     if (ftask) { sIn[fr1 * W1C + fc1] = fcs; sIn[PS1 + fr1 * W1C + fc1] = fsn; }
+#ifndef FT_DIAG
     if (dbg && lane == 0) dbg[6 + wave] = (long long)__builtin_readcyclecounter();   // arrival at the first barrier
+#endif
     lds_barrier();
     STAMP(1);
 #ifdef FT_DIAG
@@ -359,6 +361,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
                     default: acc = conv2t_tile<KConv2Row, 3, 3, RS2, PS2>(wp, a0); break;
                 }
             }
+#ifdef FT_DIAG      // slots 6..9: wave 0 after the MFMAs / the epilogue of its two tiles; 10, 11: wave 4 (one tile)
+            if (dbg && (wave == 0 || wave == 4)) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); stampx(dbg + (wave == 0 ? 6 + 2 * it : 10)); }
+#endif
             if (pok[it]) {
                 const int ra = mu == 0 ? pv[it] : 2 * pu[it], ca = mu == 0 ? 2 * pu[it] : pv[it];   // site 0; site 1 = next column / row
                 const int ds = mu == 0 ? 1 : W1C;
@@ -373,6 +378,9 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
                         *reinterpret_cast<double2_t*>(gz1o + 8 * (size_t)(mul24(i0 + r2, L) + j0 + c2) + 2 * g) = double2_t{v2, v3};
                 }
             }
+#ifdef FT_DIAG
+            if (dbg && (wave == 0 || wave == 4)) stampx(dbg + (wave == 0 ? 7 + 2 * it : 11));
+#endif
         }
     }
     lds_barrier();

@@ -162,7 +162,7 @@ __device__ __forceinline__ void stampx(long long* slot) {
     unsigned long long t_;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0) *slot = (long long)t_;
+    if ((threadIdx.x & 63) == 0) *slot = (long long)t_;          // callers pick the wave
 }
 // DEFER: the epilogues run after ALL of the workgroup's MFMA loops (results parked in registers, one workgroup
 //        barrier in between), so that an epilogue may overwrite the planes the MFMAs read (needs UNROLL)
@@ -197,12 +197,12 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];
 #ifdef FT_DIAG
-        if (dbg) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); stampx(dbg + 2 * it); }
+        if (dbg && wave == 0) { asm volatile("" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); stampx(dbg + 2 * it); }
 #endif
         if (DEFER) { zs[it][0] = acc[0]; zs[it][1] = acc[1]; zs[it][2] = acc[2]; zs[it][3] = acc[3]; }
         else { double z4[4] = {acc[0], acc[1], acc[2], acc[3]}; epi(g, p, ok, z4, it); }
 #ifdef FT_DIAG
-        if (dbg) stampx(dbg + 2 * it + 1);
+        if (dbg && wave == 0) stampx(dbg + 2 * it + 1);
 #endif
     }
     if (DEFER) {

@@ -7,10 +7,10 @@ fp64 MFMA and fp64 VALU share one DP pipe per SIMD on gfx950 (profiles/r01_micro
 instruction of a wave occupies it for ~4.2 cycles (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU), a v_mfma_f64_16x16x4 for 64."""
 import json, os
 L, B, TILE = 64, 128, 16
-mfma = 72 + 192                                  # conv1 on tile+2 (12 tiles x 6) + conv2 on the live lines of tile+1 (8 x 24)
+mfma = 36 + 192                                  # conv1 on tile+2, frozen taps only (12 tiles x 3) + conv2 on the live lines of tile+1 (8 x 24)
 sig = (20 * 20 + 14 * 18) * 8                    # sigmoids: h1 on tile+2, h2 on the live lines of tile+1, 8 channels
 work = {                                         # SIMD-cycles per workgroup
-    'mfma_264_x_64': mfma * 64,
+    'mfma_228_x_64': mfma * 64,
     'sigmoid_5216_x_26_ops': sig * 26 * 4 / 64,
     'sincos_484_x_45_ops': 22 * 22 * 45 * 4 / 64,
     'conv3_active_sites_fma': 64 * 8 * 9 * 3 * 4 / 64,

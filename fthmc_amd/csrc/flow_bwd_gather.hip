@@ -39,7 +39,7 @@ template <int TR, int TC> struct SmemG {
     // gz2 rows are RS2 apart in LDS: odd, so that the 16 lanes of a conv2^T operand read (one per window row, below)
     // fall into 16 different banks
     static constexpr int RS2 = W2C + 1;
-    static constexpr int PS2 = ps_round(W2R * RS2), PS1 = ps_round(N1W);
+    static constexpr int PS2 = ps_round16(W2R * RS2), PS1 = ps_round(N1W);   // gz2: MFMA operand; gz1: read by four channel lanes per site
     // active lines of the g_out window: every 4th column (mu = 0) or row (mu = 1)
     static constexpr int NLC = (W3C + 3) / 4, NLR = (W3R + 3) / 4;
     static constexpr int NSLOT = cmax_(W3R * NLC, NLR * W3C);           // transform tasks

@@ -280,6 +280,18 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                 conv2_epi(g, ok && r < R2R, r, 2 * (p - lr * (R2C / 2)), 0, 1, z);
             });
     }
+    // conv3's 27 weights of this wave's input channel are wave-uniform: scalar loads straight from the weight block
+    // (constant address space -> s_load, SGPR operands of the FMAs) instead of 27 LDS reads per wave; issued ahead of
+    // the barrier so that they land while the slower waves finish conv2
+    typedef const double __attribute__((address_space(4))) * cdptr;
+    double w3[27];
+    {
+        cdptr w3p = (cdptr)(size_t)(w + (mu == 0 ? WFWD0 : WFWD1) + LF_W2 + wave * 9);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) w3[k * 9 + tp] = w3p[k * 72 + tp];
+    }
     lds_barrier();
     STAMP(3);
 #ifdef FT_DIAG
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             for (int kx = 0; kx < 3; ++kx) {
                 const double v = sH2[ci * PS2 + (ar + ky) * R2C + ac + kx];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) acc[k] = fma(v, sW[LF_W2 + (k * 8 + ci) * 9 + ky * 3 + kx], acc[k]);
+                for (int k = 0; k < 3; ++k) acc[k] = fma(v, w3[k * 9 + ky * 3 + kx], acc[k]);
             }
 #pragma unroll
         for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NAS + lane] = acc[k];

@@ -69,7 +69,10 @@ constexpr int ps_round(int n) { return ((n - 18 + 31) / 32) * 32 + 18; }
 // Plane stride of the planes an MFMA stage reads its activation operand from: = 16 (mod 32).  A ds_read_b64 is banked
 // over 32 lanes = 16 pairs x two K lane groups g, g + 1 (one plane apart): consecutive pair sites + 16 fill the 32
 // double-wide banks exactly (with 18 two lanes collide and the read takes a third LDS cycle).
-constexpr int ps_round16(int n) { return ((n - 16 + 31) / 32) * 32 + 16; }
+#ifndef FT_PSMOD
+#define FT_PSMOD 16
+#endif
+constexpr int ps_round16(int n) { return ((n - FT_PSMOD + 31) / 32) * 32 + FT_PSMOD; }
 
 template <int TR, int TC> struct Geom {
     static constexpr int R0R = TR + 6, R0C = TC + 6, N0 = R0R * R0C;   // plaquette / input window
@@ -78,7 +81,7 @@ template <int TR, int TC> struct Geom {
     static constexpr int N3 = TR * TC, NA = N3 / 4;                    // tile, active sites
     static constexpr int NAS = NA <= 32 ? 32 : 64;                     // lane stride of per-active-site scratch
     static constexpr int PS0 = ps_round16(N0), PS1 = ps_round16(N1), PS2 = ps_round(N2);   // net input, h1: MFMA operands
-    static_assert(PS0 % 32 == 16 && PS1 % 32 == 16 && PS2 % 32 == 18, "bank layout");
+    static_assert(PS0 % 32 == FT_PSMOD && PS1 % 32 == FT_PSMOD && PS2 % 32 == 18, "bank layout");
     static_assert(PS0 >= N0 && PS1 >= N1 && PS2 >= N2, "plane size");
     static_assert(TR % 4 == 0 && TC % 4 == 0 && NA <= 64, "tile shape");
 };

@@ -383,6 +383,14 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
 #endif
         }
     }
+    // conv1^T's 18 weights of this wave's hidden channel: scalar loads from the weight block (constant address space)
+    typedef const double __attribute__((address_space(4))) * cdptr;
+    double w0s[18];
+    {
+        cdptr wq = (cdptr)(size_t)(w + (mu == 0 ? WBWD1 : WBWD) + LB_W0 + wave * 18);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) w0s[k] = wq[k];
+    }
     lds_barrier();
     STAMP(3);
 #ifdef FT_DIAG
@@ -390,32 +398,44 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
 #endif
 
     // ---- conv1^T and the (cos, sin) adjoint at the tile's own frozen plaquettes ------------------
-    // thread = (frozen site, quarter of the 8 channels); the four quarters of a site sit in adjacent lanes
-    if (tid < 2 * N3) {
-        const int f = tid >> 2, qq = tid & 3;
-        int r, c;
-        if (mu == 0) { r = fdiv<TC / 2>(f); const int h = f - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
-        else { const int hh = fdiv<TC>(f); c = f - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
-        double gc[2] = {0.0, 0.0}, gsn[2] = {0.0, 0.0};
+    // wave = hidden channel co, lane = two of the tile's N3 / 2 frozen sites: the 18 weights of a channel are wave-uniform
+    // (scalar loads, requested ahead of the barrier above) and the gz1 reads of a wave stay inside ONE plane; the sum
+    // over the channels goes through LDS (the gz2 planes are free by now)
+    static_assert(NW == 8 && N3 / 2 == 2 * 64 && 8 * 2 * (N3 / 2) <= 8 * PS2, "one wave per hidden channel, two sites per lane");
+    double* sPart = sGZ2;                                                // [8 co][2: cos, sin][N3 / 2]
+    auto frozen_site = [&](int f, int& r, int& c) {
+        // mu = 0: 16 rows x 8 frozen columns, f = row + 16 h (a 32-lane group then holds an odd and an even column of 16
+        // rows: 32 different banks at row stride 18); mu = 1: 8 frozen rows x 16 columns, f = column + 16 hh
+        const int h = f >> 4, q = f & 15;
+        if (mu == 0) { r = q; c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
+        else { c = q; r = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
+    };
+    {
+        const int co = wave;
 #pragma unroll
-        for (int cq = 0; cq < 2; ++cq) {
-            const int co = 2 * qq + cq;
+        for (int sx = 0; sx < 2; ++sx) {
+            const int f = lane + 64 * sx;
+            int r, c;
+            frozen_site(f, r, c);
             const double* gz = sD1 + co * PS1 + r * W1C + c;            // window coordinates (r + 2 - ky, c + 2 - kx)
-            const double* wp = sW + LB_W0 + co * 18;
-            double gv[9], w0[9], w1[9];
+            double gv[9], gc = 0.0, gs = 0.0;
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) { gv[tp] = gz[(2 - tp / 3) * W1C + 2 - tp % 3]; w0[tp] = wp[tp]; w1[tp] = wp[9 + tp]; }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int tp = 0; tp < 9; ++tp) gv[tp] = gz[(2 - tp / 3) * W1C + 2 - tp % 3];
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) { gc[cq] = fma(gv[tp], w0[tp], gc[cq]); gsn[cq] = fma(gv[tp], w1[tp], gsn[cq]); }
+            for (int tp = 0; tp < 9; ++tp) { gc = fma(gv[tp], w0s[tp], gc); gs = fma(gv[tp], w0s[9 + tp], gs); }
+            sPart[(co * 2 + 0) * (N3 / 2) + f] = gc;
+            sPart[(co * 2 + 1) * (N3 / 2) + f] = gs;
         }
-        double gct = gc[0] + gc[1], gst = gsn[0] + gsn[1];
-        gct += __shfl_xor(gct, 1, FT_WAVE); gst += __shfl_xor(gst, 1, FT_WAVE);
-        gct += __shfl_xor(gct, 2, FT_WAVE); gst += __shfl_xor(gst, 2, FT_WAVE);
-        if (qq == 0) {
-            const int at = (r + 1) * W1C + c + 1;
-            sDir[r * TC + c] = -sIn[PS1 + at] * gct + sIn[at] * gst;
-        }
+    }
+    lds_barrier();
+    if (tid < N3 / 2) {
+        int r, c;
+        frozen_site(tid, r, c);
+        double gct = 0.0, gst = 0.0;
+#pragma unroll
+        for (int co = 0; co < 8; ++co) { gct += sPart[(co * 2 + 0) * (N3 / 2) + tid]; gst += sPart[(co * 2 + 1) * (N3 / 2) + tid]; }
+        const int at = (r + 1) * W1C + c + 1;
+        sDir[r * TC + c] = -sIn[PS1 + at] * gct + sIn[at] * gst;
     }
     lds_barrier();
     STAMP(4);

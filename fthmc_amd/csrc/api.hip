@@ -44,7 +44,7 @@ WS ws_layout(double* base, int B, int L, int nl, bool train = false) {
     w.gp = take(n1);
     w.gp2 = take(nl > 0 ? n1 : 0);                       // second plaquette-gradient field (gather-form backward)
     w.gp_part = take(nl > 0 ? (size_t)B * flow_gp_part_max(L) : 0);
-    w.lj_part = take((size_t)B * nt);
+    w.lj_part = take((size_t)(nl > 0 ? nl : 1) * B * nt);               // logJ partials [layer][chain][tile] of a sweep
     w.scal = take((size_t)SC_N * B);
     w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
     w.gw_part = take(nl > 0 ? (size_t)B * nt * FLOW_GW_STRIDE : 0);
@@ -78,11 +78,12 @@ int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, d
         a.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
         a.wint = w.wint + (size_t)l * FLOW_WINT;
         a.y = w.X + (size_t)l * w.n2;
-        a.logj_part = logdet ? w.lj_part : nullptr;
+        // logJ partials of all layers side by side, summed by ONE launch behind the sweep (layer by layer, in order)
+        a.logj_part = logdet ? w.lj_part + (size_t)l * B * flow_fwd_geom(fwd_is_mfma()).ntiles(L) : nullptr;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
         FT_TRY(flow_fwd(a, s));
-        if (logdet) FT_TRY(launch_sum_parts(w.lj_part, B, flow_fwd_geom(fwd_is_mfma()).ntiles(L), 1.0, l > 0, logdet, s));
     }
+    if (logdet && nl > 0) FT_TRY(launch_sum_parts(w.lj_part, B, flow_fwd_geom(fwd_is_mfma()).ntiles(L), 1.0, 0, logdet, s, nl));
     return FTHMC_OK;
 }
 

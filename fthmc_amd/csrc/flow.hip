@@ -20,10 +20,10 @@ using namespace fthmc;
 using namespace fthmc_flow;
 
 __global__ void k_pack_weights(const double* __restrict__ w, int n_layers, double* __restrict__ o) {
-    const int l = blockIdx.x;
+    const int l = blockIdx.x;                                    // gridDim.y workgroups per layer
     const double* c = w + (size_t)l * FTHMC_W_PER_LAYER;
     double* d = o + (size_t)l * FLOW_WINT;
-    for (int t = threadIdx.x; t < FLOW_WINT; t += blockDim.x) {
+    for (int t = blockIdx.y * blockDim.x + threadIdx.x; t < FLOW_WINT; t += gridDim.y * blockDim.x) {
         double v = 0.0;
         if (t < B1) { int co = t % 8, tap = (t / 8) % 9, ci = t / 72; v = c[CW0 + (co * 2 + ci) * 9 + tap]; }
         else if (t < W2F) v = c[CB0 + t - B1];
@@ -495,15 +495,21 @@ __global__ __launch_bounds__(256) void k_flow_layer(FlowLayerArgs A) {
 }
 
 // out[b] (+)= sign * sum_t part[b][t]
-__global__ void k_sum_parts(const double* __restrict__ part, int B, int np, double sign, int accumulate,
+__global__ void k_sum_parts(const double* __restrict__ part, int B, int np, int nsets, double sign, int accumulate,
                             double* __restrict__ out) {
     // one wave per chain: lane l sums the partials t = l, l + 64, ... in order, then a fixed xor tree
-    // (deterministic; one thread per chain read L^2 / 256 partials serially: 124 us per call at L = 256)
+    // (deterministic; one thread per chain read L^2 / 256 partials serially: 124 us per call at L = 256).
+    // nsets partial sets [set][B][np] (the layers of a sweep) are summed one after the other, in order: the same
+    // arithmetic as one accumulating call per set, in one launch.
     const int b = blockIdx.x, lane = threadIdx.x;
-    double a = 0.0;
-    for (int t = lane; t < np; t += FT_WAVE) a += part[(size_t)b * np + t];
-    a = ft_wave_sum(a);
-    if (lane == 0) out[b] = (accumulate ? out[b] : 0.0) + sign * a;
+    double tot = accumulate ? out[b] : 0.0;
+    for (int q = 0; q < nsets; ++q) {
+        double a = 0.0;
+        for (int t = lane; t < np; t += FT_WAVE) a += part[((size_t)q * B + b) * np + t];
+        a = ft_wave_sum(a);
+        tot += sign * a;
+    }
+    if (lane == 0) out[b] = tot;
 }
 
 // gp[b][i][j] (+)= sum over tiles and over every window position that wraps onto (i, j).
@@ -602,7 +608,7 @@ namespace fthmc {
 
 int launch_pack_weights(const double* w, int n_layers, double* wint, hipStream_t s) {
     if (n_layers <= 0) return FTHMC_OK;
-    hipLaunchKernelGGL(k_pack_weights, dim3(n_layers), dim3(256), 0, s, w, n_layers, wint);
+    hipLaunchKernelGGL(k_pack_weights, dim3(n_layers, 8), dim3(256), 0, s, w, n_layers, wint);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s) {
@@ -619,8 +625,8 @@ int launch_flow_bwd(const FlowLayerArgs& a, bool wgrad, hipStream_t s) {
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_sum_parts(const double* part, int B, int nparts, double sign, int accumulate, double* out,
-                     hipStream_t s) {
-    hipLaunchKernelGGL(k_sum_parts, dim3(B), dim3(FT_WAVE), 0, s, part, B, nparts, sign, accumulate, out);
+                     hipStream_t s, int nsets) {
+    hipLaunchKernelGGL(k_sum_parts, dim3(B), dim3(FT_WAVE), 0, s, part, B, nparts, nsets, sign, accumulate, out);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_gather_gp(const double* gp_part, int B, int L, FlowGeom g, int accumulate, double* gp, hipStream_t s) {

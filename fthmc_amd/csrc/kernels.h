@@ -111,7 +111,7 @@ void set_flow_variant(int v);
 int get_flow_variant();
 // out[b] (+)= sign * sum_t part[b][t]
 int launch_sum_parts(const double* part, int B, int nparts, double sign, int accumulate,
-                     double* out, hipStream_t s);
+                     double* out, hipStream_t s, int nsets = 1);   // nsets partial sets [set][B][nparts], summed in order
 // gp[b][i][j] (+)= sum of every partial window position that maps to (i, j)
 int launch_gather_gp(const double* gp_part, int B, int L, FlowGeom g, int accumulate, double* gp, hipStream_t s);
 // gx = gy + adj(gp)

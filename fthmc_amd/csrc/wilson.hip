@@ -191,17 +191,17 @@ __global__ void k_metropolis(const double* __restrict__ x_old, const double* __r
                              double* __restrict__ acc,
                              const double* __restrict__ obs_old, const double* __restrict__ obs_new,
                              double* __restrict__ obs_out, int n_obs, int B) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x;                                    // gridDim.y workgroups share the copy of a chain
     const double d = H1[b] - H0[b];
     const bool a = u[b] < exp(-d);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
         if (dH) dH[b] = d;
         if (acc) acc[b] = a ? 1.0 : 0.0;
         for (int k = 0; k < n_obs; ++k)
             if (obs_out) obs_out[k * B + b] = a ? obs_new[k * B + b] : obs_old[k * B + b];
     }
     const size_t o = (size_t)b * n2;
-    for (int s = threadIdx.x; s < n2; s += blockDim.x) {
+    for (int s = blockIdx.y * blockDim.x + threadIdx.x; s < n2; s += gridDim.y * blockDim.x) {
         double v;
         if (a) {
             v = x_prop[o + s];
@@ -382,7 +382,9 @@ int launch_metropolis(const double* x_old, const double* x_prop, const double* u
                       const double* H1, int B, int L, int xform, double* x_new, double* dH,
                       double* acc, const double* obs_old, const double* obs_new, double* obs_out,
                       int n_obs, hipStream_t s) {
-    hipLaunchKernelGGL(k_metropolis, dim3(B), dim3(256), 0, s, x_old, x_prop, u, H0, H1,
+    int gy = (2 * L * L + 2047) / 2048;                          // ~8 sites per thread; one workgroup per chain left the copy latency-bound
+    if (gy > 16) gy = 16;
+    hipLaunchKernelGGL(k_metropolis, dim3(B, gy), dim3(256), 0, s, x_old, x_prop, u, H0, H1,
                        2 * L * L, xform, x_new, dH, acc, obs_old, obs_new, obs_out, n_obs, B);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }

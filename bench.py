@@ -254,6 +254,12 @@ def main():
                 out[k].copy_(r[k])
             _, qn, pn = ops.wilson_action_charge(out['x_new'], BETA)
             out['plaq'].copy_(pn); out['Q'].copy_(qn)
+        # the chain state moves on and the run statistics accumulate inside the same (captured) sequence
+        x.copy_(out['x_new'])
+        if flowed:
+            state.copy_(out['state'])
+        stats.add(out['acc'], out['plaq'], out['Q'], out['Q'] - qold, out['dH'])
+        qold.copy_(out['Q'])
 
     graph = None
     if not args.no_graph:
@@ -275,12 +281,6 @@ def main():
             graph.replay()
         else:
             enqueue()
-        x.copy_(out['x_new'])
-        if flowed:
-            state.copy_(out['state'])
-        dq = out['Q'] - qold
-        stats.add(out['acc'], out['plaq'], out['Q'], dq, out['dH'])
-        qold.copy_(out['Q'])
         if pending[0] is not None:
             pending[0].wait()
         pending[0] = stats.reduce(async_op=world > 1)

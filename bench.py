@@ -244,8 +244,7 @@ def main():
 
     def enqueue():
         """momentum refresh + one trajectory of every chain of this GPU, forked from the current stream"""
-        vv, uu = ops.random_momenta(seeds, x.shape)
-        v.copy_(vv); u.copy_(uu)
+        ops.random_momenta(seeds, x.shape, out_v=v, out_u=u)
         if flowed:
             ops.ft_trajectory(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=state, groups=Gsplit)
         else:

@@ -164,8 +164,9 @@ def kinetic(v):
     return K
 
 
-def random_momenta(seeds, shape, need_u=True):
-    """v ~ N(0,1) of `shape` = (B, 2, L, L) and u ~ U[0,1) [B] from per-chain int64 seeds."""
+def random_momenta(seeds, shape, need_u=True, out_v=None, out_u=None):
+    """v ~ N(0,1) of `shape` = (B, 2, L, L) and u ~ U[0,1) [B] from per-chain int64 seeds
+    (written into out_v / out_u when given: contiguous float64 device tensors of those shapes)."""
     if not seeds.is_cuda or seeds.dtype != torch.int64:
         raise FthmcError('seeds: expected an int64 tensor on the HIP device')
     seeds = seeds.contiguous()
@@ -174,8 +175,11 @@ def random_momenta(seeds, shape, need_u=True):
         n *= int(d)
     if seeds.numel() != B:
         raise FthmcError(f'seeds: expected {B}, got {seeds.numel()}')
-    v = torch.empty(tuple(shape), dtype=torch.float64, device=seeds.device)
-    u = torch.empty(B, dtype=torch.float64, device=seeds.device) if need_u else None
+    for t, want in ((out_v, B * n), (out_u, B)):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != want):
+            raise FthmcError('random_momenta: out tensors must be contiguous float64 device tensors of the result shapes')
+    v = out_v if out_v is not None else torch.empty(tuple(shape), dtype=torch.float64, device=seeds.device)
+    u = out_u if out_u is not None else (torch.empty(B, dtype=torch.float64, device=seeds.device) if need_u else None)
     check(_lib.load().fthmc_random_momenta(_p(seeds), B, n, _p(v), _p(u), _stream(v)), 'fthmc_random_momenta')
     return v, u
 

@@ -247,6 +247,35 @@ def test_train_grad_vs_oracle_random(B, L, nl, beta):
             close(gws[li][pi], grads[li][pi], rtol=1e-8, atol=1e-11)
 
 
+@pytest.mark.parametrize('B,L,nl,act,scale,beta', [(2, 4, 8, 'silu', 1.0, 2.0), (3, 16, 4, 'relu', 1.0, 3.0),
+                                                  (2, 28, 3, 'leaky_relu', 1.0, 2.5), (2, 16, 4, 'silu', 4.0, 4.0),
+                                                  (1, 36, 2, 'relu', 3.0, 2.0), (10, 8, 5, 'leaky_relu', 2.0, 2.0)])
+def test_activations_and_extremes_vs_oracle(B, L, nl, act, scale, beta):
+    """Every activation on lattices of every kind (the smallest one, ragged tiles, a partial block group), weights
+    scaled up until the sigmoids saturate and the transform's slopes get steep, plaquettes pinned near +-pi:
+    forward, log det, force and the training gradient against the oracle."""
+    gen = torch.Generator().manual_seed(4242 + L + nl)
+    flow = [tuple(t * scale for t in lw) for lw in R.default_flow(nl, gen)]
+    x = (torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+    x[0, 0, 0, :] = math.pi - 1e-9                       # plaquettes at the branch cut of the wrap / of tan(P/2)
+    x[0, 1, :, 0] = -math.pi + 1e-9
+    w = W(flow)
+    y, ld = R.flow_forward(x, flow, act)
+    yg, ldg = ops.flow_forward(x.cuda(), w, nl, act)
+    angle_close(yg, y, atol=1e-9); close(ldg, ld, rtol=1e-9, atol=1e-9)
+    F = R.ft_force(x, flow, beta, act)
+    Fg = ops.ft_force(x.cuda(), w, nl, beta, act)
+    close(Fg, F, rtol=1e-7, atol=1e-7 * float(F.abs().max()))
+    out, grads = R.train_grads(x, flow, beta, act)
+    r = ops.train_grad(x.cuda(), w, nl, beta, act)
+    close(r['logq'], out['logq'], rtol=1e-9); close(r['logp'], out['logp'], rtol=1e-9)
+    gws = ops.unpack_weight_grads(r['gw'], nl)
+    gmax = max(float(g.abs().max()) for lg in grads for g in lg)
+    for li in range(nl):
+        for pi in range(6):
+            close(gws[li][pi], grads[li][pi], rtol=1e-7, atol=1e-9 * max(gmax, 1.0))
+
+
 def test_config5_shape_properties():
     """BASELINE config 5 shard shape (L=256, 16 layers; 2 chains here): size-independent properties of the
     force and training paths."""

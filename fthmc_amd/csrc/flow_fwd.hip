@@ -1,13 +1,14 @@
 // Coupling-layer forward on the matrix cores (GaugeEquivCouplingLayer.forward, fthmc/utils/layers.py:196-202,
 // with NCPPlaqCouplingLayer.forward :348-371, the conv net :138-167 and the tan-mixture transform :58-90).
 //
-// A workgroup (512 threads) owns a 16 x 16 tile of one chain, two workgroups share a CU; everything
+// A workgroup (512 threads) owns a 16 x 16 tile of one chain, three workgroups share a CU; everything
 // between the link loads and the link update lives in LDS:
 //   plaquettes + net input (cos P, sin P) on tile+3  ->  conv1 (2 -> 8) + act on tile+2  ->  conv2 (8 -> 8) + act
 //   on the live lines of tile+1  ->  conv3 (8 -> 3) at the tile's active sites  ->  tan-mixture transform,
 //   log J  ->  link update x' = wrap(x +- (P' - P)) at the active links.
-// conv1 and conv2 are implicit GEMMs on v_mfma_f64_16x16x4_f64 (flow_mfma_common.h: mfma_stage), both
-// operands one ds_read_b64 per MFMA out of LDS; conv3 (N = 3) stays on the fp64 VALU.
+// conv1 and conv2 are implicit GEMMs on v_mfma_f64_16x16x4_f64 (conv2: flow_mfma_common.h mfma_stage; conv1: the frozen
+// taps only, below), both operands one ds_read_b64 per MFMA out of LDS; conv3 (N = 3) stays on the fp64 VALU with its
+// wave-uniform weights in SGPRs.
 // With a.stash the kernel also writes what the backward needs (struct Stash: act'(z1), act'(z2), the
 // transform's adjoint coefficients, cos/sin of the frozen plaquettes, and h1, h2 for the weight gradients),
 // so that flow_bwd_gather.hip never re-runs the network.
@@ -493,7 +494,7 @@ void set_flow_variant(int v) { g_variant = v; }
 int get_flow_variant() { return g_variant; }
 
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
-    // forward needs half the LDS of backward: 16 x 16 tiles (less halo work) still fit twice per CU
+    // 16 x 16 tiles, three workgroups per CU (SmemF)
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
     if (wrap_fast_ok(a.L, MF_FWD_TR, MF_FWD_TC)) hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, true, false>), grid, dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, false, false>), grid, dim3(NT), 0, s, a);

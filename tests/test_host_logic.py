@@ -2,6 +2,7 @@
 sharding, multi-process statistics over gloo) and that the C-ABI library loads and exports
 every symbol include/fthmc_hip.h declares.  No compute calls: there is no GPU here."""
 import os
+import shutil
 import re
 import subprocess
 import sys
@@ -279,3 +280,52 @@ def test_unsupported_net_shapes_fail_loudly():
         ops.pack_weights([w])                                  # n_mixture_comps = 3
     header = open(os.path.join(ROOT, 'include', 'fthmc_hip.h')).read()
     assert 'hidden_sizes=[8,8], kernel_size=3, n_mixture_comps=2' in header and 'FTHMC_ERR_UNSUPPORTED' in header
+
+
+def _device_code_objects(path, tmp):
+    """gfx950 code objects embedded in a host object / shared library (one clang offload bundle per translation unit)."""
+    import subprocess
+    llvm = '/opt/rocm/lib/llvm/bin'
+    fat = os.path.join(tmp, 'fat.bin')
+    subprocess.run(['objcopy', '-O', 'binary', '--only-section=.hip_fatbin', path, fat], check=True)
+    blob = open(fat, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+    outs = []
+    for k, a in enumerate(starts):
+        part = os.path.join(tmp, f'bundle{k}.bin')
+        open(part, 'wb').write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        dev = os.path.join(tmp, f'dev{k}.o')
+        subprocess.run([f'{llvm}/clang-offload-bundler', '--unbundle', '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
+                        f'--input={part}', f'--output={dev}'], check=True, capture_output=True)
+        if os.path.getsize(dev):
+            outs.append(dev)
+    return outs
+
+
+def test_hot_kernels_are_what_the_build_intends(tmp_path):
+    """Static check of the shipped library's gfx950 code (no GPU needed): the three coupling-layer kernels run on
+    v_mfma_f64_16x16x4_f64, feed it with ds_read_b64 (the Makefile switches the ds_read2_b64 pairing off: half the LDS
+    bandwidth) and use no scratch memory (no register spills)."""
+    import re
+    import subprocess
+    from fthmc_amd import _lib
+    llvm = '/opt/rocm/lib/llvm/bin'
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(f'{llvm}/llvm-objdump') and shutil.which('objcopy')):
+        pytest.skip('library or LLVM tools not present')
+    seen = {}
+    for dev in _device_code_objects(_lib.LIB_PATH, str(tmp_path)):
+        dis = subprocess.run([f'{llvm}/llvm-objdump', '-d', dev], check=True, capture_output=True, text=True).stdout
+        notes = subprocess.run([f'{llvm}/llvm-readelf', '--notes', dev], check=True, capture_output=True, text=True).stdout
+        for name, body in re.findall(r'<(_Z\w+)>:\n(.*?)(?=\n\n|\Z)', dis, flags=re.S):
+            for key in ('k_flow_fwd', 'k_flow_bwd_gather', 'k_flow_wgrad'):
+                if key in name:
+                    m = re.search(r'\.name:\s+' + re.escape(name) + r'\s.*?\.private_segment_fixed_size:\s+(\d+)', notes, flags=re.S)
+                    seen.setdefault(key, []).append((body.count('v_mfma_f64_16x16x4'), body.count('ds_read2_b64'),
+                                                     body.count('ds_read_b64'), int(m.group(1)) if m else -1))
+    assert set(seen) == {'k_flow_fwd', 'k_flow_bwd_gather', 'k_flow_wgrad'}, seen.keys()
+    for key, variants in seen.items():
+        for mfma, read2, read1, scratch in variants:
+            assert mfma > 0 and read1 > 0, (key, mfma, read1)
+            assert read2 == 0, f'{key}: {read2} ds_read2_b64 (LDSFLAGS of csrc/Makefile not applied?)'
+            assert scratch == 0, f'{key}: {scratch} bytes of scratch per lane (spills)'

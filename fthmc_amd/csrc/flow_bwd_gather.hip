@@ -145,8 +145,8 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         // wave-uniform base + 32-bit per-lane offset everywhere: the address costs no VALU op per load
         const unsigned ia = (unsigned)stash_active_idx(i, j, L, mu);
 #pragma unroll
-        for (int q = 0; q < 4 * NMIX; q += 2) {                             // site-major [n/4][k][A B C E]: 16 bytes per load
-            const double2_t t2 = ldu2(stc, ia * (4u * NMIX) + q);
+        for (int q = 0; q < 4 * NMIX; q += 2) {                             // [k][n/4][A B C E] (struct Stash): 16 bytes per load
+            const double2_t t2 = ldu2(stc + (size_t)(q >> 2) * n, ia * 4u + (q & 3));
             tcv[q] = t2.x; tcv[q + 1] = t2.y;
         }
         // upstream gradient: a link field (first layer of a standalone call) or the plaquette-gradient field

@@ -426,8 +426,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             // coefficients of the transform's adjoint (struct Stash): the backward kernel then needs no
             // plaquettes, sincos or exp at the active sites of its tile+3 window
             const double sinP = 2.0 * sincs, invD2 = invD * invD;
-            // site-major [n/4][k][A B C E]: this wave's four coefficients are 32 contiguous bytes
-            double* tc = sv.tc + 4 * NMIX * (size_t)stash_active_idx(ai, aj, L, mu) + 4 * wave;
+            // component-major [k][n/4][A B C E]: the wave of component k writes whole cache lines (site-major, two waves
+            // wrote the two 32-byte halves of every 64-byte record at different times)
+            double* tc = sv.tc + (size_t)wave * n + 4 * (size_t)stash_active_idx(ai, aj, L, mu);
             *reinterpret_cast<double2_t*>(tc) = double2_t{sinP * invD / NMIX,                      // A_k
                                                          (ems * cs2 - es * sn2) * invD2};          // B_k
             *reinterpret_cast<double2_t*>(tc + 2) = double2_t{invD / NMIX,                         // C_k

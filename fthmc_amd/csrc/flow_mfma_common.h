@@ -92,7 +92,7 @@ template <int TR, int TC> struct Geom {
 //   d1  [n][8]     act'(z1), channel-minor        d2  [n][8]   act'(z2)  (dead lines unwritten)
 //                  (64 B per site: a window row of 20 sites is 10 cache lines for all channels, not 8 x 2..3,
 //                   and the channel pair (2 g, 2 g + 1) of a lane is one 16-byte access)
-//   tc  [n/4][K][4] adjoint coefficients of the tan-mixture transform at the ACTIVE sites, compact, site-major:
+//   tc  [K][n/4][4] adjoint coefficients of the tan-mixture transform at the ACTIVE sites, compact, component-major:
 //                  per mixture component k the four values A_k, B_k, C_k, E_k.  With g = upstream dL/d delta,
 //                  cb = dL/dlogJ and the softmax normaliser rs = 1 / (K sum_k C_k)  (C_k = 1 / (K D_k)):
 //                  dL/ds_k = g A_k + cb rs B_k,   dL/dP = -g + sum_k (g C_k - cb rs E_k)

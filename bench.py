@@ -82,6 +82,12 @@ def parse():
                          'streams (chains are independent: one group fills the CUs the other leaves idle while a '
                          'kernel drains); default: 2 for large launches, else 1')
     ap.add_argument('--group-sizes', type=str, default=None, help='explicit chain-group sizes, e.g. 96,32 (experiments)')
+    ap.add_argument('--regions', type=int, default=None,
+                    help='timed regions of --steps trajectories each (value = the median region); default: 1, or 5 when '
+                         'the first region is shorter than 1 s')
+    ap.add_argument('--dump', type=str, default=None,
+                    help='write every rank\'s per-chain end state (global chain ids, field, last dH / acc / Q) to '
+                         'DUMP.<world>.<rank>.npz (sharding tests)')
     return ap.parse_args()
 
 
@@ -95,11 +101,35 @@ def launch_command(n, argv, port):
             '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT any HIP / torch.cuda call (the parent of a self-launched job
+    must not initialise the GPU): the *_VISIBLE_DEVICES lists, else the GPU nodes of the KFD topology in sysfs."""
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(',') if t.strip() != ''])
+    n = 0
+    base = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, 'properties')) as f:
+                props = dict(line.split(None, 1) for line in f if ' ' in line)
+            if int(props.get('simd_count', '0')) > 0:           # CPU nodes report 0 SIMDs
+                n += 1
+    except (OSError, ValueError):
+        return None
+    return n
+
+
 def self_launch(args):
-    """--gpus N > 1 outside torchrun: start N fresh ranks as a child job and relay its output.  This process
-    has not touched the GPU (torch.cuda.device_count() does not initialise it) and never execs."""
+    """--gpus N > 1 outside torchrun: start N fresh ranks as a CHILD job and relay its output.  This process never
+    touches the GPU (devices are counted from the environment / sysfs, visible_gpus()) and never replaces itself
+    with another program (no exec: forbidden on the GPU pool once a runtime is up; tests/test_host_logic.py
+    asserts this file has none)."""
     env = dict(os.environ)
-    have = torch.cuda.device_count()
+    have = visible_gpus()
+    if have is None:
+        have = args.gpus                      # unknown topology: trust the caller, RCCL reports a shortfall itself
     if have < args.gpus and 'FTHMC_DIST_BACKEND' not in env:
         # rehearsal on a smaller box: ranks share GPUs, which RCCL refuses -> gloo for the 8-double all-reduce
         log(f'{args.gpus} ranks on {have} GPU(s): ranks share devices, collectives over gloo (rehearsal, not a scaling number)')
@@ -128,9 +158,24 @@ def host_threads():
     return max(1, min(n, 16))
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources this library was built from (fthmc_amd/csrc/*.hip, *.h, in name order):
+    tools/pmc_summary.py stores it with a counter summary, and a summary taken on other kernels is reported stale."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'fthmc_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.h')):
+            with open(os.path.join(d, name), 'rb') as f:
+                h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of this command
-    (profiles/rNN_pmc_summary.json: FETCH_SIZE + WRITE_SIZE, KiB, raw) and which summary that was."""
+    (profiles/rNN_pmc_summary.json: FETCH_SIZE + WRITE_SIZE, KiB, raw) and which summary that was.  Counters cannot
+    be read from inside the timed process (rocprofv3 must be the parent and serialises the launches), so the value is
+    the committed one; `stale` says whether the kernel sources have changed since it was taken."""
     prof = os.path.join(ROOT, 'profiles')
     try:
         names = sorted(f for f in os.listdir(prof) if f.endswith('_pmc_summary.json'))
@@ -138,7 +183,8 @@ def pmc_traffic(kernel):
             d = json.load(f)
         k = next(v for n, v in d['kernels'].items() if kernel in n)
         return (round((k['FETCH_SIZE']['mean_per_launch'] + k['WRITE_SIZE']['mean_per_launch']) * 1024),
-                {'file': 'profiles/' + names[-1], 'commit': d.get('commit'), 'launch_shape': d.get('launch_shape')})
+                {'file': 'profiles/' + names[-1], 'commit': d.get('commit'), 'launch_shape': d.get('launch_shape'),
+                 'csrc_sha16': d.get('csrc_sha16'), 'stale': d.get('csrc_sha16') != csrc_sha16()})
     except Exception:
         return None, None
 
@@ -186,6 +232,15 @@ def main():
     local = local % torch.cuda.device_count()          # ranks may share a GPU in a gloo rehearsal
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    nccl = world > 1 and torch.distributed.get_backend() == 'nccl'
+    if world > 1:
+        # first collective NOW: RCCL builds its communicator (and fails, if it is going to) before any graph is
+        # captured or any timing starts, on the device this rank will compute on
+        t_ = torch.ones(1, dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t_)
+        torch.cuda.synchronize()
+        if int(t_.item()) != world:
+            raise SystemExit(f'rank {rank}: warm-up all-reduce returned {t_.item()} for {world} ranks')
     cfg = CONFIGS[args.config]
     L, BETA, N_LAYERS = cfg['L'], cfg['beta'], cfg['n_layers']
     batch = args.batch if args.batch is not None else cfg['B']
@@ -204,17 +259,16 @@ def main():
     gen = torch.Generator(device='cpu').manual_seed(SEED)
     flow = make_flow(gen, N_LAYERS)
     w = ops.pack_weights(flow, device=dev) if flowed else None
-    gx = torch.Generator(device='cpu').manual_seed(SEED + 1 + rank)
     # Untimed preparation: a hot start U(-pi, pi) at large beta rejects every trajectory, so the chains start
     # near-cold (|x| < 0.1) and are brought to the Wilson ensemble at this beta by plain HMC on the HIP path.
     # The flow is untrained (random init, as the workload prescribes), so the timed ftHMC trajectories accept
     # rarely (5.7 % at config 3): the number measured is throughput of the MD path, not a tuned sampler.
-    x0 = ((torch.rand(B, 2, L, L, generator=gx, dtype=torch.float64) * 2 - 1) * 0.1)
-    x = x0.to(dev)
-    gt = torch.Generator(device='cpu').manual_seed(SEED + 7 + rank)
+    # Every draw is keyed by the GLOBAL chain id (Philox streams, parallel.chain_seeds), never by the rank: a chain
+    # starts from and runs through the same numbers on 1 or 8 GPUs.
+    g0, _ = ops.random_momenta(parallel.chain_seeds(SEED + 1, lo, hi, 0).to(dev), (B, 2, L, L), need_u=False)
+    x = (0.1 * torch.erf(g0 / math.sqrt(2.0))).contiguous()             # U(-0.1, 0.1) from the chain's normal draws
     for it in range(args.thermalize):
-        vt = torch.randn(B, 2, L, L, generator=gt, dtype=torch.float64).to(dev)
-        ut = torch.rand(B, generator=gt, dtype=torch.float64).to(dev)
+        vt, ut = ops.random_momenta(parallel.chain_seeds(SEED + 7, lo, hi, it).to(dev), (B, 2, L, L))
         x = ops.hmc_trajectory(x, vt, ut, BETA, 0.05, 20)['x_new']
     x0 = x.cpu()
 
@@ -268,7 +322,8 @@ def main():
             enqueue()                       # warm allocator / workspaces before capture
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
+            # thread_local: the process group's watchdog thread may poll its events while this thread captures
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
                 enqueue()
 
     traj = [0]
@@ -287,35 +342,51 @@ def main():
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            torch.distributed.barrier(device_ids=[local]) if nccl else torch.distributed.barrier()
         torch.cuda.synchronize()
 
     log(f'rank {rank}/{world}: config {args.config}, {B} chains here / {B_total} in total, groups {G}, '
         f'graph={"yes" if graph is not None else "no"}; warmup {args.warmup}')
+    def region():
+        """EXACTLY --steps trajectories between two (barrier + device synchronize) brackets; seconds, MAX over ranks"""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t)
+
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             step()
         barrier()
         log('timed region ...')
         stats.vec.zero_(); stats.glob = None
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        if pending[0] is not None:
-            pending[0].wait()
-        barrier()
-        t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(elapsed)
+        times = [region()]
+        # a region shorter than a second is at the mercy of the clock ramp and of one late host wake-up: time more
+        # regions of the same --steps trajectories and report the median one (every rank sees the same MAX-reduced
+        # time, so all ranks agree on the count)
+        nreg = args.regions if args.regions else (5 if times[0] < 1.0 else 1)
+        while len(times) < nreg:
+            times.append(region())
+    elapsed = sorted(times)[len(times) // 2]
+    if args.dump:
+        import numpy as np
+        np.savez(f'{args.dump}.{world}.{rank}.npz', lo=lo, hi=hi, x=x.cpu().numpy(), dH=out['dH'].cpu().numpy(),
+                 acc=out['acc'].cpu().numpy(), Q=out['Q'].cpu().numpy(), plaq=out['plaq'].cpu().numpy(), x0=x0.numpy())
 
     # ---- training leg (config 5): train_step's compute = ops.train_grad on a fixed prior draw, all ranks,
     #      gradients all-reduced (C2) like train.train_step does
     train = None
     if cfg['train']:
-        gxi = torch.Generator(device='cpu').manual_seed(SEED + 31 + rank)
-        xi = ((torch.rand(B, 2, L, L, generator=gxi, dtype=torch.float64) * 2 - 1) * math.pi).to(dev)
+        gxi, _ = ops.random_momenta(parallel.chain_seeds(SEED + 31, lo, hi, 0).to(dev), (B, 2, L, L), need_u=False)
+        xi = (math.pi * torch.erf(gxi / math.sqrt(2.0))).contiguous()          # prior draw U(-pi, pi), keyed by chain id
         Gt = ops.default_groups(B, L)
 
         def tstep():
@@ -349,7 +420,8 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    log(f'timed region done: {elapsed:.3f} s for {args.steps} trajectories')
+    log(f'timed region(s) done: {len(times)} x {args.steps} trajectories, median {elapsed:.3f} s '
+        f'(min {min(times):.3f}, max {max(times):.3f})')
     chain_steps = B_total * NSTEP * args.steps
     value = chain_steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -498,6 +570,10 @@ def main():
                    'nstep': NSTEP, 'tau': TAU, 'parallelism': f'chains sharded x{world}',
                    'launch': 'eager' if graph is None else 'hipGraph replay', 'chain_groups': G},
         'batched_leapfrog_steps_per_s': round(NSTEP * args.steps / elapsed, 3),
+        'regions': {'n': len(times), 'seconds': [round(t, 5) for t in times], 'value_from': 'median region',
+                    'spread': round((max(times) - min(times)) / elapsed, 4),
+                    'note': f'each region = exactly {args.steps} trajectories between barrier + synchronize brackets, '
+                            'MAX over ranks; more than one region is timed when the first is shorter than 1 s'},
         'acceptance': round(m['acc'], 4), 'plaq': round(m['plaq'], 6),
         'acceptance_note': 'untrained random-init flow as the workload prescribes: throughput of the MD path, not a tuned sampler',
         'roofline': roofline, 'cpu_baseline': cpu,

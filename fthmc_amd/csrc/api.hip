@@ -395,19 +395,20 @@ int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, in
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
     double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
     if (hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
-    // every layer runs out of place (ping-pong between two workspace fields): a workgroup reads a 3-site
-    // link halo that its neighbours' link updates would otherwise overwrite within the same launch
+    // The last layer maps y -> x, the others run in place on x.  In place is safe: a layer only rewrites its ACTIVE links,
+    // every plaquette the kernel USES (the frozen ones of its window, the active ones of its own tile) is built from
+    // links the layer never writes plus the workgroup's own active links, which it loads before it stores them; the
+    // active / passive plaquettes of the halo, which a neighbour's update can tear, are never read.
     const double* src = y;
     for (int l = n_layers - 1; l >= 0; --l) {
-        double* dst = src == W.xa ? W.xb : W.xa;
         FlowLayerArgs a{};
-        a.x = src; a.wint = W.wint + (size_t)l * FLOW_WINT; a.y = dst; a.logj_part = W.lj_part; a.tol = tol;
+        a.x = src; a.wint = W.wint + (size_t)l * FLOW_WINT; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
         FT_TRY(flow_rev(a, s));
         FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(false).ntiles(L), 1.0, 1, ld, s));
-        src = dst;
+        src = x;
     }
-    if (src != x && hipMemcpyAsync(x, src, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    if (n_layers == 0 && x != y && hipMemcpyAsync(x, y, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return FTHMC_ERR_LAUNCH;
     return FTHMC_OK;
 }

@@ -53,6 +53,7 @@ template <int TR, int TC> struct SmemG {
     static constexpr int SIZE = SW + LB_SIZE;
     static_assert(W1R % 2 == 0, "row pairs");
     static_assert(NTT <= NT && 2 * N3 <= NT && N1W <= NT, "thread maps");
+    static_assert(2 * SIZE * 8 <= 160 * 1024, "two workgroups per CU (160 KB of LDS on gfx950)");
 };
 
 // One conv2^T tile: the 18 live K steps of a pair window whose line KD (of its four lines across the pairing direction,

@@ -3,6 +3,12 @@
 #pragma once
 #include "flow_common.h"
 
+// These kernels are written for ONE chip: 160 KB of LDS per CU (their static LDS exceeds the 64 KB of other gfx9
+// parts), v_mfma_f64_16x16x4_f64, wave64.  Anything else would fail late, at launch, with an opaque error.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the fthmc MFMA kernels target gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 // accumulator chains of the MFMA stages (0 = default rule); a build-time knob for A/B runs
 #ifndef FT_NCH
 #define FT_NCH 0

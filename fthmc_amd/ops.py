@@ -11,7 +11,8 @@ from . import _lib
 from ._lib import ACT_CODES, MODE_LITERAL, MODE_MD, W_PER_LAYER, FthmcError, check
 
 _WS = {}           # (device index, stream) -> workspace tensor (grown on demand)
-_WS_RETIRED = []   # superseded workspaces, kept alive: a captured hipGraph may still point into them
+_WS_CAPTURED = set()   # keys whose CURRENT workspace was handed out during a graph capture
+_WS_RETIRED = []   # superseded workspaces a captured hipGraph may still point into, kept alive
 
 
 def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -58,10 +59,14 @@ def _ws(t: torch.Tensor, B: int, L: int, nl: int, train: bool = False):
             raise FthmcError(f'the workspace of this stream would have to be {"allocated" if buf is None else "grown"} '
                              f'({need} bytes) during graph capture: run the same call once eagerly on this stream '
                              f'first (warm-up), then capture')
-        if buf is not None:
-            _WS_RETIRED.append(buf)        # a graph captured earlier on this stream replays into it
+        if buf is not None and key in _WS_CAPTURED:
+            _WS_RETIRED.append(buf)        # a graph captured on this stream replays into it: keep it alive
+        # (a buffer no capture ever saw is simply dropped: the allocator orders its reuse behind this stream's work)
+        _WS_CAPTURED.discard(key)
         buf = torch.empty((need + 7) // 8, dtype=torch.float64, device=t.device)
         _WS[key] = buf
+    if torch.cuda.is_current_stream_capturing():
+        _WS_CAPTURED.add(key)
     return buf.data_ptr(), buf.numel() * 8
 
 
@@ -69,6 +74,7 @@ def release_workspaces():
     """Drop every cached workspace (current and superseded).  Only when no captured graph that used them will
     be replayed again."""
     _WS.clear()
+    _WS_CAPTURED.clear()
     _WS_RETIRED.clear()
 
 

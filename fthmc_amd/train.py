@@ -45,11 +45,33 @@ def get_model(config: TrainConfig) -> FlowModel:
     return FlowModel(prior=prior, layers=layers)
 
 
-def restore_model_from_checkpoint(infile, train_config: TrainConfig):
-    """train.py:77-92 (same checkpoint dict keys as io.save_checkpoint, io.py:148-170)."""
-    # the history inside the .tar holds numpy arrays (train_step returns grab(...)): a trusted, self-written file,
-    # loaded like the reference does (torch >= 2.6 defaults to weights_only=True, which rejects numpy pickles)
-    checkpoint = torch.load(infile, map_location=device(), weights_only=False)
+def _plain(obj):
+    """numpy arrays / scalars inside a history -> tensors / Python numbers, so that the checkpoint unpickles with
+    `weights_only=True` (no arbitrary code on load)."""
+    import numpy as np
+    if isinstance(obj, dict):
+        return {k: _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_plain(v) for v in obj)
+    if isinstance(obj, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(obj))
+    if isinstance(obj, np.generic):
+        return obj.item()
+    return obj
+
+
+def restore_model_from_checkpoint(infile, train_config: TrainConfig, trusted: bool = False):
+    """train.py:77-92 (same checkpoint dict keys as io.save_checkpoint, io.py:148-170).  Checkpoints written by
+    `save_checkpoint` here hold tensors and plain numbers only and load with `weights_only=True`.  A checkpoint
+    written by the reference pickles numpy arrays in its history: pass `trusted=True` for such a file -- unpickling
+    it can run arbitrary code, so only for files you wrote yourself."""
+    try:
+        checkpoint = torch.load(infile, map_location=device(), weights_only=True)
+    except Exception as e:                                      # pickle.UnpicklingError and friends
+        if not trusted:
+            raise RuntimeError(f'{infile} does not load with weights_only=True ({type(e).__name__}); if you wrote '
+                               f'this file yourself, call restore_model_from_checkpoint(..., trusted=True)') from e
+        checkpoint = torch.load(infile, map_location=device(), weights_only=False)
     model = get_model(train_config)
     optimizer = optim.AdamW(model.layers.parameters(), lr=train_config.base_lr, weight_decay=1e-5)
     model.layers.load_state_dict(checkpoint['model_state_dict'])
@@ -62,7 +84,7 @@ def save_checkpoint(era: int, epoch: int, model: nn.Module, optimizer, history: 
     os.makedirs(outdir, exist_ok=True)
     path = os.path.join(outdir, f'ckpt-era{era}-epoch{epoch}.tar')
     torch.save({'era': era, 'epoch': epoch, 'model_state_dict': model.state_dict(),
-                'optimizer_state_dict': optimizer.state_dict(), 'history': history}, path)
+                'optimizer_state_dict': optimizer.state_dict(), 'history': _plain(history)}, path)
     return path
 
 

@@ -127,7 +127,8 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
 /* (x, logJ[B]) = GaugeEquivCouplingLayer.reverse(y): fthmc/utils/layers.py:204-210,
  * :373-396.  The scalar inverse is solved per site to |f(x) - y| <= tol by
  * safeguarded Newton/bisection on [-pi, pi] (the reference bisects to a global
- * 1e-6, layers.py:294-320). */
+ * 1e-6, layers.py:294-320).  x may alias y (a layer rewrites only its active links, and every
+ * plaquette a workgroup uses is built from links the layer leaves alone plus its own). */
 int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu, int off,
                          int act, double tol, double* x, double* logJ,
                          void* ws, size_t ws_bytes, void* stream);
@@ -147,7 +148,8 @@ int fthmc_plaq_coupling_rev(const double* fP, const double* w, int B, int L, int
  * fthmc/utils/qed_helpers.py:191-198 (ft_flow).  y, logdet may be NULL. */
 int fthmc_flow_forward(const double* x, const double* w, int n_layers, int B, int L, int act,
                        double* y, double* logdet, void* ws, size_t ws_bytes, void* stream);
-/* x = F^-1(y), logdet[B].  fthmc/ft_hmc.py:152-160, qed_helpers.py:201-209. */
+/* x = F^-1(y), logdet[B].  fthmc/ft_hmc.py:152-160, qed_helpers.py:201-209.  x may alias y: the last layer maps
+ * y -> x and the remaining layers run in place on x (see fthmc_flow_layer_rev). */
 int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, int L, int act,
                        double tol, double* x, double* logdet,
                        void* ws, size_t ws_bytes, void* stream);

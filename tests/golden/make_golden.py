@@ -368,6 +368,46 @@ def main():
              hist_logq=np.asarray(hist['logq'], dtype=np.float64), hist_logp=np.asarray(hist['logp'], dtype=np.float64),
              hist_acc=np.asarray(hist['acc'], dtype=np.float64), **flow_arrays(model.layers))
 
+    # ---- 10. delta-Q^2 versus MD-time lag and its blocked error (ipynb/ft_hmc.py:16-53, 168-176).  That module runs a
+    #          whole experiment at import, so it is only PARSED here: the statistics helpers' function definitions (and
+    #          the `n_block` constant they read) are compiled from its syntax tree into an empty namespace and called
+    #          on seeded charge histories; nothing else of the file executes.
+    import ast
+    with open(os.path.join(REF, 'ipynb', 'ft_hmc.py')) as f:
+        tree = ast.parse(f.read())
+    want = {'average', 'sigma', 'sub_avg', 'block_list', 'change_sqr', 'change_sqr_vs_dt', 'save_topo_change_sqr'}
+    keep = [n for n in tree.body
+            if (isinstance(n, ast.FunctionDef) and n.name in want) or
+               (isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id == 'n_block' for t in n.targets))]
+    assert {n.name for n in keep if isinstance(n, ast.FunctionDef)} == want
+    ns = {'np': np, 'sys': sys, 'topo_history': []}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), 'ipynb/ft_hmc.py[statistics]', 'exec'), ns)
+    rng = np.random.default_rng(4242)
+    obs = {'n_block': np.int64(ns['n_block'])}
+    for tag, nhist in (('long', 1500), ('short', 40), ('tiny', 9)):
+        # integer charge history: lazy random walk, as a tunnelling topological charge looks
+        q = np.cumsum(rng.integers(-1, 2, size=nhist) * (rng.random(nhist) < 0.3)).astype(np.float64)
+        obs[f'q_{tag}'] = q
+        # a lag the history is too short for yields the bare [lag] (change_sqr returns []): stored as NaN
+        obs[f'rows_{tag}'] = np.array([r if len(r) == 3 else [r[0], np.nan, np.nan]
+                                       for r in ns['change_sqr_vs_dt'](list(q), 10)], dtype=np.float64)
+        obs[f'blocks_{tag}'] = np.array([np.mean(b) for b in ns['block_list'](list(q))], dtype=np.float64)
+        if tag == 'tiny':
+            continue                                             # the reference's writer raises IndexError on such rows
+        ns['topo_history'][:] = list(q)                          # save_topo_change_sqr reads the module global
+        fn = os.path.join(work, f'dq2_{tag}.txt')
+        devnull, stdout = open(os.devnull, 'w'), sys.stdout
+        try:
+            sys.stdout = devnull                                 # it prints every row
+            ns['save_topo_change_sqr'](fn)
+        finally:
+            sys.stdout = stdout
+            devnull.close()
+        obs[f'file_{tag}'] = np.loadtxt(fn, ndmin=2)
+    obs['sub_avg'] = np.asarray(ns['sub_avg'](list(obs['q_short'])), dtype=np.float64)
+    obs['sigma_short'] = np.float64(ns['sigma'](list(obs['q_short'])))
+    save('observables', **obs)
+
 
 if __name__ == '__main__':
     main()

@@ -216,3 +216,28 @@ def test_independence_sampler_chain():
     assert 0 < np.sum(g['hist_acc']) < len(g['hist_acc'])            # the fixture holds accepts and rejects
     for k in ('q', 'dqsq', 'logq', 'logp'):
         close(h[k], g['hist_' + k], rtol=2e-7, atol=1e-6)            # float32 histories
+
+
+def test_observables_tooling_golden(tmp_path):
+    """delta-Q^2 versus lag, block means and their error against the outputs of the reference's own
+    statistics helpers (ipynb/ft_hmc.py:16-53, 168-176; fixture written by make_golden.py section 10)."""
+    from fthmc_amd.utils import observables as O
+    g = load_golden('observables')
+    assert int(g['n_block']) == O.N_BLOCK
+    for tag in ('long', 'short', 'tiny'):
+        q, want = g[f'q_{tag}'], g[f'rows_{tag}']
+        rows = np.array(O.change_sqr_vs_dt(q, 10, reference_literal=True))
+        np.testing.assert_allclose(rows, want, rtol=1e-13, atol=1e-15, equal_nan=True)
+        np.testing.assert_allclose(O.block_means(q), g[f'blocks_{tag}'], rtol=1e-14)
+        # the default error is the standard error of the block means; the reference's is var / sqrt(n - 1)
+        std = np.array(O.change_sqr_vs_dt(q, 10))
+        np.testing.assert_allclose(std[:, 1], want[:, 1], rtol=1e-13, atol=1e-15, equal_nan=True)
+        ok = np.isfinite(want[:, 2]) & (want[:, 2] > 0)
+        nblk = np.minimum(len(q) - np.arange(1, 11), O.N_BLOCK)[ok]          # block means behind each row
+        np.testing.assert_allclose(std[ok, 2] ** 2, want[ok, 2] / np.sqrt(nblk - 1), rtol=1e-12)
+        if tag != 'tiny':
+            fn = tmp_path / f'dq2_{tag}.txt'
+            O.save_topo_change_sqr(str(fn), q, reference_literal=True)
+            np.testing.assert_allclose(np.loadtxt(fn, ndmin=2), g[f'file_{tag}'], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(O.sub_avg(g['q_short']), g['sub_avg'], rtol=1e-14, atol=1e-14)
+    np.testing.assert_allclose(O.sigma(g['q_short'], reference_literal=True), float(g['sigma_short']), rtol=1e-13)

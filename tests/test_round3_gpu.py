@@ -1,0 +1,230 @@
+"""GPU tests added in round 3: BASELINE configs[3] (1024 chains) on one GPU through size-independent properties, a
+multi-rank rehearsal of bench.py whose chains equal the one-rank run bit for bit, the reference's `fthmc.*` import path
+on goldens, aliased (in-place) layer calls, and the small-lattice fused force path against goldens and the tiled path."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_flow, load_golden
+
+pytestmark = pytest.mark.gpu
+
+ops = None
+R = None
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _mods():
+    global ops, R
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from fthmc_amd import ops as _ops
+    from oracle import ref_cpu as _R
+    ops, R = _ops, _R
+    ops.set_variant(1)
+
+
+def D(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float64).copy()).cuda()
+
+
+def H(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def close(a, b, rtol=1e-10, atol=1e-10):
+    np.testing.assert_allclose(H(a), H(b), rtol=rtol, atol=atol)
+
+
+def angle_close(a, b, atol=1e-9):
+    d = (H(a) - H(b) + np.pi) % (2 * np.pi) - np.pi
+    assert np.max(np.abs(d)) < atol, np.max(np.abs(d))
+
+
+# ---------------------------------------------------------------- BASELINE configs[3]: 1024 chains
+def test_config4_1024_chains_on_one_gpu():
+    """configs[3] = 1024 chains of L=64, beta=6, 8 layers (128 per GPU on 8 GPUs).  All of them fit one MI355X
+    (workspace 6.3 GB): size-independent properties on the full batch, and any chain of the 1024 equals the same
+    chain run alone and run inside its 128-chain shard, bit for bit (what sharding over ranks relies on)."""
+    gen = torch.Generator().manual_seed(1024)
+    B, L, nl, beta, dt, nstep = 1024, 64, 8, 6.0, 0.1, 10
+    flow = R.default_flow(nl, gen)
+    w = ops.pack_weights(flow, device='cuda')
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    y, ld = ops.flow_forward(x, w, nl)
+    S, Q, plaq = ops.wilson_action_charge(y, beta)
+    assert float((Q - Q.round()).abs().max()) < 1e-8                       # integer topological charge
+    xb, ldb = ops.flow_reverse(y, w, nl, tol=1e-13)
+    angle_close(xb, x, atol=1e-9); close(ldb, -ld, atol=1e-6)             # forward o reverse = id
+    F = ops.ft_force(x, w, nl, beta)
+    assert torch.equal(F, ops.ft_force(x, w, nl, beta))                    # deterministic
+    d = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()
+    eps = 1e-5
+    fd = (ops.ft_action(x + eps * d, w, nl, beta)[0] - ops.ft_action(x - eps * d, w, nl, beta)[0]) / (2 * eps)
+    close((F * d).flatten(1).sum(1), fd, rtol=2e-5, atol=5e-3)             # force = gradient of S_eff
+    # gauge invariance of the effective action: x_mu(n) -> x_mu(n) + a(n) - a(n + mu)
+    a = (torch.rand(B, L, L, generator=gen, dtype=torch.float64) * 2 * math.pi).cuda()
+    xg = torch.stack([x[:, 0] + a - torch.roll(a, -1, 2), x[:, 1] + a - torch.roll(a, -1, 1)], 1).contiguous()
+    close(ops.ft_action(xg, w, nl, beta)[0], ops.ft_action(x, w, nl, beta)[0], rtol=1e-10, atol=1e-7)
+    # whole trajectories: chain k of the 1024 == chain k alone == chain k inside its 128-chain shard (rank k // 128)
+    v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()
+    u = torch.rand(B, generator=gen, dtype=torch.float64).cuda()
+    x_cold = (0.2 * x).contiguous()
+    r = ops.ft_trajectory(x_cold, v, u, w, nl, beta, dt, nstep, groups=2)
+    assert float(r['dH'].abs().max()) < 1e3 and bool(torch.isfinite(r['x_new']).all())
+    for k in (0, 517, 1023):
+        r1 = ops.ft_trajectory(x_cold[k:k + 1].contiguous(), v[k:k + 1].contiguous(), u[k:k + 1].contiguous(), w, nl, beta, dt, nstep)
+        for key in ('x_new', 'dH', 'acc', 'H0', 'H1', 'plaq', 'Q'):
+            assert torch.equal(r1[key][0], r[key][k]), (k, key)
+    lo = 512
+    rs = ops.ft_trajectory(x_cold[lo:lo + 128].contiguous(), v[lo:lo + 128].contiguous(), u[lo:lo + 128].contiguous(),
+                           w, nl, beta, dt, nstep, groups=2)
+    for key in ('x_new', 'dH', 'acc', 'H0', 'H1', 'plaq', 'Q'):
+        assert torch.equal(rs[key], r[key][lo:lo + 128]), key
+    # leapfrog reversibility on the full batch
+    xo, vo = ops.ft_leapfrog(x_cold, v, w, nl, beta, dt, nstep)
+    xr, vr = ops.ft_leapfrog(xo, -vo, w, nl, beta, dt, nstep)
+    angle_close(xr, x_cold, atol=1e-8); close(-vr, v, rtol=1e-8, atol=1e-8)
+    ops.release_workspaces()
+
+
+# ---------------------------------------------------------------- bench.py over several ranks == one rank, per chain
+def _bench(tmp, tag, gpus, batch, extra=()):
+    env = dict(os.environ, FTHMC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    dump = str(tmp / tag)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--config', '2', '--batch', str(batch),
+                        '--steps', '2', '--warmup', '1', '--thermalize', '3', '--regions', '1', '--no-cpu-baseline', '--dump', dump,
+                        *extra], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    parts = [dict(np.load(f'{dump}.{gpus}.{r}.npz')) for r in range(gpus)]
+    return line, parts
+
+
+def test_bench_multi_rank_rehearsal_equals_one_rank(tmp_path):
+    """`bench.py --gpus 4 --config 2 --batch 4` (four ranks sharing this GPU, collectives over gloo: the code path of the
+    driver's 8-GPU run up to the backend; at most 6 processes may use a GPU box's card, so 4 ranks here and 8 ranks in
+    the CPU test tests/test_host_logic.py::test_eight_rank_gloo_equals_single_process) reports n_gpus 4 and 16 chains,
+    and every chain ends where it ends in the one-rank run of the same 16 chains: start field, thermalisation, momenta
+    and accept draws are keyed by the global chain id."""
+    one, p1 = _bench(tmp_path, 'one', 1, 16)
+    four, p4 = _bench(tmp_path, 'four', 4, 4)
+    assert four['n_gpus'] == 4 and four['config']['chains_total'] == 16 and four['config']['chains_per_gpu'] == 4
+    assert one['n_gpus'] == 1 and one['config']['chains_total'] == 16
+    assert [(int(p['lo']), int(p['hi'])) for p in p4] == [(0, 4), (4, 8), (8, 12), (12, 16)]
+    for key in ('x0', 'x', 'dH', 'acc', 'Q', 'plaq'):
+        got = np.concatenate([p[key] for p in p4])
+        assert np.array_equal(got, p1[0][key]), key
+    # the global statistics (C1 all-reduce) agree with the one-rank run
+    assert abs(four['acceptance'] - one['acceptance']) < 1e-12 and abs(four['plaq'] - one['plaq']) < 1e-9
+    assert four['regions']['n'] == 1 and one['value'] > 0 and four['value'] > 0
+    # strong scaling keeps the total
+    strong, _ = _bench(tmp_path, 'strong', 2, 16, ('--scaling', 'strong'))
+    assert strong['n_gpus'] == 2 and strong['config']['chains_total'] == 16 and strong['config']['chains_per_gpu'] == 8
+
+
+def test_bench_times_several_regions_when_one_is_short(tmp_path):
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '1', '--steps', '5', '--warmup', '2',
+                        '--thermalize', '2', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    reg = line['regions']
+    assert reg['n'] == 5 and len(reg['seconds']) == 5 and line['steps'] == 5
+    med = sorted(reg['seconds'])[2]
+    assert abs(line['ms_per_step'] - med / 5 * 1e3) < 1e-3 * max(1.0, line['ms_per_step'])
+    assert abs(line['value'] - line['config']['chains_total'] * 10 * 5 / med) < 1e-3 * line['value']
+
+
+# ---------------------------------------------------------------- the reference's import path
+def test_reference_style_caller_through_fthmc_alias():
+    """What a user of nftqcd/fthmc writes (fthmc/main.py:73-104, fthmc/train.py:162-228), imports unchanged."""
+    from fthmc.config import FlowModel, TrainConfig, lfConfig
+    from fthmc.ft_hmc import FieldTransformation
+    from fthmc.train import train_step
+    import fthmc.utils.layers as layers
+    import fthmc.utils.qed_helpers as qed
+    from fthmc.utils.distributions import MultivariateUniform
+
+    def build(g, L):
+        nl = int(g['n_layers'])
+        flow = layers.make_u1_equiv_layers(n_layers=nl, n_mixture_comps=2, lattice_shape=(L, L), hidden_sizes=[8, 8],
+                                           kernel_size=3, activation_fn='silu')
+        names = ['net.0.weight', 'net.0.bias', 'net.2.weight', 'net.2.bias', 'net.4.weight', 'net.4.bias']
+        flow.load_state_dict({f'{li}.plaq_coupling.{n}': D(g[f'w{li}_{pi}']) for li in range(nl) for pi, n in enumerate(names)})
+        return flow
+    # run_fthmc's body: FieldTransformation(flow=..., config=..., lfconfig=...) then trajectories
+    g = load_golden('traj_md_L16')
+    flow = build(g, 16)
+    config = TrainConfig(L=16, beta=float(g['beta']), n_layers=len(flow))
+    lfconfig = lfConfig(tau=float(g['dt']) * int(g['nstep']), nstep=int(g['nstep']))
+    ft = FieldTransformation(flow=flow, config=config, lfconfig=lfconfig)
+    xnew, m = ft._batch_hmc(D(g['x']), v=D(g['v']), u=D(g['u']))
+    close(m['dh'], g['dH'], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(H(m['acc']) > 0.5, g['acc'])
+    close(qed.ft_action(config, flow, D(g['x'])) + 0.5 * (D(g['v']) ** 2).flatten(1).sum(1), g['H0'], rtol=1e-10)
+    # train_step on the golden prior draw
+    g = load_golden('train_L8')
+    flow = build(g, 8)
+    B = g['xi'].shape[0]
+    cfg = TrainConfig(L=8, beta=float(g['beta']), n_layers=len(flow), batch_size=B, base_lr=float(g['lr']))
+    prior = MultivariateUniform(-math.pi * torch.ones(2, 8, 8, dtype=torch.float64, device='cuda'),
+                                math.pi * torch.ones(8, 8, dtype=torch.float64, device='cuda'))
+    model = FlowModel(prior=prior, layers=flow)
+    opt = torch.optim.Adam(flow.parameters(), lr=cfg.base_lr)
+    met = train_step(model, cfg, qed.BatchAction(float(g['beta'])), opt, B, xi=D(g['xi']))
+    close(met['loss_dkl'], g['loss_dkl'], rtol=1e-10); close(met['ess'], g['ess'], rtol=1e-8)
+
+
+# ---------------------------------------------------------------- aliased layer calls
+@pytest.mark.parametrize('variant', [1, 0])
+def test_layer_calls_with_output_aliasing_input(variant):
+    """include/fthmc_hip.h: y may alias x in fthmc_flow_layer_fwd / _rev and in fthmc_flow_reverse -- lattices of several
+    tiles per chain (halos cross tile borders), both kernel variants, all (mu, off), against the out-of-place call."""
+    from fthmc_amd import _lib
+    lib = _lib.load()
+    ops.set_variant(variant)
+    try:
+        gen = torch.Generator().manual_seed(33)
+        B, L = 3, 48
+        flow = R.default_flow(8, gen)
+        w = ops.pack_weights(flow, device='cuda')
+        x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+        wsb = torch.empty(ops.ws_bytes(B, L, 8) // 8 + 1, dtype=torch.float64, device='cuda')
+        st = torch.cuda.current_stream().cuda_stream
+        for li in range(8):
+            mu, off = li % 2, (li // 2) % 4
+            wl = w[li * 955:(li + 1) * 955].contiguous()
+            y, lj = ops.flow_layer_fwd(x, wl, mu, off)
+            xa = x.clone(); lja = torch.empty_like(lj)
+            assert lib.fthmc_flow_layer_fwd(xa.data_ptr(), wl.data_ptr(), B, L, mu, off, 0, xa.data_ptr(), lja.data_ptr(),
+                                            wsb.data_ptr(), wsb.numel() * 8, st) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(xa, y) and torch.equal(lja, lj), (mu, off)
+            xr, ljr = ops.flow_layer_rev(y, wl, mu, off)
+            ya = y.clone(); ljb = torch.empty_like(lj)
+            assert lib.fthmc_flow_layer_rev(ya.data_ptr(), wl.data_ptr(), B, L, mu, off, 0, 1e-12, ya.data_ptr(), ljb.data_ptr(),
+                                            wsb.data_ptr(), wsb.numel() * 8, st) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(ya, xr) and torch.equal(ljb, ljr), (mu, off)
+            angle_close(xr, x, atol=1e-9)
+        # the sweep (last layer out of place, the rest in place) == explicit out-of-place layer calls
+        yfull, _ = ops.flow_forward(x, w, 8)
+        xs, lds = ops.flow_reverse(yfull, w, 8)
+        cur, tot = yfull, torch.zeros(B, dtype=torch.float64, device='cuda')
+        for li in reversed(range(8)):
+            cur, lj = ops.flow_layer_rev(cur, w[li * 955:(li + 1) * 955].contiguous(), li % 2, (li // 2) % 4)
+            tot = tot + lj
+        assert torch.equal(xs, cur)
+        close(lds, tot, rtol=1e-13, atol=1e-12)
+    finally:
+        ops.set_variant(1)

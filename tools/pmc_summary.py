@@ -21,6 +21,12 @@ LAUNCH_SHAPE = ('bench.py config 3 with two chain groups: one launch of a coupli
 COMMIT = None
 
 
+def csrc_sha16():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.csrc_sha16()
+
+
 def main(src, dst):
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for path in glob.glob(os.path.join(src, '**', '*counter_collection.csv'), recursive=True):
@@ -41,6 +47,7 @@ def main(src, dst):
                  'GRBM_GUI_ACTIVE summed over 8 XCDs',
         'launch_shape': LAUNCH_SHAPE,
         'commit': COMMIT,
+        'csrc_sha16': csrc_sha16(),           # fingerprint of fthmc_amd/csrc at collection time (bench.py reports `stale` against it)
         'kernels': {fam: {c: {'launches': v[1], 'mean_per_launch': v[0] / v[1]} for c, v in sorted(cs.items())}
                     for fam, cs in acc.items()},
     }

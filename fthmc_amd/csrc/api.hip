@@ -66,6 +66,13 @@ inline int flow_fwd(const FlowLayerArgs& a, hipStream_t s) {
 
 inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
 
+// small lattices: the fused single-launch path (flow_small.hip)
+inline SmallArgs small_args(const double* x, const WS& w, int nl, int B, int act, double beta, int mode) {
+    SmallArgs a{};
+    a.x = x; a.wint = w.wint; a.stash = w.stash; a.beta = beta; a.mode = mode; a.B = B; a.nl = nl; a.act = act;
+    return a;
+}
+
 #define FT_TRY(expr) do { int rc_ = (expr); if (rc_ != FTHMC_OK) return rc_; } while (0)
 
 // Forward sweep x -> X[0..nl-1] (X[l] = output of layer l).  logdet (device [B]) optional.
@@ -188,6 +195,13 @@ int fthmc_set_variant(int v) {
     return FTHMC_OK;
 }
 int fthmc_get_variant(void) { return get_flow_variant(); }
+
+int fthmc_set_small_path(int on) {
+    if (on != 0 && on != 1) return FTHMC_ERR_ARG;
+    set_small_path(on);
+    return FTHMC_OK;
+}
+int fthmc_get_small_path(void) { return get_small_path(); }
 
 const char* fthmc_last_error(void) { return fthmc::g_last_error; }
 
@@ -381,6 +395,11 @@ int fthmc_flow_forward(const double* x, const double* w, int n_layers, int B, in
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
     double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
     if (n_layers == 0 && hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    if (ft_small_ok(L, n_layers)) {
+        SmallArgs a = small_args(x, W, n_layers, B, act, 1.0, 0);
+        a.x_out = y; a.logdet = ld;
+        return launch_ft_small(a, L, s);
+    }
     FT_TRY(sweep_forward(x, W, n_layers, B, L, act, ld, s));
     if (y && hipMemcpyAsync(y, phys_field(x, W, n_layers), W.n2 * sizeof(double),
                             hipMemcpyDeviceToDevice, s) != hipSuccess) return FTHMC_ERR_LAUNCH;
@@ -421,6 +440,11 @@ int fthmc_ft_action(const double* x, const double* w, int n_layers, int B, int L
     FT_WS(n_layers);
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
     if (n_layers == 0 && logdet && hipMemsetAsync(logdet, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    if (ft_small_ok(L, n_layers)) {
+        SmallArgs a = small_args(x, W, n_layers, B, act, beta, 0);
+        a.S_eff = S_eff; a.logdet = logdet; a.plaq = plaq; a.Q = Q;
+        return launch_ft_small(a, L, s);
+    }
     return eval_action(x, W, n_layers, B, L, act, beta, S_eff, logdet, plaq, Q, s);
 }
 
@@ -430,6 +454,11 @@ int fthmc_ft_force(const double* x, const double* w, int n_layers, int B, int L,
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    if (ft_small_ok(L, n_layers)) {
+        SmallArgs a = small_args(x, W, n_layers, B, act, beta, 1);
+        a.F = F;
+        return launch_ft_small(a, L, s);
+    }
     FT_TRY(force_gp(x, W, n_layers, B, L, act, beta, -1.0, nullptr, s));
     return launch_kick_from_gp(W.gp, nullptr, nullptr, F, B, L, 0.0, 0.0, s);
 }
@@ -442,6 +471,11 @@ int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, int n_l
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    if (ft_small_ok(L, n_layers)) {
+        SmallArgs a = small_args(x, W, n_layers, B, act, beta, 2);
+        a.v = v; a.dt = dt; a.nstep = nstep; a.x_out = x_out; a.v_out = v_out;
+        return launch_ft_small(a, L, s);
+    }
     FT_TRY(ft_leapfrog_ws(x, v, W, n_layers, B, L, act, beta, dt, nstep, s));
     if (hipMemcpyAsync(x_out, W.xa, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess ||
         hipMemcpyAsync(v_out, W.va, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -466,6 +500,12 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
     double* neu = W.scal + (size_t)SC_NEW0 * B;
     double* sel = state_out ? state_out : W.scal + (size_t)SC_S * B;
     FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    if (mode == FTHMC_MODE_MD && ft_small_ok(L, n_layers)) {          // the whole trajectory in one launch
+        SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
+        a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = x_new; a.state_in = state_in; a.state_out = state_out;
+        a.dH = dH; a.acc = acc; a.H0 = H0; a.H1 = H1; a.plaq = plaq; a.Q = Q;
+        return launch_ft_small(a, L, s);
+    }
     if (state_in) {       // chained trajectories: S_eff and observables of x are the previous call's state_out
         if (hipMemcpyAsync(old, state_in, (size_t)3 * B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
             return FTHMC_ERR_LAUNCH;

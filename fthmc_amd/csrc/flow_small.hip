@@ -1,0 +1,632 @@
+// Small lattices (L <= 16): a whole chain lives in ONE workgroup, and whole sequences of the flowed path run in ONE launch.
+//
+// The tiled kernels (flow_fwd.hip, flow_bwd_gather.hip) give every 16 x 16 tile of a chain its own workgroup and one
+// launch per layer.  At L <= 16 a chain IS one tile: a launch is B workgroups on 256 CUs, each alone on its CU, and a
+// trajectory is ~100 dependent launches whose length is the latency of one lone workgroup, most of it halo work the
+// periodic lattice does not need (a 22 x 22 plaquette window, 20 x 20 conv1 outputs for 16 x 16 sites).  Here
+//   * one 512-thread workgroup per chain holds the links (latent and flowed), the plaquette gradient and every activation
+//     plane in LDS as PERIODIC planes: (L + 2) x (L + 2) with a one-site border that the producing stage fills with the
+//     wrapped duplicates, so the implicit-GEMM stages keep their constant tap offsets and nothing is computed twice;
+//   * a force evaluation (all layers forward with the activation stash, Wilson seed, all layers backward, momentum kick),
+//     the leapfrog loop around it, the two effective-action evaluations and the Metropolis step of a trajectory are
+//     device-side loops: fthmc_ft_trajectory / _ft_leapfrog / _ft_force / _ft_action / _flow_forward are one launch each;
+//   * conv1, conv2 and conv2^T are the same implicit GEMMs on v_mfma_f64_16x16x4_f64 over the same weight blocks
+//     (flow_common.h), conv3 / conv3^T / conv1^T / the tan-mixture transform the same VALU stages as in the tiled kernels;
+//   * the activation stash keeps the layout of struct Stash (flow_mfma_common.h) in the caller's workspace: it is
+//     written and read back by the same workgroup within one launch (L2-resident).
+//
+// Reference: GaugeEquivCouplingLayer.forward (fthmc/utils/layers.py:196-202, 348-371), ft_action / ft_force
+// (fthmc/utils/qed_helpers.py:212-242), the leapfrog and accept step of ipynb/ft_hmc.py:394-435.
+#include "flow_mfma_common.h"
+
+namespace {
+
+using namespace fthmc;
+using namespace fthmc_flow;
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// conv1 (2 -> 8) as a 6-step implicit GEMM, pairs = columns (c, c + 1) of one row: 3 x 4 window.
+// K slot (g, t): input channel g & 1, window column 2 (g >> 1) + t / 3, tap row t % 3 (KConv1, flow_mfma_common.h, is the
+// same with rows and columns exchanged); table P1[ky][ci][c5][row] of the mu = 0 forward block.
+struct KConv1Col {
+    static constexpr int NSTEP = 6;
+    template <int RSA, int PSA> static __device__ __forceinline__ int alane(int g) { return (g & 1) * PSA + (g >> 1) * 2; }
+    template <int RSA, int PSA> static constexpr int aimm(int t) { return (t / 3) + (t % 3) * RSA; }
+    static constexpr int bimm(int t) { return (t % 3) * 96 + (t / 3) * 8; }
+    static __device__ __forceinline__ int wlane(int g, int cN, int dd) { return cN + (g & 1) * 48 + (2 * (g >> 1) + 1 - dd) * 8; }
+};
+
+template <int L> struct GS {
+    static constexpr int N = L * L, NA = N / 4, NF = N / 2, NPAIR = N / 2;
+    static constexpr int PL = L + 2, RS = PL;                    // periodic plane: one-site border of wrapped duplicates
+    static constexpr int PSZ = ps_round16(PL * RS);              // plane stride (MFMA operand planes)
+    static constexpr int NAS = 64;
+    static_assert(L % 4 == 0 && L >= 8 && L <= 16, "whole-lattice kernel: L = 8, 12, 16");
+    static_assert(NA <= 64 && N <= NT / 2 + NT / 2 && (NPAIR + 15) / 16 <= NW, "one MFMA tile per wave, one wave of active sites");
+    // LDS plan (doubles)
+    static constexpr int X = 0;                                  // [2][N] links being transformed (a sweep runs in place)
+    static constexpr int XL = X + 2 * N;                         // [2][N] latent links of the trajectory
+    static constexpr int GP = XL + 2 * N;                        // [N] plaquette gradient
+    static constexpr int DIR = GP + N;                           // [N] a layer's contribution to it
+    static constexpr int PA = DIR + N;                           // [4][NAS] per active site: P, cos P/2, sin P/2, t
+    static constexpr int IN = PA + 4 * NAS;                      // fwd [2][PSZ] cos, sin   | bwd [3][PSZ] g_out
+    static constexpr int A8 = IN + 3 * PSZ;                      // fwd [8][PSZ] h1         | bwd gz2, then conv1^T partials
+    static constexpr int B8 = A8 + 8 * PSZ;                      // fwd [8][PSZ] h2         | bwd gz1
+    static constexpr int ST = B8 + 8 * PSZ;                      // [8][3][NAS] conv3 partials
+    static constexpr int T2 = ST + 8 * 3 * NAS;                  // [NMIX][2][NAS] y_k, 1 / D_k
+    static constexpr int SW = T2 + NMIX * 2 * NAS;               // [LF_BLOCK] weight block of the layer in flight
+    static constexpr int RED = SW + (LF_BLOCK > LB_SIZE ? LF_BLOCK : LB_SIZE);
+    static constexpr int SIZE = RED + 16;
+    static_assert(8 * 2 * NF <= 8 * PSZ, "conv1^T partials fit over gz2");
+    static_assert(SIZE * 8 <= 160 * 1024, "LDS of one CU");
+};
+
+// value v of site (r, c) into a periodic plane: the site itself and its wrapped duplicates on the border
+template <int L, int RS>
+__device__ __forceinline__ void put1(double* p, int r, int c, double v) {
+    const int m = (r + 1) * RS + c + 1;
+    const int rr = r == 0 ? (L + 1) * RS : (r == L - 1 ? 0 : -1);
+    const int cc = c == 0 ? L + 1 : (c == L - 1 ? 0 : -1);
+    p[m] = v;
+    if (rr >= 0) p[rr + c + 1] = v;
+    if (cc >= 0) p[(r + 1) * RS + cc] = v;
+    if (rr >= 0 && cc >= 0) p[rr + cc] = v;
+}
+// the same for two planes PS apart (the channel pair 2 g, 2 g + 1 of an MFMA lane)
+template <int L, int RS, int PS>
+__device__ __forceinline__ void put2(double* p, int r, int c, double va, double vb) {
+    const int m = (r + 1) * RS + c + 1;
+    const int rr = r == 0 ? (L + 1) * RS : (r == L - 1 ? 0 : -1);
+    const int cc = c == 0 ? L + 1 : (c == L - 1 ? 0 : -1);
+    p[m] = va; p[PS + m] = vb;
+    if (rr >= 0) { p[rr + c + 1] = va; p[PS + rr + c + 1] = vb; }
+    if (cc >= 0) { p[(r + 1) * RS + cc] = va; p[PS + (r + 1) * RS + cc] = vb; }
+    if (rr >= 0 && cc >= 0) { p[rr + cc] = va; p[PS + rr + cc] = vb; }
+}
+
+__device__ __forceinline__ double2_t ldg2(const double* p) { return *reinterpret_cast<const double2_t*>(p); }
+
+template <int L> struct Chain {
+    using G = GS<L>;
+    double* sm;
+    const SmallArgs& A;
+    int b, tid, lane, wave;
+    __device__ Chain(double* sm_, const SmallArgs& A_, int b_) : sm(sm_), A(A_), b(b_) {
+        tid = threadIdx.x; lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    }
+    __device__ __forceinline__ double* stash(int l) const { return A.stash + (size_t)l * ((size_t)A.B * 19 * L * L); }   // kernels.h flow_stash_doubles
+
+    // active site a (compact index of struct Stash) -> lattice site
+    static __device__ __forceinline__ void active_site(int a, int mu, int off, int& i, int& j) {
+        if (mu == 0) { i = fdiv<L / 4>(a); j = off + 4 * (a - i * (L / 4)); }
+        else { const int m = fdiv<L>(a); j = a - m * L; i = off + 4 * m; }
+    }
+    // frozen site f in [0, N / 2): line q along the stripes, h-th frozen line across them
+    static __device__ __forceinline__ void frozen_site(int f, int mu, int off, int& r, int& c) {
+        const int h = fdiv<L>(f), q = f - h * L, x = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3);
+        if (mu == 0) { r = q; c = x; } else { c = q; r = x; }
+    }
+
+    // ---- one coupling layer forward, in place on the links in LDS.  STASH: also write what the backward needs.
+    //      log J of the layer is returned in thread 0 (want_logj), 0 elsewhere.
+    __device__ double layer_fwd(int l, const bool STASH, bool want_logj) {
+        constexpr int N = G::N, NA = G::NA, NAS = G::NAS, RS = G::RS, PSZ = G::PSZ, TQ = 2;
+        const int mu = l & 1, off = (l >> 1) & 3, act = A.act;
+        double* sX = sm + G::X;  double* sIn = sm + G::IN;  double* sH1 = sm + G::A8;  double* sH2 = sm + G::B8;
+        double* sPA = sm + G::PA;  double* sST = sm + G::ST;  double* sT2 = sm + G::T2;  double* sW = sm + G::SW;
+        double* sDL = sm + G::DIR;
+        const double* __restrict__ wl = A.wint + (size_t)l * FLOW_WINT;
+        const Stash sv = STASH ? stash_view(stash(l), A.B, b, N) : Stash{};
+        // this layer's forward weight block: requested first, lands under the plaquette stage
+        constexpr int NWC = (LF_BLOCK + NT - 1) / NT;
+        double wv[NWC];
+        {
+            const double* wb = wl + (mu == 0 ? WFWD0 : WFWD1);
+#pragma unroll
+            for (int k = 0; k < NWC; ++k) wv[k] = ldu(wb, (unsigned)min(tid + k * NT, LF_BLOCK - 1));
+        }
+        // ---- plaquettes, net input (cos P, sin P on the frozen lines, (1, 0) elsewhere), P / 2 at the active sites
+        if (tid < N) {
+            const int i = fdiv<L>(tid), j = tid - i * L;
+            const int ip = i + 1 == L ? 0 : i + 1, jp = j + 1 == L ? 0 : j + 1;
+            const double p = sX[tid] - sX[N + tid] - sX[i * L + jp] + sX[N + ip * L + j];
+            const int sel = ((mu == 0 ? j : i) - off) & 3;
+            const bool frozen = sel == 1 || sel == 2;
+            double sn = 0.0, cs = 1.0;
+            if (frozen || sel == 0) ft_sincos(frozen ? p : 0.5 * p, &sn, &cs);
+            put1<L, RS>(sIn, i, j, frozen ? cs : 1.0);
+            put1<L, RS>(sIn + PSZ, i, j, frozen ? sn : 0.0);
+            if (sel == 0) {
+                const int a = stash_active_idx(i, j, L, mu);
+                sPA[a] = p; sPA[NAS + a] = cs; sPA[2 * NAS + a] = sn;
+            }
+            if (STASH && frozen) {
+                double* cs_ = sv.cs + stash_frozen_idx(i, j, L, mu, off);
+                cs_[0] = cs; cs_[N >> 1] = sn;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NWC; ++k) if (tid + k * NT < LF_BLOCK) sW[tid + k * NT] = wv[k];
+        lds_barrier();
+
+        double* const st_d1 = STASH ? sv.d1 + 2 * (lane >> 4) : nullptr;
+        double* const st_d2 = STASH ? sv.d2 + 2 * (lane >> 4) : nullptr;
+        // ---- conv1 (2 -> 8) + act: pairs = columns for mu = 0, rows for mu = 1 (the layout of the packed table P1)
+        auto conv1_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
+            const double b0 = sW[LF_B0 + 2 * g], b1 = sW[LF_B0 + 2 * g + 1];
+            double h[4], d[4];
+            z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
+            act_eval4(z, act, h, d);
+            if (!ok) return;
+            put2<L, RS, PSZ>(sH1 + 2 * g * PSZ, r, c, h[0], h[1]);
+            put2<L, RS, PSZ>(sH1 + 2 * g * PSZ, r + dr, c + dc, h[2], h[3]);
+            if (STASH) {
+                const int at = r * L + c;
+                *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)at) = double2_t{d[0], d[1]};
+                *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dr * L + dc)) = double2_t{d[2], d[3]};
+            }
+        };
+        if (mu == 0) {
+            mfma_stage<KConv1Col, G::NPAIR, RS, PSZ, false, false, 1>(sIn, sW + LF_P1, wave, lane,
+                [&](int p) { const int r = fdiv<L / 2>(p); return r * RS + 2 * (p - r * (L / 2)); },
+                [&](int g, int p, bool ok, double (&z)[4], int) { const int r = fdiv<L / 2>(p); conv1_epi(g, ok, r, 2 * (p - r * (L / 2)), 0, 1, z); });
+        } else {
+            mfma_stage<KConv1, G::NPAIR, RS, PSZ, false, false, 1>(sIn, sW + LF_P1, wave, lane,
+                [&](int p) { const int pr = fdiv<L>(p); return 2 * pr * RS + (p - pr * L); },
+                [&](int g, int p, bool ok, double (&z)[4], int) { const int pr = fdiv<L>(p); conv1_epi(g, ok, 2 * pr, p - pr * L, 1, 0, z); });
+        }
+        lds_barrier();
+
+        // ---- conv2 (8 -> 8) + act: pairs = rows for mu = 0, columns for mu = 1 (table P2)
+        auto conv2_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
+            const double b0 = sW[LF_B1 + 2 * g], b1 = sW[LF_B1 + 2 * g + 1];
+            double h[4], d[4];
+            z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
+            act_eval4(z, act, h, d);
+            if (!ok) return;
+            put2<L, RS, PSZ>(sH2 + 2 * g * PSZ, r, c, h[0], h[1]);
+            put2<L, RS, PSZ>(sH2 + 2 * g * PSZ, r + dr, c + dc, h[2], h[3]);
+            if (STASH) {
+                const int at = r * L + c;
+                *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)at) = double2_t{d[0], d[1]};
+                *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)(at + dr * L + dc)) = double2_t{d[2], d[3]};
+            }
+        };
+        if (mu == 0) {
+            mfma_stage<KConv2Row, G::NPAIR, RS, PSZ, false, false, 1>(sH1, sW + LF_P2, wave, lane,
+                [&](int p) { const int pr = fdiv<L>(p); return 2 * pr * RS + (p - pr * L); },
+                [&](int g, int p, bool ok, double (&z)[4], int) { const int pr = fdiv<L>(p); conv2_epi(g, ok, 2 * pr, p - pr * L, 1, 0, z); });
+        } else {
+            mfma_stage<KConv2Col, G::NPAIR, RS, PSZ, false, false, 1>(sH1, sW + LF_P2, wave, lane,
+                [&](int p) { const int r = fdiv<L / 2>(p); return r * RS + 2 * (p - r * (L / 2)); },
+                [&](int g, int p, bool ok, double (&z)[4], int) { const int r = fdiv<L / 2>(p); conv2_epi(g, ok, r, 2 * (p - r * (L / 2)), 0, 1, z); });
+        }
+        // conv3's 27 weights of this wave's input channel: scalar loads straight from the weight block
+        typedef const double __attribute__((address_space(4))) * cdptr;
+        double w3[27];
+        {
+            cdptr w3p = (cdptr)(size_t)(wl + (mu == 0 ? WFWD0 : WFWD1) + LF_W2 + wave * 9);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) w3[k * 9 + tp] = w3p[k * 72 + tp];
+        }
+        lds_barrier();
+
+        // ---- conv3 (8 -> 3) at the NA active sites; one input channel per wave
+        const bool alane = lane < NA;
+        int ai = 0, aj = 0;
+        active_site(alane ? lane : 0, mu, off, ai, aj);
+        if (alane) {
+            double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const double v = sH2[wave * PSZ + (ai + ky) * RS + aj + kx];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc[k] = fma(v, w3[k * 9 + ky * 3 + kx], acc[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NAS + lane] = acc[k];
+        }
+        lds_barrier();
+
+        // ---- tan-mixture transform: wave k evaluates mixture component k (flow_fwd.hip, same arithmetic)
+        double Pa = 0.0;
+        if (wave < NMIX && alane) {
+            Pa = sPA[lane];
+            double sk = sW[LF_B2 + wave];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
+            const double cs = sPA[NAS + lane], sn = sPA[2 * NAS + lane];
+            const double es = ft_exp(sk), ems = ft_rcp(es);
+            const double cs2 = cs * cs, sn2 = sn * sn, sincs = sn * cs;
+            const double invD = ft_rcp(ems * cs2 + es * sn2);
+            sT2[(wave * TQ + 1) * NAS + lane] = invD;
+            sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
+            if (STASH) {
+                const double sinP = 2.0 * sincs, invD2 = invD * invD;
+                double* tc = sv.tc + (size_t)wave * N + 4 * (size_t)lane;
+                *reinterpret_cast<double2_t*>(tc) = double2_t{sinP * invD / NMIX, (ems * cs2 - es * sn2) * invD2};
+                *reinterpret_cast<double2_t*>(tc + 2) = double2_t{invD / NMIX, sinP * 0.5 * (es - ems) * invD2};
+            }
+        }
+        if (wave == NMIX && alane) {
+            double tv = sW[LF_B2 + NMIX];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tv += sST[(q * 3 + NMIX) * NAS + lane];
+            sPA[3 * NAS + lane] = tv;
+        }
+        lds_barrier();
+        double logj = 0.0;
+        if (wave == 0) {
+            double ysum = 0.0, si = 0.0;
+#pragma unroll
+            for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * TQ) * NAS + lane]; si += sT2[(k * TQ + 1) * NAS + lane]; }
+            const double newP = ft_wrap(ysum / NMIX + sPA[3 * NAS + lane]);
+            if (alane) sDL[ai * L + aj] = newP - Pa;
+            if (want_logj) {
+                const double tot = ft_wave_sum(alane ? log(si) - log((double)NMIX) : 0.0);
+                if (lane == 0) logj = tot;
+            }
+        }
+        lds_barrier();
+        // ---- link update x' = wrap(x +- delta) at the active links
+        if (tid < N) {
+            const int i = fdiv<L>(tid), j = tid - i * L;
+            if ((((mu == 0 ? j : i) - off) & 3) == 0) {
+                const double d = sDL[tid];
+                if (mu == 0) sX[tid] = ft_wrap(d + sX[tid]); else sX[N + tid] = ft_wrap(-d + sX[N + tid]);
+            }
+        }
+        lds_barrier();
+        return logj;
+    }
+
+    // ---- one coupling layer backward from the stash (gather form, flow_bwd_gather.hip): gP += this layer's contribution
+    __device__ void layer_bwd(int l, double cb) {
+        constexpr int N = G::N, NA = G::NA, NF = G::NF, RS = G::RS, PSZ = G::PSZ;
+        const int mu = l & 1, off = (l >> 1) & 3;
+        double* sGP = sm + G::GP;  double* sDir = sm + G::DIR;  double* sGO = sm + G::IN;  double* sGZ2 = sm + G::A8;
+        double* sD1 = sm + G::B8;  double* sW = sm + G::SW;  double* sPart = sm + G::A8;
+        const double* __restrict__ wl = A.wint + (size_t)l * FLOW_WINT;
+        const Stash sv = stash_view(stash(l), A.B, b, N);
+        // ---- load phase: everything this layer reads from the stash, issued in the order of use
+        constexpr int NWC = (LB_SIZE + NT - 1) / NT;
+        double wsw[NWC];
+#pragma unroll
+        for (int k = 0; k < NWC; ++k) wsw[k] = ldu(wl + (mu == 0 ? WBWD1 : WBWD), (unsigned)min(tid + k * NT, LB_SIZE - 1));
+        const bool ttask = tid < NA;                                       // transform adjoint at active site tid
+        double tcv[4 * NMIX];
+        {
+            const int a = ttask ? tid : 0;
+#pragma unroll
+            for (int q = 0; q < 4 * NMIX; q += 2) {
+                const double2_t t2 = ldg2(sv.tc + (size_t)(q >> 2) * N + 4 * a + (q & 3));
+                tcv[q] = t2.x; tcv[q + 1] = t2.y;
+            }
+        }
+        const bool ftask = tid < NF;                                       // cos / sin of frozen site tid
+        int fr = 0, fc = 0;
+        frozen_site(ftask ? tid : 0, mu, off, fr, fc);
+        double fcs, fsn;
+        {
+            const int ic = stash_frozen_idx(fr, fc, L, mu, off);
+            fcs = sv.cs[ic]; fsn = sv.cs[(N >> 1) + ic];
+        }
+        // conv3^T task = (site, half of the 8 channels): act'(z2) of its four channels
+        const int c3half = tid >= N ? 1 : 0;
+        const int c3s = tid - c3half * N;
+        const bool c3task = tid < 2 * N;
+        double d2v[4];
+        {
+            const double* pl = sv.d2 + 8 * (size_t)(c3task ? c3s : 0) + 4 * c3half;
+            const double2_t va = ldg2(pl), vb = ldg2(pl + 2);
+            d2v[0] = va.x; d2v[1] = va.y; d2v[2] = vb.x; d2v[3] = vb.y;
+        }
+        // conv2^T: this lane's pair of tile `wave` (one tile per wave) and act'(z1) of its channels 2 g, 2 g + 1 at both sites
+        int pr_ = 0, pc_ = 0;                                              // site 0 of the pair; site 1 = next column (mu = 0) / row (mu = 1)
+        bool pok;
+        double d1v[4];
+        {
+            const int p_ = wave * 16 + (lane & 15);
+            pok = p_ < G::NPAIR;
+            const int p = pok ? p_ : G::NPAIR - 1;
+            if (mu == 0) { pr_ = fdiv<L / 2>(p); pc_ = 2 * (p - pr_ * (L / 2)); }
+            else { const int q = fdiv<L>(p); pr_ = 2 * q; pc_ = p - q * L; }
+            const int s0 = pr_ * L + pc_, s1 = s0 + (mu == 0 ? 1 : L);
+            const double2_t va = ldg2(sv.d1 + 8 * (size_t)s0 + 2 * (lane >> 4)), vb = ldg2(sv.d1 + 8 * (size_t)s1 + 2 * (lane >> 4));
+            d1v[0] = va.x; d1v[1] = va.y; d1v[2] = vb.x; d1v[3] = vb.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- consume: weights -> LDS, adjoint of the tan-mixture transform at the active sites
+#pragma unroll
+        for (int k = 0; k < NWC; ++k) if (tid + k * NT < LB_SIZE) sW[tid + k * NT] = wsw[k];
+        if (ttask) {
+            int i, j;
+            active_site(tid, mu, off, i, j);
+            const double g0 = sGP[i * L + j];
+            const double g1 = mu == 0 ? sGP[i * L + (j == 0 ? L - 1 : j - 1)] : sGP[(i == 0 ? L - 1 : i - 1) * L + j];
+            const double gdelta = g0 - g1;
+            double csum = 0.0, esum = 0.0;
+#pragma unroll
+            for (int k = 0; k < NMIX; ++k) { csum += tcv[4 * k + 2]; esum += tcv[4 * k + 3]; }
+            const double tsum = NMIX * csum;
+            double rs = __builtin_amdgcn_rcp(tsum);
+            rs = fma(fma(-tsum, rs, 1.0), rs, rs);
+            rs = fma(fma(-tsum, rs, 1.0), rs, rs);
+            const double cbr = cb * rs;
+#pragma unroll
+            for (int k = 0; k < NMIX; ++k) put1<L, RS>(sGO + k * PSZ, i, j, gdelta * tcv[4 * k] + cbr * tcv[4 * k + 1]);
+            put1<L, RS>(sGO + NMIX * PSZ, i, j, gdelta);
+            sDir[i * L + j] = gdelta * (csum - 1.0) - cbr * esum;
+        }
+        lds_barrier();
+
+        // ---- conv3^T on the VALU (the one tap line that holds an active site), times act'(z2) -> gz2
+        if (c3task) {
+            const int r = fdiv<L>(c3s), c = c3s - r * L;
+            const int ksel = ((mu == 0 ? c : r) + 1 - off) & 3;           // the one kx (mu = 0) / ky (mu = 1) whose source is active
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ksel <= 2) {
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    double wq[3][4], g0[3];
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
+                        g0[kk] = sGO[co * PSZ + (r + 2 - ky) * RS + c + 2 - kx];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wq[kk][k] = sW[LB_W2 + (co * 8 + c3half * 4 + k) * 9 + ky * 3 + kx];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k] = fma(g0[kk], wq[kk][k], acc[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = ksel <= 2 ? d2v[k] * acc[k] : 0.0;
+            put2<L, RS, PSZ>(sGZ2 + (c3half * 4) * PSZ, r, c, acc[0], acc[1]);
+            put2<L, RS, PSZ>(sGZ2 + (c3half * 4 + 2) * PSZ, r, c, acc[2], acc[3]);
+        }
+        lds_barrier();
+
+        // ---- conv2^T (MFMA over the flipped, transposed table T2), times act'(z1) -> gz1
+        {
+            auto epi = [&](int g, int, bool ok, double (&z)[4], int) {
+                if (!ok) return;
+                put2<L, RS, PSZ>(sD1 + 2 * g * PSZ, pr_, pc_, z[0] * d1v[0], z[1] * d1v[1]);
+                put2<L, RS, PSZ>(sD1 + 2 * g * PSZ, pr_ + (mu == 0 ? 0 : 1), pc_ + (mu == 0 ? 1 : 0), z[2] * d1v[2], z[3] * d1v[3]);
+            };
+            if (mu == 0)
+                mfma_stage<KConv2Col, G::NPAIR, RS, PSZ, false, false, 2>(sGZ2, sW + LB_T2, wave, lane,
+                    [&](int p) { const int r = fdiv<L / 2>(p); return r * RS + 2 * (p - r * (L / 2)); }, epi);
+            else
+                mfma_stage<KConv2Row, G::NPAIR, RS, PSZ, false, false, 2>(sGZ2, sW + LB_T2, wave, lane,
+                    [&](int p) { const int q = fdiv<L>(p); return 2 * q * RS + (p - q * L); }, epi);
+        }
+        typedef const double __attribute__((address_space(4))) * cdptr;
+        double w0s[18];
+        {
+            cdptr wq = (cdptr)(size_t)(wl + (mu == 0 ? WBWD1 : WBWD) + LB_W0 + wave * 18);
+#pragma unroll
+            for (int k = 0; k < 18; ++k) w0s[k] = wq[k];
+        }
+        lds_barrier();
+
+        // ---- conv1^T at the frozen sites: wave = hidden channel, the sum over the channels through LDS
+        for (int f = lane; f < NF; f += 64) {
+            int r, c;
+            frozen_site(f, mu, off, r, c);
+            const double* gz = sD1 + wave * PSZ + r * RS + c;              // padded coordinates (r + 2 - ky, c + 2 - kx)
+            double gv[9], gc = 0.0, gs = 0.0;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) gv[tp] = gz[(2 - tp / 3) * RS + 2 - tp % 3];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) { gc = fma(gv[tp], w0s[tp], gc); gs = fma(gv[tp], w0s[9 + tp], gs); }
+            sPart[(wave * 2 + 0) * NF + f] = gc;
+            sPart[(wave * 2 + 1) * NF + f] = gs;
+        }
+        lds_barrier();
+        if (ftask) {
+            double gct = 0.0, gst = 0.0;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) { gct += sPart[(co * 2 + 0) * NF + tid]; gst += sPart[(co * 2 + 1) * NF + tid]; }
+            sDir[fr * L + fc] = -fsn * gct + fcs * gst;
+        }
+        lds_barrier();
+        if (tid < N) {
+            const int i = fdiv<L>(tid), j = tid - i * L;
+            if ((((mu == 0 ? j : i) - off) & 3) != 3) sGP[tid] += sDir[tid];
+        }
+        lds_barrier();
+    }
+
+    // ---- Wilson pieces on the links in sX ------------------------------------------------------------------
+    __device__ __forceinline__ double plaq_at(const double* sX, int s) const {
+        constexpr int N = G::N;
+        const int i = fdiv<L>(s), j = s - i * L;
+        const int ip = i + 1 == L ? 0 : i + 1, jp = j + 1 == L ? 0 : j + 1;
+        return sX[s] - sX[N + s] - sX[i * L + jp] + sX[N + ip * L + j];
+    }
+    // S_W = -beta sum cos P, Q = sum wrap(P) / 2 pi of the field in sX; results valid in every thread
+    __device__ void action_charge(double beta, double& S, double& Q) {
+        constexpr int N = G::N;
+        const double* sX = sm + G::X;
+        double* red = sm + G::RED;
+        double c = 0.0, q = 0.0;
+        if (tid < N) {
+            const int i = fdiv<L>(tid), j = tid - i * L;
+            const int ip = i + 1 == L ? 0 : i + 1, jp = j + 1 == L ? 0 : j + 1;
+            const double a = sX[tid], bb = sX[N + tid], cc = sX[i * L + jp], d = sX[N + ip * L + j];
+            double sn_, cs_;
+            ft_sincos(a + d - cc - bb, &sn_, &cs_);                        // summation order of BatchAction._u1_plaq
+            c = cs_;
+            q = ft_wrap(a - bb - cc + d);                                  // summation order of batch_plaqs
+        }
+        c = ft_block_sum(c, red);
+        q = ft_block_sum(q, red);
+        S = (-beta) * c;
+        Q = q / FT_TWO_PI;
+    }
+    // gP = beta sin P of the flowed field: seeds the backward sweep
+    __device__ void wilson_seed(double beta) {
+        constexpr int N = G::N;
+        if (tid < N) {
+            double sn_, cs_;
+            ft_sincos(plaq_at(sm + G::X, tid), &sn_, &cs_);
+            sm[G::GP + tid] = beta * sn_;
+        }
+        lds_barrier();
+    }
+    // force of site tid from sGP (adjoint of the plaquette stencil)
+    __device__ __forceinline__ void site_force(double& f0, double& f1) const {
+        const double* g = sm + G::GP;
+        const int i = fdiv<L>(tid), j = tid - i * L;
+        const int im = i == 0 ? L - 1 : i - 1, jm = j == 0 ? L - 1 : j - 1;
+        const double gc = g[tid];
+        f0 = gc - g[i * L + jm];
+        f1 = g[im * L + j] - gc;
+    }
+};
+
+enum { SM_ACTION = 0, SM_FORCE = 1, SM_LEAPFROG = 2, SM_TRAJ = 3 };
+
+// One launch = a sequence of SWEEPS over the layers of one chain.  A sweep copies the latent links, runs every layer forward
+// in place, and then either evaluates the Wilson action and charge of the flowed field (EVAL sweep: S_eff = S_W - log det J)
+// or seeds the plaquette gradient with beta sin P and runs every layer backward (FORCE sweep: gP of S_eff).
+//   action:      [EVAL]
+//   force:       [FORCE] -> F
+//   leapfrog:    x += dt/2 v; nstep x ([FORCE]; v -= dt F; x += dt v (dt/2 after the last))
+//   trajectory:  [EVAL] (unless state_in carries it), the leapfrog, regularize, [EVAL], Metropolis
+// The sweep loop has ONE call site of the layer bodies (the kernel is register- and code-size-bound otherwise).
+template <int L>
+__global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs A) {
+    using G = GS<L>;
+    constexpr int N = G::N;
+    __shared__ __attribute__((aligned(16))) double sm[G::SIZE];
+    const int b = blockIdx.x;
+    Chain<L> C(sm, A, b);
+    const int tid = C.tid;
+    double* red = sm + G::RED;
+    const double* xb = A.x + (size_t)b * 2 * N;
+    for (int s = tid; s < 2 * N; s += NT) sm[G::XL + s] = xb[s];
+    const double beta = A.beta, dt = A.dt;
+    const int mode = A.mode;
+    const bool moves = mode == SM_LEAPFROG || mode == SM_TRAJ;
+    const int nforce = mode == SM_ACTION ? 0 : (mode == SM_FORCE ? 1 : A.nstep);
+    // sweeps it = first .. last: it < 0 and it == nforce are EVAL sweeps, 0 <= it < nforce FORCE sweeps
+    const int first = (mode == SM_ACTION || (mode == SM_TRAJ && !A.state_in)) ? -1 : 0;
+    const int last = mode == SM_TRAJ ? nforce : (mode == SM_ACTION ? -1 : nforce - 1);
+    // momenta of site tid in registers
+    double v0 = 0.0, v1 = 0.0;
+    if (moves && tid < N) { v0 = A.v[(size_t)b * 2 * N + tid]; v1 = A.v[(size_t)b * 2 * N + N + tid]; }
+    double st_old[3] = {0.0, 0.0, 0.0}, st_new[3] = {0.0, 0.0, 0.0}, ld_eval = 0.0, k0 = 0.0;   // thread 0
+    if (mode == SM_TRAJ) {
+        if (A.state_in && tid == 0) { st_old[0] = A.state_in[b]; st_old[1] = A.state_in[A.B + b]; st_old[2] = A.state_in[2 * A.B + b]; }
+        k0 = ft_block_sum(v0 * v0 + v1 * v1, red);
+    }
+    lds_barrier();
+
+    for (int it = first; it <= last; ++it) {
+        const bool force = it >= 0 && it < nforce;
+        if (it == 0 && moves && tid < N) { sm[G::XL + tid] += 0.5 * dt * v0; sm[G::XL + N + tid] += 0.5 * dt * v1; }   // own site
+        if (it == nforce && mode == SM_TRAJ && tid < N) {                  // end of the MD: regularize (ipynb/ft_hmc.py:426)
+            sm[G::XL + tid] = ft_regularize(sm[G::XL + tid]); sm[G::XL + N + tid] = ft_regularize(sm[G::XL + N + tid]);
+        }
+        if (tid < N) { sm[G::X + tid] = sm[G::XL + tid]; sm[G::X + N + tid] = sm[G::XL + N + tid]; }
+        lds_barrier();
+        double ld = 0.0;
+        for (int l = 0; l < A.nl; ++l) ld += C.layer_fwd(l, force, !force);
+        if (force) {
+            // the stash of this sweep was written by other threads of this workgroup: complete and visible before it is read
+            __syncthreads();
+            C.wilson_seed(beta);
+            for (int l = A.nl - 1; l >= 0; --l) C.layer_bwd(l, -1.0);
+            if (tid < N) {
+                double f0, f1;
+                C.site_force(f0, f1);
+                if (mode == SM_FORCE) { A.F[(size_t)b * 2 * N + tid] = f0; A.F[(size_t)b * 2 * N + N + tid] = f1; }
+                else {
+                    v0 -= dt * f0; v1 -= dt * f1;
+                    const double a = it == nforce - 1 ? 0.5 * dt : dt;
+                    sm[G::XL + tid] += a * v0; sm[G::XL + N + tid] += a * v1;
+                }
+            }
+        } else {
+            double S, Q;
+            C.action_charge(beta, S, Q);
+            double* st = it < 0 ? st_old : st_new;
+            st[0] = S - ld; st[1] = (-S) / (beta * (double)N); st[2] = Q;   // meaningful in thread 0 (ld lives there)
+            ld_eval = ld;
+        }
+    }
+
+    if (mode == SM_ACTION) {
+        if (tid == 0) {
+            if (A.S_eff) A.S_eff[b] = st_old[0];
+            if (A.logdet) A.logdet[b] = ld_eval;
+            if (A.plaq) A.plaq[b] = st_old[1];
+            if (A.Q) A.Q[b] = st_old[2];
+        }
+        if (A.x_out && tid < N) { A.x_out[(size_t)b * 2 * N + tid] = sm[G::X + tid]; A.x_out[(size_t)b * 2 * N + N + tid] = sm[G::X + N + tid]; }
+        return;
+    }
+    if (mode == SM_LEAPFROG) {
+        if (tid < N) {
+            A.x_out[(size_t)b * 2 * N + tid] = sm[G::XL + tid]; A.x_out[(size_t)b * 2 * N + N + tid] = sm[G::XL + N + tid];
+            A.v_out[(size_t)b * 2 * N + tid] = v0; A.v_out[(size_t)b * 2 * N + N + tid] = v1;
+        }
+        return;
+    }
+    if (mode != SM_TRAJ) return;
+    // ---- Metropolis (ipynb/ft_hmc.py:427-435)
+    const double k1 = ft_block_sum(v0 * v0 + v1 * v1, red);
+    if (tid == 0) {
+        const double h0 = st_old[0] + 0.5 * k0, h1 = st_new[0] + 0.5 * k1;
+        const double d = h1 - h0;
+        const bool ok = A.u[b] < exp(-d);
+        if (A.dH) A.dH[b] = d;
+        if (A.acc) A.acc[b] = ok ? 1.0 : 0.0;
+        if (A.H0) A.H0[b] = h0;
+        if (A.H1) A.H1[b] = h1;
+        const double* sel = ok ? st_new : st_old;
+        if (A.state_out) { A.state_out[b] = sel[0]; A.state_out[A.B + b] = sel[1]; A.state_out[2 * A.B + b] = sel[2]; }
+        if (A.plaq) A.plaq[b] = sel[1];
+        if (A.Q) A.Q[b] = sel[2];
+        red[0] = ok ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const bool ok = red[0] > 0.5;
+    if (tid < N) {
+        A.x_out[(size_t)b * 2 * N + tid] = ok ? sm[G::XL + tid] : xb[tid];
+        A.x_out[(size_t)b * 2 * N + N + tid] = ok ? sm[G::XL + N + tid] : xb[N + tid];
+    }
+}
+
+int g_small = 1;
+
+}  // namespace
+
+namespace fthmc {
+
+void set_small_path(int v) { g_small = v; }
+int get_small_path() { return g_small; }
+bool ft_small_ok(int L, int nl) { return g_small && get_flow_variant() == 1 && nl >= 1 && (L == 8 || L == 12 || L == 16); }
+
+int launch_ft_small(const SmallArgs& a, int L, hipStream_t s) {
+    const dim3 grid(a.B), block(NT);
+    switch (L) {
+        case 8: hipLaunchKernelGGL(k_ft_small<8>, grid, block, 0, s, a); break;
+        case 12: hipLaunchKernelGGL(k_ft_small<12>, grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL(k_ft_small<16>, grid, block, 0, s, a); break;
+        default: return FTHMC_ERR_UNSUPPORTED;
+    }
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+
+}  // namespace fthmc

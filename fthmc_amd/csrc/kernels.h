@@ -106,6 +106,26 @@ inline size_t flow_gz_doubles(int B, int L) { return (size_t)B * 17 * L * L; }
 inline int flow_wgrad_parts(int L) { return 2 * FlowGeom{MG_TR, MG_TC}.ntiles(L); }
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }
+// ---- flow_small.hip: L <= 16, one workgroup per chain, whole sequences of the flowed path in one launch
+struct SmallArgs {
+    const double* x;         // [B][2][L][L] latent links
+    const double* v;         // leapfrog / trajectory: momenta
+    const double* u;         // trajectory: accept uniforms [B]
+    const double* wint;      // n_layers * FLOW_WINT, kernel weight layout
+    double* stash;           // n_layers * flow_stash_doubles(B, L): the activation stash of a force evaluation
+    const double* state_in;  // trajectory: [3][B] (S_eff, plaq, Q) of x, or null
+    double* state_out;       // trajectory: [3][B] of x_new, or null
+    double* x_out;           // action: F(x) (or null); leapfrog: x'; trajectory: x_new
+    double* v_out;           // leapfrog: v'
+    double* F;               // force
+    double *dH, *acc, *H0, *H1, *S_eff, *logdet, *plaq, *Q;   // per chain [B], each may be null
+    double beta, dt;
+    int nstep, mode, B, nl, act;   // mode: 0 action (forward sweep), 1 force, 2 leapfrog, 3 trajectory
+};
+bool ft_small_ok(int L, int n_layers);          // the fused path serves this shape (and is switched on)
+int launch_ft_small(const SmallArgs& a, int L, hipStream_t s);
+void set_small_path(int v);
+int get_small_path();
 // 0: VALU kernels everywhere; 1 (default): MFMA kernels for forward and backward-wrt-x
 void set_flow_variant(int v);
 int get_flow_variant();

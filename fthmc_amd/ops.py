@@ -87,6 +87,15 @@ def get_variant() -> int:
     return int(_lib.load().fthmc_get_variant())
 
 
+def set_small_path(on: bool):
+    """Lattices of L = 8, 12, 16: one fused launch per trajectory / force / action (default) or the tiled kernels."""
+    check(_lib.load().fthmc_set_small_path(int(bool(on))), 'fthmc_set_small_path')
+
+
+def get_small_path() -> bool:
+    return bool(_lib.load().fthmc_get_small_path())
+
+
 def act_code(act) -> int:
     key = act.lower() if isinstance(act, str) else act
     if key not in ACT_CODES:

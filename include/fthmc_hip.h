@@ -58,6 +58,11 @@ const char* fthmc_last_error(void);
  * Same results to rounding; kept selectable for A/B measurement and cross-checks. */
 int fthmc_set_variant(int v);
 int fthmc_get_variant(void);
+/* Lattices of L = 8, 12, 16 take a fused path by default (csrc/flow_small.hip): one workgroup holds a whole chain in
+ * LDS, and fthmc_ft_trajectory / _ft_leapfrog / _ft_force / _ft_action / _flow_forward are ONE launch each instead of
+ * one launch per layer.  0 switches it off (the tiled kernels then serve every L): A/B runs and parity tests. */
+int fthmc_set_small_path(int on);
+int fthmc_get_small_path(void);
 
 /* Bytes of scratch the flow / trajectory entry points need for (B, L, n_layers). */
 size_t fthmc_ws_bytes(int B, int L, int n_layers);

@@ -69,7 +69,7 @@ def test_config4_1024_chains_on_one_gpu():
     close((F * d).flatten(1).sum(1), fd, rtol=2e-5, atol=5e-3)             # force = gradient of S_eff
     # gauge invariance of the effective action: x_mu(n) -> x_mu(n) + a(n) - a(n + mu)
     a = (torch.rand(B, L, L, generator=gen, dtype=torch.float64) * 2 * math.pi).cuda()
-    xg = torch.stack([x[:, 0] + a - torch.roll(a, -1, 2), x[:, 1] + a - torch.roll(a, -1, 1)], 1).contiguous()
+    xg = torch.stack([x[:, 0] + a - torch.roll(a, -1, 1), x[:, 1] + a - torch.roll(a, -1, 2)], 1).contiguous()
     close(ops.ft_action(xg, w, nl, beta)[0], ops.ft_action(x, w, nl, beta)[0], rtol=1e-10, atol=1e-7)
     # whole trajectories: chain k of the 1024 == chain k alone == chain k inside its 128-chain shard (rank k // 128)
     v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()

@@ -439,7 +439,33 @@ def main():
             'avg_launch_ms': round(ms_traj, 5), 'steps_per_launch': 10,
             'algorithmic_GBps': round(64.0 * L * L * B * 10 / (ms_traj * 1e-3) / 1e9, 1),
             'note': 'no HBM traffic between steps: the per-step HBM model is an upper bound'}
-    if flowed:
+    small = flowed and L <= 16 and ops.get_small_path() and ops.get_variant() == 1
+    if small:
+        # small lattices: ONE launch per trajectory (csrc/flow_small.hip: a chain per workgroup, the whole MD loop on the
+        # device).  Algorithmic flops of a launch = the dense conv flops of its sweeps: nstep force evaluations
+        # (forward + adjoint) and two action evaluations (H0, H1; the timed region carries H0 over and runs one).
+        with torch.cuda.stream(stream):
+            ms_k = ops.time_small(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, reps=40)
+        sweeps_fwd, sweeps_bwd = NSTEP + 2, NSTEP
+        flops_launch = CONV_FLOPS_PER_SITE * L * L * N_LAYERS * B * (sweeps_fwd + sweeps_bwd)
+        achieved = flops_launch / (ms_k * 1e-3) / 1e12
+        step_flops = 2 * CONV_FLOPS_PER_SITE * L * L * N_LAYERS * B
+        roofline = {
+            'bound': 'mfma', 'kernel': f'k_ft_small<{L}> (whole ftHMC trajectory in one launch: one 512-thread workgroup per '
+                                       f'chain, links / activations / plaquette gradient in LDS, conv1 / conv2 / conv2^T on '
+                                       f'v_mfma_f64_16x16x4_f64; {sweeps_fwd} forward and {sweeps_bwd} backward sweeps of {N_LAYERS} layers)',
+            'achieved': round(achieved, 3), 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / FP64_PEAK_TFLOPS, 4),
+            'traffic': None, 'avg_launch_ms': round(ms_k, 4), 'algorithmic_flops_per_launch': flops_launch,
+            'chains_per_launch': B, 'workgroups_per_launch': B,
+            'frac_of_occupied_cus': round(achieved / (FP64_PEAK_TFLOPS * min(B, 256) / 256), 4),
+            'whole_step_tflops': round(step_flops * (NSTEP * args.steps) / elapsed / 1e12, 3),
+            'whole_step_frac': round(step_flops * (NSTEP * args.steps) / elapsed / 1e12 / FP64_PEAK_TFLOPS, 4),
+            'note': f'{B} chains = {B} workgroups on 256 CUs: the launch is bound by the latency of ONE chain through its '
+                    f'{(sweeps_fwd + sweeps_bwd) * N_LAYERS} dependent layer passes, not by the chip; frac_of_occupied_cus '
+                    'prices the kernel against the CUs it can occupy',
+            'stencil': stencil,
+        }
+    elif flowed:
         # launch shape of the timed region: one launch = one layer over one chain group (B / G chains)
         Bl = (max(Gsplit) if isinstance(Gsplit, list) else B // G) if G > 1 else B
         with torch.cuda.stream(stream):
@@ -568,9 +594,11 @@ def main():
         'config': {'workload': cfg['label'], 'baseline_config': args.config,
                    'chains_per_gpu': B, 'chains_total': B_total, 'L': L, 'beta': BETA, 'n_layers': N_LAYERS,
                    'nstep': NSTEP, 'tau': TAU, 'parallelism': f'chains sharded x{world}',
-                   'launch': 'eager' if graph is None else 'hipGraph replay', 'chain_groups': G},
+                   'launch': 'eager' if graph is None else 'hipGraph replay', 'chain_groups': G,
+                   'path': 'small-lattice fused (one launch per trajectory)' if (flowed and L <= 16 and ops.get_small_path()) else
+                           ('tiled, one launch per layer' if flowed else 'plain HMC, one launch per trajectory')},
         'batched_leapfrog_steps_per_s': round(NSTEP * args.steps / elapsed, 3),
-        'regions': {'n': len(times), 'seconds': [round(t, 5) for t in times], 'value_from': 'median region',
+        'regions': {'n': len(times), 'seconds': [round(t, 7) for t in times], 'value_from': 'median region',
                     'spread': round((max(times) - min(times)) / elapsed, 4),
                     'note': f'each region = exactly {args.steps} trajectories between barrier + synchronize brackets, '
                             'MAX over ranks; more than one region is timed when the first is shorter than 1 s'},

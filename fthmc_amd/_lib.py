@@ -62,6 +62,10 @@ SIGNATURES = {
     'fthmc_train_grad': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
     'fthmc_time_kernel': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double, c_int,
                           ctypes.POINTER(c_double), _P, c_size_t, _P],
+    'fthmc_time_small': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int,
+                         ctypes.POINTER(c_double), _P, c_size_t, _P],
+    'fthmc_small_profile': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
+                            ctypes.POINTER(c_double), _P, c_size_t, _P],
     'fthmc_profile_stages': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double,
                              ctypes.POINTER(c_double), _P, c_size_t, _P],
 }

@@ -612,6 +612,56 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     return rc;
 }
 
+int fthmc_time_small(const double* x, const double* v, const double* u, const double* w, int n_layers, int B, int L, int act,
+                     double beta, double dt, int nstep, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !v || !u || !w || !ms_avg_host || bad_shape(B, L) || n_layers < 1 || nstep < 1 || reps < 1) return FTHMC_ERR_ARG;
+    if (!ft_small_ok(L, n_layers)) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(n_layers);
+    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
+    a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = W.xb;
+    // H0 is evaluated in the launch (no state_in): nstep force sweeps + 2 action sweeps
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return FTHMC_ERR_LAUNCH; }
+    int rc = FTHMC_OK;
+    for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
+        if (it == 0) (void)hipEventRecord(e0, s);
+        rc = launch_ft_small(a, L, s);
+    }
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_avg_host = (double)ms / reps;
+    return rc;
+}
+
+int fthmc_small_profile(const double* x, const double* v, const double* u, const double* w, int n_layers, int B, int L,
+                        int act, double beta, double dt, int nstep, double* cycles_host32, void* ws, size_t ws_bytes,
+                        void* stream) {
+    if (!x || !v || !u || !w || !cycles_host32 || bad_shape(B, L) || n_layers < 1 || nstep < 1) return FTHMC_ERR_ARG;
+    if (!ft_small_ok(L, n_layers)) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(n_layers);
+    long long* dbg = reinterpret_cast<long long*>(W.gw_part);            // unused by the force path; B * 32 stamps fit
+    if (hipMemsetAsync(dbg, 0, (size_t)B * 32 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
+    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
+    a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = W.xb; a.dbg = dbg;
+    FT_TRY(launch_ft_small(a, L, s));
+    long long* h = (long long*)malloc((size_t)B * 32 * sizeof(long long));
+    if (!h) return FTHMC_ERR_ARG;
+    if (hipMemcpyAsync(h, dbg, (size_t)B * 32 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) { free(h); return FTHMC_ERR_LAUNCH; }
+    for (int k = 0; k < 32; ++k) {
+        cycles_host32[k] = 0.0;
+        for (int b = 0; b < B; ++b) cycles_host32[k] += (double)h[(size_t)b * 32 + k] / B;
+    }
+    free(h);
+    return FTHMC_OK;
+}
+
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;

@@ -204,8 +204,12 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) accs[ch] = double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int t = 0; t < NSTEP; ++t)
+        for (int t = 0; t < NSTEP; ++t) {
             accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[KO::bimm(t)], a0[KO::template aimm<RSA, PSA>(t)], accs[t % NCH], 0, 0, 0);
+#ifdef FT_MFMA_FENCE      // a scheduling fence every FT_MFMA_FENCE K steps: bounds how many operand reads are hoisted (register budget)
+            if (t % FT_MFMA_FENCE == FT_MFMA_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
         double4_t acc = accs[0];
 #pragma unroll
         for (int ch = 1; ch < NCH; ++ch) acc += accs[ch];

@@ -26,6 +26,12 @@ using namespace fthmc_flow;
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// timing-only builds (results wrong): bit 0 no stash stores, 1 no border duplicates, 2 identity activation, 3 no weight loads,
+// 4 no stash loads in the backward.  tools/small_knobs.sh builds and times them; the product build has FT_KNOB = 0.
+#ifndef FT_KNOB
+#define FT_KNOB 0
+#endif
+
 // conv1 (2 -> 8) as a 6-step implicit GEMM, pairs = columns (c, c + 1) of one row: 3 x 4 window.
 // K slot (g, t): input channel g & 1, window column 2 (g >> 1) + t / 3, tap row t % 3 (KConv1, flow_mfma_common.h, is the
 // same with rows and columns exchanged); table P1[ky][ci][c5][row] of the mu = 0 forward block.
@@ -49,15 +55,18 @@ template <int L> struct GS {
     static constexpr int XL = X + 2 * N;                         // [2][N] latent links of the trajectory
     static constexpr int GP = XL + 2 * N;                        // [N] plaquette gradient
     static constexpr int DIR = GP + N;                           // [N] a layer's contribution to it
-    static constexpr int PA = DIR + N;                           // [4][NAS] per active site: P, cos P/2, sin P/2, t
+    static constexpr int PA = DIR + N;                           // [4][NAS] per active site: P, cos P/2, sin P/2
     static constexpr int IN = PA + 4 * NAS;                      // fwd [2][PSZ] cos, sin   | bwd [3][PSZ] g_out
     static constexpr int A8 = IN + 3 * PSZ;                      // fwd [8][PSZ] h1         | bwd gz2, then conv1^T partials
     static constexpr int B8 = A8 + 8 * PSZ;                      // fwd [8][PSZ] h2         | bwd gz1
     static constexpr int ST = B8 + 8 * PSZ;                      // [8][3][NAS] conv3 partials
-    static constexpr int T2 = ST + 8 * 3 * NAS;                  // [NMIX][2][NAS] y_k, 1 / D_k
-    static constexpr int SW = T2 + NMIX * 2 * NAS;               // [LF_BLOCK] weight block of the layer in flight
-    static constexpr int RED = SW + (LF_BLOCK > LB_SIZE ? LF_BLOCK : LB_SIZE);
-    static constexpr int SIZE = RED + 16;
+    static constexpr int T2 = ST + 8 * 3 * NAS;                  // [2 NMIX + 1][NAS] y_k, 1 / D_k per component, t
+    static constexpr int SW = T2 + (2 * NMIX + 1) * NAS;         // [2][LF_BLOCK] weight blocks: the pass in flight, the next pass
+    static constexpr int RED = SW + 2 * LF_BLOCK;
+    static_assert(LF_BLOCK >= LB_SIZE, "one buffer size for forward and backward blocks");
+    static constexpr int STT = RED + 16;                         // [8] (S_eff, plaq, Q) of x and of the proposal, K0, log det J
+    static constexpr int PROF = STT + 8;                         // [32] cycle sums of a profiling run
+    static constexpr int SIZE = PROF + 32;
     static_assert(8 * 2 * NF <= 8 * PSZ, "conv1^T partials fit over gz2");
     static_assert(SIZE * 8 <= 160 * 1024, "LDS of one CU");
 };
@@ -69,6 +78,7 @@ __device__ __forceinline__ void put1(double* p, int r, int c, double v) {
     const int rr = r == 0 ? (L + 1) * RS : (r == L - 1 ? 0 : -1);
     const int cc = c == 0 ? L + 1 : (c == L - 1 ? 0 : -1);
     p[m] = v;
+    if (FT_KNOB & 2) return;
     if (rr >= 0) p[rr + c + 1] = v;
     if (cc >= 0) p[(r + 1) * RS + cc] = v;
     if (rr >= 0 && cc >= 0) p[rr + cc] = v;
@@ -80,22 +90,78 @@ __device__ __forceinline__ void put2(double* p, int r, int c, double va, double 
     const int rr = r == 0 ? (L + 1) * RS : (r == L - 1 ? 0 : -1);
     const int cc = c == 0 ? L + 1 : (c == L - 1 ? 0 : -1);
     p[m] = va; p[PS + m] = vb;
+    if (FT_KNOB & 2) return;
     if (rr >= 0) { p[rr + c + 1] = va; p[PS + rr + c + 1] = vb; }
     if (cc >= 0) { p[(r + 1) * RS + cc] = va; p[PS + (r + 1) * RS + cc] = vb; }
     if (rr >= 0 && cc >= 0) { p[rr + cc] = va; p[PS + rr + cc] = vb; }
 }
 
-__device__ __forceinline__ double2_t ldg2(const double* p) { return *reinterpret_cast<const double2_t*>(p); }
+__device__ __forceinline__ double2_t ldg2(const double* p) {
+    if (FT_KNOB & 16) return double2_t{0.5, 0.25};
+    return *reinterpret_cast<const double2_t*>(p);
+}
+
+// What a pass over one layer needs from the kernel arguments, and nothing else: the full argument block stays in the
+// kernarg segment and is read where it is used (cold()), so that a dozen output pointers do not sit in SGPRs (and spill)
+// through the whole trajectory.
+struct Hot {
+    const double* wint;
+    double* stash;
+    long long* dbg;
+    int B, nl, act;
+};
+__device__ __forceinline__ const SmallArgs& cold() {
+    const SmallArgs* p = (const SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // the one explicit kernel argument, offset 0
+    asm volatile("" : "+s"(p));
+    return *p;
+}
+
+// the stash values a backward pass multiplies by, loaded one pass ahead
+struct BwdPre { double tcv[4 * NMIX], fcs, fsn, d2v[4], d1v[4]; };
 
 template <int L> struct Chain {
     using G = GS<L>;
+    static constexpr int NWC = (LF_BLOCK + NT - 1) / NT;         // weight-block doubles per thread (LF_BLOCK >= LB_SIZE)
     double* sm;
-    const SmallArgs& A;
+    Hot A;
     int b, tid, lane, wave;
-    __device__ Chain(double* sm_, const SmallArgs& A_, int b_) : sm(sm_), A(A_), b(b_) {
+    int wcur;                                                    // which of the two LDS weight buffers the pass in flight reads
+    double pfw[NWC];                                             // the next pass's weight block, on its way
+    BwdPre pre;                                                  // this backward pass's stash values
+    long long last;                                              // profiling runs (A.dbg): time of the previous stamp
+    __device__ Chain(double* sm_, const Hot& A_, int b_) : sm(sm_), A(A_), b(b_) {
         tid = threadIdx.x; lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        wcur = 0;
+        last = A.dbg ? (long long)__builtin_readcyclecounter() : 0;
+    }
+    // profiling runs only: thread 0 adds the cycles since its previous stamp to slot k of this chain's record
+    __device__ __forceinline__ void stamp(int k) {
+        if (A.dbg && tid == 0) {
+            const long long t = (long long)__builtin_readcyclecounter();
+            reinterpret_cast<long long*>(sm + G::PROF)[k] += t - last;      // LDS: a global read-modify-write would be timed itself
+            last = (long long)__builtin_readcyclecounter();
+        }
     }
     __device__ __forceinline__ double* stash(int l) const { return A.stash + (size_t)l * ((size_t)A.B * 19 * L * L); }   // kernels.h flow_stash_doubles
+    __device__ __forceinline__ double* sW() const { return sm + G::SW + wcur * LF_BLOCK; }
+
+    // ---- weight blocks: the pass in flight reads one LDS buffer while the next pass's block travels global -> registers
+    //      (issued at the top of the pass) -> the other buffer (committed at its end, behind the pass's last LDS reads of it)
+    static __device__ __forceinline__ const double* block_of(const double* wint, bool bwd, int l) {
+        const int mu = l & 1;
+        return wint + (size_t)l * FLOW_WINT + (bwd ? (mu == 0 ? WBWD1 : WBWD) : (mu == 0 ? WFWD0 : WFWD1));
+    }
+    __device__ __forceinline__ void weights_issue(bool bwd, int l) {
+        const double* wb = block_of(A.wint, bwd, l);
+        const int n = bwd ? LB_SIZE : LF_BLOCK;
+#pragma unroll
+        for (int k = 0; k < NWC; ++k) pfw[k] = (FT_KNOB & 8) ? 0.01 : ldu(wb, (unsigned)min(tid + k * NT, n - 1));
+    }
+    __device__ __forceinline__ void weights_commit() {            // the size of the larger block: the tail of a smaller one is never read
+        double* dst = sm + G::SW + (wcur ^ 1) * LF_BLOCK;
+#pragma unroll
+        for (int k = 0; k < NWC; ++k) if (tid + k * NT < LF_BLOCK) dst[tid + k * NT] = pfw[k];
+    }
 
     // active site a (compact index of struct Stash) -> lattice site
     static __device__ __forceinline__ void active_site(int a, int mu, int off, int& i, int& j) {
@@ -107,25 +173,31 @@ template <int L> struct Chain {
         const int h = fdiv<L>(f), q = f - h * L, x = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3);
         if (mu == 0) { r = q; c = x; } else { c = q; r = x; }
     }
+    // conv2^T: site 0 of this lane's pair in tile `wave` (site 1 = next column for mu = 0, next row for mu = 1)
+    __device__ __forceinline__ bool pair_site(int mu, int& r, int& c) const {
+        const int p_ = wave * 16 + (lane & 15);
+        const bool ok = p_ < G::NPAIR;
+        const int p = ok ? p_ : G::NPAIR - 1;
+        if (mu == 0) { r = fdiv<L / 2>(p); c = 2 * (p - r * (L / 2)); }
+        else { const int q = fdiv<L>(p); r = 2 * q; c = p - q * L; }
+        return ok;
+    }
 
     // ---- one coupling layer forward, in place on the links in LDS.  STASH: also write what the backward needs.
-    //      log J of the layer is returned in thread 0 (want_logj), 0 elsewhere.
-    __device__ double layer_fwd(int l, const bool STASH, bool want_logj) {
-        constexpr int N = G::N, NA = G::NA, NAS = G::NAS, RS = G::RS, PSZ = G::PSZ, TQ = 2;
+    //      log J of the layer is returned in thread 0 (want_logj), 0 elsewhere.  (nb, nl_): the pass that follows, or nl_ < 0.
+    __device__ double layer_fwd(int l, const bool STASH_, bool want_logj, bool nb, int nl_) {
+        const bool STASH = (FT_KNOB & 1) ? false : STASH_;
+        constexpr int N = G::N, NA = G::NA, NAS = G::NAS, RS = G::RS, PSZ = G::PSZ;
+        // thread coordinates opaque per pass: otherwise every index expression of every stage is hoisted out of the layer
+        // loops and lives in registers for the whole kernel (hundreds of them: they spilled)
+        int tid = this->tid, lane = this->lane;
+        asm volatile("" : "+v"(tid), "+v"(lane));
         const int mu = l & 1, off = (l >> 1) & 3, act = A.act;
         double* sX = sm + G::X;  double* sIn = sm + G::IN;  double* sH1 = sm + G::A8;  double* sH2 = sm + G::B8;
-        double* sPA = sm + G::PA;  double* sST = sm + G::ST;  double* sT2 = sm + G::T2;  double* sW = sm + G::SW;
-        double* sDL = sm + G::DIR;
-        const double* __restrict__ wl = A.wint + (size_t)l * FLOW_WINT;
+        double* sPA = sm + G::PA;  double* sST = sm + G::ST;
+        const double* sWc = sW();
         const Stash sv = STASH ? stash_view(stash(l), A.B, b, N) : Stash{};
-        // this layer's forward weight block: requested first, lands under the plaquette stage
-        constexpr int NWC = (LF_BLOCK + NT - 1) / NT;
-        double wv[NWC];
-        {
-            const double* wb = wl + (mu == 0 ? WFWD0 : WFWD1);
-#pragma unroll
-            for (int k = 0; k < NWC; ++k) wv[k] = ldu(wb, (unsigned)min(tid + k * NT, LF_BLOCK - 1));
-        }
+        if (nl_ >= 0) weights_issue(nb, nl_);
         // ---- plaquettes, net input (cos P, sin P on the frozen lines, (1, 0) elsewhere), P / 2 at the active sites
         if (tid < N) {
             const int i = fdiv<L>(tid), j = tid - i * L;
@@ -146,17 +218,17 @@ template <int L> struct Chain {
                 cs_[0] = cs; cs_[N >> 1] = sn;
             }
         }
-#pragma unroll
-        for (int k = 0; k < NWC; ++k) if (tid + k * NT < LF_BLOCK) sW[tid + k * NT] = wv[k];
         lds_barrier();
+        stamp(0);
 
         double* const st_d1 = STASH ? sv.d1 + 2 * (lane >> 4) : nullptr;
         double* const st_d2 = STASH ? sv.d2 + 2 * (lane >> 4) : nullptr;
         // ---- conv1 (2 -> 8) + act: pairs = columns for mu = 0, rows for mu = 1 (the layout of the packed table P1)
         auto conv1_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
-            const double b0 = sW[LF_B0 + 2 * g], b1 = sW[LF_B0 + 2 * g + 1];
+            const double b0 = sWc[LF_B0 + 2 * g], b1 = sWc[LF_B0 + 2 * g + 1];
             double h[4], d[4];
             z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
+            if (FT_KNOB & 4) { for (int q = 0; q < 4; ++q) { h[q] = z[q]; d[q] = 1.0; } } else
             act_eval4(z, act, h, d);
             if (!ok) return;
             put2<L, RS, PSZ>(sH1 + 2 * g * PSZ, r, c, h[0], h[1]);
@@ -168,21 +240,23 @@ template <int L> struct Chain {
             }
         };
         if (mu == 0) {
-            mfma_stage<KConv1Col, G::NPAIR, RS, PSZ, false, false, 1>(sIn, sW + LF_P1, wave, lane,
+            mfma_stage<KConv1Col, G::NPAIR, RS, PSZ, false, false, 1>(sIn, sWc + LF_P1, wave, lane,
                 [&](int p) { const int r = fdiv<L / 2>(p); return r * RS + 2 * (p - r * (L / 2)); },
                 [&](int g, int p, bool ok, double (&z)[4], int) { const int r = fdiv<L / 2>(p); conv1_epi(g, ok, r, 2 * (p - r * (L / 2)), 0, 1, z); });
         } else {
-            mfma_stage<KConv1, G::NPAIR, RS, PSZ, false, false, 1>(sIn, sW + LF_P1, wave, lane,
+            mfma_stage<KConv1, G::NPAIR, RS, PSZ, false, false, 1>(sIn, sWc + LF_P1, wave, lane,
                 [&](int p) { const int pr = fdiv<L>(p); return 2 * pr * RS + (p - pr * L); },
                 [&](int g, int p, bool ok, double (&z)[4], int) { const int pr = fdiv<L>(p); conv1_epi(g, ok, 2 * pr, p - pr * L, 1, 0, z); });
         }
         lds_barrier();
+        stamp(1);
 
         // ---- conv2 (8 -> 8) + act: pairs = rows for mu = 0, columns for mu = 1 (table P2)
         auto conv2_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
-            const double b0 = sW[LF_B1 + 2 * g], b1 = sW[LF_B1 + 2 * g + 1];
+            const double b0 = sWc[LF_B1 + 2 * g], b1 = sWc[LF_B1 + 2 * g + 1];
             double h[4], d[4];
             z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
+            if (FT_KNOB & 4) { for (int q = 0; q < 4; ++q) { h[q] = z[q]; d[q] = 1.0; } } else
             act_eval4(z, act, h, d);
             if (!ok) return;
             put2<L, RS, PSZ>(sH2 + 2 * g * PSZ, r, c, h[0], h[1]);
@@ -194,11 +268,11 @@ template <int L> struct Chain {
             }
         };
         if (mu == 0) {
-            mfma_stage<KConv2Row, G::NPAIR, RS, PSZ, false, false, 1>(sH1, sW + LF_P2, wave, lane,
+            mfma_stage<KConv2Row, G::NPAIR, RS, PSZ, false, false, 1>(sH1, sWc + LF_P2, wave, lane,
                 [&](int p) { const int pr = fdiv<L>(p); return 2 * pr * RS + (p - pr * L); },
                 [&](int g, int p, bool ok, double (&z)[4], int) { const int pr = fdiv<L>(p); conv2_epi(g, ok, 2 * pr, p - pr * L, 1, 0, z); });
         } else {
-            mfma_stage<KConv2Col, G::NPAIR, RS, PSZ, false, false, 1>(sH1, sW + LF_P2, wave, lane,
+            mfma_stage<KConv2Col, G::NPAIR, RS, PSZ, false, false, 1>(sH1, sWc + LF_P2, wave, lane,
                 [&](int p) { const int r = fdiv<L / 2>(p); return r * RS + 2 * (p - r * (L / 2)); },
                 [&](int g, int p, bool ok, double (&z)[4], int) { const int r = fdiv<L / 2>(p); conv2_epi(g, ok, r, 2 * (p - r * (L / 2)), 0, 1, z); });
         }
@@ -206,13 +280,14 @@ template <int L> struct Chain {
         typedef const double __attribute__((address_space(4))) * cdptr;
         double w3[27];
         {
-            cdptr w3p = (cdptr)(size_t)(wl + (mu == 0 ? WFWD0 : WFWD1) + LF_W2 + wave * 9);
+            cdptr w3p = (cdptr)(size_t)(block_of(A.wint, false, l) + LF_W2 + wave * 9);
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) w3[k * 9 + tp] = w3p[k * 72 + tp];
         }
         lds_barrier();
+        stamp(2);
 
         // ---- conv3 (8 -> 3) at the NA active sites; one input channel per wave
         const bool alane = lane < NA;
@@ -232,20 +307,21 @@ template <int L> struct Chain {
             for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NAS + lane] = acc[k];
         }
         lds_barrier();
+        stamp(3);
 
-        // ---- tan-mixture transform: wave k evaluates mixture component k (flow_fwd.hip, same arithmetic)
-        double Pa = 0.0;
+        // ---- tan-mixture transform: wave k evaluates mixture component k, wave NMIX the shift t (flow_fwd.hip, same
+        //      arithmetic); then ONE wave: the new plaquette, log J and the link update of the lane's own active link
+        double* sT2 = sm + G::T2;
         if (wave < NMIX && alane) {
-            Pa = sPA[lane];
-            double sk = sW[LF_B2 + wave];
+            double sk = sWc[LF_B2 + wave];
 #pragma unroll
             for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
             const double cs = sPA[NAS + lane], sn = sPA[2 * NAS + lane];
             const double es = ft_exp(sk), ems = ft_rcp(es);
             const double cs2 = cs * cs, sn2 = sn * sn, sincs = sn * cs;
             const double invD = ft_rcp(ems * cs2 + es * sn2);
-            sT2[(wave * TQ + 1) * NAS + lane] = invD;
-            sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
+            sT2[(wave * 2 + 1) * NAS + lane] = invD;
+            sT2[(wave * 2 + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
             if (STASH) {
                 const double sinP = 2.0 * sincs, invD2 = invD * invD;
                 double* tc = sv.tc + (size_t)wave * N + 4 * (size_t)lane;
@@ -254,97 +330,102 @@ template <int L> struct Chain {
             }
         }
         if (wave == NMIX && alane) {
-            double tv = sW[LF_B2 + NMIX];
+            double tv = sWc[LF_B2 + NMIX];
 #pragma unroll
             for (int q = 0; q < 8; ++q) tv += sST[(q * 3 + NMIX) * NAS + lane];
-            sPA[3 * NAS + lane] = tv;
+            sT2[2 * NMIX * NAS + lane] = tv;
         }
+        if (nl_ >= 0) weights_commit();
         lds_barrier();
+        stamp(4);
         double logj = 0.0;
         if (wave == 0) {
-            double ysum = 0.0, si = 0.0;
+            double lj = 0.0;
+            if (alane) {
+                double ysum = 0.0, si = 0.0;
 #pragma unroll
-            for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * TQ) * NAS + lane]; si += sT2[(k * TQ + 1) * NAS + lane]; }
-            const double newP = ft_wrap(ysum / NMIX + sPA[3 * NAS + lane]);
-            if (alane) sDL[ai * L + aj] = newP - Pa;
+                for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * 2) * NAS + lane]; si += sT2[(k * 2 + 1) * NAS + lane]; }
+                const double d = ft_wrap(ysum / NMIX + sT2[2 * NMIX * NAS + lane]) - sPA[lane];
+                const int at = ai * L + aj;
+                if (mu == 0) sX[at] = ft_wrap(d + sX[at]); else sX[N + at] = ft_wrap(-d + sX[N + at]);
+                if (want_logj) lj = log(si) - log((double)NMIX);
+            }
             if (want_logj) {
-                const double tot = ft_wave_sum(alane ? log(si) - log((double)NMIX) : 0.0);
+                const double tot = ft_wave_sum(lj);
                 if (lane == 0) logj = tot;
             }
         }
         lds_barrier();
-        // ---- link update x' = wrap(x +- delta) at the active links
-        if (tid < N) {
-            const int i = fdiv<L>(tid), j = tid - i * L;
-            if ((((mu == 0 ? j : i) - off) & 3) == 0) {
-                const double d = sDL[tid];
-                if (mu == 0) sX[tid] = ft_wrap(d + sX[tid]); else sX[N + tid] = ft_wrap(-d + sX[N + tid]);
-            }
-        }
-        lds_barrier();
+        if (nl_ >= 0) wcur ^= 1;
+        stamp(5);
         return logj;
     }
 
-    // ---- one coupling layer backward from the stash (gather form, flow_bwd_gather.hip): gP += this layer's contribution
-    __device__ void layer_bwd(int l, double cb) {
+    // the stash values of backward pass l (struct Stash), each in the thread that multiplies by it; four groups, so that a
+    // pass can refill each group for the pass behind it as soon as it has consumed it (no second copy in registers)
+    __device__ __forceinline__ void issue_tc(int l, BwdPre& q) const {
+        constexpr int N = G::N, NA = G::NA;
+        const Stash sv = stash_view(stash(l), A.B, b, N);
+        const int a = tid < NA ? tid : 0;                                  // transform adjoint at active site tid
+#pragma unroll
+        for (int k = 0; k < 4 * NMIX; k += 2) {
+            const double2_t t2 = ldg2(sv.tc + (size_t)(k >> 2) * N + 4 * a + (k & 3));
+            q.tcv[k] = t2.x; q.tcv[k + 1] = t2.y;
+        }
+    }
+    __device__ __forceinline__ void issue_cs(int l, BwdPre& q) const {
+        constexpr int N = G::N, NF = G::NF;
+        const int mu = l & 1, off = (l >> 1) & 3;
+        const Stash sv = stash_view(stash(l), A.B, b, N);
+        int fr, fc;
+        frozen_site(tid < NF ? tid : 0, mu, off, fr, fc);                  // cos / sin of frozen site tid
+        const int ic = stash_frozen_idx(fr, fc, L, mu, off);
+        if (FT_KNOB & 16) { q.fcs = 0.6; q.fsn = 0.8; } else { q.fcs = sv.cs[ic]; q.fsn = sv.cs[(N >> 1) + ic]; }
+    }
+    __device__ __forceinline__ void issue_d2(int l, BwdPre& q) const {
+        constexpr int N = G::N;
+        const Stash sv = stash_view(stash(l), A.B, b, N);
+        const int c3half = tid >= N ? 1 : 0, c3s = tid - c3half * N;       // conv3^T task = (site, half of the channels)
+        const double* pl = sv.d2 + 8 * (size_t)(tid < 2 * N ? c3s : 0) + 4 * c3half;
+        const double2_t va = ldg2(pl), vb = ldg2(pl + 2);
+        q.d2v[0] = va.x; q.d2v[1] = va.y; q.d2v[2] = vb.x; q.d2v[3] = vb.y;
+    }
+    __device__ __forceinline__ void issue_d1(int l, BwdPre& q) const {
+        constexpr int N = G::N;
+        const int mu = l & 1;
+        const Stash sv = stash_view(stash(l), A.B, b, N);
+        int r, c;
+        pair_site(mu, r, c);                                               // conv2^T epilogue: channels 2 g, 2 g + 1 at both sites
+        const int s0 = r * L + c, s1 = s0 + (mu == 0 ? 1 : L);
+        const double2_t va = ldg2(sv.d1 + 8 * (size_t)s0 + 2 * (lane >> 4)), vb = ldg2(sv.d1 + 8 * (size_t)s1 + 2 * (lane >> 4));
+        q.d1v[0] = va.x; q.d1v[1] = va.y; q.d1v[2] = vb.x; q.d1v[3] = vb.y;
+    }
+    __device__ __forceinline__ void bwd_issue(int l, BwdPre& q) const { issue_tc(l, q); issue_cs(l, q); issue_d2(l, q); issue_d1(l, q); }
+
+    // ---- one coupling layer backward from the stash (gather form, flow_bwd_gather.hip): gP += this layer's contribution.
+    //      `pre` holds this pass's stash values (bwd_issue); (nb, nl_): the pass that follows, or nl_ < 0.
+    __device__ void layer_bwd(int l, double cb, bool nb, int nl_) {
         constexpr int N = G::N, NA = G::NA, NF = G::NF, RS = G::RS, PSZ = G::PSZ;
         const int mu = l & 1, off = (l >> 1) & 3;
-        double* sGP = sm + G::GP;  double* sDir = sm + G::DIR;  double* sGO = sm + G::IN;  double* sGZ2 = sm + G::A8;
-        double* sD1 = sm + G::B8;  double* sW = sm + G::SW;  double* sPart = sm + G::A8;
-        const double* __restrict__ wl = A.wint + (size_t)l * FLOW_WINT;
-        const Stash sv = stash_view(stash(l), A.B, b, N);
-        // ---- load phase: everything this layer reads from the stash, issued in the order of use
-        constexpr int NWC = (LB_SIZE + NT - 1) / NT;
-        double wsw[NWC];
-#pragma unroll
-        for (int k = 0; k < NWC; ++k) wsw[k] = ldu(wl + (mu == 0 ? WBWD1 : WBWD), (unsigned)min(tid + k * NT, LB_SIZE - 1));
-        const bool ttask = tid < NA;                                       // transform adjoint at active site tid
-        double tcv[4 * NMIX];
-        {
-            const int a = ttask ? tid : 0;
-#pragma unroll
-            for (int q = 0; q < 4 * NMIX; q += 2) {
-                const double2_t t2 = ldg2(sv.tc + (size_t)(q >> 2) * N + 4 * a + (q & 3));
-                tcv[q] = t2.x; tcv[q + 1] = t2.y;
-            }
-        }
-        const bool ftask = tid < NF;                                       // cos / sin of frozen site tid
+        int tid = this->tid, lane = this->lane;                            // opaque per pass (see layer_fwd)
+        asm volatile("" : "+v"(tid), "+v"(lane));
+        double* sGP = sm + G::GP;  double* sGO = sm + G::IN;  double* sGZ2 = sm + G::A8;
+        double* sD1 = sm + G::B8;  double* sPart = sm + G::A8;
+        const double* sWc = sW();
+        // the next pass's weight block is requested first; its stash values (when it is a backward pass) refill `pre`
+        // group by group behind this pass's last use of each
+        const bool refill = nl_ >= 0 && nb;
+        if (nl_ >= 0) weights_issue(nb, nl_);
+        const bool ttask = tid < NA, ftask = tid < NF, c3task = tid < 2 * N;
+        const int c3half = tid >= N ? 1 : 0, c3s = tid - c3half * N;
         int fr = 0, fc = 0;
         frozen_site(ftask ? tid : 0, mu, off, fr, fc);
-        double fcs, fsn;
-        {
-            const int ic = stash_frozen_idx(fr, fc, L, mu, off);
-            fcs = sv.cs[ic]; fsn = sv.cs[(N >> 1) + ic];
-        }
-        // conv3^T task = (site, half of the 8 channels): act'(z2) of its four channels
-        const int c3half = tid >= N ? 1 : 0;
-        const int c3s = tid - c3half * N;
-        const bool c3task = tid < 2 * N;
-        double d2v[4];
-        {
-            const double* pl = sv.d2 + 8 * (size_t)(c3task ? c3s : 0) + 4 * c3half;
-            const double2_t va = ldg2(pl), vb = ldg2(pl + 2);
-            d2v[0] = va.x; d2v[1] = va.y; d2v[2] = vb.x; d2v[3] = vb.y;
-        }
-        // conv2^T: this lane's pair of tile `wave` (one tile per wave) and act'(z1) of its channels 2 g, 2 g + 1 at both sites
-        int pr_ = 0, pc_ = 0;                                              // site 0 of the pair; site 1 = next column (mu = 0) / row (mu = 1)
-        bool pok;
-        double d1v[4];
-        {
-            const int p_ = wave * 16 + (lane & 15);
-            pok = p_ < G::NPAIR;
-            const int p = pok ? p_ : G::NPAIR - 1;
-            if (mu == 0) { pr_ = fdiv<L / 2>(p); pc_ = 2 * (p - pr_ * (L / 2)); }
-            else { const int q = fdiv<L>(p); pr_ = 2 * q; pc_ = p - q * L; }
-            const int s0 = pr_ * L + pc_, s1 = s0 + (mu == 0 ? 1 : L);
-            const double2_t va = ldg2(sv.d1 + 8 * (size_t)s0 + 2 * (lane >> 4)), vb = ldg2(sv.d1 + 8 * (size_t)s1 + 2 * (lane >> 4));
-            d1v[0] = va.x; d1v[1] = va.y; d1v[2] = vb.x; d1v[3] = vb.y;
-        }
+        int pr_ = 0, pc_ = 0;
+        pair_site(mu, pr_, pc_);
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- consume: weights -> LDS, adjoint of the tan-mixture transform at the active sites
-#pragma unroll
-        for (int k = 0; k < NWC; ++k) if (tid + k * NT < LB_SIZE) sW[tid + k * NT] = wsw[k];
+        // ---- adjoint of the tan-mixture transform at the active sites; their own gP is complete here: nobody else reads
+        //      the gradient of an active plaquette (a task reads its own and its passive neighbour's)
         if (ttask) {
             int i, j;
             active_site(tid, mu, off, i, j);
@@ -353,18 +434,20 @@ template <int L> struct Chain {
             const double gdelta = g0 - g1;
             double csum = 0.0, esum = 0.0;
 #pragma unroll
-            for (int k = 0; k < NMIX; ++k) { csum += tcv[4 * k + 2]; esum += tcv[4 * k + 3]; }
+            for (int k = 0; k < NMIX; ++k) { csum += pre.tcv[4 * k + 2]; esum += pre.tcv[4 * k + 3]; }
             const double tsum = NMIX * csum;
             double rs = __builtin_amdgcn_rcp(tsum);
             rs = fma(fma(-tsum, rs, 1.0), rs, rs);
             rs = fma(fma(-tsum, rs, 1.0), rs, rs);
             const double cbr = cb * rs;
 #pragma unroll
-            for (int k = 0; k < NMIX; ++k) put1<L, RS>(sGO + k * PSZ, i, j, gdelta * tcv[4 * k] + cbr * tcv[4 * k + 1]);
+            for (int k = 0; k < NMIX; ++k) put1<L, RS>(sGO + k * PSZ, i, j, gdelta * pre.tcv[4 * k] + cbr * pre.tcv[4 * k + 1]);
             put1<L, RS>(sGO + NMIX * PSZ, i, j, gdelta);
-            sDir[i * L + j] = gdelta * (csum - 1.0) - cbr * esum;
+            sGP[i * L + j] = g0 + (gdelta * (csum - 1.0) - cbr * esum);
         }
+        if (refill) issue_tc(nl_, pre);
         lds_barrier();
+        stamp(8);
 
         // ---- conv3^T on the VALU (the one tap line that holds an active site), times act'(z2) -> gz2
         if (c3task) {
@@ -380,7 +463,7 @@ template <int L> struct Chain {
                         const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
                         g0[kk] = sGO[co * PSZ + (r + 2 - ky) * RS + c + 2 - kx];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) wq[kk][k] = sW[LB_W2 + (co * 8 + c3half * 4 + k) * 9 + ky * 3 + kx];
+                        for (int k = 0; k < 4; ++k) wq[kk][k] = sWc[LB_W2 + (co * 8 + c3half * 4 + k) * 9 + ky * 3 + kx];
                     }
 #pragma unroll
                     for (int kk = 0; kk < 3; ++kk)
@@ -389,34 +472,38 @@ template <int L> struct Chain {
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] = ksel <= 2 ? d2v[k] * acc[k] : 0.0;
+            for (int k = 0; k < 4; ++k) acc[k] = ksel <= 2 ? pre.d2v[k] * acc[k] : 0.0;
             put2<L, RS, PSZ>(sGZ2 + (c3half * 4) * PSZ, r, c, acc[0], acc[1]);
             put2<L, RS, PSZ>(sGZ2 + (c3half * 4 + 2) * PSZ, r, c, acc[2], acc[3]);
         }
+        if (refill) issue_d2(nl_, pre);
         lds_barrier();
+        stamp(9);
 
         // ---- conv2^T (MFMA over the flipped, transposed table T2), times act'(z1) -> gz1
         {
             auto epi = [&](int g, int, bool ok, double (&z)[4], int) {
                 if (!ok) return;
-                put2<L, RS, PSZ>(sD1 + 2 * g * PSZ, pr_, pc_, z[0] * d1v[0], z[1] * d1v[1]);
-                put2<L, RS, PSZ>(sD1 + 2 * g * PSZ, pr_ + (mu == 0 ? 0 : 1), pc_ + (mu == 0 ? 1 : 0), z[2] * d1v[2], z[3] * d1v[3]);
+                put2<L, RS, PSZ>(sD1 + 2 * g * PSZ, pr_, pc_, z[0] * pre.d1v[0], z[1] * pre.d1v[1]);
+                put2<L, RS, PSZ>(sD1 + 2 * g * PSZ, pr_ + (mu == 0 ? 0 : 1), pc_ + (mu == 0 ? 1 : 0), z[2] * pre.d1v[2], z[3] * pre.d1v[3]);
             };
             if (mu == 0)
-                mfma_stage<KConv2Col, G::NPAIR, RS, PSZ, false, false, 2>(sGZ2, sW + LB_T2, wave, lane,
+                mfma_stage<KConv2Col, G::NPAIR, RS, PSZ, false, false, 2>(sGZ2, sWc + LB_T2, wave, lane,
                     [&](int p) { const int r = fdiv<L / 2>(p); return r * RS + 2 * (p - r * (L / 2)); }, epi);
             else
-                mfma_stage<KConv2Row, G::NPAIR, RS, PSZ, false, false, 2>(sGZ2, sW + LB_T2, wave, lane,
+                mfma_stage<KConv2Row, G::NPAIR, RS, PSZ, false, false, 2>(sGZ2, sWc + LB_T2, wave, lane,
                     [&](int p) { const int q = fdiv<L>(p); return 2 * q * RS + (p - q * L); }, epi);
         }
         typedef const double __attribute__((address_space(4))) * cdptr;
         double w0s[18];
         {
-            cdptr wq = (cdptr)(size_t)(wl + (mu == 0 ? WBWD1 : WBWD) + LB_W0 + wave * 18);
+            cdptr wq = (cdptr)(size_t)(block_of(A.wint, true, l) + LB_W0 + wave * 18);
 #pragma unroll
             for (int k = 0; k < 18; ++k) w0s[k] = wq[k];
         }
+        if (refill) issue_d1(nl_, pre);
         lds_barrier();
+        stamp(10);
 
         // ---- conv1^T at the frozen sites: wave = hidden channel, the sum over the channels through LDS
         for (int f = lane; f < NF; f += 64) {
@@ -432,18 +519,19 @@ template <int L> struct Chain {
             sPart[(wave * 2 + 1) * NF + f] = gs;
         }
         lds_barrier();
+        stamp(11);
+        // the (cos, sin) adjoint lands in the gradient of the frozen plaquette itself: nothing else touches it in this pass
         if (ftask) {
             double gct = 0.0, gst = 0.0;
 #pragma unroll
             for (int co = 0; co < 8; ++co) { gct += sPart[(co * 2 + 0) * NF + tid]; gst += sPart[(co * 2 + 1) * NF + tid]; }
-            sDir[fr * L + fc] = -fsn * gct + fcs * gst;
+            sGP[fr * L + fc] += -pre.fsn * gct + pre.fcs * gst;
         }
+        if (refill) issue_cs(nl_, pre);
+        if (nl_ >= 0) weights_commit();
         lds_barrier();
-        if (tid < N) {
-            const int i = fdiv<L>(tid), j = tid - i * L;
-            if ((((mu == 0 ? j : i) - off) & 3) != 3) sGP[tid] += sDir[tid];
-        }
-        lds_barrier();
+        if (nl_ >= 0) wcur ^= 1;
+        stamp(12);
     }
 
     // ---- Wilson pieces on the links in sX ------------------------------------------------------------------
@@ -505,31 +593,41 @@ enum { SM_ACTION = 0, SM_FORCE = 1, SM_LEAPFROG = 2, SM_TRAJ = 3 };
 //   trajectory:  [EVAL] (unless state_in carries it), the leapfrog, regularize, [EVAL], Metropolis
 // The sweep loop has ONE call site of the layer bodies (the kernel is register- and code-size-bound otherwise).
 template <int L>
-__global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs A) {
+__global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
     using G = GS<L>;
     constexpr int N = G::N;
     __shared__ __attribute__((aligned(16))) double sm[G::SIZE];
     const int b = blockIdx.x;
-    Chain<L> C(sm, A, b);
+    const Hot hot{Aarg.wint, Aarg.stash, Aarg.dbg, Aarg.B, Aarg.nl, Aarg.act};
+    Chain<L> C(sm, hot, b);
     const int tid = C.tid;
     double* red = sm + G::RED;
-    const double* xb = A.x + (size_t)b * 2 * N;
-    for (int s = tid; s < 2 * N; s += NT) sm[G::XL + s] = xb[s];
-    const double beta = A.beta, dt = A.dt;
-    const int mode = A.mode;
+    const int mode = Aarg.mode, nl = hot.nl;
+    const double beta = Aarg.beta, dt = Aarg.dt;
+    const bool have_state = Aarg.state_in != nullptr;
+    {
+        const double* xb = cold().x + (size_t)b * 2 * N;
+        for (int s = tid; s < 2 * N; s += NT) sm[G::XL + s] = xb[s];
+    }
+    if (hot.dbg && tid < 32) reinterpret_cast<long long*>(sm + G::PROF)[tid] = 0;
     const bool moves = mode == SM_LEAPFROG || mode == SM_TRAJ;
-    const int nforce = mode == SM_ACTION ? 0 : (mode == SM_FORCE ? 1 : A.nstep);
+    const int nforce = mode == SM_ACTION ? 0 : (mode == SM_FORCE ? 1 : Aarg.nstep);
     // sweeps it = first .. last: it < 0 and it == nforce are EVAL sweeps, 0 <= it < nforce FORCE sweeps
-    const int first = (mode == SM_ACTION || (mode == SM_TRAJ && !A.state_in)) ? -1 : 0;
+    const int first = (mode == SM_ACTION || (mode == SM_TRAJ && !have_state)) ? -1 : 0;
     const int last = mode == SM_TRAJ ? nforce : (mode == SM_ACTION ? -1 : nforce - 1);
     // momenta of site tid in registers
     double v0 = 0.0, v1 = 0.0;
-    if (moves && tid < N) { v0 = A.v[(size_t)b * 2 * N + tid]; v1 = A.v[(size_t)b * 2 * N + N + tid]; }
-    double st_old[3] = {0.0, 0.0, 0.0}, st_new[3] = {0.0, 0.0, 0.0}, ld_eval = 0.0, k0 = 0.0;   // thread 0
+    if (moves && tid < N) { const double* vb = cold().v + (size_t)b * 2 * N; v0 = vb[tid]; v1 = vb[N + tid]; }
+    double* stt = sm + G::STT;                                             // thread 0's scalars live in LDS, not in registers of every lane
     if (mode == SM_TRAJ) {
-        if (A.state_in && tid == 0) { st_old[0] = A.state_in[b]; st_old[1] = A.state_in[A.B + b]; st_old[2] = A.state_in[2 * A.B + b]; }
-        k0 = ft_block_sum(v0 * v0 + v1 * v1, red);
+        if (have_state && tid == 0) { const double* si = cold().state_in; stt[0] = si[b]; stt[1] = si[hot.B + b]; stt[2] = si[2 * hot.B + b]; }
+        const double k0 = ft_block_sum(v0 * v0 + v1 * v1, red);
+        if (tid == 0) stt[6] = k0;
     }
+    // the first pass's weight block
+    C.weights_issue(false, 0);
+    C.weights_commit();
+    C.wcur ^= 1;
     lds_barrier();
 
     for (int it = first; it <= last; ++it) {
@@ -540,38 +638,50 @@ __global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs A) {
         }
         if (tid < N) { sm[G::X + tid] = sm[G::XL + tid]; sm[G::X + N + tid] = sm[G::XL + N + tid]; }
         lds_barrier();
+        C.stamp(16);
         double ld = 0.0;
-        for (int l = 0; l < A.nl; ++l) ld += C.layer_fwd(l, force, !force);
+        for (int l = 0; l < nl; ++l) {
+            // the pass behind this one: the next layer, the first backward pass, or the first layer of the next sweep
+            const bool nb = l + 1 == nl && force;
+            const int nl_ = l + 1 < nl ? l + 1 : (force ? nl - 1 : (it < last ? 0 : -1));
+            ld += C.layer_fwd(l, force, !force, nb, nl_);
+        }
         if (force) {
             // the stash of this sweep was written by other threads of this workgroup: complete and visible before it is read
             __syncthreads();
+            C.bwd_issue(nl - 1, C.pre);
             C.wilson_seed(beta);
-            for (int l = A.nl - 1; l >= 0; --l) C.layer_bwd(l, -1.0);
+            C.stamp(17);
+            for (int l = nl - 1; l >= 0; --l) C.layer_bwd(l, -1.0, l > 0, l > 0 ? l - 1 : (it < last ? 0 : -1));
             if (tid < N) {
                 double f0, f1;
                 C.site_force(f0, f1);
-                if (mode == SM_FORCE) { A.F[(size_t)b * 2 * N + tid] = f0; A.F[(size_t)b * 2 * N + N + tid] = f1; }
+                if (mode == SM_FORCE) { double* F = cold().F + (size_t)b * 2 * N; F[tid] = f0; F[N + tid] = f1; }
                 else {
                     v0 -= dt * f0; v1 -= dt * f1;
                     const double a = it == nforce - 1 ? 0.5 * dt : dt;
                     sm[G::XL + tid] += a * v0; sm[G::XL + N + tid] += a * v1;
                 }
             }
+            C.stamp(18);
         } else {
             double S, Q;
             C.action_charge(beta, S, Q);
-            double* st = it < 0 ? st_old : st_new;
-            st[0] = S - ld; st[1] = (-S) / (beta * (double)N); st[2] = Q;   // meaningful in thread 0 (ld lives there)
-            ld_eval = ld;
+            if (tid == 0) {                                                // ld lives in thread 0
+                double* st = stt + (it < 0 ? 0 : 3);
+                st[0] = S - ld; st[1] = (-S) / (beta * (double)N); st[2] = Q; stt[7] = ld;
+            }
+            C.stamp(19);
         }
     }
 
+    const SmallArgs& A = cold();                                           // outputs: read from the kernarg segment here
     if (mode == SM_ACTION) {
         if (tid == 0) {
-            if (A.S_eff) A.S_eff[b] = st_old[0];
-            if (A.logdet) A.logdet[b] = ld_eval;
-            if (A.plaq) A.plaq[b] = st_old[1];
-            if (A.Q) A.Q[b] = st_old[2];
+            if (A.S_eff) A.S_eff[b] = stt[0];
+            if (A.logdet) A.logdet[b] = stt[7];
+            if (A.plaq) A.plaq[b] = stt[1];
+            if (A.Q) A.Q[b] = stt[2];
         }
         if (A.x_out && tid < N) { A.x_out[(size_t)b * 2 * N + tid] = sm[G::X + tid]; A.x_out[(size_t)b * 2 * N + N + tid] = sm[G::X + N + tid]; }
         return;
@@ -584,17 +694,18 @@ __global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs A) {
         return;
     }
     if (mode != SM_TRAJ) return;
+    if (A.dbg && tid == 0) for (int k = 0; k < 32; ++k) A.dbg[(size_t)b * 32 + k] = reinterpret_cast<long long*>(sm + G::PROF)[k];
     // ---- Metropolis (ipynb/ft_hmc.py:427-435)
     const double k1 = ft_block_sum(v0 * v0 + v1 * v1, red);
     if (tid == 0) {
-        const double h0 = st_old[0] + 0.5 * k0, h1 = st_new[0] + 0.5 * k1;
+        const double h0 = stt[0] + 0.5 * stt[6], h1 = stt[3] + 0.5 * k1;
         const double d = h1 - h0;
         const bool ok = A.u[b] < exp(-d);
         if (A.dH) A.dH[b] = d;
         if (A.acc) A.acc[b] = ok ? 1.0 : 0.0;
         if (A.H0) A.H0[b] = h0;
         if (A.H1) A.H1[b] = h1;
-        const double* sel = ok ? st_new : st_old;
+        const double* sel = stt + (ok ? 3 : 0);
         if (A.state_out) { A.state_out[b] = sel[0]; A.state_out[A.B + b] = sel[1]; A.state_out[2 * A.B + b] = sel[2]; }
         if (A.plaq) A.plaq[b] = sel[1];
         if (A.Q) A.Q[b] = sel[2];
@@ -603,6 +714,7 @@ __global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs A) {
     __syncthreads();
     const bool ok = red[0] > 0.5;
     if (tid < N) {
+        const double* xb = A.x + (size_t)b * 2 * N;
         A.x_out[(size_t)b * 2 * N + tid] = ok ? sm[G::XL + tid] : xb[tid];
         A.x_out[(size_t)b * 2 * N + N + tid] = ok ? sm[G::XL + N + tid] : xb[N + tid];
     }

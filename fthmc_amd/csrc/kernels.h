@@ -121,6 +121,7 @@ struct SmallArgs {
     double *dH, *acc, *H0, *H1, *S_eff, *logdet, *plaq, *Q;   // per chain [B], each may be null
     double beta, dt;
     int nstep, mode, B, nl, act;   // mode: 0 action (forward sweep), 1 force, 2 leapfrog, 3 trajectory
+    long long* dbg;          // profiling runs: [B][32] cycles per stage, accumulated by thread 0 of each chain (else null)
 };
 bool ft_small_ok(int L, int n_layers);          // the fused path serves this shape (and is switched on)
 int launch_ft_small(const SmallArgs& a, int L, hipStream_t s);

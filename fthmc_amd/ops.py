@@ -491,3 +491,25 @@ def profile_stages(kind: str, x, w, mu=0, off=0, act='silu', beta=1.0):
     check(_lib.load().fthmc_profile_stages(k, _p(x), _p(_w1(w, x)), B, L, int(mu), int(off), act_code(act),
                                            float(beta), buf, ws, nb, _stream(x)), 'fthmc_profile_stages')
     return list(buf)
+
+
+def small_profile(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu'):
+    """Mean cycles per stage (32 slots, include/fthmc_hip.h) of one trajectory on the small-lattice fused path."""
+    import ctypes
+    x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
+    buf = (ctypes.c_double * 32)()
+    ws, nb = _ws(x, B, L, n_layers)
+    check(_lib.load().fthmc_small_profile(_p(x), _p(v), _p(u), _p(_wall(w, n_layers)), n_layers, B, L, act_code(act), float(beta),
+                                          float(dt), int(nstep), buf, ws, nb, _stream(x)), 'fthmc_small_profile')
+    return list(buf)
+
+
+def time_small(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', reps=20) -> float:
+    """Average milliseconds per launch of the small-lattice fused trajectory kernel (HIP events on the current stream)."""
+    import ctypes
+    x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
+    ms = ctypes.c_double(0.0)
+    ws, nb = _ws(x, B, L, n_layers)
+    check(_lib.load().fthmc_time_small(_p(x), _p(v), _p(u), _p(_wall(w, n_layers)), n_layers, B, L, act_code(act), float(beta),
+                                       float(dt), int(nstep), int(reps), ctypes.byref(ms), ws, nb, _stream(x)), 'fthmc_time_small')
+    return ms.value

@@ -209,6 +209,17 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
                       int act, double beta, int reps, double* ms_avg_host,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* Measurement hook: average milliseconds per launch of the small-lattice fused trajectory kernel (two action sweeps,
+ * nstep force sweeps, Metropolis), `reps` launches back to back between two HIP events on `stream`.  Synchronises. */
+int fthmc_time_small(const double* x, const double* v, const double* u, const double* w, int n_layers, int B, int L, int act,
+                     double beta, double dt, int nstep, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream);
+/* Measurement hook: one trajectory on the small-lattice fused path (fthmc_set_small_path) with cycle stamps of thread 0
+ * of every chain; cycles_host32[k] = mean over chains of the cycles spent in stage k, summed over the trajectory
+ * (0..6 forward layer stages, 8..13 backward layer stages, 16 copy, 17 Wilson seed, 18 kick, 19 action / charge).
+ * Synchronises. */
+int fthmc_small_profile(const double* x, const double* v, const double* u, const double* w, int n_layers, int B, int L,
+                        int act, double beta, double dt, int nstep, double* cycles_host32, void* ws, size_t ws_bytes,
+                        void* stream);
 /* Diagnostic (synchronises, mallocs on the host): one launch of the MFMA forward (kind 0), stash backward
  * (kind 1) or training backward (kind 2, ws: fthmc_train_ws_bytes) kernel with per-workgroup cycle stamps at every stage boundary;
  * cycles_host16[k] = mean cycles spent between stamp k-1 and stamp k. */

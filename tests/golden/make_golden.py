@@ -408,6 +408,37 @@ def main():
     obs['sigma_short'] = np.float64(ns['sigma'](list(obs['q_short'])))
     save('observables', **obs)
 
+    # ---- 11. BASELINE configs[1] at its real shape: 32 chains of L = 16, beta = 4, 4-layer flow, tau = 1, nstep = 10, one MD
+    #          trajectory with captured v, u (the structure of section 5 A); a warm start so that some chains accept
+    B, L, beta, nl, tau, nstep = 32, 16, 4.0, 4, 1.0, 10
+    flow = make_flow(nl, L, 3100)
+    param = cfg.Param(beta=beta, L=L, tau=tau, nstep=nstep)
+    torch.manual_seed(3101)
+    x = torch.empty(B, 2, L, L).uniform_(-math.pi, math.pi) * 0.12
+    v = torch.randn_like(x)
+    u = torch.rand(B, dtype=torch.float64)
+    dt = param.dt
+    with torch.no_grad():
+        h0 = qed.ft_action(param, flow, x) + 0.5 * (v * v).flatten(1).sum(1)
+    x_ = x + 0.5 * dt * v
+    p_ = v + (-dt) * qed.ft_force(param, flow, x_)
+    for _ in range(nstep - 1):
+        x_ = x_ + dt * p_
+        p_ = p_ + (-dt) * qed.ft_force(param, flow, x_)
+    x_ = x_ + 0.5 * dt * p_
+    xr = qed.regularize(x_)
+    with torch.no_grad():
+        h1 = qed.ft_action(param, flow, xr) + 0.5 * (p_ * p_).flatten(1).sum(1)
+        dH = h1 - h0
+        acc = u < torch.exp(-dH)
+        newx = torch.where(acc[:, None, None, None], xr, x)
+        yphys = qed.ft_flow(flow, newx)
+    print('config-2 golden: accepted', int(acc.sum()), 'of', B, ' max |dH|', float(dH.abs().max()))
+    save('traj_md_config2', x=npy(x), v=npy(v), u=npy(u), beta=beta, dt=dt, nstep=nstep,
+         lf_x=npy(x_), lf_p=npy(p_), H0=npy(h0), H1=npy(h1), dH=npy(dH), acc=npy(acc).astype(bool),
+         newx=npy(newx), plaq=npy(-qed.BatchAction(beta)(yphys) / (beta * L * L)),
+         Q=npy(qed.batch_charges(yphys)), **flow_arrays(flow))
+
 
 if __name__ == '__main__':
     main()

@@ -24,12 +24,15 @@ def _mods():
     ops, R = _ops, _R
 
 
-@pytest.fixture(params=[1, 0], ids=['mfma', 'valu'], autouse=True)
+@pytest.fixture(params=[(1, 1), (0, 1), (1, 0)], ids=['mfma', 'valu', 'mfma-tiled'], autouse=True)
 def variant(request, _mods):
-    """Every parity test runs against both conv-kernel variants (C ABI: fthmc_set_variant)."""
-    ops.set_variant(request.param)
-    yield request.param
+    """Every parity test runs against both conv-kernel variants (C ABI: fthmc_set_variant), and the MFMA variant also
+    with the small-lattice fused path switched off (fthmc_set_small_path: L = 8, 12, 16 then take the tiled kernels)."""
+    ops.set_variant(request.param[0])
+    ops.set_small_path(bool(request.param[1]))
+    yield request.param[0]
     ops.set_variant(1)
+    ops.set_small_path(True)
 
 
 def D(a):
@@ -150,7 +153,7 @@ def test_ft_action_force_golden(name):
     close(ldb, -g['logdet'], atol=1e-7)
 
 
-@pytest.mark.parametrize('name', ['traj_md_L8', 'traj_md_L16'])
+@pytest.mark.parametrize('name', ['traj_md_L8', 'traj_md_L16', 'traj_md_config2'])
 def test_traj_md_golden(name):
     g = load_golden(name)
     flow = golden_flow(g); nl = len(flow)

@@ -127,7 +127,7 @@ def test_ft_action_force(name):
         close(ldb, g['rev_logdet'], rtol=1e-8, atol=1e-8)
 
 
-@pytest.mark.parametrize('name', ['traj_md_L8', 'traj_md_L16'])
+@pytest.mark.parametrize('name', ['traj_md_L8', 'traj_md_L16', 'traj_md_config2'])
 def test_traj_md(name):
     g = load_golden(name)
     flow = golden_flow(g)

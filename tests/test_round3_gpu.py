@@ -141,8 +141,8 @@ def test_bench_times_several_regions_when_one_is_short(tmp_path):
     reg = line['regions']
     assert reg['n'] == 5 and len(reg['seconds']) == 5 and line['steps'] == 5
     med = sorted(reg['seconds'])[2]
-    assert abs(line['ms_per_step'] - med / 5 * 1e3) < 1e-3 * max(1.0, line['ms_per_step'])
-    assert abs(line['value'] - line['config']['chains_total'] * 10 * 5 / med) < 1e-3 * line['value']
+    assert abs(line['ms_per_step'] - med / 5 * 1e3) < 1e-2 * line['ms_per_step']
+    assert abs(line['value'] - line['config']['chains_total'] * 10 * 5 / med) < 1e-2 * line['value']
 
 
 # ---------------------------------------------------------------- the reference's import path
@@ -228,3 +228,89 @@ def test_layer_calls_with_output_aliasing_input(variant):
         close(lds, tot, rtol=1e-13, atol=1e-12)
     finally:
         ops.set_variant(1)
+
+
+# ---------------------------------------------------------------- small-lattice fused path (csrc/flow_small.hip)
+def _both_paths(fn):
+    ops.set_small_path(True)
+    try:
+        a = fn()
+        ops.set_small_path(False)
+        b = fn()
+    finally:
+        ops.set_small_path(True)
+    return a, b
+
+
+@pytest.mark.parametrize('L,nl,B,beta,act', [(16, 4, 32, 4.0, 'silu'), (8, 2, 3, 2.0, 'silu'), (12, 8, 5, 3.0, 'silu'),
+                                             (16, 16, 2, 4.0, 'relu'), (8, 8, 1, 2.0, 'leaky_relu'), (12, 1, 7, 4.0, 'silu')])
+def test_small_lattice_path_equals_tiled_path(L, nl, B, beta, act):
+    """L = 8, 12, 16 run by default as ONE launch per trajectory / force / action (one workgroup per chain, periodic planes
+    in LDS).  Same results as the tiled kernels (one launch per layer) on the same inputs: every entry point that takes
+    the path, to fp64 round-off (1e-11; trajectories 1e-9 after 6 MD steps)."""
+    import bench
+    gen = torch.Generator().manual_seed(100 + L + nl)
+    flow = bench.make_flow(gen, nl)
+    w = ops.pack_weights(flow, device='cuda')
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()
+    u = torch.rand(B, generator=gen, dtype=torch.float64).cuda()
+    (ya, lda), (yb, ldb) = _both_paths(lambda: ops.flow_forward(x, w, nl, act))
+    angle_close(ya, yb, atol=1e-11); close(lda, ldb, rtol=1e-12, atol=1e-10)
+    (Sa, la, pa, qa), (Sb, lb, pb, qb) = _both_paths(lambda: ops.ft_action(x, w, nl, beta, act))
+    close(Sa, Sb, rtol=1e-12, atol=1e-10); close(la, lb, rtol=1e-12, atol=1e-10); close(pa, pb, rtol=1e-12); close(qa, qb, atol=1e-10)
+    Fa, Fb = _both_paths(lambda: ops.ft_force(x, w, nl, beta, act))
+    close(Fa, Fb, rtol=1e-10, atol=1e-11 * float(Fb.abs().max()))
+    assert torch.equal(Fa, ops.ft_force(x, w, nl, beta, act))                       # deterministic
+    xs = (0.3 * x).contiguous()
+    (xa, va), (xb_, vb) = _both_paths(lambda: ops.ft_leapfrog(xs, v, w, nl, beta, 0.05, 4, act))
+    angle_close(xa, xb_, atol=1e-10); close(va, vb, rtol=1e-9, atol=1e-9)
+    ra, rb = _both_paths(lambda: ops.ft_trajectory(xs, v, u, w, nl, beta, 0.05, 6, act))
+    close(ra['H0'], rb['H0'], rtol=1e-12); close(ra['H1'], rb['H1'], rtol=1e-10); close(ra['dH'], rb['dH'], atol=1e-8)
+    assert torch.equal(ra['acc'], rb['acc'])
+    angle_close(ra['x_new'], rb['x_new'], atol=1e-9); close(ra['state'], rb['state'], rtol=1e-10, atol=1e-9)
+    close(ra['plaq'], rb['plaq'], rtol=1e-10); close(ra['Q'], rb['Q'], atol=1e-9)
+    # chained (state_in from the previous launch) == stateless, bit for bit; a chain alone == the chain in its batch
+    rc = ops.ft_trajectory(ra['x_new'].clone(), v, u, w, nl, beta, 0.05, 6, act, state_in=ra['state'].clone())
+    rd = ops.ft_trajectory(ra['x_new'].clone(), v, u, w, nl, beta, 0.05, 6, act)
+    for k in ('x_new', 'dH', 'H0', 'H1', 'acc', 'state', 'plaq', 'Q'):
+        assert torch.equal(rc[k], rd[k]), k
+    k = B - 1
+    r1 = ops.ft_trajectory(xs[k:k + 1].contiguous(), v[k:k + 1].contiguous(), u[k:k + 1].contiguous(), w, nl, beta, 0.05, 6, act)
+    for key in ('x_new', 'dH', 'H0', 'H1', 'acc'):
+        assert torch.equal(r1[key][0], ra[key][k]), key
+
+
+def test_small_lattice_path_against_the_oracle_and_in_a_graph():
+    """Config-2 shape against the oracle (not only against the other kernels), and the one-launch trajectory captured
+    into a hipGraph and replayed."""
+    gen = torch.Generator().manual_seed(2)
+    B, L, nl, beta, dt, nstep = 6, 16, 4, 4.0, 0.1, 10
+    flow = R.default_flow(nl, gen)
+    w = ops.pack_weights(flow, device='cuda')
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * 0.4).contiguous()
+    v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64)
+    u = torch.rand(B, generator=gen, dtype=torch.float64)
+    assert ops.get_small_path()
+    r = ops.ft_trajectory(x.cuda(), v.cuda(), u.cuda(), w, nl, beta, dt, nstep)
+    dH, _, acc, newx, h0, h1 = R.ft_hmc(x, v, u, flow, beta, dt, nstep, mode='md')
+    close(r['H0'], h0, rtol=1e-11); close(r['H1'], h1, rtol=1e-8); close(r['dH'], dH, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(H(r['acc']) > 0.5, H(acc))
+    angle_close(r['x_new'], newx, atol=1e-7)
+    close(ops.ft_force(x.cuda(), w, nl, beta), R.ft_force(x, flow, beta), rtol=1e-9, atol=1e-9)
+    # graph capture: workspace warmed by the eager call above
+    xd, vd, ud = x.cuda(), v.cuda(), u.cuda()
+    out = {k: torch.empty_like(t) for k, t in r.items()}
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ops.ft_trajectory(xd, vd, ud, w, nl, beta, dt, nstep, out=out)
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            ops.ft_trajectory(xd, vd, ud, w, nl, beta, dt, nstep, out=out)
+        for t in out.values():
+            t.zero_()
+        g.replay()
+        st.synchronize()
+    for k in ('x_new', 'dH', 'H0', 'H1', 'acc', 'plaq', 'Q'):
+        assert torch.equal(out[k], r[k]), k

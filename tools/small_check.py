@@ -85,5 +85,14 @@ for small in (True, False):
         torch.cuda.synchronize()
         print(f'   {name}: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms', flush=True)
 ops.set_small_path(True)
+cyc = ops.small_profile(x, v, u, w, nl, beta, 0.1, 10)
+names = {0: 'fwd weights+plaq+sincos', 1: 'fwd conv1', 2: 'fwd conv2', 3: 'fwd conv3', 4: 'fwd transform', 5: 'fwd newP/logJ', 6: 'fwd link update',
+         8: 'bwd loads+transform adj', 9: 'bwd conv3T', 10: 'bwd conv2T', 11: 'bwd conv1T', 12: 'bwd channel sum', 13: 'bwd gP update',
+         16: 'copy latent', 17: 'sync+wilson seed', 18: 'kick/drift', 19: 'action/charge'}
+tot = sum(cyc)
+print(f'profile (cycles of thread 0, one trajectory = 44 fwd + 40 bwd layers, total {tot:.0f}):')
+for k, nme in names.items():
+    per = cyc[k] / (44 if k < 8 else 40 if k < 16 else 1)
+    print(f'   {k:2d} {nme:28s} {cyc[k]:10.0f}  ({100 * cyc[k] / tot:4.1f} %)  per layer {per:8.0f}')
 print('WORST', worst)
 sys.exit(0 if worst < 1e-9 else 1)

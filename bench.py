@@ -430,7 +430,9 @@ def main():
     with torch.cuda.stream(stream):
         ms_leap = ops.time_kernel('leap_step', x, beta=BETA, reps=40)
         ms_traj = ops.time_kernel('hmc_trajectory', x, beta=BETA, reps=20) if L <= 64 else None
-    stencil = {'kernel': 'k_force<1> (fused plain-HMC leapfrog step, one launch per step)',
+    stencil = {'kernel': ('k_leap_rows<8> (fused plain-HMC leapfrog step: 8 rows x 64 columns per workgroup, two sites and 16-byte '
+                          'accesses per thread, one launch per step)' if L % 64 == 0 else
+                          'k_force<1> (fused plain-HMC leapfrog step on 16 x 16 tiles, one launch per step)'),
                'avg_launch_ms': round(ms_leap, 5),
                'achieved_GBps': round(64.0 * L * L * B / (ms_leap * 1e-3) / 1e9, 1), 'peak_GBps': HBM_PEAK_GBPS}
     if ms_traj is not None:

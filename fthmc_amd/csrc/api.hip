@@ -191,6 +191,7 @@ const char* fthmc_version(void) { return "fthmc_hip 0.1 (gfx950)"; }
 
 int fthmc_set_variant(int v) {
     if (v != 0 && v != 1) return FTHMC_ERR_ARG;
+    if (const char* e = getenv("FTHMC_LEAP_ROWS")) set_leap_rows(atoi(e) != 0);     // measurement switch, read with the variant
     set_flow_variant(v);
     return FTHMC_OK;
 }

@@ -156,6 +156,82 @@ __global__ __launch_bounds__(256) void k_force(const double* __restrict__ x,
     }
 }
 
+// Fused leapfrog step for lattices whose rows are whole multiples of 64 sites: x' = x + a p ; p' = p - dt F(x').
+// A workgroup owns TR rows x 64 columns of one chain; a thread owns TWO adjacent sites of one row, so every access to the
+// four planes (x0, x1, p0, p1) is one 16-byte load / store per lane and a wave covers two whole 512-byte row segments.
+// The drifted links of the (TR + 2) x 66 window go through LDS once (the momenta of the halo are folded in at the load and
+// never stored; the own momenta stay in registers), beta sin P is evaluated once per plaquette of the (TR + 1) x 65
+// window, the force of a site is two differences of it.  HBM-bound: 64 B per site and launch algorithmically; the halo
+// rows (2.5 of TR + ... per plane pair) are re-reads that the neighbouring workgroup's own loads leave in L2.
+template <int TR>
+__global__ __launch_bounds__(TR * 32) void k_leap_rows(const double* __restrict__ x, const double* __restrict__ p,
+                                                       double* __restrict__ xo, double* __restrict__ po,
+                                                       int L, double beta, double a, double dt) {
+    constexpr int TC = 64, WC = TC + 2, NTH = TR * 32;
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    // window row r <-> lattice row i0 - 1 + r, window column c <-> lattice column j0 - 1 + c
+    __shared__ __attribute__((aligned(16))) double sx0[(TR + 1) * WC], sx1[(TR + 2) * WC], ss[(TR + 1) * WC];
+    const int b = blockIdx.z, i0 = blockIdx.y * TR, j0 = blockIdx.x * TC;
+    const int n = L * L, t = threadIdx.x;
+    const double* x0 = x + (size_t)b * 2 * n;
+    const double* p0 = p + (size_t)b * 2 * n;
+    auto wrapi = [&](int v) { return v < 0 ? v + L : (v >= L ? v - L : v); };
+    // own sites: row i0 + tr, columns j0 + 2 q, j0 + 2 q + 1
+    const int tr = t >> 5, q = t & 31;
+    const int own = (i0 + tr) * L + j0 + 2 * q;
+    const double2_t vx0 = *reinterpret_cast<const double2_t*>(x0 + own), vx1 = *reinterpret_cast<const double2_t*>(x0 + n + own);
+    const double2_t vp0 = *reinterpret_cast<const double2_t*>(p0 + own), vp1 = *reinterpret_cast<const double2_t*>(p0 + n + own);
+    // halo rows: plane 0 at i0 - 1, plane 1 at i0 - 1 and at i0 + TR (16 bytes per lane), then the halo columns
+    // (plane 0 at j0 + 64 and j0 - 1, plane 1 at j0 - 1: one site per lane)
+    double2_t hx = {0.0, 0.0}, hp = {0.0, 0.0};
+    double cx = 0.0, cp = 0.0;
+    int hrow = -1, hplane = 0, crow = -1, ccol = 0, cplane = 0;
+    if (t < 96) {
+        const int which = t >> 5;
+        hplane = which == 0 ? 0 : 1;
+        hrow = which == 2 ? TR + 1 : 0;
+        const int at = hplane * n + wrapi(i0 - 1 + hrow) * L + j0 + 2 * q;
+        hx = *reinterpret_cast<const double2_t*>(x0 + at); hp = *reinterpret_cast<const double2_t*>(p0 + at);
+    } else if (t < 96 + 3 * TR + 2) {
+        const int k = t - 96;
+        if (k < TR + 1) { cplane = 0; ccol = TC + 1; crow = k; }                  // x0' at column j0 + 64, rows 0 .. TR
+        else if (k < 2 * TR + 1) { cplane = 0; ccol = 0; crow = k - TR; }          // x0' at column j0 - 1, rows 1 .. TR
+        else { cplane = 1; ccol = 0; crow = k - 2 * TR; }                          // x1' at column j0 - 1, rows 1 .. TR + 1
+        const int at = cplane * n + wrapi(i0 - 1 + crow) * L + wrapi(j0 - 1 + ccol);
+        cx = x0[at]; cp = p0[at];
+    }
+    // drift (own sites in registers, the window through LDS)
+    const double2_t nx0 = {vx0.x + a * vp0.x, vx0.y + a * vp0.y}, nx1 = {vx1.x + a * vp1.x, vx1.y + a * vp1.y};
+    {
+        const int at = (tr + 1) * WC + 1 + 2 * q;
+        sx0[at] = nx0.x; sx0[at + 1] = nx0.y; sx1[at] = nx1.x; sx1[at + 1] = nx1.y;
+    }
+    if (hrow >= 0) {
+        double* d = (hplane == 0 ? sx0 : sx1) + hrow * WC + 1 + 2 * q;
+        d[0] = hx.x + a * hp.x; d[1] = hx.y + a * hp.y;
+    }
+    if (crow >= 0) (cplane == 0 ? sx0 : sx1)[crow * WC + ccol] = cx + a * cp;
+    __syncthreads();
+    // beta sin P on window rows 0 .. TR, columns 0 .. 64 (the corner (0, 0) is never used)
+    for (int u = t; u < (TR + 1) * (TC + 1); u += NTH) {
+        const int r = u / (TC + 1), c = u - r * (TC + 1);
+        double sn, cs;
+        ft_sincos(sx0[r * WC + c] - sx1[r * WC + c] - sx0[r * WC + c + 1] + sx1[(r + 1) * WC + c], &sn, &cs);
+        ss[r * WC + c] = beta * sn;
+    }
+    __syncthreads();
+    {
+        const int at = (tr + 1) * WC + 1 + 2 * q;
+        const double s_l = ss[at - 1], s_a = ss[at], s_b = ss[at + 1], u_a = ss[at - WC], u_b = ss[at - WC + 1];
+        const double2_t np0 = {vp0.x - dt * (s_a - s_l), vp0.y - dt * (s_b - s_a)};
+        const double2_t np1 = {vp1.x - dt * (u_a - s_a), vp1.y - dt * (u_b - s_b)};
+        double* xb = xo + (size_t)b * 2 * n;
+        double* pb = po + (size_t)b * 2 * n;
+        *reinterpret_cast<double2_t*>(xb + own) = nx0; *reinterpret_cast<double2_t*>(xb + n + own) = nx1;
+        *reinterpret_cast<double2_t*>(pb + own) = np0; *reinterpret_cast<double2_t*>(pb + n + own) = np1;
+    }
+}
+
 // v' = v - dt * adj(gP)   (adjoint of the plaquette stencil applied to a plaquette-
 // gradient field; closes one flowed leapfrog kick), optionally followed by the
 // drift x' = x + a v'.  In place on v (and x): every thread touches its own site only.
@@ -313,12 +389,16 @@ __global__ __launch_bounds__(TJ_NT) void k_hmc_trajectory(const double* __restri
         }
 }
 
+int g_leap_rows = 1;     // FTHMC_LEAP_ROWS=0 in the environment: the 16 x 16-tile kernel for every L (A/B runs)
+
 inline int ew_grid(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 2048 ? 2048 : (g ? g : 1)); }
 inline dim3 tile_grid(int B, int L) { return dim3((L + TS - 1) / TS, (L + TS - 1) / TS, B); }
 
 }  // namespace
 
 namespace fthmc {
+
+void set_leap_rows(int v) { g_leap_rows = v; }
 
 int launch_wrap(const double* x, double* o, size_t n, int reg, hipStream_t s) {
     if (n == 0) return FTHMC_OK;
@@ -358,6 +438,11 @@ int launch_wilson_force(const double* x, int B, int L, double beta, double* F, h
 }
 int launch_leap_step(const double* x, const double* p, double* xo, double* po, int B, int L,
                      double beta, double a, double dt, hipStream_t s) {
+    if (L % 64 == 0 && g_leap_rows) {            // whole 64-site row segments: 16-byte accesses, two sites per thread
+        constexpr int TR = 8;
+        hipLaunchKernelGGL(k_leap_rows<TR>, dim3(L / 64, L / TR, B), dim3(TR * 32), 0, s, x, p, xo, po, L, beta, a, dt);
+        FT_LAUNCH_CHECK(); return FTHMC_OK;
+    }
     hipLaunchKernelGGL(k_force<1>, tile_grid(B, L), dim3(256), 0, s, x, p, xo, po, L, beta, a, dt);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }

@@ -314,3 +314,27 @@ def test_small_lattice_path_against_the_oracle_and_in_a_graph():
         st.synchronize()
     for k in ('x_new', 'dH', 'H0', 'H1', 'acc', 'plaq', 'Q'):
         assert torch.equal(out[k], r[k]), k
+
+
+# ---------------------------------------------------------------- row-strip leapfrog kernel (L % 64 == 0)
+@pytest.mark.parametrize('B,L', [(3, 64), (2, 128), (1, 192)])
+def test_row_strip_leapfrog_kernel(B, L):
+    """k_leap_rows (16-byte accesses, two sites per thread; serves L % 64 == 0) == the 16 x 16-tile kernel bit for bit
+    (same arithmetic per site), == the oracle's leapfrog to round-off, and reversible."""
+    gen = torch.Generator().manual_seed(64 + L)
+    beta, dt, nstep = 3.0, 0.1, 5
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi)
+    p = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64)
+    xa, pa = ops.leapfrog(x.cuda(), p.cuda(), beta, dt, nstep)
+    os.environ['FTHMC_LEAP_ROWS'] = '0'
+    try:
+        ops.set_variant(1)
+        xb, pb = ops.leapfrog(x.cuda(), p.cuda(), beta, dt, nstep)
+    finally:
+        os.environ['FTHMC_LEAP_ROWS'] = '1'
+        ops.set_variant(1)
+    assert torch.equal(xa, xb) and torch.equal(pa, pb)
+    xr, pr = R.leapfrog(x, p, lambda y: R.wilson_force_analytic(y, beta), dt, nstep)
+    close(xa, xr, rtol=1e-11, atol=1e-11); close(pa, pr, rtol=1e-11, atol=1e-11)
+    x2, p2 = ops.leapfrog(xa, -pa, beta, dt, nstep)
+    close(x2, x, rtol=1e-10, atol=1e-10); close(-p2, p, rtol=1e-10, atol=1e-10)

@@ -40,6 +40,9 @@ template <int TR, int TC> struct SmemG {
     // fall into 16 different banks
     static constexpr int RS2 = W2C + 1;
     static constexpr int PS2 = ps_round16(W2R * RS2), PS1 = ps_round(N1W);   // gz2: MFMA operand; gz1: read by four channel lanes per site
+    // (cos, sin) of the frozen plaquettes: on the tile+2 window when conv1 is recomputed here (its MFMA operand), else tile+1
+    static constexpr int WIR = FT_RECOMP_D1 ? TR + 4 : W1R, WIC = FT_RECOMP_D1 ? TC + 4 : W1C, NIW = WIR * WIC;
+    static constexpr int PSI = FT_RECOMP_D1 ? ps_round16(NIW) : PS1, IOFF = FT_RECOMP_D1 ? 2 : 1;   // IOFF: window origin = tile - IOFF
     // active lines of the g_out window: every 4th column (mu = 0) or row (mu = 1)
     static constexpr int NLC = (W3C + 3) / 4, NLR = (W3R + 3) / 4;
     static constexpr int NSLOT = cmax_(W3R * NLC, NLR * W3C);           // transform tasks
@@ -47,12 +50,13 @@ template <int TR, int TC> struct SmemG {
     static constexpr int GO = 0;                                        // [3][N3W] g(s0, s1, t)
     static constexpr int GZ2 = GO + 3 * N3W;                            // [8][PS2] gz2
     static constexpr int D1 = GZ2 + 8 * PS2;                            // [8][PS1] gz1
-    static constexpr int IN = D1 + 8 * PS1;                             // [2][PS1] cos, sin (tile+1 coordinates)
-    static constexpr int DIR = IN + 2 * PS1;                            // [N3] layer's contribution at own sites
+    static constexpr int IN = D1 + 8 * PS1;                             // [2][PSI] cos, sin
+    static constexpr int DIR = IN + 2 * PSI;                            // [N3] layer's contribution at own sites
+    static constexpr int P1 = D1;                                       // [LF_P1_SIZE] conv1 tables, until conv2^T's epilogues write gz1 there
     static constexpr int SW = DIR + N3;                                 // [LB_SIZE] backward weight block (flow_common.h)
     static constexpr int SIZE = SW + LB_SIZE;
     static_assert(W1R % 2 == 0, "row pairs");
-    static_assert(NTT <= NT && 2 * N3 <= NT && N1W <= NT, "thread maps");
+    static_assert(NTT <= NT && 2 * N3 <= NT && N1W <= NT && NIW <= NT && LF_P1_SIZE <= NT && LF_P1_SIZE <= 8 * PS1, "thread maps");
     static_assert(2 * SIZE * 8 <= 160 * 1024, "two workgroups per CU (160 KB of LDS on gfx950)");
 };
 
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     using S = SmemG<TR, TC>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
     constexpr int W1R = S::W1R, W1C = S::W1C, N3 = S::N3, PS1 = S::PS1, PS2 = S::PS2, RS2 = S::RS2;
+    constexpr int WIC = S::WIC, NIW = S::NIW, PSI = S::PSI, IOFF = S::IOFF;
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
     double* sGO = sm + S::GO;   double* sGZ2 = sm + S::GZ2;  double* sD1 = sm + S::D1;
     double* sIn = sm + S::IN;   double* sDir = sm + S::DIR;  double* sW = sm + S::SW;
@@ -156,21 +161,37 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         ag[0] = ldu(gsrc, (unsigned)(iL + j));
         ag[1] = ldu(gsrc, (unsigned)(mu == 0 ? iL + WJ(tc3 - 4) : WI(tr3 - 4) + j));   // unused with up_link
     }
-    // (2) cos / sin of the tile's own frozen plaquettes.  Stored in tile+1 coordinates.
-    int fr1 = 1, fc1 = 1;                                                // tile+1 coordinates of this thread's site
+    // (2) cos / sin of the frozen plaquettes: of the tile's own sites (the adjoint of the net input), and with FT_RECOMP_D1 of
+    //     the whole tile+2 window (the input of the recomputed conv1), one window site per thread; a non-frozen site feeds the
+    //     net the constant (1, 0).  Idle and non-frozen lanes read element 0 and drop it.
+    int fwin = 0;                                                        // this thread's slot in the (cos, sin) planes
     bool ftask = false;
-    if (tid < N3 / 2) {
-        int r, c;
-        if (mu == 0) { r = fdiv<TC / 2>(tid); const int h = tid - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
-        else { const int hh = fdiv<TC>(tid); c = tid - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
-        fr1 = r + 1; fc1 = c + 1; ftask = true;
-    }
-    double fcs, fsn;                                                     // the net sees (1, 0) at non-frozen sites
-    {
+    double fcs, fsn;
+    if (FT_RECOMP_D1) {
+        const int r = fdiv<WIC>(tid), c = tid - r * WIC;
+        ftask = tid < NIW;
+        fwin = ftask ? tid : 0;
+        const int cls = ((mu == 0 ? j0 + c : i0 + r) - IOFF - off) & 3;
+        const bool frozen = ftask && (cls == 1 || cls == 2);
+        const unsigned ic = frozen ? (unsigned)stash_frozen_idx(wi(r - IOFF), WJ(c - IOFF), L, mu, off) : 0u;
+        fcs = ldu(scs, ic); fsn = ldu(scs + (n >> 1), ic);
+        if (!frozen) { fcs = 1.0; fsn = 0.0; }
+    } else {
+        int fr1 = 1, fc1 = 1;                                            // tile+1 coordinates of this thread's site
+        if (tid < N3 / 2) {
+            int r, c;
+            if (mu == 0) { r = fdiv<TC / 2>(tid); const int h = tid - r * (TC / 2); c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
+            else { const int hh = fdiv<TC>(tid); c = tid - hh * TC; r = 4 * (hh >> 1) + ((off + 1 + (hh & 1)) & 3); }
+            fr1 = r + 1; fc1 = c + 1; ftask = true;
+        }
+        fwin = fr1 * W1C + fc1;
         const unsigned ic = ftask ? (unsigned)stash_frozen_idx(wi(fr1 - 1), WJ(fc1 - 1), L, mu, off) : 0u;
         fcs = ldu(scs, ic); fsn = ldu(scs + (n >> 1), ic);
         if (!ftask) { fcs = 1.0; fsn = 0.0; }
     }
+    // the conv1 tables of the forward block (P1, BC: flow_common.h), one entry per thread
+    double wp1 = 0.0;
+    if (FT_RECOMP_D1) wp1 = ldu(w + (mu == 0 ? WFWD0 : WFWD1) + LF_P1, (unsigned)min(tid, LF_P1_SIZE - 1));
     // (3) upstream gradient of the own sites (pass-through term)
     const int orr = fdiv<TC>(tid), occ = tid - orr * TC;
     const bool ovalid = tid < N3 && orr < rmax && occ < cmax;
@@ -229,9 +250,11 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         else { pu[it] = 2 * (i >> 1) + (T - NU); pv[it] = 16 + (i & 1); pok[it] = T < NTILE1 && pu[it] < NU; if (!pok[it]) { pu[it] = 0; pv[it] = 0; } }
         const int ra = mu == 0 ? pv[it] : 2 * pu[it], ca = mu == 0 ? 2 * pu[it] : pv[it];
         const int ga = WI(ra - 1) + WJ(ca - 1), gb = mu == 0 ? WI(ra - 1) + WJ(ca) : WI(ra) + WJ(ca - 1);
-        const unsigned og = 2u * (unsigned)(lane >> 4);                      // channels 2 g, 2 g + 1: one 16-byte load per site
-        const double2_t va = ldu2(st1, (unsigned)ga * 8u + og), vb = ldu2(st1, (unsigned)gb * 8u + og);
-        d1v[it][0] = va.x; d1v[it][1] = va.y; d1v[it][2] = vb.x; d1v[it][3] = vb.y;
+        if (!FT_RECOMP_D1) {
+            const unsigned og = 2u * (unsigned)(lane >> 4);                  // channels 2 g, 2 g + 1: one 16-byte load per site
+            const double2_t va = ldu2(st1, (unsigned)ga * 8u + og), vb = ldu2(st1, (unsigned)gb * 8u + og);
+            d1v[it][0] = va.x; d1v[it][1] = va.y; d1v[it][2] = vb.x; d1v[it][3] = vb.y;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -264,7 +287,8 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
             }
         }
     }
-    if (ftask) { sIn[fr1 * W1C + fc1] = fcs; sIn[PS1 + fr1 * W1C + fc1] = fsn; }
+    if (ftask) { sIn[fwin] = fcs; sIn[PSI + fwin] = fsn; }
+    if (FT_RECOMP_D1 && tid < LF_P1_SIZE) sm[S::P1 + tid] = wp1;
 #ifndef FT_DIAG
     if (dbg && lane == 0) dbg[6 + wave] = (long long)__builtin_readcyclecounter();   // arrival at the first barrier
 #endif
@@ -326,6 +350,34 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
                 double* po = gz2o + 8 * (size_t)(mul24(i0 + rb, L) + j0 + cb_) + 4 * half;
                 *reinterpret_cast<double2_t*>(po) = double2_t{acc1[0], acc1[1]}; *reinterpret_cast<double2_t*>(po + 2) = double2_t{acc1[2], acc1[3]};
             }
+        }
+    }
+    if (FT_RECOMP_D1) {
+        // ---- act'(z1) of this lane's conv2^T pairs, recomputed: conv1 (2 -> 8) on the frozen taps exactly as the forward
+        //      kernel runs it (flow_fwd.hip: pairs across the stripe lines, K = 2 frozen lines x 3 taps x 2 channels = 3 MFMA
+        //      steps, the constant lines in the bias table BC), on the pair map of conv2^T, so that the result lands in the
+        //      registers of the lane that multiplies by it.  Operands: the (cos, sin) planes of the tile+2 window.
+        const int g = lane >> 4, i = lane & 15, cN = i & 7, dd = i >> 3;
+        const double* sP1 = sm + S::P1;
+        const int sbase = ((mu == 0 ? j0 : i0) - IOFF - off) & 3;        // stripe class of the input window's first line
+        const int lstep = mu == 0 ? 1 : WIC, astep = mu == 0 ? WIC : 1;  // LDS step across the lines / along them
+#pragma unroll
+        for (int it = 0; it < NIT1; ++it) {
+            const int T = wave + NW * it;
+            if (T >= NTILE1) break;
+            const int par = (T < NU ? T : T - NU) & 1;                   // parity of the tile's pair positions across the lines
+            const int s4 = (sbase + 2 * par) & 3;                        // class of the pair window's first line (wave-uniform)
+            const int fl = ((g >> 1) + 1 - s4) & 3;                      // this lane group's frozen line of the four
+            const double* a0 = sIn + (g & 1) * PSI + (2 * pu[it] + fl) * lstep + pv[it] * astep;
+            const double* wp = sP1 + cN + (g & 1) * 48 + (fl + 1 - dd) * 8;
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[t * 96], a0[t * astep], acc, 0, 0, 0);
+            const double* bc = sP1 + LF_BC + s4 * 16 + 2 * g;
+            double z[4] = {acc[0] + bc[0], acc[1] + bc[1], acc[2] + bc[8], acc[3] + bc[9]};
+            double h_[4];
+            act_eval4(z, A.act, h_, d1v[it]);
         }
     }
     lds_barrier();
@@ -435,8 +487,8 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         double gct = 0.0, gst = 0.0;
 #pragma unroll
         for (int co = 0; co < 8; ++co) { gct += sPart[(co * 2 + 0) * (N3 / 2) + tid]; gst += sPart[(co * 2 + 1) * (N3 / 2) + tid]; }
-        const int at = (r + 1) * W1C + c + 1;
-        sDir[r * TC + c] = -sIn[PS1 + at] * gct + sIn[at] * gst;
+        const int at = (r + IOFF) * WIC + c + IOFF;
+        sDir[r * TC + c] = -sIn[PSI + at] * gct + sIn[at] * gst;
     }
     lds_barrier();
     STAMP(4);

@@ -186,15 +186,15 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             const int ds = mu == 0 ? 1 : R1C;
             double* ph = sH1 + 2 * g * PS1 + r * R1C + c;
             ph[0] = h[0]; ph[PS1] = h[1]; ph[ds] = h[2]; ph[PS1 + ds] = h[3];
-            if (A.stash) {                                  // act'(z1) (and h1) of the tile's own sites
+            if (FT_RECOMP_D1 ? (A.stash && A.stash_h) : (A.stash != nullptr)) {   // act'(z1) (and h1) of the tile's own sites
                 const int r0 = r - 2, c0 = c - 2, r1 = mu == 0 ? r0 : r0 + 1, c1 = mu == 0 ? c0 + 1 : c0;
                 const int at = mul24(i0 + r0, L) + j0 + c0, dat = mu == 0 ? 1 : L;
                 if ((unsigned)r0 < (unsigned)rmax && (unsigned)c0 < (unsigned)cmax) {
-                    *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)at) = double2_t{d[0], d[1]};
+                    if (!FT_RECOMP_D1) *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)at) = double2_t{d[0], d[1]};
                     if (A.stash_h) *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)at) = double2_t{h[0], h[1]};
                 }
                 if ((unsigned)r1 < (unsigned)rmax && (unsigned)c1 < (unsigned)cmax) {
-                    *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dat)) = double2_t{d[2], d[3]};
+                    if (!FT_RECOMP_D1) *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dat)) = double2_t{d[2], d[3]};
                     if (A.stash_h) *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)(at + dat)) = double2_t{h[2], h[3]};
                 }
             }
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             const int rr = r - 2, cc = c - 2;
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
                 const int at = mul24(i0 + rr, L) + j0 + cc;
-                sv.d1[8 * (size_t)at + co] = d;
+                if (!FT_RECOMP_D1) sv.d1[8 * (size_t)at + co] = d;
                 if (A.stash_h) sv.h1[8 * (size_t)at + co] = h;
             }
         }

@@ -38,9 +38,9 @@ __global__ void k_pack_weights(const double* __restrict__ w, int n_layers, doubl
         else if (t >= WFWD0 && t < WFWD1 + LF_BLOCK) {                   // forward blocks of the MFMA kernels (flow_common.h)
             const int col = t >= WFWD1, u = t - (col ? WFWD1 : WFWD0);
             if (u < LF_B1) v = c[CB0 + u];
-            else if (u < LF_W2) v = c[CB1 + u - LF_B1];
-            else if (u < LF_B2) v = c[CW2 + u - LF_W2];
+            else if (u < LF_B2) v = c[CB1 + u - LF_B1];
             else if (u < LF_P2) v = u - LF_B2 < 3 ? c[CB2 + u - LF_B2] : 0.0;
+            else if (u >= LF_W2) v = c[CW2 + u - LF_W2];
             else if (u < LF_P1) {
                 const int e = u - LF_P2, a3 = e / 320, ci = 4 * ((e / 40) % 2) + (e / 80) % 4, l5 = (e / 8) % 5 - 1, co = ft_chan(e % 8);
                 const int ky = col ? a3 : l5, kx = col ? l5 : a3;

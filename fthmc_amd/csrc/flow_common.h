@@ -44,7 +44,7 @@ static_assert(WCAN + WCAN_SIZE <= FLOW_WINT, "weight layout");
 // read 32 different LDS banks.  ft_chan: a lane holds MFMA rows g and g + 4; with row r carrying channel
 // 2 (r & 3) + (r >> 2) those are the ADJACENT channels 2 g, 2 g + 1, which the channel-minor activation stash
 // (flow_mfma_common.h: struct Stash) stores and loads as one 16-byte access.
-//   forward block (one per mu):  b0[8] b1[8] w2[3][8][9] b2[3]+0  P2[960]  |  P1[3][2 ci: stride 48][5 padded lines: stride 8][8 co]  BC[4 s][2 dd][8 co]
+//   forward block (one per mu):  b0[8] b1[8] b2[3]+0  P2[960]  |  P1[3][2 ci: stride 48][5 padded lines: stride 8][8 co]  BC[4 s][2 dd][8 co]  |  w2[3][8][9]
 //       conv1 pairs its output sites ACROSS the stripe lines (flow_fwd.hip), conv2 along them:
 //       mu = 0 (conv1 pairs = columns):  P1[ky][ci][c5][co] = w0[co][ci][ky][c5 - 1]
 //       mu = 1 (conv1 pairs = rows):     P1[kx][ci][r5][co] = w0[co][ci][r5 - 1][kx]
@@ -57,8 +57,9 @@ static_assert(WCAN + WCAN_SIZE <= FLOW_WINT, "weight layout");
 //       mu = 1 (pairs = rows):     T2[kx][g][h][r5][ci] = w1[4 h + g][ci][2 - (r5 - 1)][2 - kx]
 //       mu = 0 (pairs = columns):  T2[ky][g][h][c5][ci] = w1[4 h + g][ci][2 - ky][2 - (c5 - 1)]
 __host__ __device__ constexpr int ft_chan(int row) { return 2 * (row & 3) + (row >> 2); }
-constexpr int LF_B0 = 0, LF_B1 = 8, LF_W2 = 16, LF_B2 = 232, LF_P2 = 236, LF_SIZE = LF_P2 + 960;   // resident part
-constexpr int LF_P1 = LF_SIZE, LF_BC = 288, LF_P1_SIZE = LF_BC + 64, LF_BLOCK = LF_P1 + LF_P1_SIZE;   // conv1 tables: conv1 stage only
+constexpr int LF_B0 = 0, LF_B1 = 8, LF_B2 = 16, LF_P2 = 20, LF_SIZE = LF_P2 + 960;   // resident part of the LDS copy
+constexpr int LF_P1 = LF_SIZE, LF_BC = 288, LF_P1_SIZE = LF_BC + 64, LF_LDS = LF_P1 + LF_P1_SIZE;   // conv1 tables: conv1 stage only
+constexpr int LF_W2 = LF_LDS, LF_BLOCK = LF_W2 + 216;   // conv3's weights: never copied to LDS (wave-uniform: scalar loads into SGPRs)
 constexpr int LB_W0 = 0, LB_W2 = 144, LB_T2 = 360, LB_SIZE = LB_T2 + 960;
 constexpr int WFWD0 = 2944, WFWD1 = WFWD0 + LF_BLOCK, WBWD = WFWD1 + LF_BLOCK, WBWD1 = WBWD + LB_SIZE;   // WBWD: rows, WBWD1: columns
 static_assert(WBWD1 + LB_SIZE <= FLOW_WINT, "weight layout");

@@ -34,10 +34,10 @@ template <int TR, int TC> struct SmemF {
     static constexpr int T2 = ST + 8 * 3 * G::NAS;            // [NMIX][2][NAS] y_k, 1/D_k
     static constexpr int P1 = IN + 2 * G::PS0;                // [LF_P1_SIZE] conv1 weight table (until conv1 is done)
     static constexpr int PG = IN + cmax2(2 * G::PS0 + LF_P1_SIZE, 8 * 3 * G::NAS + NMIX * 2 * G::NAS);   // [N0] plaquettes
-    static constexpr int SW = PG + G::PS0;                    // [LF_SIZE] resident weight block
+    static constexpr int SW = PG + G::N0;                     // [LF_SIZE] resident weight block
     static constexpr int SIZE = SW + LF_SIZE;
     static_assert(G::N3 <= 8 * 3 * G::NAS, "delta must fit over the conv3 partials");
-    static_assert(3 * SIZE * 8 <= 160 * 1024, "three workgroups per CU");
+    static_assert(G::N0 % 2 == 0 && 3 * ((SIZE * 8 + 1279) / 1280 * 1280) <= 160 * 1024, "three workgroups per CU (LDS is granted in 1280-byte units)");
 };
 
 // REV: the inverse layer (GaugeEquivCouplingLayer.reverse, layers.py:204-210, 373-396): same net on the same
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
-    constexpr int N0 = G::N0, N3 = G::N3, NA = G::NA, NAS = G::NAS, TQ = 2;
+    constexpr int N0 = G::N0, N3 = G::N3, NA = G::NA, NAS = G::NAS, TQ = 2, RS1 = G::RS1;
     constexpr int PS0 = G::PS0, PS1 = G::PS1, PS2 = G::PS2;
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
     double* sIn = sm + S::IN;  double* sP = sm + S::PG;   double* sH1 = sm + S::H1;  double* sH2 = sm + S::H2;
@@ -78,12 +78,12 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     // this layer's forward weight block (the conv2 table padded along the pair direction of this mu): the loads are
     // issued FIRST and land under the plaquette loads and the sincos; issued behind them (where they are consumed) the
     // stage pays two memory latencies in a row.  Unconditional, clamped: straight-line code keeps the waits counted.
-    constexpr int NWC = (LF_BLOCK + NT - 1) / NT;
+    constexpr int NWC = (LF_LDS + NT - 1) / NT;
     double wv[NWC];
     {
         const double* wb = w + (mu == 0 ? WFWD0 : WFWD1);
 #pragma unroll
-        for (int k = 0; k < NWC; ++k) wv[k] = ldu(wb, (unsigned)min(tid + k * NT, LF_BLOCK - 1));
+        for (int k = 0; k < NWC; ++k) wv[k] = ldu(wb, (unsigned)min(tid + k * NT, LF_LDS - 1));
     }
     // the tile's own links for the final link update: issued now, consumed in the last stage
     double xv0 = 0.0, xv1 = 0.0;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
 #pragma unroll
     for (int k = 0; k < NWC; ++k) {
         const int t = tid + k * NT;
-        if (t < LF_SIZE) sW[t] = wv[k]; else if (t < LF_BLOCK) sP1[t - LF_SIZE] = wv[k];
+        if (t < LF_SIZE) sW[t] = wv[k]; else if (t < LF_LDS) sP1[t - LF_SIZE] = wv[k];
     }
     lds_barrier();
     STAMP(1);
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             double h[4], d[4];
             act_eval4(z, act, h, d);
             const int r = mu == 0 ? v : 2 * u, c = mu == 0 ? 2 * u : v;  // site 0 in h1-window coordinates; site 1 = next column / row
-            const int ds = mu == 0 ? 1 : R1C;
-            double* ph = sH1 + 2 * g * PS1 + r * R1C + c;
+            const int ds = mu == 0 ? 1 : RS1;
+            double* ph = sH1 + 2 * g * PS1 + r * RS1 + c;
             ph[0] = h[0]; ph[PS1] = h[1]; ph[ds] = h[2]; ph[PS1 + ds] = h[3];
             if (FT_RECOMP_D1 ? (A.stash && A.stash_h) : (A.stash != nullptr)) {   // act'(z1) (and h1) of the tile's own sites
                 const int r0 = r - 2, c0 = c - 2, r1 = mu == 0 ? r0 : r0 + 1, c1 = mu == 0 ? c0 + 1 : c0;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                 z = fma(in[ci * PS0 + (tp / 3) * R0C + tp % 3], wp[(mu == 0 ? tp / 3 : tp % 3) * 96 + ci * 48 + (mu == 0 ? tp % 3 : tp / 3) * 8], z);
         double h, d;
         act_eval(z, act, h, d);
-        sH1[co * PS1 + r * R1C + c] = h;
+        sH1[co * PS1 + r * RS1 + c] = h;
         if (A.stash) {
             const int rr = r - 2, cc = c - 2;
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
@@ -266,16 +266,16 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     };
     if (mu == 0) {
         // B[k = (tap = ky4 * 3 + kx, ci)][n = (co, dd)] = W1[co][ci][ky4 - dd][kx]; pairs = rows (2 pr, 2 pr + 1)
-        mfma_stage<KConv2Row, (R2R / 2) * NLC, R1C, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
-            [&](int p) { const int pr = fdiv<NLC>(p); return 2 * pr * R1C + min(live_line(p - pr * NLC, d0), R2C - 1); },
+        mfma_stage<KConv2Row, (R2R / 2) * NLC, RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
+            [&](int p) { const int pr = fdiv<NLC>(p); return 2 * pr * RS1 + min(live_line(p - pr * NLC, d0), R2C - 1); },
             [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int pr = fdiv<NLC>(p), c = live_line(p - pr * NLC, d0);
                 conv2_epi(g, ok && c < R2C, 2 * pr, c, 1, 0, z);
             }, dbg ? dbg + 11 : nullptr);
     } else {
         // B[k = (tap = ky * 4 + kx4, ci)][n = (co, dd)] = W1[co][ci][ky][kx4 - dd]; pairs = columns (2 pc, 2 pc + 1)
-        mfma_stage<KConv2Col, NLR * (R2C / 2), R1C, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
-            [&](int p) { const int lr = fdiv<R2C / 2>(p); return min(live_line(lr, d0), R2R - 1) * R1C + 2 * (p - lr * (R2C / 2)); },
+        mfma_stage<KConv2Col, NLR * (R2C / 2), RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
+            [&](int p) { const int lr = fdiv<R2C / 2>(p); return min(live_line(lr, d0), R2R - 1) * RS1 + 2 * (p - lr * (R2C / 2)); },
             [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int lr = fdiv<R2C / 2>(p), r = live_line(lr, d0);
                 conv2_epi(g, ok && r < R2R, r, 2 * (p - lr * (R2C / 2)), 0, 1, z);

@@ -94,12 +94,15 @@ constexpr int ps_round16(int n) { return ((n - FT_PSMOD + 31) / 32) * 32 + FT_PS
 template <int TR, int TC> struct Geom {
     static constexpr int R0R = TR + 6, R0C = TC + 6, N0 = R0R * R0C;   // plaquette / input window
     static constexpr int R1R = TR + 4, R1C = TC + 4, N1 = R1R * R1C;   // h1 window
+    // LDS row stride of the h1 planes: odd, so that a column of sites (the conv1 epilogue's stores for mu = 0 run down one:
+    // 16 consecutive rows per MFMA tile) spreads over 16 bank pairs; with the window width (20) they collapsed onto 8
+    static constexpr int RS1 = R1C + 1;
     static constexpr int R2R = TR + 2, R2C = TC + 2, N2 = R2R * R2C;   // h2 window
     static constexpr int N3 = TR * TC, NA = N3 / 4;                    // tile, active sites
     static constexpr int NAS = NA <= 32 ? 32 : 64;                     // lane stride of per-active-site scratch
-    static constexpr int PS0 = ps_round16(N0), PS1 = ps_round16(N1), PS2 = ps_round(N2);   // net input, h1: MFMA operands
+    static constexpr int PS0 = ps_round16(N0), PS1 = ps_round16(R1R * RS1), PS2 = ps_round(N2);   // net input, h1: MFMA operands
     static_assert(PS0 % 32 == FT_PSMOD && PS1 % 32 == FT_PSMOD && PS2 % 32 == 18, "bank layout");
-    static_assert(PS0 >= N0 && PS1 >= N1 && PS2 >= N2, "plane size");
+    static_assert(PS0 >= N0 && PS1 >= R1R * RS1 && PS2 >= N2, "plane size");
     static_assert(TR % 4 == 0 && TC % 4 == 0 && NA <= 64, "tile shape");
 };
 

@@ -61,9 +61,9 @@ template <int L> struct GS {
     static constexpr int B8 = A8 + 8 * PSZ;                      // fwd [8][PSZ] h2         | bwd gz1
     static constexpr int ST = B8 + 8 * PSZ;                      // [8][3][NAS] conv3 partials
     static constexpr int T2 = ST + 8 * 3 * NAS;                  // [2 NMIX + 1][NAS] y_k, 1 / D_k per component, t
-    static constexpr int SW = T2 + (2 * NMIX + 1) * NAS;         // [2][LF_BLOCK] weight blocks: the pass in flight, the next pass
-    static constexpr int RED = SW + 2 * LF_BLOCK;
-    static_assert(LF_BLOCK >= LB_SIZE, "one buffer size for forward and backward blocks");
+    static constexpr int SW = T2 + (2 * NMIX + 1) * NAS;         // [2][LF_LDS] weight blocks: the pass in flight, the next pass
+    static constexpr int RED = SW + 2 * LF_LDS;
+    static_assert(LF_LDS >= LB_SIZE, "one buffer size for forward and backward blocks");
     static constexpr int STT = RED + 16;                         // [8] (S_eff, plaq, Q) of x and of the proposal, K0, log det J
     static constexpr int PROF = STT + 8;                         // [32] cycle sums of a profiling run
     static constexpr int SIZE = PROF + 32;
@@ -121,7 +121,7 @@ struct BwdPre { double tcv[4 * NMIX], fcs, fsn, d2v[4], d1v[4]; };
 
 template <int L> struct Chain {
     using G = GS<L>;
-    static constexpr int NWC = (LF_BLOCK + NT - 1) / NT;         // weight-block doubles per thread (LF_BLOCK >= LB_SIZE)
+    static constexpr int NWC = (LF_LDS + NT - 1) / NT;         // weight-block doubles per thread (LF_LDS >= LB_SIZE)
     double* sm;
     Hot A;
     int b, tid, lane, wave;
@@ -143,7 +143,7 @@ template <int L> struct Chain {
         }
     }
     __device__ __forceinline__ double* stash(int l) const { return A.stash + (size_t)l * ((size_t)A.B * 19 * L * L); }   // kernels.h flow_stash_doubles
-    __device__ __forceinline__ double* sW() const { return sm + G::SW + wcur * LF_BLOCK; }
+    __device__ __forceinline__ double* sW() const { return sm + G::SW + wcur * LF_LDS; }
 
     // ---- weight blocks: the pass in flight reads one LDS buffer while the next pass's block travels global -> registers
     //      (issued at the top of the pass) -> the other buffer (committed at its end, behind the pass's last LDS reads of it)
@@ -153,14 +153,14 @@ template <int L> struct Chain {
     }
     __device__ __forceinline__ void weights_issue(bool bwd, int l) {
         const double* wb = block_of(A.wint, bwd, l);
-        const int n = bwd ? LB_SIZE : LF_BLOCK;
+        const int n = bwd ? LB_SIZE : LF_LDS;
 #pragma unroll
         for (int k = 0; k < NWC; ++k) pfw[k] = (FT_KNOB & 8) ? 0.01 : ldu(wb, (unsigned)min(tid + k * NT, n - 1));
     }
     __device__ __forceinline__ void weights_commit() {            // the size of the larger block: the tail of a smaller one is never read
-        double* dst = sm + G::SW + (wcur ^ 1) * LF_BLOCK;
+        double* dst = sm + G::SW + (wcur ^ 1) * LF_LDS;
 #pragma unroll
-        for (int k = 0; k < NWC; ++k) if (tid + k * NT < LF_BLOCK) dst[tid + k * NT] = pfw[k];
+        for (int k = 0; k < NWC; ++k) if (tid + k * NT < LF_LDS) dst[tid + k * NT] = pfw[k];
     }
 
     // active site a (compact index of struct Stash) -> lattice site

@@ -18,6 +18,7 @@
 // Reference: GaugeEquivCouplingLayer.forward (fthmc/utils/layers.py:196-202, 348-371), ft_action / ft_force
 // (fthmc/utils/qed_helpers.py:212-242), the leapfrog and accept step of ipynb/ft_hmc.py:394-435.
 #include "flow_mfma_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -720,15 +721,18 @@ __global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
     }
 }
 
-int g_small = 1;
+int g_small = -1;        // -1: not decided yet (FTHMC_SMALL_PATH=0 in the environment switches the path off: A/B runs)
 
 }  // namespace
 
 namespace fthmc {
 
 void set_small_path(int v) { g_small = v; }
-int get_small_path() { return g_small; }
-bool ft_small_ok(int L, int nl) { return g_small && get_flow_variant() == 1 && nl >= 1 && (L == 8 || L == 12 || L == 16); }
+int get_small_path() {
+    if (g_small < 0) { const char* e = getenv("FTHMC_SMALL_PATH"); g_small = e ? (atoi(e) != 0) : 1; }
+    return g_small;
+}
+bool ft_small_ok(int L, int nl) { return get_small_path() && get_flow_variant() == 1 && nl >= 1 && (L == 8 || L == 12 || L == 16); }
 
 int launch_ft_small(const SmallArgs& a, int L, hipStream_t s) {
     const dim3 grid(a.B), block(NT);

@@ -6,7 +6,8 @@ from collections import defaultdict
 FAMILIES = [('k_ft_small', 'k_ft_small (small-lattice fused trajectory / force / action)'),
             ('k_flow_bwd_gather', 'k_flow_bwd_gather<16,16> (coupling-layer backward wrt x, force path)'),
             ('k_flow_fwd', 'k_flow_fwd<16,16> (coupling-layer forward)'),
-            ('k_force<1', 'k_force<1> (fused plain-HMC leapfrog step)'),
+            ('k_leap_rows', 'k_leap_rows<8> (fused plain-HMC leapfrog step, row strips, 16-byte accesses)'),
+            ('k_force<1', 'k_force<1> (fused plain-HMC leapfrog step, 16 x 16 tiles)'),
             ('k_hmc_trajectory', 'k_hmc_trajectory (single-launch plain-HMC trajectory)')]
 
 

@@ -1,25 +1,39 @@
 #!/bin/bash
 # Everything under profiles/ that is measured at HEAD, in one call on the GPU box (repo root):
 #   bash tools/refresh_profiles.sh OUTDIR COMMIT
-# bench lines of configs 3, 1, 2, 5; rocprofv3 kernel stats; the counter passes (in-bench launches and full-batch
-# launches); instructions per stage (needs experiments/lib_diag.so = the -DFT_DIAG build of HEAD); workgroup lifetimes.
+# bench lines of configs 3, 1, 2, 5 (+ config 2 on the tiled path); rocprofv3 kernel stats of the headline and of config 2;
+# the counter passes (in-bench launches, full-batch launches, the small-lattice kernel, the plain-HMC leapfrog kernels);
+# instructions per stage (needs experiments/lib_diag.so = the -DFT_DIAG build of HEAD); workgroup lifetimes; the A/B of the
+# act'(z1)-recompute build (experiments/lib_recomp_d1.so = make EXTRA=-DFT_RECOMP_D1=1) with its HBM traffic.
 ROOT=$(pwd); OUT=$1; COMMIT=${2:-unknown}; mkdir -p "$OUT"; export TMPDIR=/tmp
+case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT";; esac
 for c in 3 1 2 5; do
   python3 bench.py --config $c --steps 100 --warmup 10 > "$OUT/bench_config$c.json" 2> "$OUT/bench_config$c.log" || echo "bench config $c failed: $?" >> "$OUT/errors.txt"
   echo "[refresh] bench config $c done"
 done
+FTHMC_SMALL_PATH=0 python3 bench.py --config 2 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/bench_config2_tiled.json" 2> "$OUT/bench_config2_tiled.log"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/stats.log" 2>&1)
 cp $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -- python3 "$ROOT/bench.py" --config 2 --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/stats2.log" 2>&1)
+cp $(find "$OUT/stats2" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats_config2.csv"
 echo "[refresh] kernel stats done"
 bash tools/collect_pmc.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1
 python3 tools/pmc_summary.py "$OUT/pmc" "$OUT/pmc_summary.json" "" "$COMMIT" > /dev/null
 echo "[refresh] in-bench counters done"
+FTHMC_LIB=$ROOT/experiments/lib_recomp_d1.so bash tools/collect_pmc.sh "$OUT/pmcr" > "$OUT/pmcr.log" 2>&1
+python3 tools/pmc_summary.py "$OUT/pmcr" "$OUT/pmc_summary_recomp_d1.json" "bench.py config 3, two chain groups (64-chain launches), library built with -DFT_RECOMP_D1=1: act'(z1) recomputed in the backward, not stashed" "$COMMIT" > /dev/null
+echo "[refresh] recompute-build traffic done"
 bash tools/pmc_kernels.sh "$OUT/pmck" > "$OUT/pmck.log" 2>&1
-python3 tools/pmc_summary.py "$OUT/pmck" "$OUT/pmc_kernels_fullbatch.json" "tools/kernel_loop.py: each coupling-layer kernel launched alone over the FULL batch: 128 chains x 16 tiles = 2048 workgroups of 16x16 sites (L=64, fp64), 16384 waves per launch" "$COMMIT" > /dev/null
+python3 tools/pmc_summary.py "$OUT/pmck" "$OUT/pmc_kernels_fullbatch.json" "tools/kernel_loop.py: each coupling-layer kernel launched alone over the FULL batch: 128 chains x 16 tiles = 2048 workgroups of 16x16 sites (L=64, fp64), 16384 waves per launch; k_leap_rows / k_force<1>: one plain-HMC leapfrog step of 128 chains" "$COMMIT" > /dev/null
 echo "[refresh] full-batch counters done"
+bash tools/pmc_small.sh "$OUT/pmcs" > "$OUT/pmcs.log" 2>&1
+python3 tools/pmc_summary.py "$OUT/pmcs" "$OUT/pmc_small.json" "tools/small_loop.py: one launch of k_ft_small<16> = one config-2 trajectory (L=16, 4 layers, nstep 10) of 32 chains = 32 workgroups of 8 waves" "$COMMIT" > /dev/null
+echo "[refresh] small-lattice counters done"
 bash tools/pmc_stages.sh "$OUT/stg" > "$OUT/instructions_per_stage.txt" 2>&1
 echo "[refresh] stages done"
 python3 tools/lifetime.py 16 48 64 128 > "$OUT/workgroup_lifetime.txt" 2>&1
-FTHMC_LIB=$ROOT/experiments/lib_diag.so python3 tools/lifetime.py 16 128 > "$OUT/workgroup_lifetime_diag_stamps.txt" 2>&1
-rm -rf "$OUT/stats" "$OUT/pmc/pass"* "$OUT/pmck/pass"* "$OUT/stg/stop"*
+python3 tools/small_profile.py > "$OUT/small_lattice_stage_cycles.txt" 2>&1
+python3 tools/leap_check.py > "$OUT/leapfrog_kernels.txt" 2>&1
+bash tools/abn.sh 2 fthmc_amd/libfthmc_hip.so experiments/lib_recomp_d1.so > "$OUT/ab_recomp_d1.txt" 2>&1
+rm -rf "$OUT/stats" "$OUT/stats2" "$OUT"/pmc*/pass*/ "$OUT/stg/stop"*
 echo "[refresh] done"

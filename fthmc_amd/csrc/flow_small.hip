@@ -143,22 +143,34 @@ template <int L> struct Chain {
             last = (long long)__builtin_readcyclecounter();
         }
     }
-    __device__ __forceinline__ double* stash(int l) const { return A.stash + (size_t)l * ((size_t)A.B * 19 * L * L); }   // kernels.h flow_stash_doubles
+    // uniform values re-derived per use on the scalar unit: made opaque, or every per-layer pointer is hoisted out of the
+    // layer loops, outlives its SGPRs and comes back through v_readlane (a VALU slot each)
+    __device__ __forceinline__ int chain() const { int c = b; asm volatile("" : "+s"(c)); return c; }
+    __device__ __forceinline__ double* stash(int l) const {
+        double* p = A.stash; int B_ = A.B;
+        asm volatile("" : "+s"(p), "+s"(B_));
+        return p + (size_t)l * ((size_t)B_ * 19 * L * L);                  // kernels.h flow_stash_doubles
+    }
     __device__ __forceinline__ double* sW() const { return sm + G::SW + wcur * LF_LDS; }
 
     // ---- weight blocks: the pass in flight reads one LDS buffer while the next pass's block travels global -> registers
     //      (issued at the top of the pass) -> the other buffer (committed at its end, behind the pass's last LDS reads of it)
     static __device__ __forceinline__ const double* block_of(const double* wint, bool bwd, int l) {
+        asm volatile("" : "+s"(wint));
         const int mu = l & 1;
         return wint + (size_t)l * FLOW_WINT + (bwd ? (mu == 0 ? WBWD1 : WBWD) : (mu == 0 ? WFWD0 : WFWD1));
     }
     __device__ __forceinline__ void weights_issue(bool bwd, int l) {
+        int tid = this->tid;
+        asm volatile("" : "+v"(tid));
         const double* wb = block_of(A.wint, bwd, l);
         const int n = bwd ? LB_SIZE : LF_LDS;
 #pragma unroll
         for (int k = 0; k < NWC; ++k) pfw[k] = (FT_KNOB & 8) ? 0.01 : ldu(wb, (unsigned)min(tid + k * NT, n - 1));
     }
     __device__ __forceinline__ void weights_commit() {            // the size of the larger block: the tail of a smaller one is never read
+        int tid = this->tid;
+        asm volatile("" : "+v"(tid));
         double* dst = sm + G::SW + (wcur ^ 1) * LF_LDS;
 #pragma unroll
         for (int k = 0; k < NWC; ++k) if (tid + k * NT < LF_LDS) dst[tid + k * NT] = pfw[k];
@@ -175,7 +187,7 @@ template <int L> struct Chain {
         if (mu == 0) { r = q; c = x; } else { c = q; r = x; }
     }
     // conv2^T: site 0 of this lane's pair in tile `wave` (site 1 = next column for mu = 0, next row for mu = 1)
-    __device__ __forceinline__ bool pair_site(int mu, int& r, int& c) const {
+    __device__ __forceinline__ bool pair_site(int lane, int mu, int& r, int& c) const {
         const int p_ = wave * 16 + (lane & 15);
         const bool ok = p_ < G::NPAIR;
         const int p = ok ? p_ : G::NPAIR - 1;
@@ -197,7 +209,7 @@ template <int L> struct Chain {
         double* sX = sm + G::X;  double* sIn = sm + G::IN;  double* sH1 = sm + G::A8;  double* sH2 = sm + G::B8;
         double* sPA = sm + G::PA;  double* sST = sm + G::ST;
         const double* sWc = sW();
-        const Stash sv = STASH ? stash_view(stash(l), A.B, b, N) : Stash{};
+        const Stash sv = STASH ? stash_view(stash(l), A.B, chain(), N) : Stash{};
         if (nl_ >= 0) weights_issue(nb, nl_);
         // ---- plaquettes, net input (cos P, sin P on the frozen lines, (1, 0) elsewhere), P / 2 at the active sites
         if (tid < N) {
@@ -364,9 +376,9 @@ template <int L> struct Chain {
 
     // the stash values of backward pass l (struct Stash), each in the thread that multiplies by it; four groups, so that a
     // pass can refill each group for the pass behind it as soon as it has consumed it (no second copy in registers)
-    __device__ __forceinline__ void issue_tc(int l, BwdPre& q) const {
+    __device__ __forceinline__ void issue_tc(int tid, int l, BwdPre& q) const {
         constexpr int N = G::N, NA = G::NA;
-        const Stash sv = stash_view(stash(l), A.B, b, N);
+        const Stash sv = stash_view(stash(l), A.B, chain(), N);
         const int a = tid < NA ? tid : 0;                                  // transform adjoint at active site tid
 #pragma unroll
         for (int k = 0; k < 4 * NMIX; k += 2) {
@@ -374,34 +386,38 @@ template <int L> struct Chain {
             q.tcv[k] = t2.x; q.tcv[k + 1] = t2.y;
         }
     }
-    __device__ __forceinline__ void issue_cs(int l, BwdPre& q) const {
+    __device__ __forceinline__ void issue_cs(int tid, int l, BwdPre& q) const {
         constexpr int N = G::N, NF = G::NF;
         const int mu = l & 1, off = (l >> 1) & 3;
-        const Stash sv = stash_view(stash(l), A.B, b, N);
+        const Stash sv = stash_view(stash(l), A.B, chain(), N);
         int fr, fc;
         frozen_site(tid < NF ? tid : 0, mu, off, fr, fc);                  // cos / sin of frozen site tid
         const int ic = stash_frozen_idx(fr, fc, L, mu, off);
         if (FT_KNOB & 16) { q.fcs = 0.6; q.fsn = 0.8; } else { q.fcs = sv.cs[ic]; q.fsn = sv.cs[(N >> 1) + ic]; }
     }
-    __device__ __forceinline__ void issue_d2(int l, BwdPre& q) const {
+    __device__ __forceinline__ void issue_d2(int tid, int l, BwdPre& q) const {
         constexpr int N = G::N;
-        const Stash sv = stash_view(stash(l), A.B, b, N);
+        const Stash sv = stash_view(stash(l), A.B, chain(), N);
         const int c3half = tid >= N ? 1 : 0, c3s = tid - c3half * N;       // conv3^T task = (site, half of the channels)
         const double* pl = sv.d2 + 8 * (size_t)(tid < 2 * N ? c3s : 0) + 4 * c3half;
         const double2_t va = ldg2(pl), vb = ldg2(pl + 2);
         q.d2v[0] = va.x; q.d2v[1] = va.y; q.d2v[2] = vb.x; q.d2v[3] = vb.y;
     }
-    __device__ __forceinline__ void issue_d1(int l, BwdPre& q) const {
+    __device__ __forceinline__ void issue_d1(int lane, int l, BwdPre& q) const {
         constexpr int N = G::N;
         const int mu = l & 1;
-        const Stash sv = stash_view(stash(l), A.B, b, N);
+        const Stash sv = stash_view(stash(l), A.B, chain(), N);
         int r, c;
-        pair_site(mu, r, c);                                               // conv2^T epilogue: channels 2 g, 2 g + 1 at both sites
+        pair_site(lane, mu, r, c);                                         // conv2^T epilogue: channels 2 g, 2 g + 1 at both sites
         const int s0 = r * L + c, s1 = s0 + (mu == 0 ? 1 : L);
         const double2_t va = ldg2(sv.d1 + 8 * (size_t)s0 + 2 * (lane >> 4)), vb = ldg2(sv.d1 + 8 * (size_t)s1 + 2 * (lane >> 4));
         q.d1v[0] = va.x; q.d1v[1] = va.y; q.d1v[2] = vb.x; q.d1v[3] = vb.y;
     }
-    __device__ __forceinline__ void bwd_issue(int l, BwdPre& q) const { issue_tc(l, q); issue_cs(l, q); issue_d2(l, q); issue_d1(l, q); }
+    __device__ __forceinline__ void bwd_issue(int l, BwdPre& q) const {
+        int t = tid, ln = lane;
+        asm volatile("" : "+v"(t), "+v"(ln));
+        issue_tc(t, l, q); issue_cs(t, l, q); issue_d2(t, l, q); issue_d1(ln, l, q);
+    }
 
     // ---- one coupling layer backward from the stash (gather form, flow_bwd_gather.hip): gP += this layer's contribution.
     //      `pre` holds this pass's stash values (bwd_issue); (nb, nl_): the pass that follows, or nl_ < 0.
@@ -422,7 +438,7 @@ template <int L> struct Chain {
         int fr = 0, fc = 0;
         frozen_site(ftask ? tid : 0, mu, off, fr, fc);
         int pr_ = 0, pc_ = 0;
-        pair_site(mu, pr_, pc_);
+        pair_site(lane, mu, pr_, pc_);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- adjoint of the tan-mixture transform at the active sites; their own gP is complete here: nobody else reads
@@ -446,7 +462,7 @@ template <int L> struct Chain {
             put1<L, RS>(sGO + NMIX * PSZ, i, j, gdelta);
             sGP[i * L + j] = g0 + (gdelta * (csum - 1.0) - cbr * esum);
         }
-        if (refill) issue_tc(nl_, pre);
+        if (refill) issue_tc(tid, nl_, pre);
         lds_barrier();
         stamp(8);
 
@@ -477,7 +493,7 @@ template <int L> struct Chain {
             put2<L, RS, PSZ>(sGZ2 + (c3half * 4) * PSZ, r, c, acc[0], acc[1]);
             put2<L, RS, PSZ>(sGZ2 + (c3half * 4 + 2) * PSZ, r, c, acc[2], acc[3]);
         }
-        if (refill) issue_d2(nl_, pre);
+        if (refill) issue_d2(tid, nl_, pre);
         lds_barrier();
         stamp(9);
 
@@ -502,7 +518,7 @@ template <int L> struct Chain {
 #pragma unroll
             for (int k = 0; k < 18; ++k) w0s[k] = wq[k];
         }
-        if (refill) issue_d1(nl_, pre);
+        if (refill) issue_d1(lane, nl_, pre);
         lds_barrier();
         stamp(10);
 
@@ -528,7 +544,7 @@ template <int L> struct Chain {
             for (int co = 0; co < 8; ++co) { gct += sPart[(co * 2 + 0) * NF + tid]; gst += sPart[(co * 2 + 1) * NF + tid]; }
             sGP[fr * L + fc] += -pre.fsn * gct + pre.fcs * gst;
         }
-        if (refill) issue_cs(nl_, pre);
+        if (refill) issue_cs(tid, nl_, pre);
         if (nl_ >= 0) weights_commit();
         lds_barrier();
         if (nl_ >= 0) wcur ^= 1;

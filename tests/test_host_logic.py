@@ -253,17 +253,25 @@ def test_observables_tooling(tmp_path):
     assert len(out) == 3 and len(open(tmp_path / 'dq2.txt').read().splitlines()) == 3
 
 
-@pytest.mark.parametrize('name', ['r01_bench.json', 'r02_bench.json', 'r02_bench_config5.json'])
+@pytest.mark.parametrize('name', ['r01_bench.json', 'r02_bench.json', 'r02_bench_config5.json', 'r03_bench.json',
+                                  'r03_bench_config2.json', 'r03_bench_config5.json'])
 def test_committed_bench_line_follows_the_contract(name):
     """profiles/rNN_bench*.json is one JSON line of bench.py: every key the driver and the judge read is there,
     and the numbers are mutually consistent."""
     import json
     line = open(os.path.join(ROOT, 'profiles', name)).read().strip().splitlines()[-1]
     d = json.loads(line)
-    if name.startswith('r02'):
+    if not name.startswith('r01'):
         assert d['cpu_baseline']['parity']['ok'] is True and d['cpu_baseline']['one_thread']['cores'] == 1
-        assert d['roofline']['attainable']['kernel'].startswith('k_flow_fwd') and 'traffic_source' in d['roofline']
-        assert d['config']['baseline_config'] in (3, 5) and ('train' in d) == (d['config']['baseline_config'] == 5)
+        assert d['config']['baseline_config'] in (2, 3, 5) and ('train' in d) == (d['config']['baseline_config'] == 5)
+        if d['config']['baseline_config'] == 2:                # small lattice: the fused single-launch kernel is the dominant one
+            assert d['roofline']['kernel'].startswith('k_ft_small<16>') and d['config']['path'].startswith('small-lattice')
+        else:
+            assert d['roofline']['attainable']['kernel'].startswith('k_flow_fwd') and 'traffic_source' in d['roofline']
+    if name.startswith('r03'):
+        reg = d['regions']
+        assert reg['n'] == len(reg['seconds']) >= 1 and reg['value_from'] == 'median region'
+        assert abs(d['ms_per_step'] - sorted(reg['seconds'])[len(reg['seconds']) // 2] / d['steps'] * 1e3) < 1e-3 * d['ms_per_step']
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k

@@ -32,6 +32,8 @@ SIGNATURES = {
     'fthmc_last_error': [],
     'fthmc_set_variant': [c_int],
     'fthmc_get_variant': [],
+    'fthmc_set_arch': [c_int, ctypes.POINTER(c_int), c_int, c_int],
+    'fthmc_arch_params': [],
     'fthmc_set_small_path': [c_int],
     'fthmc_get_small_path': [],
     'fthmc_ws_bytes': [c_int, c_int, c_int],

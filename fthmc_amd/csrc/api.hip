@@ -25,6 +25,7 @@ inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct WS {
     double *wint, *X, *gp, *gp2, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *gw_tmp, *stash, *gz;
+    double *hbuf, *gbuf;   // generic net shapes (flow_generic.hip): activation scratch, gradient ping-pong
     size_t n2;       // doubles per field batch: B * 2 * L * L
     size_t total;    // doubles
 };
@@ -49,8 +50,12 @@ WS ws_layout(double* base, int B, int L, int nl, bool train = false) {
     w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
     w.gw_part = take(nl > 0 ? (size_t)B * nt * FLOW_GW_STRIDE : 0);
     w.gw_tmp = take(nl > 0 ? (size_t)FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE : 0);
-    w.stash = take((size_t)nl * flow_stash_doubles(B, L, train));   // activation stash of a force evaluation
-    w.gz = take(train && nl > 0 ? flow_gz_doubles(B, L) : 0);       // training: pre-activation gradients of the layer in flight
+    const bool gen = !arch_default();
+    // activation stash of a force evaluation (generic shapes: every layer's planes, at least one region as scratch)
+    w.stash = take(gen ? (size_t)(nl > 0 ? nl : 1) * gen_stash_doubles(B, L) : (size_t)nl * flow_stash_doubles(B, L, train));
+    w.gz = take(train && nl > 0 && !gen ? flow_gz_doubles(B, L) : 0);   // training: pre-activation gradients of the layer in flight
+    w.hbuf = take(gen ? (size_t)B * arch_cmax() * L * L : 0);
+    w.gbuf = take(gen ? (size_t)2 * B * arch_cmax() * L * L : 0);
     w.total = o;
     return w;
 }
@@ -66,6 +71,22 @@ inline int flow_fwd(const FlowLayerArgs& a, hipStream_t s) {
 
 inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
 
+// The caller's canonical weights: the tuned kernels read their own expansion (k_pack_weights -> W.wint), the kernels for
+// other net shapes (flow_generic.hip) read the canonical layout itself.
+thread_local const double* g_wcan = nullptr;
+inline int use_weights(const double* w, int nl, const WS& W, hipStream_t s) {
+    g_wcan = w;
+    return arch_default() ? launch_pack_weights(w, nl, W.wint, s) : FTHMC_OK;
+}
+inline GenLayerArgs gen_args(const WS& w, int l, int B, int L, int act, bool own_region) {
+    GenLayerArgs g{};
+    g.w = g_wcan + (size_t)l * arch_params();
+    g.stash = w.stash + (own_region ? (size_t)l * gen_stash_doubles(B, L) : 0);
+    g.hbuf = w.hbuf; g.gbuf = w.gbuf;
+    g.B = B; g.L = L; g.mu = l % 2; g.off = (l / 2) % 4; g.act = act;
+    return g;
+}
+
 // small lattices: the fused single-launch path (flow_small.hip)
 inline SmallArgs small_args(const double* x, const WS& w, int nl, int B, int act, double beta, int mode) {
     SmallArgs a{};
@@ -78,6 +99,16 @@ inline SmallArgs small_args(const double* x, const WS& w, int nl, int B, int act
 // Forward sweep x -> X[0..nl-1] (X[l] = output of layer l).  logdet (device [B]) optional.
 int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, double* logdet,
                   hipStream_t s, bool stash = false, bool train = false) {
+    if (!arch_default()) {                                // any other net shape: plain kernels, one stash region per layer
+        for (int l = 0; l < nl; ++l) {
+            GenLayerArgs g = gen_args(w, l, B, L, act, stash);
+            g.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
+            g.y = w.X + (size_t)l * w.n2;
+            g.logj = logdet; g.logj_accumulate = l > 0;
+            FT_TRY(launch_gen_fwd(g, false, s));
+        }
+        return FTHMC_OK;
+    }
     for (int l = 0; l < nl; ++l) {
         FlowLayerArgs a{};
         a.stash = stash ? w.stash + (size_t)l * flow_stash_doubles(B, L, train) : nullptr;
@@ -113,6 +144,20 @@ int eval_action(const double* x, const WS& w, int nl, int B, int L, int act, dou
 // with dL/dlogJ = glogj.  gw != null also accumulates weight gradients (training).
 int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double beta_scaled,
              double glogj, double* gw, hipStream_t s, bool have_forward = false) {
+    if (!arch_default()) {                                // any other net shape (flow_generic.hip)
+        if (nl > 0 && !have_forward) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s, true));
+        double* gcur = (nl & 1) ? w.gp2 : w.gp;
+        double* galt = gcur == w.gp ? w.gp2 : w.gp;
+        FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, gcur, s));
+        for (int l = nl - 1; l >= 0; --l) {
+            GenLayerArgs g = gen_args(w, l, B, L, act, true);
+            g.up_gp = gcur; g.glogj_const = glogj; g.gp_out = galt;
+            g.gw = gw ? gw + (size_t)l * arch_params() : nullptr;
+            FT_TRY(launch_gen_bwd(g, s));
+            double* t_ = gcur; gcur = galt; galt = t_;
+        }
+        return FTHMC_OK;
+    }
     // MFMA path without weight gradients: the forward sweep stashes act'(z1), act'(z2), s per site
     // and the backward kernels read them back instead of recomputing the network
     // (training: the caller ran the forward with the h planes stashed too, have_forward = true)
@@ -196,6 +241,11 @@ int fthmc_set_variant(int v) {
     return FTHMC_OK;
 }
 int fthmc_get_variant(void) { return get_flow_variant(); }
+
+int fthmc_set_arch(int n_hidden, const int* hidden_sizes, int kernel_size, int n_mix) {
+    return set_flow_arch(n_hidden, hidden_sizes, kernel_size, n_mix);
+}
+int fthmc_arch_params(void) { return arch_params(); }
 
 int fthmc_set_small_path(int on) {
     if (on != 0 && on != 1) return FTHMC_ERR_ARG;
@@ -304,7 +354,12 @@ int fthmc_flow_layer_fwd(const double* x, const double* w, int B, int L, int mu,
     if (!x || !w || !y || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(1);
-    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FT_TRY(use_weights(w, 1, W, s));
+    if (!arch_default()) {
+        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+        g.mu = mu; g.off = off; g.x = x; g.y = y; g.logj = logJ;
+        return launch_gen_fwd(g, false, s);
+    }
     FlowLayerArgs a{};
     a.x = x; a.wint = W.wint; a.y = y; a.logj_part = W.lj_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
@@ -318,7 +373,12 @@ int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu,
     if (!y || !w || !x || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(1);
-    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FT_TRY(use_weights(w, 1, W, s));
+    if (!arch_default()) {
+        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+        g.mu = mu; g.off = off; g.x = y; g.y = x; g.logj = logJ; g.tol = tol;
+        return launch_gen_fwd(g, true, s);
+    }
     FlowLayerArgs a{};
     a.x = y; a.wint = W.wint; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
@@ -331,9 +391,14 @@ int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu,
 static int plaq_coupling(const double* P, const double* w, int B, int L, int mu, int off, int act, double tol,
                          bool rev, double* out, double* logJ, void* ws, size_t ws_bytes, void* stream) {
     if (!P || !w || !out || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
-    if (act < 0 || act > 2 || get_flow_variant() != 1) return FTHMC_ERR_UNSUPPORTED;
+    if (act < 0 || act > 2 || (get_flow_variant() != 1 && arch_default())) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(1);
-    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FT_TRY(use_weights(w, 1, W, s));
+    if (!arch_default()) {
+        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+        g.mu = mu; g.off = off; g.pin = P; g.pout = out; g.logj = logJ; g.tol = tol;
+        return launch_gen_fwd(g, rev, s);
+    }
     FlowLayerArgs a{};
     a.x = P; a.pin = P; a.pout = out; a.wint = W.wint; a.logj_part = W.lj_part; a.tol = tol;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
@@ -363,7 +428,17 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
     if (!ws || ws_bytes < (gw && mfma ? fthmc_train_ws_bytes(B, L, 1) : fthmc_ws_bytes(B, L, 1))) return FTHMC_ERR_WS;
     const WS W = ws_layout(static_cast<double*>(ws), B, L, 1, gw != nullptr && mfma);
     hipStream_t s = ft_stream(stream);
-    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FT_TRY(use_weights(w, 1, W, s));
+    if (!arch_default()) {
+        // forward once (fills the layer's planes), then the adjoint seeded by the link gradient; W.gp holds the layer's
+        // plaquette gradient alone
+        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+        g.mu = mu; g.off = off; g.x = x;
+        FT_TRY(launch_gen_fwd(g, false, s));
+        g.up_link = gy; g.glogj = glogJ; g.gp_out = W.gp; g.gw = gw;
+        FT_TRY(launch_gen_bwd(g, s));
+        return launch_adj_add(W.gp, gy, B, L, gx, s);
+    }
     FlowLayerArgs a{};
     a.x = x; a.wint = W.wint; a.up_link = gy; a.glogj = glogJ;
     a.gp_part = W.gp_part; a.gw_part = W.gw_part;
@@ -393,7 +468,7 @@ int fthmc_flow_forward(const double* x, const double* w, int n_layers, int B, in
     if (!x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
-    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(use_weights(w, n_layers, W, s));
     double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
     if (n_layers == 0 && hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     if (ft_small_ok(L, n_layers)) {
@@ -412,7 +487,7 @@ int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, in
     if (!y || !x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
-    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(use_weights(w, n_layers, W, s));
     double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
     if (hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     // The last layer maps y -> x, the others run in place on x.  In place is safe: a layer only rewrites its ACTIVE links,
@@ -420,6 +495,17 @@ int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, in
     // links the layer never writes plus the workgroup's own active links, which it loads before it stores them; the
     // active / passive plaquettes of the halo, which a neighbour's update can tear, are never read.
     const double* src = y;
+    if (!arch_default()) {
+        for (int l = n_layers - 1; l >= 0; --l) {
+            GenLayerArgs g = gen_args(W, l, B, L, act, false);
+            g.x = src; g.y = x; g.logj = ld; g.logj_accumulate = 1; g.tol = tol;
+            FT_TRY(launch_gen_fwd(g, true, s));
+            src = x;
+        }
+        if (n_layers == 0 && x != y && hipMemcpyAsync(x, y, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return FTHMC_ERR_LAUNCH;
+        return FTHMC_OK;
+    }
     for (int l = n_layers - 1; l >= 0; --l) {
         FlowLayerArgs a{};
         a.x = src; a.wint = W.wint + (size_t)l * FLOW_WINT; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
@@ -439,7 +525,7 @@ int fthmc_ft_action(const double* x, const double* w, int n_layers, int B, int L
     if (!x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
-    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(use_weights(w, n_layers, W, s));
     if (n_layers == 0 && logdet && hipMemsetAsync(logdet, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     if (ft_small_ok(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 0);
@@ -454,7 +540,7 @@ int fthmc_ft_force(const double* x, const double* w, int n_layers, int B, int L,
     if (!x || !F || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
-    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(use_weights(w, n_layers, W, s));
     if (ft_small_ok(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 1);
         a.F = F;
@@ -471,7 +557,7 @@ int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, int n_l
         return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
-    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(use_weights(w, n_layers, W, s));
     if (ft_small_ok(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 2);
         a.v = v; a.dt = dt; a.nstep = nstep; a.x_out = x_out; a.v_out = v_out;
@@ -500,7 +586,7 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
     double* old = W.scal + (size_t)SC_OLD0 * B;      // slots SC_OLD0.. : 3 consecutive
     double* neu = W.scal + (size_t)SC_NEW0 * B;
     double* sel = state_out ? state_out : W.scal + (size_t)SC_S * B;
-    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(use_weights(w, n_layers, W, s));
     if (mode == FTHMC_MODE_MD && ft_small_ok(L, n_layers)) {          // the whole trajectory in one launch
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
         a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = x_new; a.state_in = state_in; a.state_out = state_out;
@@ -546,12 +632,12 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
     if (!ws || ws_bytes < fthmc_train_ws_bytes(B, L, n_layers)) return FTHMC_ERR_WS;
     const WS W = ws_layout(static_cast<double*>(ws), B, L, n_layers, true);
     hipStream_t s = ft_stream(stream);
-    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(use_weights(w, n_layers, W, s));
     double* ld = W.scal + (size_t)SC_LOGDET * B;
     double* S = W.scal + (size_t)SC_S * B;
     // one forward sweep serves both the outputs (x, logq, logp) and the backward pass; with the MFMA
     // kernels it stashes act', s and h of every layer for the weight-gradient backward
-    const bool mfma = get_flow_variant() == 1;
+    const bool mfma = get_flow_variant() == 1 || !arch_default();       // paths whose backward reads the forward's stash
     FT_TRY(sweep_forward(xi, W, n_layers, B, L, act, ld, s, mfma && gw != nullptr, mfma && gw != nullptr));
     if (x || logq || logp) {
         FT_TRY(launch_action_charge(phys_field(xi, W, n_layers), B, L, beta, S, nullptr, nullptr, s));
@@ -571,11 +657,12 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
 int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                       double beta, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 3) return FTHMC_ERR_ARG;
+    if (!arch_default() && kind < 2) return FTHMC_ERR_UNSUPPORTED;
     if (kind < 2 && !w) return FTHMC_ERR_ARG;
     FT_WS(1);
     FlowLayerArgs a{};
     if (kind < 2) {
-        FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+        FT_TRY(use_weights(w, 1, W, s));
         FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
         a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
         a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.gp_out = W.gp2;
@@ -618,7 +705,7 @@ int fthmc_time_small(const double* x, const double* v, const double* u, const do
     if (!x || !v || !u || !w || !ms_avg_host || bad_shape(B, L) || n_layers < 1 || nstep < 1 || reps < 1) return FTHMC_ERR_ARG;
     if (!ft_small_ok(L, n_layers)) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
-    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(use_weights(w, n_layers, W, s));
     SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
     a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = W.xb;
     // H0 is evaluated in the launch (no state_in): nstep force sweeps + 2 action sweeps
@@ -647,7 +734,7 @@ int fthmc_small_profile(const double* x, const double* v, const double* u, const
     FT_WS(n_layers);
     long long* dbg = reinterpret_cast<long long*>(W.gw_part);            // unused by the force path; B * 32 stamps fit
     if (hipMemsetAsync(dbg, 0, (size_t)B * 32 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
-    FT_TRY(launch_pack_weights(w, n_layers, W.wint, s));
+    FT_TRY(use_weights(w, n_layers, W, s));
     SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
     a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = W.xb; a.dbg = dbg;
     FT_TRY(launch_ft_small(a, L, s));
@@ -666,6 +753,7 @@ int fthmc_small_profile(const double* x, const double* v, const double* u, const
 int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
+    if (!arch_default()) return FTHMC_ERR_UNSUPPORTED;
     (void)hipGetLastError();
     const bool train = kind == 2;                                  // kind 2: the backward in training mode (also writes A.gz)
     if (!ws || ws_bytes < (train ? fthmc_train_ws_bytes(B, L, 1) : fthmc_ws_bytes(B, L, 1))) return FTHMC_ERR_WS;
@@ -675,7 +763,7 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int 
     // stamp buffer: a workspace region the profiled launch does not write (B * ntiles * 16 stamps fit in either)
     long long* dbg = reinterpret_cast<long long*>(train ? W.gp_part : W.gw_part);
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
-    FT_TRY(launch_pack_weights(w, 1, W.wint, s));
+    FT_TRY(use_weights(w, 1, W, s));
     FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
     FlowLayerArgs a{};
     a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;

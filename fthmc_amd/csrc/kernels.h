@@ -107,6 +107,38 @@ inline size_t flow_gz_doubles(int B, int L) { return (size_t)B * 17 * L * L; }
 inline int flow_wgrad_parts(int L) { return 2 * FlowGeom{MG_TR, MG_TC}.ntiles(L); }
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }
+// ---- flow_generic.hip: any s/t net shape (hidden sizes, kernel size, mixture components); plain kernels, HBM-resident planes
+constexpr int FLOW_ARCH_MAXH = 8;
+struct FlowArch { int nh; int hid[FLOW_ARCH_MAXH]; int k; int nmix; };
+const FlowArch& flow_arch();
+int set_flow_arch(int n_hidden, const int* hidden_sizes, int kernel_size, int n_mix);
+bool arch_default();                    // 2 -> 8 -> 8 -> 3, k = 3, two components: the tuned kernels serve it
+int arch_params();                      // doubles per layer in the canonical (PyTorch-order) weight layout
+int arch_cmax();                        // widest activation
+size_t gen_stash_doubles(int B, int L); // per layer: P, (cos, sin), every pre-activation
+struct GenLayerArgs {
+    const double* x;         // [B][2][L][L] layer input (null with pin)
+    const double* pin;       // plaquette-level map: input plaquette field [B][L][L]
+    const double* w;         // this layer's weights, canonical layout
+    double* y;               // forward / reverse: output links (may alias x), or null
+    double* pout;            // plaquette-level map: output plaquette field
+    double* logj;            // [B] or null
+    int logj_accumulate;     // logj[b] += instead of =
+    double tol;              // reverse
+    double* stash;           // this layer's region (gen_stash_doubles): written by the forward, read by the backward
+    double* hbuf;            // [B][cmax][n] scratch: activations of the conv input
+    double* gbuf;            // [2][B][cmax][n] scratch: gradients, ping-pong
+    const double* up_gp;     // backward: upstream plaquette gradient [B][L][L] or null
+    const double* up_link;   // backward: upstream link gradient [B][2][L][L] or null
+    const double* glogj;     // backward: [B] or null (then glogj_const)
+    double glogj_const;
+    double* gp_out;          // backward: plaquette gradient behind this layer (not up_gp)
+    double* gw;              // backward: this layer's weight gradient (canonical layout) or null
+    int B, L, mu, off, act;
+};
+int launch_gen_fwd(const GenLayerArgs& a, bool rev, hipStream_t s);
+int launch_gen_bwd(const GenLayerArgs& a, hipStream_t s);
+
 // ---- flow_small.hip: L <= 16, one workgroup per chain, whole sequences of the flowed path in one launch
 struct SmallArgs {
     const double* x;         // [B][2][L][L] latent links

@@ -78,6 +78,49 @@ def release_workspaces():
     _WS_RETIRED.clear()
 
 
+# ---------------------------------------------------------------- s/t net shape
+DEFAULT_ARCH = ((8, 8), 3, 2)          # hidden_sizes, kernel_size, n_mixture_comps: the reference default (tuned kernels)
+_ARCH = [DEFAULT_ARCH]                 # what the library is currently set to (fthmc_set_arch is process-global state)
+
+
+def arch_params(arch=DEFAULT_ARCH) -> int:
+    """Doubles per layer of the canonical weight layout [w0 b0 w1 b1 ...] for a net 2 -> hidden... -> n_mix + 1."""
+    hidden, k, n_mix = arch
+    chans = [2, *hidden, n_mix + 1]
+    return sum(co * ci * k * k + co for ci, co in zip(chans[:-1], chans[1:]))
+
+
+def set_arch(arch=DEFAULT_ARCH):
+    """Select the s/t net shape of the following calls (C ABI fthmc_set_arch).  Any shape other than the default runs on
+    the plain kernels of csrc/flow_generic.hip.  The ops below call this themselves from the shape recorded on `w`."""
+    import ctypes
+    hidden, k, n_mix = tuple(int(h) for h in arch[0]), int(arch[1]), int(arch[2])
+    arch = (hidden, k, n_mix)
+    if arch != _ARCH[0]:
+        hs = (ctypes.c_int * max(len(hidden), 1))(*hidden)
+        check(_lib.load().fthmc_set_arch(len(hidden), hs, k, n_mix), f'fthmc_set_arch{arch}')
+        _ARCH[0] = arch
+    return arch
+
+
+def arch_of(w) -> tuple:
+    """Net shape recorded on a packed weight tensor by pack_weights (default shape for a plain tensor)."""
+    return getattr(w, '_fthmc_arch', DEFAULT_ARCH)
+
+
+def _use_arch(w) -> int:
+    """Make the library's net shape the one of `w`; -> doubles per layer."""
+    return arch_params(set_arch(arch_of(w)))
+
+
+def _tag(t, like):
+    """carry the net shape of `like` over to a tensor derived from it"""
+    a = arch_of(like)
+    if a != DEFAULT_ARCH:
+        t._fthmc_arch = a
+    return t
+
+
 def set_variant(v: int):
     """1: MFMA conv kernels (default), 0: VALU conv kernels."""
     check(_lib.load().fthmc_set_variant(int(v)), 'fthmc_set_variant')
@@ -104,26 +147,47 @@ def act_code(act) -> int:
 
 
 def pack_weights(nets: Sequence[Sequence[torch.Tensor]], device=None) -> torch.Tensor:
-    """[(w0,b0,w1,b1,w2,b2), ...] -> flat [n_layers*955] fp64 (PyTorch order)."""
-    rows = []
+    """[(w0, b0, w1, b1, ...), ...] -> flat [n_layers * params] fp64 (PyTorch order).  The conv nets may have any
+    hidden sizes / odd kernel size / number of mixture components (all layers alike); the shape is recorded on the
+    result (`arch_of`) and selects the kernels: the tuned ones for the reference default 2 -> 8 -> 8 -> 3, k = 3."""
+    rows, arch = [], None
     for w in nets:
         w = list(w)
         shapes = [tuple(t.shape) for t in w]
-        if shapes != [(8, 2, 3, 3), (8,), (8, 8, 3, 3), (8,), (3, 8, 3, 3), (3,)]:
-            raise FthmcError(f'unsupported s/t net {shapes}: the HIP kernels implement the reference '
-                             f'default hidden_sizes=[8,8], kernel_size=3, n_mixture_comps=2')
+        ok = len(w) >= 2 and len(w) % 2 == 0
+        ci, k = 2, (shapes[0][-1] if ok and len(shapes[0]) == 4 else 0)
+        for wi, bi in zip(shapes[0::2], shapes[1::2]):
+            ok = ok and len(wi) == 4 and wi[1] == ci and wi[2] == wi[3] == k and bi == (wi[0],)
+            ci = wi[0] if len(wi) == 4 else 0
+        if not ok or k % 2 == 0 or ci < 2:
+            raise FthmcError(f'unsupported s/t net {shapes}: expected Conv2d weights (c1, 2, k, k), (c1,), (c2, c1, k, k), ... '
+                             f'with one odd kernel size and n_mix + 1 >= 2 output channels')
+        a = (tuple(s_[0] for s_ in shapes[0:-2:2]), k, ci - 1)
+        if arch is not None and a != arch:
+            raise FthmcError(f'layers of one flow must share the net shape: {arch} vs {a}')
+        arch = a
         rows.append(torch.cat([t.detach().reshape(-1).to(torch.float64) for t in w]))
+    if arch is not None and (len(arch[0]) > 8 or max(arch[0] + (1,)) > 256 or arch[1] > 15 or arch[2] > 64):
+        raise FthmcError(f'net shape {arch} beyond the limits of the HIP kernels (8 hidden layers of <= 256 channels, '
+                         f'kernel_size <= 15, 64 mixture components)')
     out = torch.stack(rows).contiguous() if rows else torch.zeros(0, W_PER_LAYER, dtype=torch.float64)
     if device is not None:
         out = out.to(device)
-    return out.reshape(-1)
+    out = out.reshape(-1)
+    if arch is not None and arch != DEFAULT_ARCH:
+        out._fthmc_arch = arch
+    return out
 
 
-def unpack_weight_grads(gw: torch.Tensor, n_layers: int):
-    """flat [n_layers*955] -> list of 6-tuples shaped like the conv parameters."""
-    sizes = [(8, 2, 3, 3), (8,), (8, 8, 3, 3), (8,), (3, 8, 3, 3), (3,)]
+def unpack_weight_grads(gw: torch.Tensor, n_layers: int, arch=None):
+    """flat [n_layers * params] -> list of tuples shaped like the conv parameters (w0, b0, w1, b1, ...)."""
+    hidden, k, n_mix = arch if arch is not None else arch_of(gw)
+    chans = [2, *hidden, n_mix + 1]
+    sizes = []
+    for ci, co in zip(chans[:-1], chans[1:]):
+        sizes += [(co, ci, k, k), (co,)]
     out = []
-    g = gw.reshape(n_layers, W_PER_LAYER)
+    g = gw.reshape(n_layers, -1)
     for l in range(n_layers):
         o, row = 0, []
         for s in sizes:
@@ -224,9 +288,10 @@ def hmc_trajectory(x, v, u, beta: float, dt: float, nstep: int):
 
 # ---------------------------------------------------------------- coupling layer
 def _w1(w, x):
-    w = _dev(w, 'w').reshape(-1)
-    if w.numel() != W_PER_LAYER:
-        raise FthmcError(f'w: expected {W_PER_LAYER} doubles for one layer, got {w.numel()}')
+    npl = _use_arch(w)
+    w = _tag(_dev(w, 'w').reshape(-1), w)
+    if w.numel() != npl:
+        raise FthmcError(f'w: expected {npl} doubles for one layer of net shape {_ARCH[0]}, got {w.numel()}')
     return w
 
 
@@ -243,7 +308,7 @@ def flow_layer_bwd(x, w, gy, glogJ, mu: int, off: int, act='silu', need_gw=False
     x = _field(x); w = _w1(w, x); gy = _field(gy, 'gy'); glogJ = _dev(glogJ, 'glogJ').reshape(-1)
     B, _, L, _ = x.shape
     gx = torch.empty_like(x)
-    gw = torch.empty(W_PER_LAYER, dtype=x.dtype, device=x.device) if need_gw else None
+    gw = _tag(torch.empty(w.numel(), dtype=x.dtype, device=x.device), w) if need_gw else None
     ws, nb = _ws(x, B, L, 1, train=need_gw)
     check(_lib.load().fthmc_flow_layer_bwd(_p(x), _p(w), _p(gy), _p(glogJ), B, L, int(mu), int(off), act_code(act),
                                            _p(gx), _p(gw), ws, nb, _stream(x)), 'fthmc_flow_layer_bwd')
@@ -290,9 +355,10 @@ def plaq_coupling_rev(fP, w, mu: int, off: int, act='silu', tol: float = 1e-12):
 
 # ---------------------------------------------------------------- whole flow
 def _wall(w, n_layers):
-    w = _dev(w, 'w').reshape(-1)
-    if w.numel() != n_layers * W_PER_LAYER:
-        raise FthmcError(f'w: expected {n_layers}*{W_PER_LAYER} doubles, got {w.numel()}')
+    npl = _use_arch(w)
+    w = _tag(_dev(w, 'w').reshape(-1), w)
+    if w.numel() != n_layers * npl:
+        raise FthmcError(f'w: expected {n_layers}*{npl} doubles for net shape {_ARCH[0]}, got {w.numel()}')
     return w
 
 
@@ -446,7 +512,7 @@ def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, grou
     else:
         x, logq, logp = _out
     if G > 1:
-        gws = torch.empty(G, n_layers * W_PER_LAYER, dtype=xi.dtype, device=xi.device) if need_gw else None
+        gws = torch.empty(G, w.numel(), dtype=xi.dtype, device=xi.device) if need_gw else None
         main = torch.cuda.current_stream(xi.device)
         sides = _side_streams(xi.device, G - 1)
         for st in sides:
@@ -459,8 +525,8 @@ def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, grou
                     torch.mul(r['gw'], (b_ - a) / B, out=gws[gi])
         for st in sides:
             main.wait_stream(st)
-        return {'x': x, 'logq': logq, 'logp': logp, 'gw': gws.sum(0) if need_gw else None}
-    gw = torch.empty(n_layers * W_PER_LAYER, dtype=xi.dtype, device=xi.device) if need_gw else None
+        return {'x': x, 'logq': logq, 'logp': logp, 'gw': _tag(gws.sum(0), w) if need_gw else None}
+    gw = _tag(torch.empty(w.numel(), dtype=xi.dtype, device=xi.device), w) if need_gw else None
     ws, nb = _ws(xi, B, L, n_layers, train=True)
     check(_lib.load().fthmc_train_grad(_p(xi), _p(w), n_layers, B, L, act_code(act), float(beta), _p(x), _p(logq),
                                        _p(logp), _p(gw), ws, nb, _stream(xi)), 'fthmc_train_grad')

@@ -153,12 +153,12 @@ def _(x, gy, glogJ, w, mu, off, n_mix, act):
 
 @flow_layer_bwd_w.register_fake
 def _(x, gy, glogJ, w, mu, off, n_mix, act):
-    return x.new_empty(ops.W_PER_LAYER)
+    return x.new_empty(w.numel())
 
 
 @flow_layer_bwd.register_fake
 def _(x, gy, glogJ, w, mu, off, n_mix, act):
-    return torch.empty_like(x), x.new_empty(ops.W_PER_LAYER)
+    return torch.empty_like(x), x.new_empty(w.numel())
 
 
 @flow_layer_rev.register_fake
@@ -178,7 +178,7 @@ def _(x, v, u, w_all, n_layers, beta, dt, nstep, mode, act):
 
 @train_grad.register_fake
 def _(xi, w_all, n_layers, beta, act):
-    return torch.empty_like(xi), _b(xi), _b(xi), xi.new_empty(n_layers * ops.W_PER_LAYER)
+    return torch.empty_like(xi), _b(xi), _b(xi), xi.new_empty(w_all.numel())
 
 
 # ---------------------------------------------------------------- autograd formulas

@@ -119,7 +119,7 @@ def train_step(model: FlowModel, config: TrainConfig, action: ActionFn, optimize
         x, logq, logp = r['x'], r['logq'], r['logp']
         gw = r['gw'] * (dkl_factor / world)          # kernel seeds 1/B_local; loss is the global mean
         parallel.allreduce_grads(gw)
-        for layer, gl in zip(layers, ops.unpack_weight_grads(gw, len(layers))):
+        for layer, gl in zip(layers, ops.unpack_weight_grads(gw, len(layers), arch=ops.arch_of(r['gw']))):
             for p, g in zip(net_weights(layer.plaq_coupling.net), gl):
                 p.grad = g.clone()
         loss_dkl = dkl_factor * parallel.global_mean(logq - logp, n_global)

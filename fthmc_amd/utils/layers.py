@@ -219,10 +219,15 @@ class GaugeEquivCouplingLayer(nn.Module):
 
 
 def _check_arch(hidden_sizes, kernel_size, n_mix):
-    if list(hidden_sizes) != [8, 8] or kernel_size != 3 or n_mix != 2:
+    """Any net shape the reference's make_conv_net accepts runs on the HIP path: the default (hidden_sizes=[8, 8],
+    kernel_size=3, n_mixture_comps=2) on the tuned kernels, anything else on the plain kernels of csrc/flow_generic.hip,
+    within their limits."""
+    hs = list(hidden_sizes)
+    if len(hs) > 8 or any(int(h) < 1 or int(h) > 256 for h in hs) or kernel_size % 2 != 1 or not 1 <= kernel_size <= 15 \
+            or not 1 <= n_mix <= 64:
         raise NotImplementedError(
-            f'HIP kernels are built for the reference default net (hidden_sizes=[8, 8], kernel_size=3, '
-            f'n_mixture_comps=2); got {list(hidden_sizes)}, {kernel_size}, {n_mix}')
+            f'net shape beyond the limits of the HIP kernels (at most 8 hidden layers of 1..256 channels, odd kernel_size '
+            f'<= 15, 1..64 mixture components); got {hs}, {kernel_size}, {n_mix}')
 
 
 def make_u1_equiv_layers(*, n_layers, n_mixture_comps, lattice_shape, hidden_sizes, kernel_size,
@@ -252,7 +257,7 @@ def make_net_from_layers(*, lattice_shape: tuple, nets: List[nn.Module]):
 
 
 def flow_weights(flow: nn.ModuleList, dev=None) -> torch.Tensor:
-    """All layers' conv parameters as the flat [n_layers * 955] buffer of the C ABI, checking
+    """All layers' conv parameters as the flat [n_layers * params] buffer of the C ABI (955 per layer for the default net), checking
     that the layers follow the reference mask schedule."""
     rows = []
     for i, layer in enumerate(flow):

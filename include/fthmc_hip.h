@@ -58,6 +58,14 @@ const char* fthmc_last_error(void);
  * Same results to rounding; kept selectable for A/B measurement and cross-checks. */
 int fthmc_set_variant(int v);
 int fthmc_get_variant(void);
+/* Shape of the s/t conv net of every following call: in_channels 2 -> hidden_sizes[0] -> ... -> n_mix + 1, square kernels of
+ * odd size, `n_mix` mixture components (make_conv_net fthmc/utils/layers.py:138-167, make_u1_equiv_layers :399-429).  The
+ * default -- (2, {8, 8}, 3, 2): the reference default and every BASELINE config -- runs on the tuned kernels; any other
+ * shape runs on plain kernels (csrc/flow_generic.hip: same results, one launch per operation, activations through HBM).
+ * Weights: n_layers * fthmc_arch_params() doubles, per layer [w0 b0 w1 b1 ...] in PyTorch order; fthmc_ws_bytes follows the
+ * shape.  n_hidden <= 8, hidden sizes <= 256, kernel_size <= 15, n_mix <= 64; FTHMC_ERR_UNSUPPORTED otherwise. */
+int fthmc_set_arch(int n_hidden, const int* hidden_sizes, int kernel_size, int n_mix);
+int fthmc_arch_params(void);   /* 955 for the default */
 /* Lattices of L = 8, 12, 16 take a fused path by default (csrc/flow_small.hip): one workgroup holds a whole chain in
  * LDS, and fthmc_ft_trajectory / _ft_leapfrog / _ft_force / _ft_action / _flow_forward are ONE launch each instead of
  * one launch per layer.  0 switches it off (the tiled kernels then serve every L): A/B runs and parity tests. */

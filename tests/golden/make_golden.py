@@ -439,6 +439,42 @@ def main():
          newx=npy(newx), plaq=npy(-qed.BatchAction(beta)(yphys) / (beta * L * L)),
          Q=npy(qed.batch_charges(yphys)), **flow_arrays(flow))
 
+    # ---- 12. s/t nets other than the default 2 -> 8 -> 8 -> 3, k = 3, two components (layers.py:138-167, 399-429 accept any
+    #          hidden_sizes / kernel_size / n_mixture_comps): flow forward, S_eff, ft_force, and one train_step
+    for tag, (hidden, k, n_mix, L, nl, B, beta, act) in {'a': ([4, 6, 5], 5, 3, 8, 3, 2, 2.0, 'silu'),
+                                                         'b': ([16], 3, 1, 12, 2, 2, 3.0, 'leaky_relu')}.items():
+        torch.manual_seed(4100 + L)
+        flow = layers.make_u1_equiv_layers(n_layers=nl, n_mixture_comps=n_mix, lattice_shape=(L, L), hidden_sizes=hidden,
+                                           kernel_size=k, activation_fn=act)
+        param = cfg.Param(beta=beta, L=L)
+        x = torch.empty(B, 2, L, L).uniform_(-math.pi, math.pi)
+        with torch.no_grad():
+            y, logdet = qed.ft_flow(flow, x), None
+            S_eff = qed.ft_action(param, flow, x)
+            ld = torch.zeros(B)
+            xx = x
+            for layer in flow:
+                xx, lj = layer.forward(xx)
+                ld = ld + lj
+        Ff = qed.ft_force(param, flow, x.clone())
+        tc = cfg.TrainConfig(L=L, beta=beta, debug=True, n_layers=nl, batch_size=B, base_lr=1e-3, hidden_sizes=hidden,
+                             kernel_size=k, n_s_nets=n_mix, activation_fn=act)
+        torch.manual_seed(4200 + L)
+        model = train.get_model(tc)
+        w_train = {f't{kk}': v for kk, v in flow_arrays(model.layers).items()}
+        optimizer = torch.optim.Adam(model.layers.parameters(), lr=tc.base_lr)
+        xi = model.prior.sample_n(B)
+        metrics = train.train_step(model, tc, qed.BatchAction(beta), optimizer, B, xi=xi.clone())
+        d = {'x': npy(x), 'beta': beta, 'act': act, 'hidden': np.array(hidden), 'kernel_size': k, 'n_mix': n_mix,
+             'y': npy(y), 'logdet': npy(ld), 'S_eff': npy(S_eff), 'ft_force': npy(Ff), 'Q': npy(qed.batch_charges(y)),
+             'xi': npy(xi), 'loss_dkl': np.float64(metrics['loss_dkl']), 'ess': np.float64(metrics['ess']),
+             'logq': np.asarray(metrics['logq'], dtype=np.float64), 'logp': np.asarray(metrics['logp'], dtype=np.float64)}
+        d.update(flow_arrays(flow)); d.update(w_train)
+        for li, layer in enumerate(model.layers):
+            for pi, p_ in enumerate(layer.parameters()):
+                d[f'tgw{li}_{pi}'] = npy(p_.grad)
+        save(f'netshape_{tag}', **d)
+
 
 if __name__ == '__main__':
     main()

@@ -339,24 +339,40 @@ def test_bench_launch_command_and_refusal_without_gpu():
         assert p.returncode != 0 and 'MI355X' in (p.stderr + p.stdout)
 
 
-def test_unsupported_net_shapes_fail_loudly():
-    """The HIP kernels are built for the reference-default s/t net (hidden_sizes=[8, 8], kernel_size=3,
-    n_mixture_comps=2; include/fthmc_hip.h): any other shape raises before anything is launched -- never a silent
-    fallback (fthmc/utils/layers.py:399-429 accepts any shape on its PyTorch path)."""
+def test_net_shapes_and_their_limits():
+    """Any s/t net the reference's make_conv_net accepts is packed for the HIP path (the default shape for the tuned kernels,
+    anything else for csrc/flow_generic.hip); what the kernels cannot take raises before anything is launched -- never a
+    silent fallback (fthmc/utils/layers.py:138-167, 399-429)."""
     from fthmc_amd import ops
     from fthmc_amd._lib import FthmcError
     from fthmc_amd.utils import layers as Lyr
-    for kw in (dict(hidden_sizes=[16, 16]), dict(hidden_sizes=[8]), dict(kernel_size=5), dict(n_mixture_comps=1),
-               dict(n_mixture_comps=3)):
+    for kw in (dict(hidden_sizes=[8] * 9), dict(hidden_sizes=[300, 8]), dict(kernel_size=17), dict(n_mixture_comps=0),
+               dict(n_mixture_comps=65)):
         args = dict(n_layers=2, n_mixture_comps=2, lattice_shape=(8, 8), hidden_sizes=[8, 8], kernel_size=3)
         args.update(kw)
-        with pytest.raises(NotImplementedError, match='reference default net'):
+        with pytest.raises(NotImplementedError, match='limits of the HIP kernels'):
             Lyr.make_u1_equiv_layers(**args)
-    w = [torch.zeros(8, 2, 3, 3), torch.zeros(8), torch.zeros(8, 8, 3, 3), torch.zeros(8), torch.zeros(4, 8, 3, 3), torch.zeros(4)]
-    with pytest.raises(FthmcError, match='unsupported s/t net'):
-        ops.pack_weights([w])                                  # n_mixture_comps = 3
+    z = torch.zeros
+    w = [z(8, 2, 3, 3), z(8), z(8, 8, 3, 3), z(8), z(3, 8, 3, 3), z(3)]
+    assert ops.arch_of(ops.pack_weights([w])) == ops.DEFAULT_ARCH == ((8, 8), 3, 2) and ops.arch_params() == 955
+    w3 = [z(8, 2, 3, 3), z(8), z(8, 8, 3, 3), z(8), z(4, 8, 3, 3), z(4)]                  # n_mixture_comps = 3
+    p = ops.pack_weights([w3, w3])
+    assert ops.arch_of(p) == ((8, 8), 3, 3) and p.numel() == 2 * ops.arch_params(((8, 8), 3, 3)) == 2 * (152 + 584 + 292)
+    w5 = [z(4, 2, 5, 5), z(4), z(6, 4, 5, 5), z(6), z(5, 6, 5, 5), z(5), z(2, 5, 5, 5), z(2)]   # three hidden layers, k = 5, one component
+    p = ops.pack_weights([w5])
+    assert ops.arch_of(p) == ((4, 6, 5), 5, 1)
+    assert [tuple(t.shape) for t in ops.unpack_weight_grads(p, 1)[0]] == [tuple(t.shape) for t in w5]
+    for bad in ([z(8, 3, 3, 3), z(8), z(3, 8, 3, 3), z(3)],          # first conv must take (cos, sin)
+                [z(8, 2, 3, 3), z(8), z(3, 7, 3, 3), z(3)],          # channel chain broken
+                [z(8, 2, 3, 3), z(8), z(3, 8, 5, 5), z(3)],          # one kernel size
+                [z(8, 2, 4, 4), z(8), z(3, 8, 4, 4), z(3)],          # odd kernels only
+                [z(8, 2, 3, 3), z(8), z(1, 8, 3, 3), z(1)]):         # needs n_mix + 1 >= 2 outputs
+        with pytest.raises(FthmcError, match='unsupported s/t net'):
+            ops.pack_weights([bad])
+    with pytest.raises(FthmcError, match='share the net shape'):
+        ops.pack_weights([w, w3])
     header = open(os.path.join(ROOT, 'include', 'fthmc_hip.h')).read()
-    assert 'hidden_sizes=[8,8], kernel_size=3, n_mixture_comps=2' in header and 'FTHMC_ERR_UNSUPPORTED' in header
+    assert 'fthmc_set_arch' in header and 'FTHMC_ERR_UNSUPPORTED' in header
 
 
 def _device_code_objects(path, tmp):

@@ -241,3 +241,29 @@ def test_observables_tooling_golden(tmp_path):
             np.testing.assert_allclose(np.loadtxt(fn, ndmin=2), g[f'file_{tag}'], rtol=1e-13, atol=1e-15)
     np.testing.assert_allclose(O.sub_avg(g['q_short']), g['sub_avg'], rtol=1e-14, atol=1e-14)
     np.testing.assert_allclose(O.sigma(g['q_short'], reference_literal=True), float(g['sigma_short']), rtol=1e-13)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_net_shapes_other_than_the_default(tag):
+    """hidden_sizes / kernel_size / n_mixture_comps the reference accepts besides its default (layers.py:138-167, 399-429):
+    the oracle on the reference's own outputs (make_golden.py section 12)."""
+    g = load_golden(f'netshape_{tag}')
+    flow, beta, act = golden_flow(g), float(g['beta']), str(g['act'])
+    assert [w.shape[0] for w in flow[0][0:-2:2]] == list(g['hidden']) and flow[0][-1].shape[0] == int(g['n_mix']) + 1
+    x = T(g['x'])
+    y, ld = R.flow_forward(x, flow, act)
+    close(y, g['y'], rtol=1e-11, atol=1e-11); close(ld, g['logdet'], rtol=1e-11, atol=1e-11)
+    close(R.ft_action(x, flow, beta, act), g['S_eff'], rtol=1e-11, atol=1e-11)
+    close(R.ft_force(x, flow, beta, act), g['ft_force'], rtol=1e-9, atol=1e-10)
+    tflow = []
+    li = 0
+    while f'tw{li}_0' in g:
+        row, pi = [], 0
+        while f'tw{li}_{pi}' in g:
+            row.append(T(g[f'tw{li}_{pi}'])); pi += 1
+        tflow.append(tuple(row)); li += 1
+    out, grads = R.train_grads(T(g['xi']), tflow, beta, act)
+    close(out['loss_dkl'], g['loss_dkl'], rtol=1e-10); close(out['logq'], g['logq'], rtol=1e-10); close(out['logp'], g['logp'], rtol=1e-10)
+    for li, row in enumerate(grads):
+        for pi, gr in enumerate(row):
+            close(gr, g[f'tgw{li}_{pi}'], rtol=1e-8, atol=1e-11)

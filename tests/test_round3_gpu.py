@@ -338,3 +338,117 @@ def test_row_strip_leapfrog_kernel(B, L):
     close(xa, xr, rtol=1e-11, atol=1e-11); close(pa, pr, rtol=1e-11, atol=1e-11)
     x2, p2 = ops.leapfrog(xa, -pa, beta, dt, nstep)
     close(x2, x, rtol=1e-10, atol=1e-10); close(-p2, p, rtol=1e-10, atol=1e-10)
+
+
+# ---------------------------------------------------------------- any s/t net shape (csrc/flow_generic.hip)
+@pytest.mark.parametrize('hidden,k,n_mix,L,nl,act', [((8, 8), 3, 3, 8, 4, 'silu'), ((4, 6, 5), 5, 1, 12, 3, 'silu'), ((16,), 3, 2, 16, 2, 'relu'),
+                                                     ((), 3, 2, 8, 8, 'silu'), ((8, 8), 1, 2, 8, 2, 'leaky_relu'), ((12, 12), 3, 4, 20, 2, 'silu')])
+def test_generic_net_shapes_against_the_oracle(hidden, k, n_mix, L, nl, act):
+    """hidden_sizes / kernel_size / n_mixture_comps other than the reference default (fthmc/utils/layers.py:138-167, 399-429
+    accept any): every flowed entry point against the oracle -- layer forward / VJP / weight gradient / reverse, the sweeps,
+    S_eff, ft_force, an MD trajectory, the training gradient -- and the default shape still takes the tuned kernels."""
+    gen = torch.Generator().manual_seed(500 + L + k + n_mix + len(hidden))
+    B, beta = 3, 2.5
+    flow = R.default_flow(nl, gen, hidden=hidden, n_mix=n_mix, k=k)
+    w = ops.pack_weights(flow, device='cuda')
+    assert ops.arch_of(w) == (tuple(hidden), k, n_mix) and w.numel() == nl * ops.arch_params(ops.arch_of(w))
+    x = (torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+    xd = x.cuda()
+    # one layer: forward, VJP, weight gradient, reverse -- all (mu, off) of the first layers
+    for li in range(min(nl, 3)):
+        mu, off = li % 2, (li // 2) % 4
+        wl = ops.pack_weights([flow[li]], device='cuda')
+        y, lj = ops.flow_layer_fwd(xd, wl, mu, off, act)
+        xr_ = x.clone().requires_grad_(True)
+        wr_ = [t.clone().requires_grad_(True) for t in flow[li]]
+        yc, ljc = R.layer_forward(xr_, wr_, mu, off, act)
+        angle_close(y, yc.detach(), atol=1e-11); close(lj, ljc.detach(), rtol=1e-11, atol=1e-11)
+        c = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64); dlog = torch.randn(B, generator=gen, dtype=torch.float64)
+        ((yc * c).sum() + (ljc * dlog).sum()).backward()
+        gx, gw = ops.flow_layer_bwd(xd, wl, c.cuda(), dlog.cuda(), mu, off, act, need_gw=True)
+        close(gx, xr_.grad, rtol=1e-9, atol=1e-10 * float(xr_.grad.abs().max()))
+        for g_, t_ in zip(ops.unpack_weight_grads(gw, 1)[0], wr_):
+            close(g_, t_.grad, rtol=1e-9, atol=1e-10 * max(1.0, float(t_.grad.abs().max())))
+        xb_, ljb = ops.flow_layer_rev(y, wl, mu, off, act)
+        angle_close(xb_, xd, atol=1e-9); close(ljb, -lj, atol=1e-8)
+    # the flow
+    y, ld = ops.flow_forward(xd, w, nl, act)
+    yc, ldc = R.flow_forward(x, flow, act)
+    angle_close(y, yc, atol=1e-10); close(ld, ldc, rtol=1e-10, atol=1e-10)
+    xb_, ldb = ops.flow_reverse(y, w, nl, act)
+    angle_close(xb_, xd, atol=1e-8); close(ldb, -ld, atol=1e-7)
+    S, ld2, plq, Q = ops.ft_action(xd, w, nl, beta, act)
+    close(S, R.ft_action(x, flow, beta, act), rtol=1e-11, atol=1e-10); close(plq, R.plaq_mean(yc, beta), rtol=1e-10); close(Q, R.charge(yc), atol=1e-9)
+    F = ops.ft_force(xd, w, nl, beta, act)
+    Fc = R.ft_force(x, flow, beta, act)
+    close(F, Fc, rtol=1e-9, atol=1e-10 * float(Fc.abs().max()))
+    assert torch.equal(F, ops.ft_force(xd, w, nl, beta, act))
+    v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64); u = torch.rand(B, generator=gen, dtype=torch.float64)
+    xs = 0.3 * x
+    r = ops.ft_trajectory(xs.cuda(), v.cuda(), u.cuda(), w, nl, beta, 0.05, 4, act)
+    dH, _, acc, newx, h0, h1 = R.ft_hmc(xs, v, u, flow, beta, 0.05, 4, act=act, mode='md')
+    close(r['H0'], h0, rtol=1e-11); close(r['H1'], h1, rtol=1e-9); close(r['dH'], dH, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(H(r['acc']) > 0.5, H(acc))
+    angle_close(r['x_new'], newx, atol=1e-8)
+    outc, gc = R.train_grads(x, flow, beta, act)
+    tr = ops.train_grad(xd, w, nl, beta, act)
+    close(tr['logq'], outc['logq'], rtol=1e-10); close(tr['logp'], outc['logp'], rtol=1e-10)
+    for li, row in enumerate(ops.unpack_weight_grads(tr['gw'], nl)):
+        for g_, t_ in zip(row, gc[li]):
+            close(g_, t_, rtol=1e-8, atol=1e-10 * max(1.0, float(t_.abs().max())))
+    # plaquette-level map
+    P = (torch.rand(B, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+    fP, lj = ops.plaq_coupling_fwd(P.cuda(), ops.pack_weights([flow[0]], device='cuda'), 0, 0, act)
+    fPc, ljc = R.plaq_coupling_forward(P, flow[0], 0, 0, act)
+    angle_close(fP, fPc, atol=1e-11); close(lj, ljc, rtol=1e-11, atol=1e-11)
+    Pb, _ = ops.plaq_coupling_rev(fP, ops.pack_weights([flow[0]], device='cuda'), 0, 0, act)
+    angle_close(Pb, P, atol=1e-9)
+    # back to the default shape: the tuned kernels again (the library's shape is process-global state)
+    fd = R.default_flow(2, gen)
+    wd = ops.pack_weights(fd, device='cuda')
+    xq = (torch.rand(2, 2, 8, 8, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+    close(ops.ft_force(xq.cuda(), wd, 2, beta), R.ft_force(xq, fd, beta), rtol=1e-10, atol=1e-10)
+    assert ops._ARCH[0] == ops.DEFAULT_ARCH
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_net_shapes_golden_through_the_reference_api(tag):
+    """The same through the reference-shaped Python API on goldens of the reference itself: make_u1_equiv_layers with
+    other hidden_sizes / kernel_size / n_mixture_comps, qed.ft_flow / ft_action / ft_force, train_step."""
+    from fthmc.config import FlowModel, Param, TrainConfig
+    from fthmc.train import get_model, train_step
+    import fthmc.utils.layers as layers
+    import fthmc.utils.qed_helpers as qed
+    g = load_golden(f'netshape_{tag}')
+    hidden, k, n_mix, act, beta = [int(h) for h in g['hidden']], int(g['kernel_size']), int(g['n_mix']), str(g['act']), float(g['beta'])
+    L, nl = g['x'].shape[-1], int(g['n_layers'])
+
+    def load(flow, prefix):
+        sd = {}
+        for li in range(nl):
+            for pi in range(2 * (len(hidden) + 1)):
+                sd[f'{li}.plaq_coupling.net.{2 * (pi // 2)}.{"weight" if pi % 2 == 0 else "bias"}'] = D(g[f'{prefix}{li}_{pi}'])
+        flow.load_state_dict(sd)                              # the reference's state_dict keys: Conv2d at even indices
+    flow = layers.make_u1_equiv_layers(n_layers=nl, n_mixture_comps=n_mix, lattice_shape=(L, L), hidden_sizes=hidden,
+                                       kernel_size=k, activation_fn=act)
+    load(flow, 'w')
+    param = Param(beta=beta, L=L)
+    x = D(g['x'])
+    angle_close(qed.ft_flow(flow, x), g['y'], atol=1e-10)
+    close(qed.ft_action(param, flow, x), g['S_eff'], rtol=1e-11, atol=1e-10)
+    close(qed.ft_force(param, flow, x), g['ft_force'], rtol=1e-8, atol=1e-10)
+    xb = qed.ft_flow_inv(flow, D(g['y']))
+    angle_close(xb, g['x'], atol=1e-8)
+    B = g['xi'].shape[0]
+    tc = TrainConfig(L=L, beta=beta, n_layers=nl, batch_size=B, base_lr=1e-3, hidden_sizes=hidden, kernel_size=k, n_s_nets=n_mix,
+                     activation_fn=act)
+    model = get_model(tc)
+    load(model.layers, 'tw')
+    for fused in (True, False):
+        opt = torch.optim.SGD(model.layers.parameters(), lr=0.0)
+        opt.zero_grad(set_to_none=True)
+        met = train_step(model, tc, qed.BatchAction(beta), opt, B, xi=D(g['xi']), fused=fused)
+        close(met['loss_dkl'], g['loss_dkl'], rtol=1e-10); close(met['ess'], g['ess'], rtol=1e-8)
+        for li in range(nl):
+            for pi, p in enumerate(model.layers[li].parameters()):
+                close(p.grad, g[f'tgw{li}_{pi}'], rtol=1e-8, atol=1e-11)

@@ -50,6 +50,9 @@ SIGNATURES = {
                              _P, c_size_t, _P],
     'fthmc_flow_layer_fwd': [_D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
     'fthmc_flow_layer_bwd': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_layer_stash_bytes': [c_int, c_int],
+    'fthmc_flow_layer_fwd_stash': [_D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_layer_bwd_stash': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
     'fthmc_flow_layer_rev': [_D, _D, c_int, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
     'fthmc_plaq_coupling_fwd': [_D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
     'fthmc_plaq_coupling_rev': [_D, _D, c_int, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
@@ -71,7 +74,7 @@ SIGNATURES = {
     'fthmc_profile_stages': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double,
                              ctypes.POINTER(c_double), _P, c_size_t, _P],
 }
-_RESTYPE = {'fthmc_version': c_char_p, 'fthmc_last_error': c_char_p, 'fthmc_train_ws_bytes': c_size_t, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
+_RESTYPE = {'fthmc_layer_stash_bytes': c_size_t, 'fthmc_version': c_char_p, 'fthmc_last_error': c_char_p, 'fthmc_train_ws_bytes': c_size_t, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
 
 _lib = None
 

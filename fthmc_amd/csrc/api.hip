@@ -417,24 +417,26 @@ int fthmc_plaq_coupling_rev(const double* fP, const double* w, int B, int L, int
     return plaq_coupling(fP, w, B, L, mu, off, act, tol, true, P, logJ, ws, ws_bytes, stream);
 }
 
-int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, const double* glogJ,
-                         int B, int L, int mu, int off, int act, double* gx, double* gw, void* ws,
-                         size_t ws_bytes, void* stream) {
-    if (!x || !w || !gy || !glogJ || !gx || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3)
+// VJP of one layer.  `stash` != null: the forward's activation stash (fthmc_flow_layer_fwd_stash) -- nothing is recomputed;
+// else the layer is run forward first from `x`.
+static int layer_bwd_impl(const double* x, const double* stash, const double* w, const double* gy, const double* glogJ,
+                          int B, int L, int mu, int off, int act, double* gx, double* gw, void* ws, size_t ws_bytes, void* stream) {
+    if ((!x && !stash) || !w || !gy || !glogJ || !gx || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3)
         return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     const bool mfma = get_flow_variant() == 1;
+    if (stash && !mfma && arch_default()) return FTHMC_ERR_UNSUPPORTED;      // the VALU variant has no stash
     (void)hipGetLastError();
     if (!ws || ws_bytes < (gw && mfma ? fthmc_train_ws_bytes(B, L, 1) : fthmc_ws_bytes(B, L, 1))) return FTHMC_ERR_WS;
     const WS W = ws_layout(static_cast<double*>(ws), B, L, 1, gw != nullptr && mfma);
     hipStream_t s = ft_stream(stream);
     FT_TRY(use_weights(w, 1, W, s));
     if (!arch_default()) {
-        // forward once (fills the layer's planes), then the adjoint seeded by the link gradient; W.gp holds the layer's
-        // plaquette gradient alone
+        // the adjoint seeded by the link gradient; W.gp holds the layer's plaquette gradient alone
         GenLayerArgs g = gen_args(W, 0, B, L, act, false);
         g.mu = mu; g.off = off; g.x = x;
-        FT_TRY(launch_gen_fwd(g, false, s));
+        if (stash) g.stash = const_cast<double*>(stash);
+        else FT_TRY(launch_gen_fwd(g, false, s));                 // forward once: fills the layer's planes
         g.up_link = gy; g.glogj = glogJ; g.gp_out = W.gp; g.gw = gw;
         FT_TRY(launch_gen_bwd(g, s));
         return launch_adj_add(W.gp, gy, B, L, gx, s);
@@ -444,10 +446,13 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
     a.gp_part = W.gp_part; a.gw_part = W.gw_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
     if (mfma) {
-        // forward once with the stash (no link update, no log J), then the gather-form backward seeded
-        // by the link gradient; gP_out holds the layer's plaquette gradient alone (no upstream gP field)
-        a.stash = W.stash; a.stash_h = gw ? 1 : 0;
-        FT_TRY(launch_flow_fwd_mfma(a, s));
+        // the gather-form backward seeded by the link gradient; gP_out holds the layer's plaquette gradient alone (no
+        // upstream gP field).  Without a caller's stash: forward once with the stash (no link update, no log J).
+        if (stash) { a.stash = const_cast<double*>(stash); a.stash_h = 1; }
+        else {
+            a.stash = W.stash; a.stash_h = gw ? 1 : 0;
+            FT_TRY(launch_flow_fwd_mfma(a, s));
+        }
         a.gp_out = W.gp;
         a.gz = gw ? W.gz : nullptr;
         FT_TRY(launch_flow_bwd_gather(a, s));
@@ -461,6 +466,44 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
     if (gw) FT_TRY(launch_reduce_gw(W.gw_part, B * flow_geom(false).ntiles(L), 1.0, 0, gw, W.gw_tmp, s));
     FT_TRY(launch_gather_gp(W.gp_part, B, L, flow_geom(false), 0, W.gp, s));
     return launch_adj_add(W.gp, gy, B, L, gx, s);
+}
+
+int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, const double* glogJ,
+                         int B, int L, int mu, int off, int act, double* gx, double* gw, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (!x) return FTHMC_ERR_ARG;
+    return layer_bwd_impl(x, nullptr, w, gy, glogJ, B, L, mu, off, act, gx, gw, ws, ws_bytes, stream);
+}
+
+size_t fthmc_layer_stash_bytes(int B, int L) {
+    if (B <= 0 || L <= 0) return 0;
+    if (!arch_default()) return gen_stash_doubles(B, L) * sizeof(double);
+    return get_flow_variant() == 1 ? flow_stash_doubles(B, L, true) * sizeof(double) : 0;
+}
+
+int fthmc_flow_layer_fwd_stash(const double* x, const double* w, int B, int L, int mu, int off, int act, double* y,
+                               double* logJ, double* stash, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !w || !y || !stash || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2 || fthmc_layer_stash_bytes(B, L) == 0) return FTHMC_ERR_UNSUPPORTED;
+    FT_WS(1);
+    FT_TRY(use_weights(w, 1, W, s));
+    if (!arch_default()) {
+        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+        g.mu = mu; g.off = off; g.x = x; g.y = y; g.logj = logJ; g.stash = stash;
+        return launch_gen_fwd(g, false, s);
+    }
+    FlowLayerArgs a{};
+    a.x = x; a.wint = W.wint; a.y = y; a.logj_part = W.lj_part; a.stash = stash; a.stash_h = 1;
+    a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+    FT_TRY(launch_flow_fwd_mfma(a, s));
+    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_fwd_geom(true).ntiles(L), 1.0, 0, logJ, s));
+    return FTHMC_OK;
+}
+
+int fthmc_flow_layer_bwd_stash(const double* stash, const double* w, const double* gy, const double* glogJ, int B, int L,
+                               int mu, int off, int act, double* gx, double* gw, void* ws, size_t ws_bytes, void* stream) {
+    if (!stash) return FTHMC_ERR_ARG;
+    return layer_bwd_impl(nullptr, stash, w, gy, glogJ, B, L, mu, off, act, gx, gw, ws, ws_bytes, stream);
 }
 
 int fthmc_flow_forward(const double* x, const double* w, int n_layers, int B, int L, int act,

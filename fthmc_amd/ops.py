@@ -315,6 +315,33 @@ def flow_layer_bwd(x, w, gy, glogJ, mu: int, off: int, act='silu', need_gw=False
     return gx, gw
 
 
+def flow_layer_fwd_stash(x, w, mu: int, off: int, act='silu'):
+    """-> (y, logJ, stash): the layer forward that keeps its activations for `flow_layer_bwd_stash` (stash is None where
+    the kernels have none -- the VALU variant: use flow_layer_bwd then)."""
+    x = _field(x); w = _w1(w, x); B, _, L, _ = x.shape
+    nbytes = int(_lib.load().fthmc_layer_stash_bytes(B, L))
+    if nbytes == 0:
+        return (*flow_layer_fwd(x, w, mu, off, act), None)
+    y = torch.empty_like(x); logJ = torch.empty(B, dtype=x.dtype, device=x.device)
+    stash = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
+    ws, nb = _ws(x, B, L, 1)
+    check(_lib.load().fthmc_flow_layer_fwd_stash(_p(x), _p(w), B, L, int(mu), int(off), act_code(act), _p(y), _p(logJ),
+                                                 _p(stash), ws, nb, _stream(x)), 'fthmc_flow_layer_fwd_stash')
+    return y, logJ, stash
+
+
+def flow_layer_bwd_stash(stash, shape, w, gy, glogJ, mu: int, off: int, act='silu', need_gw=False):
+    """VJP of the layer from the stash of `flow_layer_fwd_stash` (`shape` = that call's x.shape): nothing recomputed."""
+    w_ = _w1(w, gy); gy = _field(gy, 'gy'); glogJ = _dev(glogJ, 'glogJ').reshape(-1)
+    B, _, L, _ = shape
+    gx = torch.empty_like(gy)
+    gw = _tag(torch.empty(w_.numel(), dtype=gy.dtype, device=gy.device), w_) if need_gw else None
+    ws, nb = _ws(gy, B, L, 1, train=need_gw)
+    check(_lib.load().fthmc_flow_layer_bwd_stash(_p(stash), _p(w_), _p(gy), _p(glogJ), B, L, int(mu), int(off), act_code(act),
+                                                 _p(gx), _p(gw), ws, nb, _stream(gy)), 'fthmc_flow_layer_bwd_stash')
+    return gx, gw
+
+
 def flow_layer_rev(y, w, mu: int, off: int, act='silu', tol: float = 1e-12):
     y = _field(y, 'y'); w = _w1(w, y); B, _, L, _ = y.shape
     x = torch.empty_like(y); logJ = torch.empty(B, dtype=y.dtype, device=y.device)

@@ -145,19 +145,30 @@ class _CouplingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mu, off, act, *params):
         w = ops.pack_weights([params], device=x.device)
-        y, logJ = ops.flow_layer_fwd(x, w, mu, off, act)
-        ctx.save_for_backward(x, w)
-        ctx.meta = (mu, off, act, [p.shape for p in params], any(p.requires_grad for p in params))
+        need_gw = any(p.requires_grad for p in params)
+        stash = None
+        if x.requires_grad or need_gw:
+            # keep the layer's activations for the backward (fthmc_flow_layer_fwd_stash): nothing is run twice
+            y, logJ, stash = ops.flow_layer_fwd_stash(x, w, mu, off, act)
+        else:
+            y, logJ = ops.flow_layer_fwd(x, w, mu, off, act)
+        ctx.save_for_backward(x, w, *([stash] if stash is not None else []))
+        ctx.meta = (mu, off, act, [p.shape for p in params], need_gw, ops.arch_of(w))
         return y, logJ
 
     @staticmethod
     def backward(ctx, gy, glogJ):
-        x, w = ctx.saved_tensors
-        mu, off, act, shapes, need_gw = ctx.meta
+        x, w, *rest = ctx.saved_tensors
+        mu, off, act, shapes, need_gw, arch = ctx.meta
+        if arch != ops.DEFAULT_ARCH:
+            w._fthmc_arch = arch                                  # saved_tensors hands back a plain tensor
         gy = torch.zeros_like(x) if gy is None else gy.contiguous()
         glogJ = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device) if glogJ is None else glogJ.contiguous()
-        gx, gw = ops.flow_layer_bwd(x, w, gy, glogJ, mu, off, act, need_gw=need_gw)
-        gparams = list(ops.unpack_weight_grads(gw, 1)[0]) if need_gw else [None] * len(shapes)
+        if rest:
+            gx, gw = ops.flow_layer_bwd_stash(rest[0], x.shape, w, gy, glogJ, mu, off, act, need_gw=need_gw)
+        else:                                                     # no stash on this kernel variant: forward again inside
+            gx, gw = ops.flow_layer_bwd(x, w, gy, glogJ, mu, off, act, need_gw=need_gw)
+        gparams = list(ops.unpack_weight_grads(gw, 1, arch=arch)[0]) if need_gw else [None] * len(shapes)
         return (gx, None, None, None, *gparams)
 
 

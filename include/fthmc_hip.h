@@ -137,6 +137,16 @@ int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, con
                          int B, int L, int mu, int off, int act,
                          double* gx, double* gw,
                          void* ws, size_t ws_bytes, void* stream);
+/* The same pair for callers that keep a layer's activations between its forward and its backward (an autograd graph:
+ * fthmc/utils/layers.py:196-202 under loss.backward(), train.py:210): the forward also fills `stash`
+ * (fthmc_layer_stash_bytes(B, L) bytes, caller-owned), the backward reads it and recomputes nothing.
+ * fthmc_layer_stash_bytes is 0 where no stash exists (fthmc_set_variant(0)): use fthmc_flow_layer_bwd there. */
+size_t fthmc_layer_stash_bytes(int B, int L);
+int fthmc_flow_layer_fwd_stash(const double* x, const double* w, int B, int L, int mu, int off, int act,
+                               double* y, double* logJ, double* stash, void* ws, size_t ws_bytes, void* stream);
+int fthmc_flow_layer_bwd_stash(const double* stash, const double* w, const double* gy, const double* glogJ,
+                               int B, int L, int mu, int off, int act, double* gx, double* gw,
+                               void* ws, size_t ws_bytes, void* stream);
 /* (x, logJ[B]) = GaugeEquivCouplingLayer.reverse(y): fthmc/utils/layers.py:204-210,
  * :373-396.  The scalar inverse is solved per site to |f(x) - y| <= tol by
  * safeguarded Newton/bisection on [-pi, pi] (the reference bisects to a global

@@ -452,3 +452,52 @@ def test_net_shapes_golden_through_the_reference_api(tag):
         for li in range(nl):
             for pi, p in enumerate(model.layers[li].parameters()):
                 close(p.grad, g[f'tgw{li}_{pi}'], rtol=1e-8, atol=1e-11)
+
+
+# ---------------------------------------------------------------- autograd route: the backward reads the forward's stash
+@pytest.mark.parametrize('hidden,k,n_mix', [((8, 8), 3, 2), ((6,), 3, 3)])
+def test_layer_backward_from_the_forwards_stash(hidden, k, n_mix):
+    """fthmc_flow_layer_fwd_stash + fthmc_flow_layer_bwd_stash (what the autograd bridge of GaugeEquivCouplingLayer uses:
+    the layer is not run a second time inside its backward) == fthmc_flow_layer_bwd bit for bit; the VALU variant, which
+    has no stash, falls back to it."""
+    gen = torch.Generator().manual_seed(91)
+    B, L = 3, 24
+    flow = R.default_flow(4, gen, hidden=hidden, n_mix=n_mix, k=k)
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    gy = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()
+    gl = torch.randn(B, generator=gen, dtype=torch.float64).cuda()
+    for li in range(4):
+        mu, off = li % 2, (li // 2) % 4
+        w = ops.pack_weights([flow[li]], device='cuda')
+        y0, lj0 = ops.flow_layer_fwd(x, w, mu, off)
+        y, lj, stash = ops.flow_layer_fwd_stash(x, w, mu, off)
+        assert stash is not None and torch.equal(y, y0) and torch.equal(lj, lj0)
+        for need_gw in (False, True):
+            gx0, gw0 = ops.flow_layer_bwd(x, w, gy, gl, mu, off, need_gw=need_gw)
+            gx, gw = ops.flow_layer_bwd_stash(stash, x.shape, w, gy, gl, mu, off, need_gw=need_gw)
+            assert torch.equal(gx, gx0) and (not need_gw or torch.equal(gw, gw0))
+    if tuple(hidden) == (8, 8):
+        ops.set_variant(0)
+        try:
+            w = ops.pack_weights([flow[0]], device='cuda')
+            assert ops.flow_layer_fwd_stash(x, w, 0, 0)[2] is None
+        finally:
+            ops.set_variant(1)
+    # through autograd: a two-layer composition, gradients wrt x and wrt the weights against the oracle
+    from fthmc_amd.utils import layers as Lyr
+    nets = Lyr.make_u1_equiv_layers(n_layers=2, n_mixture_comps=n_mix, lattice_shape=(L, L), hidden_sizes=list(hidden),
+                                    kernel_size=k, activation_fn='silu')
+    names = [f'net.{2 * i}.{n}' for i in range(len(hidden) + 1) for n in ('weight', 'bias')]
+    nets.load_state_dict({f'{li}.plaq_coupling.{n}': flow[li][pi].cuda() for li in range(2) for pi, n in enumerate(names)})
+    xr = x.clone().requires_grad_(True)
+    y1, l1 = nets[0](xr); y2, l2 = nets[1](y1)
+    loss = (y2 * gy).sum() + ((l1 + l2) * gl).sum()
+    loss.backward()
+    xc = x.cpu().clone().requires_grad_(True)
+    wc = [[t.clone().requires_grad_(True) for t in flow[li]] for li in range(2)]
+    a1, b1 = R.layer_forward(xc, wc[0], 0, 0); a2, b2 = R.layer_forward(a1, wc[1], 1, 0)
+    ((a2 * gy.cpu()).sum() + ((b1 + b2) * gl.cpu()).sum()).backward()
+    close(xr.grad, xc.grad, rtol=1e-9, atol=1e-10 * float(xc.grad.abs().max()))
+    for li in range(2):
+        for p, t in zip(nets[li].parameters(), wc[li]):
+            close(p.grad, t.grad, rtol=1e-8, atol=1e-10 * max(1.0, float(t.grad.abs().max())))

@@ -251,6 +251,11 @@ def test_config5_shard_properties_and_oracle():
         for pi in range(6):
             scale = float(gc[li][pi].abs().max())
             close(gws[li][pi], gc[li][pi], rtol=1e-7, atol=1e-9 * max(scale, 1.0))
+    # a second chain of the shard against the oracle (effective action and force), from the other end of the batch
+    xc2 = x[31:32].cpu()
+    yc2, ldc2 = R.flow_forward(xc2, flow)
+    close(ops.ft_action(x[31:32].contiguous(), w, nl, beta)[0], R.action(yc2, beta) - ldc2, rtol=1e-10)
+    close(F[31:32], R.ft_force(xc2, flow, beta), rtol=1e-7, atol=1e-8)
     # full-shard training gradient = mean of per-chain gradients (chains 0..3 checked against their own calls)
     rb = ops.train_grad(x[:4].contiguous(), w, nl, beta)
     acc = sum(ops.train_grad(x[i:i + 1].contiguous(), w, nl, beta)['gw'] for i in range(4)) / 4

@@ -97,6 +97,20 @@ __device__ __forceinline__ void put2(double* p, int r, int c, double va, double 
     if (rr >= 0 && cc >= 0) { p[rr + cc] = va; p[PS + rr + cc] = vb; }
 }
 
+// interior only: planes whose readers are VALU stages (conv3, conv3^T, conv1^T) wrap their own indices, no border needed
+template <int RS>
+__device__ __forceinline__ void put1i(double* p, int r, int c, double v) { p[(r + 1) * RS + c + 1] = v; }
+template <int RS, int PS>
+__device__ __forceinline__ void put2i(double* p, int r, int c, double va, double vb) {
+    const int m = (r + 1) * RS + c + 1;
+    p[m] = va; p[PS + m] = vb;
+}
+// padded-plane row (or column) index of lattice line v - 1 + k, k = 0, 1, 2, wrapped
+template <int L>
+__device__ __forceinline__ void wrap3(int v, int (&o)[3]) {
+    o[0] = (v == 0 ? L - 1 : v - 1) + 1; o[1] = v + 1; o[2] = (v == L - 1 ? 0 : v + 1) + 1;
+}
+
 __device__ __forceinline__ double2_t ldg2(const double* p) {
     if (FT_KNOB & 16) return double2_t{0.5, 0.25};
     return *reinterpret_cast<const double2_t*>(p);
@@ -272,8 +286,8 @@ template <int L> struct Chain {
             if (FT_KNOB & 4) { for (int q = 0; q < 4; ++q) { h[q] = z[q]; d[q] = 1.0; } } else
             act_eval4(z, act, h, d);
             if (!ok) return;
-            put2<L, RS, PSZ>(sH2 + 2 * g * PSZ, r, c, h[0], h[1]);
-            put2<L, RS, PSZ>(sH2 + 2 * g * PSZ, r + dr, c + dc, h[2], h[3]);
+            put2i<RS, PSZ>(sH2 + 2 * g * PSZ, r, c, h[0], h[1]);
+            put2i<RS, PSZ>(sH2 + 2 * g * PSZ, r + dr, c + dc, h[2], h[3]);
             if (STASH) {
                 const int at = r * L + c;
                 *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)at) = double2_t{d[0], d[1]};
@@ -308,11 +322,13 @@ template <int L> struct Chain {
         active_site(alane ? lane : 0, mu, off, ai, aj);
         if (alane) {
             double acc[3] = {0.0, 0.0, 0.0};
+            int ro[3], co_[3];
+            wrap3<L>(ai, ro); wrap3<L>(aj, co_);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const double v = sH2[wave * PSZ + (ai + ky) * RS + aj + kx];
+                    const double v = sH2[wave * PSZ + ro[ky] * RS + co_[kx]];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) acc[k] = fma(v, w3[k * 9 + ky * 3 + kx], acc[k]);
                 }
@@ -458,8 +474,8 @@ template <int L> struct Chain {
             rs = fma(fma(-tsum, rs, 1.0), rs, rs);
             const double cbr = cb * rs;
 #pragma unroll
-            for (int k = 0; k < NMIX; ++k) put1<L, RS>(sGO + k * PSZ, i, j, gdelta * pre.tcv[4 * k] + cbr * pre.tcv[4 * k + 1]);
-            put1<L, RS>(sGO + NMIX * PSZ, i, j, gdelta);
+            for (int k = 0; k < NMIX; ++k) put1i<RS>(sGO + k * PSZ, i, j, gdelta * pre.tcv[4 * k] + cbr * pre.tcv[4 * k + 1]);
+            put1i<RS>(sGO + NMIX * PSZ, i, j, gdelta);
             sGP[i * L + j] = g0 + (gdelta * (csum - 1.0) - cbr * esum);
         }
         if (refill) issue_tc(tid, nl_, pre);
@@ -472,13 +488,15 @@ template <int L> struct Chain {
             const int ksel = ((mu == 0 ? c : r) + 1 - off) & 3;           // the one kx (mu = 0) / ky (mu = 1) whose source is active
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
             if (ksel <= 2) {
+                int ro[3], co_[3];                                       // padded index of line r - 1 + k: tap ky reads ro[2 - ky]
+                wrap3<L>(r, ro); wrap3<L>(c, co_);
 #pragma unroll
                 for (int co = 0; co < 3; ++co) {
                     double wq[3][4], g0[3];
 #pragma unroll
                     for (int kk = 0; kk < 3; ++kk) {
                         const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
-                        g0[kk] = sGO[co * PSZ + (r + 2 - ky) * RS + c + 2 - kx];
+                        g0[kk] = sGO[co * PSZ + ro[2 - ky] * RS + co_[2 - kx]];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) wq[kk][k] = sWc[LB_W2 + (co * 8 + c3half * 4 + k) * 9 + ky * 3 + kx];
                     }
@@ -501,8 +519,8 @@ template <int L> struct Chain {
         {
             auto epi = [&](int g, int, bool ok, double (&z)[4], int) {
                 if (!ok) return;
-                put2<L, RS, PSZ>(sD1 + 2 * g * PSZ, pr_, pc_, z[0] * pre.d1v[0], z[1] * pre.d1v[1]);
-                put2<L, RS, PSZ>(sD1 + 2 * g * PSZ, pr_ + (mu == 0 ? 0 : 1), pc_ + (mu == 0 ? 1 : 0), z[2] * pre.d1v[2], z[3] * pre.d1v[3]);
+                put2i<RS, PSZ>(sD1 + 2 * g * PSZ, pr_, pc_, z[0] * pre.d1v[0], z[1] * pre.d1v[1]);
+                put2i<RS, PSZ>(sD1 + 2 * g * PSZ, pr_ + (mu == 0 ? 0 : 1), pc_ + (mu == 0 ? 1 : 0), z[2] * pre.d1v[2], z[3] * pre.d1v[3]);
             };
             if (mu == 0)
                 mfma_stage<KConv2Col, G::NPAIR, RS, PSZ, false, false, 2>(sGZ2, sWc + LB_T2, wave, lane,
@@ -526,10 +544,12 @@ template <int L> struct Chain {
         for (int f = lane; f < NF; f += 64) {
             int r, c;
             frozen_site(f, mu, off, r, c);
-            const double* gz = sD1 + wave * PSZ + r * RS + c;              // padded coordinates (r + 2 - ky, c + 2 - kx)
+            const double* gz = sD1 + wave * PSZ;                           // source site (r + 1 - ky, c + 1 - kx), wrapped
+            int ro[3], co_[3];
+            wrap3<L>(r, ro); wrap3<L>(c, co_);
             double gv[9], gc = 0.0, gs = 0.0;
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) gv[tp] = gz[(2 - tp / 3) * RS + 2 - tp % 3];
+            for (int tp = 0; tp < 9; ++tp) gv[tp] = gz[ro[2 - tp / 3] * RS + co_[2 - tp % 3]];
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) { gc = fma(gv[tp], w0s[tp], gc); gs = fma(gv[tp], w0s[9 + tp], gs); }
             sPart[(wave * 2 + 0) * NF + f] = gc;

@@ -60,23 +60,6 @@ template <int TR, int TC> struct SmemG {
     static_assert(2 * SIZE * 8 <= 160 * 1024, "two workgroups per CU (160 KB of LDS on gfx950)");
 };
 
-// One conv2^T tile: the 18 live K steps of a pair window whose line KD (of its four lines across the pairing direction,
-// NL = lines per tap row of KO's window) is dead.  Straight-line code per (K order, KD): the operand reads pipeline freely.
-template <class KO, int NL, int KD, int RSA, int PSA>
-__device__ __forceinline__ double4_t conv2t_tile(const double* __restrict__ wp, const double* __restrict__ a0) {
-    double4_t accs[2] = {double4_t{0.0, 0.0, 0.0, 0.0}, double4_t{0.0, 0.0, 0.0, 0.0}};
-    int s = 0;
-#pragma unroll
-    for (int t = 0; t < KO::NSTEP; ++t) {
-        // tap t >> 1 of the window; the line across the pairing direction: its column (4-wide window) / its row (4-high window)
-        const int line = NL == 4 ? (t >> 1) % 4 : (t >> 1) / 3;
-        if (line == KD) continue;
-        accs[s & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[KO::bimm(t)], a0[KO::template aimm<RSA, PSA>(t)], accs[s & 1], 0, 0, 0);
-        ++s;
-    }
-    return accs[0] + accs[1];
-}
-
 // A.gz (training): the kernel additionally writes the gradients wrt the layer's pre-activations at the tile's own
 // sites -- gz2, gz1 (channel-minor) and the transform adjoint g_out at the active sites -- for k_flow_wgrad
 // (flow_wgrad.hip), which turns them into weight gradients; nothing else changes.

@@ -33,17 +33,6 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 #define FT_KNOB 0
 #endif
 
-// conv1 (2 -> 8) as a 6-step implicit GEMM, pairs = columns (c, c + 1) of one row: 3 x 4 window.
-// K slot (g, t): input channel g & 1, window column 2 (g >> 1) + t / 3, tap row t % 3 (KConv1, flow_mfma_common.h, is the
-// same with rows and columns exchanged); table P1[ky][ci][c5][row] of the mu = 0 forward block.
-struct KConv1Col {
-    static constexpr int NSTEP = 6;
-    template <int RSA, int PSA> static __device__ __forceinline__ int alane(int g) { return (g & 1) * PSA + (g >> 1) * 2; }
-    template <int RSA, int PSA> static constexpr int aimm(int t) { return (t / 3) + (t % 3) * RSA; }
-    static constexpr int bimm(int t) { return (t % 3) * 96 + (t / 3) * 8; }
-    static __device__ __forceinline__ int wlane(int g, int cN, int dd) { return cN + (g & 1) * 48 + (2 * (g >> 1) + 1 - dd) * 8; }
-};
-
 template <int L> struct GS {
     static constexpr int N = L * L, NA = N / 4, NF = N / 2, NPAIR = N / 2;
     static constexpr int PL = L + 2, RS = PL;                    // periodic plane: one-site border of wrapped duplicates
@@ -200,14 +189,14 @@ template <int L> struct Chain {
         const int h = fdiv<L>(f), q = f - h * L, x = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3);
         if (mu == 0) { r = q; c = x; } else { c = q; r = x; }
     }
-    // conv2^T: site 0 of this lane's pair in tile `wave` (site 1 = next column for mu = 0, next row for mu = 1)
+    // Pairs ACROSS the stripe lines (conv1 forward, conv2^T): tile `wave` = pair position u across the lines, lane i = position
+    // v along them; site 0 = (v, 2 u) for mu = 0 (site 1 = next column), (2 u, v) for mu = 1 (site 1 = next row).  A tile
+    // holds one u, so the stripe classes of its four-line input window are wave-uniform: conv1 runs on the two frozen lines
+    // only, conv2^T skips the dead one (flow_fwd.hip, flow_bwd_gather.hip do the same on their windows).
     __device__ __forceinline__ bool pair_site(int lane, int mu, int& r, int& c) const {
-        const int p_ = wave * 16 + (lane & 15);
-        const bool ok = p_ < G::NPAIR;
-        const int p = ok ? p_ : G::NPAIR - 1;
-        if (mu == 0) { r = fdiv<L / 2>(p); c = 2 * (p - r * (L / 2)); }
-        else { const int q = fdiv<L>(p); r = 2 * q; c = p - q * L; }
-        return ok;
+        const int u = wave < L / 2 ? wave : L / 2 - 1, v_ = lane & 15, v = v_ < L ? v_ : L - 1;
+        if (mu == 0) { r = v; c = 2 * u; } else { r = 2 * u; c = v; }
+        return wave < L / 2 && v_ < L;
     }
 
     // ---- one coupling layer forward, in place on the links in LDS.  STASH: also write what the backward needs.
@@ -250,30 +239,38 @@ template <int L> struct Chain {
 
         double* const st_d1 = STASH ? sv.d1 + 2 * (lane >> 4) : nullptr;
         double* const st_d2 = STASH ? sv.d2 + 2 * (lane >> 4) : nullptr;
-        // ---- conv1 (2 -> 8) + act: pairs = columns for mu = 0, rows for mu = 1 (the layout of the packed table P1)
-        auto conv1_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
-            const double b0 = sWc[LF_B0 + 2 * g], b1 = sWc[LF_B0 + 2 * g + 1];
+        // ---- conv1 (2 -> 8) + act on the frozen taps: pairs across the stripe lines (columns for mu = 0, rows for mu = 1)
+        {
+            // K = 2 frozen lines x 3 taps along x 2 channels = 3 MFMA steps; the constant lines (cos, sin) = (1, 0) are in the
+            // bias table BC (flow_common.h), indexed by the stripe class s4 of the window's first line
+            const int g = lane >> 4, i = lane & 15, cN = i & 7, dd = i >> 3;
+            int pr, pc;
+            const bool ok = pair_site(lane, mu, pr, pc);
+            const int u = mu == 0 ? pc >> 1 : pr >> 1, v = mu == 0 ? pr : pc;
+            const int s4 = (2 * u - 1 - off) & 3;                        // wave-uniform
+            const int fl = ((g >> 1) + 1 - s4) & 3;                      // this lane group's frozen line of the window
+            const int lstep = mu == 0 ? 1 : RS, astep = mu == 0 ? RS : 1;
+            const double* a0 = sIn + (g & 1) * PSZ + (2 * u + fl) * lstep + v * astep;
+            const double* sP1 = sWc + LF_P1;
+            const double* wp = sP1 + cN + (g & 1) * 48 + (fl + 1 - dd) * 8;
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[t * 96], a0[t * astep], acc, 0, 0, 0);
+            const double* bc = sP1 + LF_BC + s4 * 16 + 2 * g;
+            double z[4] = {acc[0] + bc[0], acc[1] + bc[1], acc[2] + bc[8], acc[3] + bc[9]};
             double h[4], d[4];
-            z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
             if (FT_KNOB & 4) { for (int q = 0; q < 4; ++q) { h[q] = z[q]; d[q] = 1.0; } } else
             act_eval4(z, act, h, d);
-            if (!ok) return;
-            put2<L, RS, PSZ>(sH1 + 2 * g * PSZ, r, c, h[0], h[1]);
-            put2<L, RS, PSZ>(sH1 + 2 * g * PSZ, r + dr, c + dc, h[2], h[3]);
-            if (STASH) {
-                const int at = r * L + c;
-                *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)at) = double2_t{d[0], d[1]};
-                *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dr * L + dc)) = double2_t{d[2], d[3]};
+            if (ok) {
+                const int dr = mu == 0 ? 0 : 1, dc = mu == 0 ? 1 : 0;
+                put2<L, RS, PSZ>(sH1 + 2 * g * PSZ, pr, pc, h[0], h[1]);
+                put2<L, RS, PSZ>(sH1 + 2 * g * PSZ, pr + dr, pc + dc, h[2], h[3]);
+                if (STASH) {
+                    const int at = pr * L + pc;
+                    *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)at) = double2_t{d[0], d[1]};
+                    *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dr * L + dc)) = double2_t{d[2], d[3]};
+                }
             }
-        };
-        if (mu == 0) {
-            mfma_stage<KConv1Col, G::NPAIR, RS, PSZ, false, false, 1>(sIn, sWc + LF_P1, wave, lane,
-                [&](int p) { const int r = fdiv<L / 2>(p); return r * RS + 2 * (p - r * (L / 2)); },
-                [&](int g, int p, bool ok, double (&z)[4], int) { const int r = fdiv<L / 2>(p); conv1_epi(g, ok, r, 2 * (p - r * (L / 2)), 0, 1, z); });
-        } else {
-            mfma_stage<KConv1, G::NPAIR, RS, PSZ, false, false, 1>(sIn, sWc + LF_P1, wave, lane,
-                [&](int p) { const int pr = fdiv<L>(p); return 2 * pr * RS + (p - pr * L); },
-                [&](int g, int p, bool ok, double (&z)[4], int) { const int pr = fdiv<L>(p); conv1_epi(g, ok, 2 * pr, p - pr * L, 1, 0, z); });
         }
         lds_barrier();
         stamp(1);
@@ -454,7 +451,7 @@ template <int L> struct Chain {
         int fr = 0, fc = 0;
         frozen_site(ftask ? tid : 0, mu, off, fr, fc);
         int pr_ = 0, pc_ = 0;
-        pair_site(lane, mu, pr_, pc_);
+        const bool pok = pair_site(lane, mu, pr_, pc_);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- adjoint of the tan-mixture transform at the active sites; their own gP is complete here: nobody else reads
@@ -522,12 +519,31 @@ template <int L> struct Chain {
                 put2i<RS, PSZ>(sD1 + 2 * g * PSZ, pr_, pc_, z[0] * pre.d1v[0], z[1] * pre.d1v[1]);
                 put2i<RS, PSZ>(sD1 + 2 * g * PSZ, pr_ + (mu == 0 ? 0 : 1), pc_ + (mu == 0 ? 1 : 0), z[2] * pre.d1v[2], z[3] * pre.d1v[3]);
             };
-            if (mu == 0)
-                mfma_stage<KConv2Col, G::NPAIR, RS, PSZ, false, false, 2>(sGZ2, sWc + LB_T2, wave, lane,
-                    [&](int p) { const int r = fdiv<L / 2>(p); return r * RS + 2 * (p - r * (L / 2)); }, epi);
-            else
-                mfma_stage<KConv2Row, G::NPAIR, RS, PSZ, false, false, 2>(sGZ2, sWc + LB_T2, wave, lane,
-                    [&](int p) { const int q = fdiv<L>(p); return 2 * q * RS + (p - q * L); }, epi);
+            // the pair's four-line window holds exactly one line on which gz2 is zero (class 2: no active site within reach):
+            // its six K steps are skipped; which line it is depends on u only (wave-uniform)
+            const int g = lane >> 4, i = lane & 15;
+            const int u = wave < L / 2 ? wave : L / 2 - 1;
+            const int kd = (off + 3 - 2 * u) & 3;
+            const double* wp = sWc + LB_T2 + KConv2Row::wlane(g, i & 7, i >> 3);
+            const double* a0 = sGZ2 + g * PSZ + pr_ * RS + pc_;             // padded origin of the pair window = site 0 - (1, 1)
+            double4_t acc;
+            if (mu == 0) {
+                switch (kd) {
+                    case 0: acc = conv2t_tile<KConv2Col, 4, 0, RS, PSZ>(wp, a0); break;
+                    case 1: acc = conv2t_tile<KConv2Col, 4, 1, RS, PSZ>(wp, a0); break;
+                    case 2: acc = conv2t_tile<KConv2Col, 4, 2, RS, PSZ>(wp, a0); break;
+                    default: acc = conv2t_tile<KConv2Col, 4, 3, RS, PSZ>(wp, a0); break;
+                }
+            } else {
+                switch (kd) {
+                    case 0: acc = conv2t_tile<KConv2Row, 3, 0, RS, PSZ>(wp, a0); break;
+                    case 1: acc = conv2t_tile<KConv2Row, 3, 1, RS, PSZ>(wp, a0); break;
+                    case 2: acc = conv2t_tile<KConv2Row, 3, 2, RS, PSZ>(wp, a0); break;
+                    default: acc = conv2t_tile<KConv2Row, 3, 3, RS, PSZ>(wp, a0); break;
+                }
+            }
+            double z4[4] = {acc[0], acc[1], acc[2], acc[3]};
+            epi(g, 0, pok, z4, 0);
         }
         typedef const double __attribute__((address_space(4))) * cdptr;
         double w0s[18];

@@ -273,7 +273,7 @@ def main():
     x0 = x.cpu()
 
     stats = parallel.RunStats.zeros(dev)
-    out = {'x_new': torch.empty_like(x)}
+    out = {'x_new': x if flowed else torch.empty_like(x)}
     for k in ('dH', 'acc', 'H0', 'H1', 'plaq', 'Q'):
         out[k] = torch.empty(B, dtype=torch.float64, device=dev)
     if flowed:
@@ -294,12 +294,14 @@ def main():
     if isinstance(Gsplit, list):
         G = len(Gsplit)
     state = torch.stack([S0, p0, q0]).contiguous()      # (S_eff, plaq, Q) of the current x, carried along
-    out['state'] = torch.empty_like(state)
+    out['state'] = state
 
     def enqueue():
         """momentum refresh + one trajectory of every chain of this GPU, forked from the current stream"""
         ops.random_momenta(seeds, x.shape, out_v=v, out_u=u)
         if flowed:
+            # in place: the accepted field replaces x, its (S_eff, plaq, Q) replace the carried state (the C ABI allows
+            # x_new == x and state_out == state_in: both are read before they are written)
             ops.ft_trajectory(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=state, groups=Gsplit)
         else:
             r = ops.hmc_trajectory(x, v, u, BETA, dt, NSTEP)
@@ -308,11 +310,9 @@ def main():
             _, qn, pn = ops.wilson_action_charge(out['x_new'], BETA)
             out['plaq'].copy_(pn); out['Q'].copy_(qn)
         # the chain state moves on and the run statistics accumulate inside the same (captured) sequence
-        x.copy_(out['x_new'])
-        if flowed:
-            state.copy_(out['state'])
-        stats.add(out['acc'], out['plaq'], out['Q'], out['Q'] - qold, out['dH'])
-        qold.copy_(out['Q'])
+        if not flowed:
+            x.copy_(out['x_new'])
+        stats.add_device(out['acc'], out['plaq'], out['Q'], qold, out['dH'])      # one launch; also qold <- Q
 
     graph = None
     if not args.no_graph:

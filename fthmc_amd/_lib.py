@@ -45,6 +45,7 @@ SIGNATURES = {
     'fthmc_wilson_force': [_D, c_int, c_int, c_double, _D, _P],
     'fthmc_leapfrog': [_D, _D, c_int, c_int, c_double, c_double, c_int, _D, _D, _P, c_size_t, _P],
     'fthmc_kinetic': [_D, c_int, c_int, _D, _P],
+    'fthmc_stats_accumulate': [_D, _D, _D, _D, _D, c_int, _D, _P],
     'fthmc_random_momenta': [_D, c_int, c_int, _D, _D, _P],
     'fthmc_hmc_trajectory': [_D, _D, _D, c_int, c_int, c_double, c_double, c_int, _D, _D, _D, _D, _D,
                              _P, c_size_t, _P],

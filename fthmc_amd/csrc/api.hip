@@ -309,6 +309,12 @@ int fthmc_kinetic(const double* v, int B, int L, double* K, void* stream) {
     return launch_kinetic(v, B, L, K, ft_stream(stream));
 }
 
+int fthmc_stats_accumulate(const double* acc, const double* plaq, const double* Q, double* qold, const double* dH, int B,
+                           double* vec8, void* stream) {
+    if (!acc || !plaq || !Q || !qold || !dH || !vec8 || B <= 0) return FTHMC_ERR_ARG;
+    return launch_stats_accumulate(acc, plaq, Q, qold, dH, B, vec8, ft_stream(stream));
+}
+
 int fthmc_random_momenta(const int64_t* seeds, int B, int n_per_chain, double* v, double* u, void* stream) {
     if (!seeds || !v || B <= 0 || n_per_chain <= 0) return FTHMC_ERR_ARG;
     return launch_random_momenta(seeds, B, n_per_chain, v, u, ft_stream(stream));

@@ -15,6 +15,8 @@ int launch_action_charge(const double* x, int B, int L, double beta, double* S, 
 int launch_kinetic(const double* v, int B, int L, double* K, hipStream_t s);
 int launch_lincomb(const double* a, double ca, const double* b, double cb, double c0, double* out,
                    int B, hipStream_t s);
+int launch_stats_accumulate(const double* acc, const double* plaq, const double* Q, double* qold, const double* dH, int B,
+                            double* vec, hipStream_t s);
 int launch_wilson_force(const double* x, int B, int L, double beta, double* F, hipStream_t s);
 void set_leap_rows(int v);      // 1 (default): row-strip leapfrog kernel when L % 64 == 0; 0: 16 x 16 tiles always
 int launch_leap_step(const double* x, const double* p, double* xo, double* po, int B, int L,

@@ -294,6 +294,24 @@ __global__ void k_lincomb(const double* __restrict__ a, double ca, const double*
     if (b < B) out[b] = ca * a[b] + (bv ? cb * bv[b] : 0.0) + c0;
 }
 
+// Run statistics of one trajectory folded into the running sums (one workgroup, fixed order):
+// vec[8] += (n, acc, plaq, Q, Q^2, |Q - Qold|, dH, exp(-dH)) summed over the chains; Qold <- Q.
+__global__ __launch_bounds__(256) void k_stats_accumulate(const double* __restrict__ acc, const double* __restrict__ plaq,
+                                                          const double* __restrict__ Q, double* __restrict__ qold,
+                                                          const double* __restrict__ dH, int B, double* __restrict__ vec) {
+    __shared__ double red[16];
+    double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const double q = Q[b], d = dH[b];
+        s[0] += 1.0; s[1] += acc[b]; s[2] += plaq[b]; s[3] += q; s[4] += q * q; s[5] += fabs(q - qold[b]); s[6] += d; s[7] += exp(-d);
+        qold[b] = q;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double t = ft_block_sum(s[k], red);
+        if (threadIdx.x == 0) vec[k] += t;
+    }
+}
 
 // ---------------------------------------------------------------- whole plain-HMC trajectory, one launch
 // One workgroup per chain, links in LDS, momenta in registers (every thread owns NSITE sites of
@@ -430,6 +448,11 @@ int launch_kinetic(const double* v, int B, int L, double* K, hipStream_t s) {
 int launch_lincomb(const double* a, double ca, const double* b, double cb, double c0, double* out,
                    int B, hipStream_t s) {
     hipLaunchKernelGGL(k_lincomb, dim3((B + 255) / 256), dim3(256), 0, s, a, ca, b, cb, c0, out, B);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_stats_accumulate(const double* acc, const double* plaq, const double* Q, double* qold, const double* dH, int B,
+                            double* vec, hipStream_t s) {
+    hipLaunchKernelGGL(k_stats_accumulate, dim3(1), dim3(256), 0, s, acc, plaq, Q, qold, dH, B, vec);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_wilson_force(const double* x, int B, int L, double beta, double* F, hipStream_t s) {

@@ -243,6 +243,16 @@ def kinetic(v):
     return K
 
 
+def stats_accumulate(acc, plaq, Q, qold, dH, vec):
+    """vec[8] += sums over the chains of (1, acc, plaq, Q, Q^2, |Q - qold|, dH, exp(-dH)); qold <- Q (in place)."""
+    B = acc.numel()
+    for t, n in ((acc, B), (plaq, B), (Q, B), (qold, B), (dH, B), (vec, 8)):
+        if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != n:
+            raise FthmcError('stats_accumulate: contiguous float64 device tensors of B (vec: 8) elements expected')
+    check(_lib.load().fthmc_stats_accumulate(_p(acc), _p(plaq), _p(Q), _p(qold), _p(dH), B, _p(vec), _stream(acc)),
+          'fthmc_stats_accumulate')
+
+
 def random_momenta(seeds, shape, need_u=True, out_v=None, out_u=None):
     """v ~ N(0,1) of `shape` = (B, 2, L, L) and u ~ U[0,1) [B] from per-chain int64 seeds
     (written into out_v / out_u when given: contiguous float64 device tensors of those shapes)."""

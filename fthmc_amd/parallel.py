@@ -73,6 +73,12 @@ class RunStats:
     def zeros(cls, device):
         return cls(torch.zeros(len(STAT_KEYS), dtype=torch.float64, device=device))
 
+    def add_device(self, acc, plaq, q, qold, dh):
+        """The same accumulation as `add` with dq = q - qold, in ONE launch of the HIP library (fthmc_stats_accumulate);
+        also moves qold on to q.  Device tensors [B_local]; `qold` is updated in place."""
+        from . import ops
+        ops.stats_accumulate(acc, plaq, q, qold, dh, self.vec)
+
     def add(self, acc, plaq, q, dq, dh):
         """Accumulate one trajectory's per-chain results (device tensors [B_local])."""
         # one stacked reduction instead of seven: this runs once per trajectory behind ~200 dependent launches

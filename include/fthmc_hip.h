@@ -104,6 +104,11 @@ int fthmc_leapfrog(const double* x, const double* p, int B, int L, double beta,
                    void* ws, size_t ws_bytes, void* stream);
 /* K[b] = sum_b v^2 (no 1/2).  Used for H = S + K/2 (qed_helpers.py:301) */
 int fthmc_kinetic(const double* v, int B, int L, double* K, void* stream);
+/* Run statistics of one trajectory (the per-trajectory metrics of fthmc/ft_hmc.py:266-270, 311-331 and hmc.py:118-149) folded
+ * into running sums on the device: vec8[0..7] += sum over the B chains of (1, acc, plaq, Q, Q^2, |Q - qold|, dH, exp(-dH)),
+ * then qold <- Q.  One launch, fixed summation order. */
+int fthmc_stats_accumulate(const double* acc, const double* plaq, const double* Q, double* qold, const double* dH, int B,
+                           double* vec8, void* stream);
 /* One trajectory per chain with supplied momenta v[B][2][L][L] and uniforms u[B]:
  * H0 = S(x) + v^2/2; leapfrog; xr = regularize(x_); dH = H1 - H0;
  * acc = u < exp(-dH); x_new = acc ? xr : x.   fthmc/utils/qed_helpers.py:298-311

@@ -501,3 +501,23 @@ def test_layer_backward_from_the_forwards_stash(hidden, k, n_mix):
     for li in range(2):
         for p, t in zip(nets[li].parameters(), wc[li]):
             close(p.grad, t.grad, rtol=1e-8, atol=1e-10 * max(1.0, float(t.grad.abs().max())))
+
+
+def test_device_side_run_statistics():
+    """RunStats.add_device (one launch of fthmc_stats_accumulate) == RunStats.add (the stacked torch reduction), and qold moves on."""
+    from fthmc_amd import parallel as P
+    gen = torch.Generator().manual_seed(17)
+    B = 37
+    a, b = P.RunStats.zeros('cuda'), P.RunStats.zeros('cuda')
+    qold = torch.randint(-3, 4, (B,), generator=gen).double().cuda()
+    qa = qold.clone()
+    for _ in range(3):
+        acc = (torch.rand(B, generator=gen) < 0.5).double().cuda()
+        plaq = torch.rand(B, generator=gen, dtype=torch.float64).cuda()
+        q = torch.randint(-3, 4, (B,), generator=gen).double().cuda()
+        dh = torch.randn(B, generator=gen, dtype=torch.float64).cuda()
+        a.add(acc, plaq, q, q - qa, dh); qa = q.clone()
+        b.add_device(acc, plaq, q, qold, dh)
+        assert torch.equal(qold, q)
+    close(b.vec, a.vec, rtol=1e-13, atol=1e-12)
+    assert float(b.vec[0]) == 3 * B

@@ -16,5 +16,5 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_I
     rocprofv3 --pmc $grp --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/tools/small_loop.py" > "$OUT/pass$i.log" 2>&1 || echo "[pmc] pass $i failed" >> "$OUT/progress.log"
 done
 cd "$ROOT"
-python3 tools/pmc_summary.py "$OUT" "$OUT/pmc_summary.json" "tools/small_loop.py: one launch of k_ft_small<16> = one config-2 trajectory (L=16, 4 layers, nstep 10) of 32 chains = 32 workgroups of 8 waves" > "$OUT/summary.txt" 2>&1
+python3 tools/pmc_summary.py "$OUT" "$OUT/pmc_summary.json" "tools/small_loop.py: one launch of k_ft_small<16> = one config-2 trajectory (L=16, 4 layers, nstep 10) of 32 chains = 32 workgroups of 8 waves" "${2:-unknown}" > "$OUT/summary.txt" 2>&1
 rm -rf "$OUT"/pass*/

@@ -26,8 +26,8 @@ echo "[refresh] recompute-build traffic done"
 bash tools/pmc_kernels.sh "$OUT/pmck" > "$OUT/pmck.log" 2>&1
 python3 tools/pmc_summary.py "$OUT/pmck" "$OUT/pmc_kernels_fullbatch.json" "tools/kernel_loop.py: each coupling-layer kernel launched alone over the FULL batch: 128 chains x 16 tiles = 2048 workgroups of 16x16 sites (L=64, fp64), 16384 waves per launch; k_leap_rows / k_force<1>: one plain-HMC leapfrog step of 128 chains" "$COMMIT" > /dev/null
 echo "[refresh] full-batch counters done"
-bash tools/pmc_small.sh "$OUT/pmcs" > "$OUT/pmcs.log" 2>&1
-python3 tools/pmc_summary.py "$OUT/pmcs" "$OUT/pmc_small.json" "tools/small_loop.py: one launch of k_ft_small<16> = one config-2 trajectory (L=16, 4 layers, nstep 10) of 32 chains = 32 workgroups of 8 waves" "$COMMIT" > /dev/null
+bash tools/pmc_small.sh "$OUT/pmcs" "$COMMIT" > "$OUT/pmcs.log" 2>&1
+cp "$OUT/pmcs/pmc_summary.json" "$OUT/pmc_small.json"
 echo "[refresh] small-lattice counters done"
 bash tools/pmc_stages.sh "$OUT/stg" > "$OUT/instructions_per_stage.txt" 2>&1
 echo "[refresh] stages done"

@@ -118,8 +118,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         sIn[PS0 + tid] = frozen ? sn : 0.0;
         if (A.stash && frozen && (unsigned)(r - 3) < (unsigned)min(TR, L - i0) &&
             (unsigned)(c - 3) < (unsigned)min(TC, L - j0)) {             // the net input of the tile's own frozen sites
-            double* cs_ = A.stash + ((size_t)A.B * 18 + b) * n + stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
-            cs_[0] = cs; cs_[n >> 1] = sn;
+            double* cs_ = uniform_ptr(A.stash, ((size_t)A.B * 18 + b) * n);
+            const unsigned fi = (unsigned)stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
+            stu(cs_, fi, cs); stu(cs_, fi + (unsigned)(n >> 1), sn);
         }
     }
 #pragma unroll
@@ -138,10 +139,12 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // tile sites inside the lattice
     const Stash sv = A.stash ? stash_view(A.stash, A.B, b, n) : Stash{};
     typedef double double2_t __attribute__((ext_vector_type(2)));
-    double* const st_d1 = sv.d1 ? sv.d1 + 2 * (lane >> 4) : nullptr;
-    double* const st_d2 = sv.d1 ? sv.d2 + 2 * (lane >> 4) : nullptr;
-    double* const st_h1 = sv.d1 ? sv.h1 + 2 * (lane >> 4) : nullptr;
-    double* const st_h2 = sv.d1 ? sv.h2 + 2 * (lane >> 4) : nullptr;
+    // uniform plane bases (SGPRs) + this lane's channel pair as part of the 32-bit element index
+    double* const st_d1 = sv.d1 ? uniform_ptr(sv.d1, 0) : nullptr;
+    double* const st_d2 = sv.d1 ? uniform_ptr(sv.d2, 0) : nullptr;
+    double* const st_h1 = sv.d1 ? uniform_ptr(sv.h1, 0) : nullptr;
+    double* const st_h2 = sv.d1 ? uniform_ptr(sv.h2, 0) : nullptr;
+    const unsigned stg = 2u * (unsigned)(lane >> 4);
 
     // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
     // The net input is (cos P, sin P) on the frozen lines and the constant (1, 0) elsewhere, so only HALF of conv1's
@@ -190,12 +193,12 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                 const int r0 = r - 2, c0 = c - 2, r1 = mu == 0 ? r0 : r0 + 1, c1 = mu == 0 ? c0 + 1 : c0;
                 const int at = mul24(i0 + r0, L) + j0 + c0, dat = mu == 0 ? 1 : L;
                 if ((unsigned)r0 < (unsigned)rmax && (unsigned)c0 < (unsigned)cmax) {
-                    if (!FT_RECOMP_D1) *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)at) = double2_t{d[0], d[1]};
-                    if (A.stash_h) *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)at) = double2_t{h[0], h[1]};
+                    if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)at + stg, double2_t{d[0], d[1]});
+                    if (A.stash_h) stu2(st_h1, 8u * (unsigned)at + stg, double2_t{h[0], h[1]});
                 }
                 if ((unsigned)r1 < (unsigned)rmax && (unsigned)c1 < (unsigned)cmax) {
-                    if (!FT_RECOMP_D1) *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dat)) = double2_t{d[2], d[3]};
-                    if (A.stash_h) *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)(at + dat)) = double2_t{h[2], h[3]};
+                    if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)(at + dat) + stg, double2_t{d[2], d[3]});
+                    if (A.stash_h) stu2(st_h1, 8u * (unsigned)(at + dat) + stg, double2_t{h[2], h[3]});
                 }
             }
         }
@@ -220,8 +223,8 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             const int rr = r - 2, cc = c - 2;
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
                 const int at = mul24(i0 + rr, L) + j0 + cc;
-                if (!FT_RECOMP_D1) sv.d1[8 * (size_t)at + co] = d;
-                if (A.stash_h) sv.h1[8 * (size_t)at + co] = h;
+                if (!FT_RECOMP_D1) stu(st_d1, 8u * (unsigned)at + (unsigned)co, d);
+                if (A.stash_h) stu(st_h1, 8u * (unsigned)at + (unsigned)co, h);
             }
         }
     }
@@ -259,8 +262,8 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             for (int q = 0; q < 2; ++q)
                 if ((unsigned)(r - 1 + q * dr) < (unsigned)rmax && (unsigned)(c - 1 + q * dc) < (unsigned)cmax) {
                     const int aq = at + q * (dr * L + dc);
-                    *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)aq) = double2_t{d[2 * q], d[2 * q + 1]};
-                    if (A.stash_h) *reinterpret_cast<double2_t*>(st_h2 + 8 * (size_t)aq) = double2_t{h[2 * q], h[2 * q + 1]};
+                    stu2(st_d2, 8u * (unsigned)aq + stg, double2_t{d[2 * q], d[2 * q + 1]});
+                    if (A.stash_h) stu2(st_h2, 8u * (unsigned)aq + stg, double2_t{h[2 * q], h[2 * q + 1]});
                 }
         }
     };
@@ -390,9 +393,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                     const double d = sDL[tid];
                     if (mu == 0) v0 = ft_wrap(d + v0); else v1 = ft_wrap(-d + v1);
                 }
-                double* y0 = A.y + (size_t)b * 2 * n;
-                const int at = mul24(i, L) + j;
-                y0[at] = v0; y0[n + at] = v1;
+                double* y0 = uniform_ptr(A.y, (size_t)b * 2 * n);
+                const unsigned at = (unsigned)(mul24(i, L) + j);
+                stu(y0, at, v0); stu(y0, (unsigned)n + at, v1);
             }
         }
         if (A.pout && tid < N3) {                                    // plaquette-level inverse: x1 at the active sites, fx elsewhere
@@ -428,11 +431,12 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             const double sinP = 2.0 * sincs, invD2 = invD * invD;
             // component-major [k][n/4][A B C E]: the wave of component k writes whole cache lines (site-major, two waves
             // wrote the two 32-byte halves of every 64-byte record at different times)
-            double* tc = sv.tc + (size_t)wave * n + 4 * (size_t)stash_active_idx(ai, aj, L, mu);
-            *reinterpret_cast<double2_t*>(tc) = double2_t{sinP * invD / NMIX,                      // A_k
-                                                         (ems * cs2 - es * sn2) * invD2};          // B_k
-            *reinterpret_cast<double2_t*>(tc + 2) = double2_t{invD / NMIX,                         // C_k
-                                                             sinP * 0.5 * (es - ems) * invD2};     // E_k
+            double* tc = uniform_ptr(sv.tc, (size_t)wave * n);
+            const unsigned ti = 4u * (unsigned)stash_active_idx(ai, aj, L, mu);
+            stu2(tc, ti, double2_t{sinP * invD / NMIX,                                             // A_k
+                                   (ems * cs2 - es * sn2) * invD2});                               // B_k
+            stu2(tc, ti + 2u, double2_t{invD / NMIX,                                               // C_k
+                                        sinP * 0.5 * (es - ems) * invD2});                         // E_k
         }
     }
     if (wave == NMIX && alane) {                                 // t on an otherwise idle wave
@@ -471,9 +475,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                     const double d = sDL[tid];
                     if (mu == 0) v0 = ft_wrap(d + v0); else v1 = ft_wrap(-d + v1);
                 }
-                double* y0 = A.y + (size_t)b * 2 * n;
-                const int at = mul24(i, L) + j;
-                y0[at] = v0; y0[n + at] = v1;
+                double* y0 = uniform_ptr(A.y, (size_t)b * 2 * n);
+                const unsigned at = (unsigned)(mul24(i, L) + j);
+                stu(y0, at, v0); stu(y0, (unsigned)n + at, v1);
             }
         }
         if (A.pout && tid < N3) {                                    // plaquette-level map: P' at the active sites, P elsewhere

@@ -64,6 +64,15 @@ template <class T> __device__ __forceinline__ T* uniform_ptr(T* base, size_t off
 __device__ __forceinline__ double ldu(const double* base, unsigned idx) {
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + idx * 8u);
 }
+// stores through a uniform base + a 32-bit element index: the address is base-in-SGPRs + one VGPR offset (one shift per
+// store); through a per-lane 64-bit pointer every stash store cost a sign extension, a 64-bit shift and a 64-bit add
+typedef double double2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stu(double* base, unsigned idx, double v) {
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + idx * 8u) = v;
+}
+__device__ __forceinline__ void stu2(double* base, unsigned idx, double2u_t v) {
+    *reinterpret_cast<double2u_t*>(reinterpret_cast<char*>(base) + idx * 8u) = v;
+}
 // Wrapped lattice coordinate (v mod L) of window line v, -L <= v.  FAST (L exceeds the window by a
 // margin, chosen at launch): the line wraps at most once, two selects.  Otherwise (small test lattices)
 // division by the launch-uniform L through its reciprocal (wrap_magic): n M >> 32 = floor(n / L) for

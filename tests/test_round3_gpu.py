@@ -521,3 +521,54 @@ def test_device_side_run_statistics():
         assert torch.equal(qold, q)
     close(b.vec, a.vec, rtol=1e-13, atol=1e-12)
     assert float(b.vec[0]) == 3 * B
+
+
+# ---------------------------------------------------------------- the sampler at an operating point with a TRAINED flow
+def test_sampler_is_exact_with_a_trained_flow():
+    """bench.py times a random-init flow (the workload prescribes it).  Here the flow is trained with the reference-shaped
+    loop (train -> train_step -> fthmc_train_grad) until the MD visibly changes, and ftHMC must still be an exact sampler:
+    <exp(-dH)> = 1 and <cos P> of the flowed field = I1(beta) / I0(beta) (config.PLAQ_EXACT; finite-volume correction
+    (I1/I0)^64 ~ 1e-10), errors from the 256 independent chains.  The trained weights (larger than any initialisation)
+    also go through force and action against the oracle."""
+    from fthmc_amd import parallel
+    from fthmc_amd.config import PLAQ_EXACT, TrainConfig
+    from fthmc_amd.train import get_model, train
+    from fthmc_amd.utils.layers import net_weights
+    L, beta, nl, B, nstep, therm, ntraj = 8, 2.0, 8, 256, 40, 60, 60
+    torch.manual_seed(1331)
+    cfg = TrainConfig(L=L, beta=beta, n_layers=nl, batch_size=512, n_era=1, n_epoch=600, base_lr=1e-3, print_freq=0)
+    model = get_model(cfg)
+    w0 = ops.pack_weights([net_weights(l.plaq_coupling.net) for l in model.layers], device='cuda')
+    hist = train(cfg, model=model, verbose=False, save=False)['history']
+    ess = [float(e) for e in hist['ess']]
+    assert np.mean(ess[-30:]) > 2 * np.mean(ess[:30]), (np.mean(ess[:30]), np.mean(ess[-30:]))     # it did train
+    layers = [net_weights(l.plaq_coupling.net) for l in model.layers]
+    w = ops.pack_weights(layers, device='cuda')
+    assert float((w - w0).abs().max()) > 0.05
+
+    # trained weights against the oracle
+    flow_cpu = [[p.detach().cpu() for p in lw] for lw in layers]
+    xs = ((torch.rand(2, 2, L, L, generator=torch.Generator().manual_seed(4), dtype=torch.float64) * 2 - 1) * math.pi)
+    S = ops.ft_action(xs.cuda(), w, nl, beta)[0]
+    close(S, R.ft_action(xs, flow_cpu, beta), rtol=1e-10)
+    close(ops.ft_force(xs.cuda(), w, nl, beta), R.ft_force(xs, flow_cpu, beta), rtol=1e-8, atol=1e-8)
+
+    def run(w_, nst):
+        g0, _ = ops.random_momenta(parallel.chain_seeds(7, 0, B, 0).cuda(), (B, 2, L, L), need_u=False)
+        x = (0.1 * torch.erf(g0 / math.sqrt(2.0))).contiguous()
+        acc = torch.zeros(B, dtype=torch.float64, device='cuda'); em = torch.zeros_like(acc); pl = torch.zeros_like(acc)
+        for it in range(therm + ntraj):
+            v, u = ops.random_momenta(parallel.chain_seeds(11, 0, B, it).cuda(), (B, 2, L, L))
+            r = ops.ft_trajectory(x, v, u, w_, nl, beta, 1.0 / nst, nst)
+            x = r['x_new']
+            if it >= therm:
+                acc += r['acc']; em += torch.exp(-r['dH']); pl += r['plaq']
+        stat = lambda t: (float((t / ntraj).mean()), float((t / ntraj).std() / math.sqrt(B)))
+        return stat(acc), stat(em), stat(pl)
+    a0, _, _ = run(w0, 10)
+    a1, _, _ = run(w, 10)
+    assert a0[0] > 0.9 and a1[0] < 0.5, (a0, a1)          # the trained map stiffens the MD at the untrained step size ...
+    acc, em, pl = run(w, nstep)
+    assert acc[0] > 0.6, acc                               # ... and a finer step restores the acceptance
+    assert abs(em[0] - 1.0) < 5 * em[1] and em[1] < 0.1, em
+    assert abs(pl[0] - PLAQ_EXACT[beta]) < 5 * pl[1] and pl[1] < 2e-3, (pl, PLAQ_EXACT[beta])

@@ -353,12 +353,12 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
             const int fl = ((g >> 1) + 1 - s4) & 3;                      // this lane group's frozen line of the four
             const double* a0 = sIn + (g & 1) * PSI + (2 * pu[it] + fl) * lstep + pv[it] * astep;
             const double* wp = sP1 + cN + (g & 1) * 48 + (fl + 1 - dd) * 8;
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            const double* bc = sP1 + LF_BC + s4 * 16 + 2 * g;            // as the forward: the bias is the accumulator's start value
+            double4_t acc = {bc[0], bc[1], bc[8], bc[9]};
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[t * 96], a0[t * astep], acc, 0, 0, 0);
-            const double* bc = sP1 + LF_BC + s4 * 16 + 2 * g;
-            double z[4] = {acc[0] + bc[0], acc[1] + bc[1], acc[2] + bc[8], acc[3] + bc[9]};
+            double z[4] = {acc[0], acc[1], acc[2], acc[3]};
             double h_[4];
             act_eval4(z, A.act, h_, d1v[it]);
         }

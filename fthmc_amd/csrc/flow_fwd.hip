@@ -176,13 +176,14 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             const int fl = ((g >> 1) + 1 - s4) & 3;                      // this lane group's frozen line of the window: classes 1, 2
             const double* a0 = sIn + (g & 1) * PS0 + (2 * u + fl) * lstep + v * astep;
             const double* wp = sP1 + cN + (g & 1) * 48 + (fl + 1 - dd) * 8;
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            // z[q]: channel 2 g + (q & 1) at site q >> 1 of the pair; bias + constant lines from BC[s4][site][channel] are the
+            // accumulator's start value
+            const double* bc = sP1 + LF_BC + s4 * 16 + 2 * g;
+            double4_t acc = {bc[0], bc[1], bc[8], bc[9]};
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[t * 96], a0[t * astep], acc, 0, 0, 0);
-            // z[q]: channel 2 g + (q & 1) at site q >> 1 of the pair; bias + constant lines from BC[s4][site][channel]
-            const double* bc = sP1 + LF_BC + s4 * 16 + 2 * g;
-            double z[4] = {acc[0] + bc[0], acc[1] + bc[1], acc[2] + bc[8], acc[3] + bc[9]};
+            double z[4] = {acc[0], acc[1], acc[2], acc[3]};
             double h[4], d[4];
             act_eval4(z, act, h, d);
             const int r = mu == 0 ? v : 2 * u, c = mu == 0 ? 2 * u : v;  // site 0 in h1-window coordinates; site 1 = next column / row
@@ -246,9 +247,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     const int d0 = ((off + 3) - (mu == 0 ? j0 : i0)) & 3;               // first dead line of the window
     auto conv2_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
         // sites (r, c) and (r + dr, c + dc) in window coordinates; z[q]: channel 2 g + (q & 1), site q >> 1
-        const double b0 = sW[LF_B1 + 2 * g], b1 = sW[LF_B1 + 2 * g + 1];
-        double h[4], d[4];
-        z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
+        double h[4], d[4];                                  // the bias came in through the accumulator (bias2 below)
         act_eval4(z, act, h, d);
         lds_barrier();                                      // h2 overwrites h1: every wave has finished its MFMA reads
         const int so = dr * R2C + dc;
@@ -267,6 +266,8 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                 }
         }
     };
+    double4_t bias2;
+    { const double b0 = sW[LF_B1 + 2 * (lane >> 4)], b1 = sW[LF_B1 + 2 * (lane >> 4) + 1]; bias2 = double4_t{b0, b1, b0, b1}; }
     if (mu == 0) {
         // B[k = (tap = ky4 * 3 + kx, ci)][n = (co, dd)] = W1[co][ci][ky4 - dd][kx]; pairs = rows (2 pr, 2 pr + 1)
         mfma_stage<KConv2Row, (R2R / 2) * NLC, RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int pr = fdiv<NLC>(p), c = live_line(p - pr * NLC, d0);
                 conv2_epi(g, ok && c < R2C, 2 * pr, c, 1, 0, z);
-            }, dbg ? dbg + 11 : nullptr);
+            }, dbg ? dbg + 11 : nullptr, bias2);
     } else {
         // B[k = (tap = ky * 4 + kx4, ci)][n = (co, dd)] = W1[co][ci][ky][kx4 - dd]; pairs = columns (2 pc, 2 pc + 1)
         mfma_stage<KConv2Col, NLR * (R2C / 2), RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             [&](int g, int p, bool ok, double (&z)[4], int) {
                 const int lr = fdiv<R2C / 2>(p), r = live_line(lr, d0);
                 conv2_epi(g, ok && r < R2R, r, 2 * (p - lr * (R2C / 2)), 0, 1, z);
-            });
+            }, nullptr, bias2);
     }
     // conv3's 27 weights of this wave's input channel are wave-uniform: scalar loads straight from the weight block
     // (constant address space -> s_load, SGPR operands of the FMAs) instead of 27 LDS reads per wave; issued ahead of

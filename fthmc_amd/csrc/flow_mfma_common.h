@@ -204,8 +204,10 @@ __device__ __forceinline__ void stampx(long long* slot) {
 //        barrier in between), so that an epilogue may overwrite the planes the MFMAs read (needs UNROLL)
 // NCHAIN: independent accumulator chains per tile (0: 4, or 3 for short K)
 template <class KO, int NPAIR, int RSA, int PSA, bool UNROLL, bool DEFER, int NCHAIN, class AMap, class Epi>
+// acc0: the accumulator's start value (the bias of this lane's rows: the epilogue then adds nothing)
 __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const double* __restrict__ Wt,
-                                           int wave, int lane, AMap amap, Epi epi, long long* dbg = nullptr) {
+                                           int wave, int lane, AMap amap, Epi epi, long long* dbg = nullptr,
+                                           double4_t acc0 = double4_t{0.0, 0.0, 0.0, 0.0}) {
     constexpr int NSTEP = KO::NSTEP, NTILE = (NPAIR + 15) / 16;
     const int g = lane >> 4, i = lane & 15;
     const double* wp = Wt + KO::wlane(g, i & 7, i >> 3);
@@ -225,7 +227,7 @@ __device__ __forceinline__ void mfma_stage(const double* __restrict__ A, const d
         constexpr int NCH = NCHAIN > 0 ? NCHAIN : (NSTEP >= 8 ? 4 : 3);
         double4_t accs[NCH];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) accs[ch] = double4_t{0.0, 0.0, 0.0, 0.0};
+        for (int ch = 0; ch < NCH; ++ch) accs[ch] = ch == 0 ? acc0 : double4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < NSTEP; ++t) {
             accs[t % NCH] = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[KO::bimm(t)], a0[KO::template aimm<RSA, PSA>(t)], accs[t % NCH], 0, 0, 0);

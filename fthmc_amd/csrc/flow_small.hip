@@ -253,11 +253,11 @@ template <int L> struct Chain {
             const double* a0 = sIn + (g & 1) * PSZ + (2 * u + fl) * lstep + v * astep;
             const double* sP1 = sWc + LF_P1;
             const double* wp = sP1 + cN + (g & 1) * 48 + (fl + 1 - dd) * 8;
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+            const double* bc = sP1 + LF_BC + s4 * 16 + 2 * g;            // bias + constant lines: the accumulator's start value
+            double4_t acc = {bc[0], bc[1], bc[8], bc[9]};
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[t * 96], a0[t * astep], acc, 0, 0, 0);
-            const double* bc = sP1 + LF_BC + s4 * 16 + 2 * g;
-            double z[4] = {acc[0] + bc[0], acc[1] + bc[1], acc[2] + bc[8], acc[3] + bc[9]};
+            double z[4] = {acc[0], acc[1], acc[2], acc[3]};
             double h[4], d[4];
             if (FT_KNOB & 4) { for (int q = 0; q < 4; ++q) { h[q] = z[q]; d[q] = 1.0; } } else
             act_eval4(z, act, h, d);
@@ -277,9 +277,7 @@ template <int L> struct Chain {
 
         // ---- conv2 (8 -> 8) + act: pairs = rows for mu = 0, columns for mu = 1 (table P2)
         auto conv2_epi = [&](int g, bool ok, int r, int c, int dr, int dc, double (&z)[4]) {
-            const double b0 = sWc[LF_B1 + 2 * g], b1 = sWc[LF_B1 + 2 * g + 1];
-            double h[4], d[4];
-            z[0] += b0; z[1] += b1; z[2] += b0; z[3] += b1;
+            double h[4], d[4];                                           // the bias came in through the accumulator (bias2)
             if (FT_KNOB & 4) { for (int q = 0; q < 4; ++q) { h[q] = z[q]; d[q] = 1.0; } } else
             act_eval4(z, act, h, d);
             if (!ok) return;
@@ -291,14 +289,18 @@ template <int L> struct Chain {
                 *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)(at + dr * L + dc)) = double2_t{d[2], d[3]};
             }
         };
+        double4_t bias2;
+        { const double b0 = sWc[LF_B1 + 2 * (lane >> 4)], b1 = sWc[LF_B1 + 2 * (lane >> 4) + 1]; bias2 = double4_t{b0, b1, b0, b1}; }
         if (mu == 0) {
             mfma_stage<KConv2Row, G::NPAIR, RS, PSZ, false, false, 1>(sH1, sWc + LF_P2, wave, lane,
                 [&](int p) { const int pr = fdiv<L>(p); return 2 * pr * RS + (p - pr * L); },
-                [&](int g, int p, bool ok, double (&z)[4], int) { const int pr = fdiv<L>(p); conv2_epi(g, ok, 2 * pr, p - pr * L, 1, 0, z); });
+                [&](int g, int p, bool ok, double (&z)[4], int) { const int pr = fdiv<L>(p); conv2_epi(g, ok, 2 * pr, p - pr * L, 1, 0, z); },
+                nullptr, bias2);
         } else {
             mfma_stage<KConv2Col, G::NPAIR, RS, PSZ, false, false, 1>(sH1, sWc + LF_P2, wave, lane,
                 [&](int p) { const int r = fdiv<L / 2>(p); return r * RS + 2 * (p - r * (L / 2)); },
-                [&](int g, int p, bool ok, double (&z)[4], int) { const int r = fdiv<L / 2>(p); conv2_epi(g, ok, r, 2 * (p - r * (L / 2)), 0, 1, z); });
+                [&](int g, int p, bool ok, double (&z)[4], int) { const int r = fdiv<L / 2>(p); conv2_epi(g, ok, r, 2 * (p - r * (L / 2)), 0, 1, z); },
+                nullptr, bias2);
         }
         // conv3's 27 weights of this wave's input channel: scalar loads straight from the weight block
         typedef const double __attribute__((address_space(4))) * cdptr;

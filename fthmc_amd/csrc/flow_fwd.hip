@@ -42,7 +42,10 @@ template <int TR, int TC> struct SmemF {
 
 // REV: the inverse layer (GaugeEquivCouplingLayer.reverse, layers.py:204-210, 373-396): same net on the same
 // frozen plaquettes, then the scalar map is inverted per active site instead of applied.
-template <int TR, int TC, bool FASTW, bool REV>
+// MU: the layer's stripe direction (A.mu) as a compile-time constant: every `mu == 0 ? a : b` below folds, the LDS steps
+// across / along the lines become immediate offsets of the operand reads, and each kernel carries one of the two conv2
+// code paths instead of both (selects on per-lane values by a uniform mu were ~5 % of the VALU instructions).
+template <int TR, int TC, bool FASTW, bool REV, int MU>
 __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
@@ -57,7 +60,8 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L = A.L, mu = A.mu, off = A.off, act = A.act;
+    constexpr int mu = MU;
+    const int L = A.L, off = A.off, act = A.act;
     const int n = L * L;
     const int nti_ = (A.L + TR - 1) / TR, ntj_ = (A.L + TC - 1) / TC;
     BlockTile bt;
@@ -161,17 +165,19 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     static_assert(NU1 % 2 == 0, "as many even as odd pair positions");
     constexpr int NTC = NPC / 16, NREMP = NPC - NTC * 16, NREM1 = 2 * (2 * NREMP) * 8;   // whole tiles per class; leftover outputs
     static_assert(2 * NTC <= 2 * NW && NREM1 <= NT / 2 && NREMP <= R1, "tile rounds; leftover outputs go to the upper waves");
+    // Tile -> pairs: tiles 0 .. NU1 - 1 hold ONE pair position u = tile across the lines and v = lane & 15 along them, so
+    // that everything that depends on u -- the window lines, the stripe class, the LDS row / column of the outputs, the
+    // stash row and its bounds -- is wave-uniform (scalar instructions) and what depends on the lane is the same for both
+    // tiles of a wave; tiles NU1, NU1 + 1 take v = 16 .. 19 of the even / odd u < 8 (four u per tile), and u = 8, 9 there are
+    // the leftover pairs below.  (Tiles of 16 consecutive pairs of a (u, v) enumeration cost ~50 VALU instructions of index
+    // arithmetic per tile and wave: division by the window width, per-lane parity, per-lane bounds.)
+    static_assert(R1 == 20 && NU1 == 10 && NTC == 6 && NREMP == 4, "conv1 tile map: 16 + 4 positions along the lines, 10 across");
     {
         const int g = lane >> 4, i = lane & 15, cN = i & 7, dd = i >> 3;
         const int sbase = ((mu == 0 ? j0 : i0) - 3 - off) & 3;           // stripe class of the input window's first line
         const int lstep = mu == 0 ? 1 : R0C;                             // LDS step across the lines / along them
         const int astep = mu == 0 ? R0C : 1;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int T = wave + it * NW;
-            if (T >= 2 * NTC) break;
-            const int par = T & 1, idx = (T >> 1) * 16 + i;              // tiles alternate between the parity classes
-            const int uu = fdiv<R1>(idx), v = idx - uu * R1, u = 2 * uu + par;
+        auto conv1_tile = [&](int u, int v, int par) {
             const int s4 = (sbase + 2 * par) & 3;                        // class of the pair window's first line (wave-uniform)
             const int fl = ((g >> 1) + 1 - s4) & 3;                      // this lane group's frozen line of the window: classes 1, 2
             const double* a0 = sIn + (g & 1) * PS0 + (2 * u + fl) * lstep + v * astep;
@@ -202,7 +208,12 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
                     if (A.stash_h) stu2(st_h1, 8u * (unsigned)(at + dat) + stg, double2_t{h[2], h[3]});
                 }
             }
-        }
+        };
+        static_assert(NW <= NU1 && 2 * NW >= NU1 + 2, "first round: whole-u tiles only; second round: the rest");
+        conv1_tile(wave, i, wave & 1);
+        const int T = wave + NW;
+        if (T < NU1) conv1_tile(T, i, T & 1);
+        else if (T < NU1 + 2) conv1_tile(2 * (i >> 2) + (T - NU1), 16 + (i & 3), T - NU1);
     }
     if (NREM1 > 0 && tid >= NT / 2 && tid < NT / 2 + NREM1) {
         // leftover pairs of either class: uu = NU1 / 2 - 1, v = R1 - NREMP ..; thread = (site, output channel), all 18 taps
@@ -268,21 +279,38 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     };
     double4_t bias2;
     { const double b0 = sW[LF_B1 + 2 * (lane >> 4)], b1 = sW[LF_B1 + 2 * (lane >> 4) + 1]; bias2 = double4_t{b0, b1, b0, b1}; }
+    // Tile -> pairs: tile T (one per wave) holds the pair line T -- pair row T for mu = 0, pair column T for mu = 1 -- with the
+    // live lines l = lane & 15 < NLC across it; the ninth pair line is spread over the two spare lanes of tiles 0 .. 6
+    // (l = 2 T + lane - NLC).  The pair line is then wave-uniform for 14 of 16 lanes and the live-line index a per-lane
+    // constant, instead of a division of the pair number by the line count per lane and tile.
+    constexpr int NPL = R2R / 2;                                        // pair lines (rows or columns of pairs)
+    static_assert(NLC == 14 && NLR == 14 && NPL == 9 && NPL - 1 == NW && 2 * (NW - 1) == NLC, "conv2 tile map");
+    auto pair_of = [&](int p, int& pl, int& ll) {                       // pair number (tile * 16 + lane) -> pair line, live-line index
+        const int T = p >> 4, i = p & 15;
+        const bool own = i < NLC;
+        pl = own ? T : NPL - 1;
+        ll = own ? i : 2 * T + i - NLC;
+        return own || T < NW - 1;
+    };
     if (mu == 0) {
         // B[k = (tap = ky4 * 3 + kx, ci)][n = (co, dd)] = W1[co][ci][ky4 - dd][kx]; pairs = rows (2 pr, 2 pr + 1)
-        mfma_stage<KConv2Row, (R2R / 2) * NLC, RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
-            [&](int p) { const int pr = fdiv<NLC>(p); return 2 * pr * RS1 + min(live_line(p - pr * NLC, d0), R2C - 1); },
-            [&](int g, int p, bool ok, double (&z)[4], int) {
-                const int pr = fdiv<NLC>(p), c = live_line(p - pr * NLC, d0);
+        mfma_stage<KConv2Row, 16 * NW, RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
+            [&](int p) { int pr, lc; pair_of(p, pr, lc); return 2 * pr * RS1 + min(live_line(lc, d0), R2C - 1); },
+            [&](int g, int p, bool, double (&z)[4], int) {
+                int pr, lc;
+                const bool ok = pair_of(p, pr, lc);
+                const int c = live_line(lc, d0);
                 conv2_epi(g, ok && c < R2C, 2 * pr, c, 1, 0, z);
             }, dbg ? dbg + 11 : nullptr, bias2);
     } else {
         // B[k = (tap = ky * 4 + kx4, ci)][n = (co, dd)] = W1[co][ci][ky][kx4 - dd]; pairs = columns (2 pc, 2 pc + 1)
-        mfma_stage<KConv2Col, NLR * (R2C / 2), RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
-            [&](int p) { const int lr = fdiv<R2C / 2>(p); return min(live_line(lr, d0), R2R - 1) * RS1 + 2 * (p - lr * (R2C / 2)); },
-            [&](int g, int p, bool ok, double (&z)[4], int) {
-                const int lr = fdiv<R2C / 2>(p), r = live_line(lr, d0);
-                conv2_epi(g, ok && r < R2R, r, 2 * (p - lr * (R2C / 2)), 0, 1, z);
+        mfma_stage<KConv2Col, 16 * NW, RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
+            [&](int p) { int pc, lr; pair_of(p, pc, lr); return min(live_line(lr, d0), R2R - 1) * RS1 + 2 * pc; },
+            [&](int g, int p, bool, double (&z)[4], int) {
+                int pc, lr;
+                const bool ok = pair_of(p, pc, lr);
+                const int r = live_line(lr, d0);
+                conv2_epi(g, ok && r < R2R, r, 2 * pc, 0, 1, z);
             }, nullptr, bias2);
     }
     // conv3's 27 weights of this wave's input channel are wave-uniform: scalar loads straight from the weight block
@@ -494,6 +522,19 @@ int g_variant = 1;
 
 }  // namespace
 
+namespace {
+template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hipStream_t s) {
+    const bool fast = wrap_fast_ok(a.L, fthmc::MF_FWD_TR, fthmc::MF_FWD_TC);
+    if (a.mu == 0) {
+        if (fast) hipLaunchKernelGGL((k_flow_fwd<fthmc::MF_FWD_TR, fthmc::MF_FWD_TC, true, REV, 0>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_fwd<fthmc::MF_FWD_TR, fthmc::MF_FWD_TC, false, REV, 0>), grid, dim3(NT), 0, s, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((k_flow_fwd<fthmc::MF_FWD_TR, fthmc::MF_FWD_TC, true, REV, 1>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_fwd<fthmc::MF_FWD_TR, fthmc::MF_FWD_TC, false, REV, 1>), grid, dim3(NT), 0, s, a);
+    }
+}
+}  // namespace
+
 namespace fthmc {
 
 void set_flow_variant(int v) { g_variant = v; }
@@ -502,14 +543,12 @@ int get_flow_variant() { return g_variant; }
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     // 16 x 16 tiles, three workgroups per CU (SmemF)
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
-    if (wrap_fast_ok(a.L, MF_FWD_TR, MF_FWD_TC)) hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, true, false>), grid, dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, false, false>), grid, dim3(NT), 0, s, a);
+    launch_fwd<false>(a, grid, s);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_rev_mfma(const FlowLayerArgs& a, hipStream_t s) {
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
-    if (wrap_fast_ok(a.L, MF_FWD_TR, MF_FWD_TC)) hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, true, true>), grid, dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((k_flow_fwd<MF_FWD_TR, MF_FWD_TC, false, true>), grid, dim3(NT), 0, s, a);
+    launch_fwd<true>(a, grid, s);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

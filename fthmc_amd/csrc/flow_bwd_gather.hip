@@ -63,7 +63,9 @@ template <int TR, int TC> struct SmemG {
 // A.gz (training): the kernel additionally writes the gradients wrt the layer's pre-activations at the tile's own
 // sites -- gz2, gz1 (channel-minor) and the transform adjoint g_out at the active sites -- for k_flow_wgrad
 // (flow_wgrad.hip), which turns them into weight gradients; nothing else changes.
-template <int TR, int TC, bool FASTW>
+// MU: the layer's stripe direction as a compile-time constant (as in k_flow_fwd: the selects on it fold, each kernel carries
+// one of the two conv2^T code paths).
+template <int TR, int TC, bool FASTW, int MU>
 __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     using S = SmemG<TR, TC>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L = A.L, mu = A.mu, off = A.off;
+    constexpr int mu = MU;
+    const int L = A.L, off = A.off;
     const int n = L * L;
     const int nti_ = (L + TR - 1) / TR, ntj_ = (L + TC - 1) / TC;
     BlockTile bt;
@@ -494,8 +497,14 @@ namespace fthmc {
 
 int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s) {
     const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
-    if (wrap_fast_ok(a.L, MG_TR, MG_TC)) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true>), grid, dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false>), grid, dim3(NT), 0, s, a);
+    const bool fast = wrap_fast_ok(a.L, MG_TR, MG_TC);
+    if (a.mu == 0) {
+        if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, 0>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, 0>), grid, dim3(NT), 0, s, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, 1>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, 1>), grid, dim3(NT), 0, s, a);
+    }
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

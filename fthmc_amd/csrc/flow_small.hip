@@ -201,14 +201,20 @@ template <int L> struct Chain {
 
     // ---- one coupling layer forward, in place on the links in LDS.  STASH: also write what the backward needs.
     //      log J of the layer is returned in thread 0 (want_logj), 0 elsewhere.  (nb, nl_): the pass that follows, or nl_ < 0.
-    __device__ double layer_fwd(int l, const bool STASH_, bool want_logj, bool nb, int nl_) {
+    //      MU = the layer's stripe direction (l & 1) as a compile-time constant: the selects on it fold and each instance
+    //      carries one of the two conv2 code paths (as in the tiled kernels).
+    __device__ __forceinline__ double layer_fwd(int l, const bool STASH_, bool want_logj, bool nb, int nl_) {
+        return (l & 1) ? layer_fwd_t<1>(l, STASH_, want_logj, nb, nl_) : layer_fwd_t<0>(l, STASH_, want_logj, nb, nl_);
+    }
+    template <int MU> __device__ double layer_fwd_t(int l, const bool STASH_, bool want_logj, bool nb, int nl_) {
         const bool STASH = (FT_KNOB & 1) ? false : STASH_;
         constexpr int N = G::N, NA = G::NA, NAS = G::NAS, RS = G::RS, PSZ = G::PSZ;
         // thread coordinates opaque per pass: otherwise every index expression of every stage is hoisted out of the layer
         // loops and lives in registers for the whole kernel (hundreds of them: they spilled)
         int tid = this->tid, lane = this->lane;
         asm volatile("" : "+v"(tid), "+v"(lane));
-        const int mu = l & 1, off = (l >> 1) & 3, act = A.act;
+        constexpr int mu = MU;
+        const int off = (l >> 1) & 3, act = A.act;
         double* sX = sm + G::X;  double* sIn = sm + G::IN;  double* sH1 = sm + G::A8;  double* sH2 = sm + G::B8;
         double* sPA = sm + G::PA;  double* sST = sm + G::ST;
         const double* sWc = sW();
@@ -436,9 +442,13 @@ template <int L> struct Chain {
 
     // ---- one coupling layer backward from the stash (gather form, flow_bwd_gather.hip): gP += this layer's contribution.
     //      `pre` holds this pass's stash values (bwd_issue); (nb, nl_): the pass that follows, or nl_ < 0.
-    __device__ void layer_bwd(int l, double cb, bool nb, int nl_) {
+    __device__ __forceinline__ void layer_bwd(int l, double cb, bool nb, int nl_) {
+        if (l & 1) layer_bwd_t<1>(l, cb, nb, nl_); else layer_bwd_t<0>(l, cb, nb, nl_);
+    }
+    template <int MU> __device__ void layer_bwd_t(int l, double cb, bool nb, int nl_) {
         constexpr int N = G::N, NA = G::NA, NF = G::NF, RS = G::RS, PSZ = G::PSZ;
-        const int mu = l & 1, off = (l >> 1) & 3;
+        constexpr int mu = MU;
+        const int off = (l >> 1) & 3;
         int tid = this->tid, lane = this->lane;                            // opaque per pass (see layer_fwd)
         asm volatile("" : "+v"(tid), "+v"(lane));
         double* sGP = sm + G::GP;  double* sGO = sm + G::IN;  double* sGZ2 = sm + G::A8;

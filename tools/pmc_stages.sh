@@ -1,7 +1,7 @@
 #!/bin/bash
 # Instruction counts (or the counters in PMC_LIST) of the forward and the backward kernel per stage: the -DFT_DIAG build returns after stage FTHMC_DBG_STOP (1..5; 0 = whole kernel);
 # differences of consecutive runs are the stages.  bash tools/pmc_stages.sh OUTDIR   (GPU box, repo root)
-ROOT=$(pwd); OUT=$1; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
+ROOT=$(pwd); OUT=$1; case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT";; esac; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
 export FTHMC_LIB=$ROOT/experiments/lib_diag.so
 for stop in 1 2 3 4 5 0; do
   FTHMC_DBG_STOP=$stop rocprofv3 --pmc ${PMC_LIST:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32} --output-format csv -d "$OUT/stop$stop" -- python3 "$ROOT/tools/kernel_loop.py" > "$OUT/stop$stop.log" 2>&1

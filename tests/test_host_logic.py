@@ -420,5 +420,7 @@ def test_hot_kernels_are_what_the_build_intends(tmp_path):
     for key, variants in seen.items():
         for mfma, read2, read1, scratch in variants:
             assert mfma > 0 and read1 > 0, (key, mfma, read1)
-            assert read2 == 0, f'{key}: {read2} ds_read2_b64 (LDSFLAGS of csrc/Makefile not applied?)'
+            # the one paired read the ISel itself forms is conv2's bias pair (the accumulator's start value, once per tile);
+            # with the pairing passes on there are dozens, in the MFMA operand streams
+            assert read2 <= 1, f'{key}: {read2} ds_read2_b64 (LDSFLAGS of csrc/Makefile not applied?)'
             assert scratch == 0, f'{key}: {scratch} bytes of scratch per lane (spills)'

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
-    constexpr int N0 = G::N0, N3 = G::N3, NA = G::NA, NAS = G::NAS, TQ = 2, RS1 = G::RS1;
+    constexpr int N3 = G::N3, NA = G::NA, NAS = G::NAS, TQ = 2, RS1 = G::RS1;
     constexpr int PS0 = G::PS0, PS1 = G::PS1, PS2 = G::PS2;
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
     double* sIn = sm + S::IN;  double* sP = sm + S::PG;   double* sH1 = sm + S::H1;  double* sH2 = sm + S::H2;
@@ -99,32 +99,62 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         }
     }
 
-    // ---- plaquette window + net input; small weights -> LDS ------------------
-    static_assert(N0 <= NT, "one window site per thread");
-    if (tid < N0) {
-        const int r = fdiv<R0C>(tid), c = tid - r * R0C;
-        const int iL = mul24(wrap_line<FASTW>(i0 - 3 + r, L, fastw), L), ipL = mul24(wrap_line<FASTW>(i0 - 2 + r, L, fastw), L);
-        const int j = wrap_line<FASTW>(j0 - 3 + c, L, fastw), jp = wrap_line<FASTW>(j0 - 2 + c, L, fastw);
-        const double p = pin ? ldu(pin, (unsigned)(iL + j))
-                             : ldu(x0, (unsigned)(iL + j)) - ldu(x1, (unsigned)(iL + j)) - ldu(x0, (unsigned)(iL + jp)) + ldu(x1, (unsigned)(ipL + j));
-        const int sel = ((mu == 0 ? j0 + c : i0 + r) - 3 - off) & 3;          // stripe class (L % 4 == 0)
-        const bool frozen = (sel == 1 || sel == 2);
-        // one sincos per thread: of P where the plaquette is frozen (the net input), of P / 2 at the tile's own
-        // active sites (the transform needs it; evaluated here it costs nothing, the frozen lanes of the wave
-        // run the same instructions) -- left in the plaquette plane next to P, in the two slots of the
-        // following lines (stripe classes 1, 2), whose own plaquettes nobody reads
-        const bool aown = sel == 0 && (unsigned)(r - 3) < (unsigned)TR && (unsigned)(c - 3) < (unsigned)TC && !REV;
-        double sn = 0.0, cs = 1.0;
-        if (frozen || aown) ft_sincos(frozen ? p : 0.5 * p, &sn, &cs);
-        if (sel == 0) sP[tid] = p;
-        if (aown) { const int st = mu == 0 ? 1 : R0C; sP[tid + st] = cs; sP[tid + 2 * st] = sn; }
-        sIn[tid] = frozen ? cs : 1.0;
-        sIn[PS0 + tid] = frozen ? sn : 0.0;
-        if (A.stash && frozen && (unsigned)(r - 3) < (unsigned)min(TR, L - i0) &&
-            (unsigned)(c - 3) < (unsigned)min(TC, L - j0)) {             // the net input of the tile's own frozen sites
-            double* cs_ = uniform_ptr(A.stash, ((size_t)A.B * 18 + b) * n);
-            const unsigned fi = (unsigned)stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
-            stu(cs_, fi, cs); stu(cs_, fi + (unsigned)(n >> 1), sn);
+    // ---- plaquettes and net input, only where somebody reads them; small weights -> LDS ------------------
+    // Of the 22 x 22 window the net reads (cos P, sin P) on the FROZEN lines only (conv1 runs on the frozen taps, the
+    // constant (1, 0) of the other lines is in its bias table) and the transform reads P at the tile's own active sites:
+    // 264 + 64 of 484 plaquettes.  One task per thread:
+    //   tid < NFT:          frozen site: position a = tid / NFL along the lines, k-th frozen line across them (the frozen
+    //                       lines come in pairs, classes 1 and 2, every four lines: x = ps + 4 (k >> 1) + (k & 1))
+    //   NFT <= tid < +NA:   own active site (the map of the conv3 / transform stages)
+    //   the next 36:        the constant (1, 0) at the non-frozen sites of the window corner that conv1's leftover pairs
+    //                       read with all 18 taps (rows and columns 16 .. 21)
+    // Five waves instead of eight run the loads, the wrapped addresses and the sincos; passive and foreign active
+    // plaquettes are never formed.
+    constexpr int NFL = (R0C + 3) / 4 * 2, NFT = R0C * NFL;
+    static_assert(G::R0R == R0C && NFT + NA + 36 <= NT && R0C == 22, "stage-0 task list");
+    {
+        const int ps = off == 3 ? -1 : off;                                // first line of the first frozen pair (class 1: x = off mod 4)
+        int r = 0, c = 0;
+        bool fz = false, ao = false;
+        if (tid < NFT) {
+            const int a = fdiv<NFL>(tid), k = tid - a * NFL;
+            const int x = ps + 4 * (k >> 1) + (k & 1);
+            fz = (unsigned)x < (unsigned)R0C;
+            r = mu == 0 ? a : x; c = mu == 0 ? x : a;
+        } else if (tid < NFT + NA) {
+            const int a = tid - NFT;
+            r = 3 + (mu == 0 ? a / (TC / 4) : off + 4 * (a / TC));
+            c = 3 + (mu == 0 ? off + 4 * (a % (TC / 4)) : a % TC);
+            ao = true;
+        } else if (tid < NFT + NA + 36) {
+            const int k = tid - (NFT + NA), rr = 16 + fdiv<6>(k), cc = 16 + (k - 6 * fdiv<6>(k));
+            const int sel = ((mu == 0 ? cc : rr) - 3 - off) & 3;
+            if (sel != 1 && sel != 2) { sIn[rr * R0C + cc] = 1.0; sIn[PS0 + rr * R0C + cc] = 0.0; }
+        }
+        if (fz || ao) {
+            const int iL = mul24(wrap_line<FASTW>(i0 - 3 + r, L, fastw), L), ipL = mul24(wrap_line<FASTW>(i0 - 2 + r, L, fastw), L);
+            const int j = wrap_line<FASTW>(j0 - 3 + c, L, fastw), jp = wrap_line<FASTW>(j0 - 2 + c, L, fastw);
+            const double p = pin ? ldu(pin, (unsigned)(iL + j))
+                                 : ldu(x0, (unsigned)(iL + j)) - ldu(x1, (unsigned)(iL + j)) - ldu(x0, (unsigned)(iL + jp)) + ldu(x1, (unsigned)(ipL + j));
+            const int at = r * R0C + c;
+            // one sincos per task: of P where the plaquette is frozen (the net input), of P / 2 at an own active site (the
+            // transform needs it) -- left in the plaquette plane next to P, in the two slots of the following lines
+            // (stripe classes 1, 2), whose own plaquettes nobody reads
+            double sn = 0.0, cs = 1.0;
+            if (fz || !REV) ft_sincos(fz ? p : 0.5 * p, &sn, &cs);
+            if (ao) {
+                sP[at] = p;
+                if (!REV) { const int st = mu == 0 ? 1 : R0C; sP[at + st] = cs; sP[at + 2 * st] = sn; }
+            } else {
+                sIn[at] = cs;
+                sIn[PS0 + at] = sn;
+                if (A.stash && (unsigned)(r - 3) < (unsigned)min(TR, L - i0) &&
+                    (unsigned)(c - 3) < (unsigned)min(TC, L - j0)) {         // the net input of the tile's own frozen sites
+                    double* cs_ = uniform_ptr(A.stash, ((size_t)A.B * 18 + b) * n);
+                    const unsigned fi = (unsigned)stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
+                    stu(cs_, fi, cs); stu(cs_, fi + (unsigned)(n >> 1), sn);
+                }
+            }
         }
     }
 #pragma unroll

@@ -315,33 +315,29 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     // constant, instead of a division of the pair number by the line count per lane and tile.
     constexpr int NPL = R2R / 2;                                        // pair lines (rows or columns of pairs)
     static_assert(NLC == 14 && NLR == 14 && NPL == 9 && NPL - 1 == NW && 2 * (NW - 1) == NLC, "conv2 tile map");
-    auto pair_of = [&](int p, int& pl, int& ll) {                       // pair number (tile * 16 + lane) -> pair line, live-line index
-        const int T = p >> 4, i = p & 15;
+    // one tile per wave: this lane's pair (pair line pl, live-line index -> window line wl) once, for the operand address and
+    // for the epilogue alike
+    int pl, wl;
+    bool pok;
+    {
+        const int i = lane & 15;
         const bool own = i < NLC;
-        pl = own ? T : NPL - 1;
-        ll = own ? i : 2 * T + i - NLC;
-        return own || T < NW - 1;
-    };
+        pl = own ? wave : NPL - 1;
+        wl = live_line(own ? i : 2 * wave + i - NLC, d0);
+        pok = (own || wave < NW - 1) && wl < R2C;
+    }
     if (mu == 0) {
         // B[k = (tap = ky4 * 3 + kx, ci)][n = (co, dd)] = W1[co][ci][ky4 - dd][kx]; pairs = rows (2 pr, 2 pr + 1)
         mfma_stage<KConv2Row, 16 * NW, RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
-            [&](int p) { int pr, lc; pair_of(p, pr, lc); return 2 * pr * RS1 + min(live_line(lc, d0), R2C - 1); },
-            [&](int g, int p, bool, double (&z)[4], int) {
-                int pr, lc;
-                const bool ok = pair_of(p, pr, lc);
-                const int c = live_line(lc, d0);
-                conv2_epi(g, ok && c < R2C, 2 * pr, c, 1, 0, z);
-            }, dbg ? dbg + 11 : nullptr, bias2);
+            [&](int) { return 2 * pl * RS1 + min(wl, R2C - 1); },
+            [&](int g, int, bool, double (&z)[4], int) { conv2_epi(g, pok, 2 * pl, wl, 1, 0, z); },
+            dbg ? dbg + 11 : nullptr, bias2);
     } else {
         // B[k = (tap = ky * 4 + kx4, ci)][n = (co, dd)] = W1[co][ci][ky][kx4 - dd]; pairs = columns (2 pc, 2 pc + 1)
         mfma_stage<KConv2Col, 16 * NW, RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
-            [&](int p) { int pc, lr; pair_of(p, pc, lr); return min(live_line(lr, d0), R2R - 1) * RS1 + 2 * pc; },
-            [&](int g, int p, bool, double (&z)[4], int) {
-                int pc, lr;
-                const bool ok = pair_of(p, pc, lr);
-                const int r = live_line(lr, d0);
-                conv2_epi(g, ok && r < R2R, r, 2 * pc, 0, 1, z);
-            }, nullptr, bias2);
+            [&](int) { return min(wl, R2R - 1) * RS1 + 2 * pl; },
+            [&](int g, int, bool, double (&z)[4], int) { conv2_epi(g, pok, wl, 2 * pl, 0, 1, z); },
+            nullptr, bias2);
     }
     // conv3's 27 weights of this wave's input channel are wave-uniform: scalar loads straight from the weight block
     // (constant address space -> s_load, SGPR operands of the FMAs) instead of 27 LDS reads per wave; issued ahead of

@@ -280,7 +280,10 @@ __device__ __forceinline__ double4_t conv2t_tile(const double* __restrict__ wp, 
 
 // Live-line map of a window whose every 4th line (first one d0) is dead: index of the l-th live line.
 // (the quotient by 3 through fdiv: a plain `/ 3` compiles to the quarter-rate v_mul_hi_u32)
-__device__ __forceinline__ int live_line(int l, int d0) { return l < d0 ? l : l + 1 + fdiv<3>(max(l - d0, 0)); }
+__device__ __forceinline__ int live_line(int l, int d0) {
+    const int e = l - d0, q = 1 + fdiv<3>(max(e, 0));                    // branch-free: one select
+    return l + (e >= 0 ? q : 0);
+}
 
 
 // XCD-aware block -> (chain, tile) map.  Blocks are dealt round-robin over the 8 XCDs (chains b and b + 8

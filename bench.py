@@ -232,8 +232,11 @@ def main():
     local = local % torch.cuda.device_count()          # ranks may share a GPU in a gloo rehearsal
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    nccl = world > 1 and torch.distributed.get_backend() == 'nccl'
-    if world > 1:
+    # a process group exists for world > 1 -- and for ONE rank under FTHMC_FORCE_PG=1 (parallel.force_group: the RCCL
+    # code path of the 8-GPU run rehearsed on a single GPU); every collective below follows the group, not the world size
+    grouped = parallel.have_group()
+    nccl = grouped and torch.distributed.get_backend() == 'nccl'
+    if grouped:
         # first collective NOW: RCCL builds its communicator (and fails, if it is going to) before any graph is
         # captured or any timing starts, on the device this rank will compute on
         t_ = torch.ones(1, dtype=torch.float64, device=dev)
@@ -337,11 +340,11 @@ def main():
             enqueue()
         if pending[0] is not None:
             pending[0].wait()
-        pending[0] = stats.reduce(async_op=world > 1)
+        pending[0] = stats.reduce(async_op=grouped)
         traj[0] += 1
 
     def barrier():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier(device_ids=[local]) if nccl else torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -358,7 +361,7 @@ def main():
             pending[0] = None
         barrier()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if grouped:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         return float(t)
 
@@ -405,7 +408,7 @@ def main():
             barrier()
             tt = time.perf_counter() - tt0
         tt_t = torch.tensor([tt], dtype=torch.float64, device=dev)
-        if world > 1:
+        if grouped:
             torch.distributed.all_reduce(tt_t, op=torch.distributed.ReduceOp.MAX)
         tt = float(tt_t)
         tflops = N_LAYERS * L * L * TRAIN_FLOPS_PER_SITE * B_total * nt / tt / 1e12
@@ -416,7 +419,7 @@ def main():
                  'note': 'fthmc_train_grad (forward with stash, backward with MFMA weight gradients) + gradient '
                          'all-reduce; the optimizer step (torch Adam on 15 280 parameters) is host-side and excluded'}
     if rank != 0:
-        if world > 1:
+        if grouped:
             torch.distributed.destroy_process_group()
         return
 
@@ -596,6 +599,7 @@ def main():
         'config': {'workload': cfg['label'], 'baseline_config': args.config,
                    'chains_per_gpu': B, 'chains_total': B_total, 'L': L, 'beta': BETA, 'n_layers': N_LAYERS,
                    'nstep': NSTEP, 'tau': TAU, 'parallelism': f'chains sharded x{world}',
+                   'process_group': (torch.distributed.get_backend() if grouped else None),
                    'launch': 'eager' if graph is None else 'hipGraph replay', 'chain_groups': G,
                    'path': 'small-lattice fused (one launch per trajectory)' if (flowed and L <= 16 and ops.get_small_path()) else
                            ('tiled, one launch per layer' if flowed else 'plain HMC, one launch per trajectory')},
@@ -611,7 +615,7 @@ def main():
     if train is not None:
         line['train'] = train
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         torch.distributed.destroy_process_group()
     if not parity_ok:
         log(f'PARITY FAILURE against the oracle (tolerance {PARITY_TOL}): {cpu["parity"]}')

@@ -66,6 +66,8 @@ SIGNATURES = {
     'fthmc_ft_trajectory': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int,
                             _D, _D, _D, _D, _D, _D, _D, _D, _D, _P, c_size_t, _P],
     'fthmc_train_grad': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
+    'fthmc_random_uniform': [_D, c_int, c_int, c_double, c_double, _D, _P],
+    'fthmc_train_metrics': [_D, _D, _D, _D, c_int, c_int, c_double, c_double, _D, _P, c_size_t, _P],
     'fthmc_time_kernel': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double, c_int,
                           ctypes.POINTER(c_double), _P, c_size_t, _P],
     'fthmc_time_small': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int,

@@ -320,6 +320,21 @@ int fthmc_random_momenta(const int64_t* seeds, int B, int n_per_chain, double* v
     return launch_random_momenta(seeds, B, n_per_chain, v, u, ft_stream(stream));
 }
 
+int fthmc_random_uniform(const int64_t* seeds, int B, int n_per_chain, double lo, double hi, double* out, void* stream) {
+    if (!seeds || !out || B <= 0 || n_per_chain <= 0 || !(hi > lo)) return FTHMC_ERR_ARG;
+    return launch_random_uniform(seeds, B, n_per_chain, lo, hi, out, ft_stream(stream));
+}
+
+int fthmc_train_metrics(const double* xi, const double* x, const double* logq, const double* logp, int B, int L,
+                        double beta, double dkl_factor, double* row, void* ws, size_t ws_bytes, void* stream) {
+    if (!xi || !x || !logq || !logp || !row || bad_shape(B, L) || !(beta != 0.0)) return FTHMC_ERR_ARG;
+    FT_WS(0);
+    double* q = W.scal + (size_t)SC_Q * B; double* qi = W.scal + (size_t)SC_OLD0 * B;
+    FT_TRY(launch_action_charge(x, B, L, beta, nullptr, q, nullptr, s));
+    FT_TRY(launch_action_charge(xi, B, L, beta, nullptr, qi, nullptr, s));
+    return launch_train_metrics(logq, logp, q, qi, B, 1.0 / (beta * L * L), dkl_factor, row, s);
+}
+
 int fthmc_leapfrog(const double* x, const double* p, int B, int L, double beta, double dt, int nstep,
                    double* x_out, double* p_out, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !p || !x_out || !p_out || bad_shape(B, L) || nstep < 1) return FTHMC_ERR_ARG;

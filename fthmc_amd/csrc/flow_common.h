@@ -161,11 +161,44 @@ __device__ __forceinline__ double ft_min_neg(double z, double hi) {
 #define FT_SIG_RATIONAL 1
 #endif
 
+// Range reduction n = round(a log2 e) without v_rndne_f64 / v_cvt_i32_f64 (FT_SIG_MAGIC, default 1): t = a log2 e + 1.5 * 2^52
+// is rounded to an integer by the FMA itself, n = t - 1.5 * 2^52 is exact, and the low dword of t IS n in two's complement
+// (2^52 + 2^51 = 0 mod 2^32), which v_ldexp_f64 takes as its exponent operand: {mul, rndne, cvt, ldexp} -> {fma, add, ldexp},
+// one fp64-pipe slot less per value.  Valid for |a log2 e| < 2^31 (a <= 700 by the clamp; z < 1.4e9 on the other side).
+#ifndef FT_SIG_MAGIC
+#define FT_SIG_MAGIC 1
+#endif
+#define FT_MAGIC52 6755399441055744.0
+// r = a - n ln 2 in ONE FMA with the correctly rounded ln 2 (FT_SIG_LN2_ONE, default 1) instead of the hi / lo pair: the
+// constant's rounding error (2.3e-17) enters r as |n| 2.3e-17, i.e. sigma picks up a RELATIVE error of |n| 2.3e-17 where it is
+// tiny (z << 0) and an ABSOLUTE error sigma (1 - sigma) |n| 2.3e-17 <= 1.3e-17 everywhere (|n| ~ 1.44 |z| grows as
+// sigma (1 - sigma) ~ e^-|z| falls): an eighth of the rounding error of a sigma near 1/2.  One fp64-pipe slot less per value.
+#ifndef FT_SIG_LN2_ONE
+#define FT_SIG_LN2_ONE 1
+#endif
+#define FT_LN2 6.93147180559945309417e-01
+__device__ __forceinline__ double ft_round_magic(double a, int& ni) {
+    double t;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t) : "v"(a), "s"(1.4426950408889634074), "v"(FT_MAGIC52));   // one SGPR operand per VOP3 on gfx9
+    ni = (int)__double2loint(t);
+    return t - FT_MAGIC52;
+}
+
 __device__ __forceinline__ double ft_sigmoid(double z) {
     const double a = ft_min_neg(z, 700.0);
+#if FT_SIG_MAGIC
+    int ni;
+    const double n = ft_round_magic(a, ni);
+#else
     const double n = rint(ft_mul_vs(a, 1.4426950408889634074));
+    const int ni = (int)n;
+#endif
+#if FT_SIG_LN2_ONE
+    const double r = ft_fma_nvsv(n, FT_LN2, a);
+#else
     double r = ft_fma_nvsv(n, 6.93147180369123816490e-01, a);
     r = ft_fma_nvsv(n, 1.90821492927058770002e-10, r);
+#endif
 #if FT_SIG_RATIONAL
     const double s = r * r;
     double P = 4.13813679705723846039e-08;
@@ -174,14 +207,14 @@ __device__ __forceinline__ double ft_sigmoid(double z) {
     P = ft_fma_vvs(P, s, -2.77777777770155933842e-03);
     P = ft_fma_vvs(P, s, 1.66666666666666019037e-01);
     const double m = 2.0 - fma(-s, P, r);
-    const double t = m + ldexp(fma(2.0, r, m), (int)n);
+    const double t = m + ldexp(fma(2.0, r, m), ni);
     double y = __builtin_amdgcn_rcp(t);
     const double u = fma(-t, y, 1.0);
     return m * fma(fma(u, u, u), y, y);
 #else
     double p;
     FT_EXP11(p, r);
-    const double t = 1.0 + ldexp(p, (int)n);
+    const double t = 1.0 + ldexp(p, ni);
     double y = __builtin_amdgcn_rcp(t);
     const double u = fma(-t, y, 1.0);
     return fma(fma(u, u, u), y, y);
@@ -206,14 +239,25 @@ __device__ __forceinline__ void act_eval(double z, int act, double& h, double& d
 // four sigmoids back to back.  Same arithmetic as ft_sigmoid.
 __device__ __forceinline__ void sigmoid4(const double (&z)[4], double (&sg)[4]) {
     double a[4], n[4], r[4], p[4], t[4], y[4], u[4];
+    int ni[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = ft_min_neg(z[q], 700.0);
+#if FT_SIG_MAGIC
 #pragma unroll
-    for (int q = 0; q < 4; ++q) n[q] = rint(ft_mul_vs(a[q], 1.4426950408889634074));
+    for (int q = 0; q < 4; ++q) n[q] = ft_round_magic(a[q], ni[q]);
+#else
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { n[q] = rint(ft_mul_vs(a[q], 1.4426950408889634074)); ni[q] = (int)n[q]; }
+#endif
+#if FT_SIG_LN2_ONE
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = ft_fma_nvsv(n[q], FT_LN2, a[q]);
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q) r[q] = ft_fma_nvsv(n[q], 6.93147180369123816490e-01, a[q]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) r[q] = ft_fma_nvsv(n[q], 1.90821492927058770002e-10, r[q]);
+#endif
 #if FT_SIG_RATIONAL
     double s[4], m[4];
 #pragma unroll
@@ -235,7 +279,7 @@ __device__ __forceinline__ void sigmoid4(const double (&z)[4], double (&sg)[4]) 
 #pragma unroll
     for (int q = 0; q < 4; ++q) p[q] = fma(2.0, r[q], m[q]);            // m exp(r)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = m[q] + ldexp(p[q], (int)n[q]);
+    for (int q = 0; q < 4; ++q) t[q] = m[q] + ldexp(p[q], ni[q]);
 #else
     {
         const double c11 = 2.5100375832561234e-08;                     // one VGPR pair for the leading coefficient, shared by the four chains
@@ -254,7 +298,7 @@ __device__ __forceinline__ void sigmoid4(const double (&z)[4], double (&sg)[4]) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) p[q] = fma(p[q], r[q], 1.0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = 1.0 + ldexp(p[q], (int)n[q]);
+    for (int q = 0; q < 4; ++q) t[q] = 1.0 + ldexp(p[q], ni[q]);
 #endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) y[q] = __builtin_amdgcn_rcp(t[q]);

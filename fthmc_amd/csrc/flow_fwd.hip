@@ -45,7 +45,9 @@ template <int TR, int TC> struct SmemF {
 // MU: the layer's stripe direction (A.mu) as a compile-time constant: every `mu == 0 ? a : b` below folds, the LDS steps
 // across / along the lines become immediate offsets of the operand reads, and each kernel carries one of the two conv2
 // code paths instead of both (selects on per-lane values by a uniform mu were ~5 % of the VALU instructions).
-template <int TR, int TC, bool FASTW, bool REV, int MU>
+// EXACT: the tiles divide the lattice (L % 16 == 0: BASELINE configs 3, 4, 5), so every tile site is a lattice site: the
+// lattice-edge halves of the bounds tests of the stash stores, the link update and the active sites fold away.
+template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT>
 __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     double xv0 = 0.0, xv1 = 0.0;
     if ((A.y || A.pout) && tid < N3) {
         const int r = fdiv<TC>(tid), c = tid - r * TC;
-        if (i0 + r < L && j0 + c < L) {
+        if (EXACT || (i0 + r < L && j0 + c < L)) {
             const unsigned at = (unsigned)(mul24(i0 + r, L) + j0 + c);
             if (pin) xv0 = ldu(pin, at); else { xv0 = ldu(x0, at); xv1 = ldu(x1, at); }
         }
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             } else {
                 sIn[at] = cs;
                 sIn[PS0 + at] = sn;
-                if (A.stash && (unsigned)(r - 3) < (unsigned)min(TR, L - i0) &&
-                    (unsigned)(c - 3) < (unsigned)min(TC, L - j0)) {         // the net input of the tile's own frozen sites
+                if (A.stash && (unsigned)(r - 3) < (unsigned)(EXACT ? TR : min(TR, L - i0)) &&
+                    (unsigned)(c - 3) < (unsigned)(EXACT ? TC : min(TC, L - j0))) {         // the net input of the tile's own frozen sites
                     double* cs_ = uniform_ptr(A.stash, ((size_t)A.B * 18 + b) * n);
                     const unsigned fi = (unsigned)stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
                     stu(cs_, fi, cs); stu(cs_, fi + (unsigned)(n >> 1), sn);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
 
     // stash of this lane's output channels 2 g, 2 g + 1, g = lane >> 4 (fixed for the kernel): act' channel-minor
     // (one 16-byte store per site), and so is h (training)
-    const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // tile sites inside the lattice
+    const int rmax = EXACT ? TR : min(TR, L - i0), cmax = EXACT ? TC : min(TC, L - j0);    // tile sites inside the lattice
     const Stash sv = A.stash ? stash_view(A.stash, A.B, b, n) : Stash{};
     typedef double double2_t __attribute__((ext_vector_type(2)));
     // uniform plane bases (SGPRs) + this lane's channel pair as part of the 32-bit element index
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     const int ac = mu == 0 ? off + 4 * (lane % (TC / 4)) : lane % TC;
     const int ai = i0 + ar, aj = j0 + ac;
     const bool alane = lane < NA;
-    const bool avalid = alane && (ai < L) && (aj < L);
+    const bool avalid = alane && (EXACT || ((ai < L) && (aj < L)));
     if (alane) {
         double acc[3] = {0.0, 0.0, 0.0};
         const int ci = wave;
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         if (A.y && tid < N3) {
             const int r = fdiv<TC>(tid), c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
-            if (i < L && j < L) {
+            if (EXACT || (i < L && j < L)) {
                 double v0 = xv0, v1 = xv1;
                 if (ft_stripe(i, j, mu, off) == 0) {
                     const double d = sDL[tid];
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         if (A.pout && tid < N3) {                                    // plaquette-level inverse: x1 at the active sites, fx elsewhere
             const int r = fdiv<TC>(tid), c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
-            if (i < L && j < L) A.pout[(size_t)b * n + mul24(i, L) + j] = ft_stripe(i, j, mu, off) == 0 ? sDL[tid] : xv0;
+            if (EXACT || (i < L && j < L)) A.pout[(size_t)b * n + mul24(i, L) + j] = ft_stripe(i, j, mu, off) == 0 ? sDL[tid] : xv0;
         }
         return;
     }
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         if (A.y && tid < N3) {
             const int r = fdiv<TC>(tid), c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
-            if (i < L && j < L) {
+            if (EXACT || (i < L && j < L)) {
                 double v0 = xv0, v1 = xv1;
                 if (ft_stripe(i, j, mu, off) == 0) {
                     const double d = sDL[tid];
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
         if (A.pout && tid < N3) {                                    // plaquette-level map: P' at the active sites, P elsewhere
             const int r = fdiv<TC>(tid), c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
-            if (i < L && j < L) A.pout[(size_t)b * n + mul24(i, L) + j] = ft_stripe(i, j, mu, off) == 0 ? sDL[tid] : xv0;
+            if (EXACT || (i < L && j < L)) A.pout[(size_t)b * n + mul24(i, L) + j] = ft_stripe(i, j, mu, off) == 0 ? sDL[tid] : xv0;
         }
         STAMP(6);
     }
@@ -550,13 +552,17 @@ int g_variant = 1;
 
 namespace {
 template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hipStream_t s) {
-    const bool fast = wrap_fast_ok(a.L, fthmc::MF_FWD_TR, fthmc::MF_FWD_TC);
+    constexpr int TR = fthmc::MF_FWD_TR, TC = fthmc::MF_FWD_TC;
+    const bool fast = wrap_fast_ok(a.L, TR, TC);
+    const bool exact = fast && a.L % TR == 0 && a.L % TC == 0;
     if (a.mu == 0) {
-        if (fast) hipLaunchKernelGGL((k_flow_fwd<fthmc::MF_FWD_TR, fthmc::MF_FWD_TC, true, REV, 0>), grid, dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((k_flow_fwd<fthmc::MF_FWD_TR, fthmc::MF_FWD_TC, false, REV, 0>), grid, dim3(NT), 0, s, a);
+        if (exact) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 0, true>), grid, dim3(NT), 0, s, a);
+        else if (fast) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 0, false>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_fwd<TR, TC, false, REV, 0, false>), grid, dim3(NT), 0, s, a);
     } else {
-        if (fast) hipLaunchKernelGGL((k_flow_fwd<fthmc::MF_FWD_TR, fthmc::MF_FWD_TC, true, REV, 1>), grid, dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((k_flow_fwd<fthmc::MF_FWD_TR, fthmc::MF_FWD_TC, false, REV, 1>), grid, dim3(NT), 0, s, a);
+        if (exact) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 1, true>), grid, dim3(NT), 0, s, a);
+        else if (fast) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 1, false>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_fwd<TR, TC, false, REV, 1, false>), grid, dim3(NT), 0, s, a);
     }
 }
 }  // namespace

@@ -33,8 +33,12 @@ int launch_metropolis(const double* x_old, const double* x_prop, const double* u
                       double* acc, const double* obs_old, const double* obs_new, double* obs_out,
                       int n_obs, hipStream_t s);
 
+int launch_train_metrics(const double* logq, const double* logp, const double* q, const double* qi, int B,
+                         double inv_beta_vol, double dkl_factor, double* row, hipStream_t s);
+
 // ---- rng.hip
 int launch_random_momenta(const int64_t* seeds, int B, int n, double* v, double* u, hipStream_t s);
+int launch_random_uniform(const int64_t* seeds, int B, int n, double lo, double hi, double* out, hipStream_t s);
 
 // ---- flow.hip
 constexpr int FLOW_TILE = 16;                 // VALU variant (flow.hip): 16 x 16 sites per tile

@@ -46,9 +46,29 @@ __global__ void k_random_momenta(const int64_t* __restrict__ seeds, int n, doubl
     }
 }
 
+// out[b][0..n) ~ U[lo, hi): the prior draw of the reverse-KL training step (MultivariateUniform.sample_n,
+// fthmc/utils/distributions.py:65-76), two values per Philox block, counter plane 2 (disjoint from the momenta's)
+__global__ void k_random_uniform(const int64_t* __restrict__ seeds, int n, double lo, double hi, double* __restrict__ out) {
+    const int b = blockIdx.y;
+    const uint64_t sd = (uint64_t)seeds[b];
+    const uint32_t k0 = (uint32_t)sd, k1 = (uint32_t)(sd >> 32);
+    const int npair = (n + 1) / 2;
+    const double w = hi - lo;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += gridDim.x * blockDim.x) {
+        const u4 r = philox4x32_10(u4{(uint32_t)p, 0u, 2u, 0u}, k0, k1);
+        out[(size_t)b * n + 2 * p] = fma(1.0 - u53(r.x, r.y), w, lo);             // 1 - (0, 1] = [0, 1)
+        if (2 * p + 1 < n) out[(size_t)b * n + 2 * p + 1] = fma(1.0 - u53(r.z, r.w), w, lo);
+    }
+}
+
 }  // namespace
 
 namespace fthmc {
+int launch_random_uniform(const int64_t* seeds, int B, int n, double lo, double hi, double* out, hipStream_t s) {
+    int gx = ((n + 1) / 2 + 255) / 256; if (gx > 32) gx = 32; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_random_uniform, dim3(gx, B), dim3(256), 0, s, seeds, n, lo, hi, out);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
 int launch_random_momenta(const int64_t* seeds, int B, int n, double* v, double* u, hipStream_t s) {
     int gx = ((n + 1) / 2 + 255) / 256; if (gx > 32) gx = 32; if (gx < 1) gx = 1;
     hipLaunchKernelGGL(k_random_momenta, dim3(gx, B), dim3(256), 0, s, seeds, n, v, u);

@@ -321,6 +321,43 @@ __global__ __launch_bounds__(256) void k_stats_accumulate(const double* __restri
 //   xr = regularize(x');  dH = S(xr) + v'^2/2 - S(x) - v^2/2;  acc = u < exp(-dH)
 constexpr int TJ_NT = 1024, TJ_MAXL = 64, TJ_NSITE = TJ_MAXL * TJ_MAXL / TJ_NT;
 
+// Metrics of one reverse-KL training step (train_step, fthmc/train.py:206-228; calc_dkl / calc_ess,
+// fthmc/utils/distributions.py:23-37) in one workgroup:
+//   row = [loss_dkl, ess, logp[B], logq[B], q[B], dq[B], plaq[B]]
+//   loss_dkl = dkl_factor * mean(logq - logp);  ess = exp(2 logsumexp(logw) - logsumexp(2 logw)) / B,  logw = logp - logq
+//   dq = sqrt((q - qi)^2);  plaq = logp / (beta V)    (train.py:219-221)
+__global__ __launch_bounds__(256) void k_train_metrics(const double* __restrict__ logq, const double* __restrict__ logp,
+                                                       const double* __restrict__ q, const double* __restrict__ qi, int B,
+                                                       double inv_beta_vol, double dkl_factor, double* __restrict__ row) {
+    __shared__ double red[16];
+    __shared__ double smax;
+    double m = -INFINITY, sd = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const double lw = logp[b] - logq[b];
+        m = fmax(m, lw); sd += logq[b] - logp[b];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, FT_WAVE));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = red[0]; for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, red[i]); smax = t; }
+    __syncthreads();
+    m = smax;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const double e = exp(logp[b] - logq[b] - m);
+        s1 += e; s2 += e * e;
+        const double qq = q[b];
+        row[2 + b] = logp[b]; row[2 + B + b] = logq[b]; row[2 + 2 * B + b] = qq;
+        row[2 + 3 * B + b] = fabs(qq - qi[b]); row[2 + 4 * B + b] = logp[b] * inv_beta_vol;
+    }
+    const double t1 = ft_block_sum(s1, red), t2 = ft_block_sum(s2, red), td = ft_block_sum(sd, red);
+    if (threadIdx.x == 0) {
+        row[0] = dkl_factor * td / B;
+        row[1] = t1 * t1 / t2 / B;                 // exp(2 (m + log s1) - (2 m + log s2)) / B
+    }
+}
+
 __global__ __launch_bounds__(TJ_NT) void k_hmc_trajectory(const double* __restrict__ x, const double* __restrict__ v,
                                                           const double* __restrict__ u, int L, double beta, double dt,
                                                           int nstep, double* __restrict__ x_new, double* __restrict__ dH,
@@ -453,6 +490,11 @@ int launch_lincomb(const double* a, double ca, const double* b, double cb, doubl
 int launch_stats_accumulate(const double* acc, const double* plaq, const double* Q, double* qold, const double* dH, int B,
                             double* vec, hipStream_t s) {
     hipLaunchKernelGGL(k_stats_accumulate, dim3(1), dim3(256), 0, s, acc, plaq, Q, qold, dH, B, vec);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_train_metrics(const double* logq, const double* logp, const double* q, const double* qi, int B,
+                         double inv_beta_vol, double dkl_factor, double* row, hipStream_t s) {
+    hipLaunchKernelGGL(k_train_metrics, dim3(1), dim3(256), 0, s, logq, logp, q, qi, B, inv_beta_vol, dkl_factor, row);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_wilson_force(const double* x, int B, int L, double beta, double* F, hipStream_t s) {

@@ -273,6 +273,47 @@ def random_momenta(seeds, shape, need_u=True, out_v=None, out_u=None):
     return v, u
 
 
+def random_uniform(seeds, shape, lo: float, hi: float, out=None):
+    """U[lo, hi) of `shape` = (B, ...) from per-chain int64 seeds: the prior draw of a training step on the device."""
+    if not seeds.is_cuda or seeds.dtype != torch.int64:
+        raise FthmcError('seeds: expected an int64 tensor on the HIP device')
+    seeds = seeds.contiguous()
+    B = int(shape[0]); n = 1
+    for d in shape[1:]:
+        n *= int(d)
+    if seeds.numel() != B:
+        raise FthmcError(f'seeds: expected {B}, got {seeds.numel()}')
+    if out is None:
+        out = torch.empty(tuple(shape), dtype=torch.float64, device=seeds.device)
+    elif not out.is_cuda or out.dtype != torch.float64 or not out.is_contiguous() or out.numel() != B * n:
+        raise FthmcError('random_uniform: out must be a contiguous float64 device tensor of the result shape')
+    check(_lib.load().fthmc_random_uniform(_p(seeds), B, n, float(lo), float(hi), _p(out), _stream(out)), 'fthmc_random_uniform')
+    return out
+
+
+def train_metrics(xi, x, logq, logp, beta: float, dkl_factor: float = 1.0, out=None):
+    """-> row [2 + 5 B] = (loss_dkl, ess, logp[B], logq[B], q[B], dq[B], plaq[B]) of one rank's training batch, on the
+    device (C ABI fthmc_train_metrics): everything train_step reports, in one buffer."""
+    xi = _field(xi, 'xi'); x = _field(x); B, _, L, _ = x.shape
+    logq = _dev(logq, 'logq').reshape(-1); logp = _dev(logp, 'logp').reshape(-1)
+    if logq.numel() != B or logp.numel() != B or xi.shape != x.shape:
+        raise FthmcError(f'train_metrics: expected logq, logp of {B} entries and xi shaped like x')
+    if out is None:
+        out = torch.empty(2 + 5 * B, dtype=torch.float64, device=x.device)
+    elif not out.is_cuda or out.dtype != torch.float64 or not out.is_contiguous() or out.numel() != 2 + 5 * B:
+        raise FthmcError(f'train_metrics: out must be a contiguous float64 device tensor of {2 + 5 * B} entries')
+    ws, nb = _ws(x, B, L, 0)
+    check(_lib.load().fthmc_train_metrics(_p(xi), _p(x), _p(logq), _p(logp), B, L, float(beta), float(dkl_factor),
+                                          _p(out), ws, nb, _stream(x)), 'fthmc_train_metrics')
+    return out
+
+
+def split_metrics(row, B: int) -> dict:
+    """views of a train_metrics row (device or host tensor / array) under train_step's keys"""
+    r = row[2:].reshape(5, B)
+    return {'loss_dkl': row[0], 'ess': row[1], 'logp': r[0], 'logq': r[1], 'q': r[2], 'dq': r[3], 'plaq': r[4]}
+
+
 def leapfrog(x, p, beta: float, dt: float, nstep: int):
     x = _field(x); p = _field(p, 'p'); B, _, L, _ = x.shape
     xo, po = torch.empty_like(x), torch.empty_like(p)
@@ -534,15 +575,19 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
     return out
 
 
-def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, groups: int = 1, _out=None):
+def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, groups: int = 1, _out=None, out_gw=None):
     """-> dict(x, logq, logp, gw): pieces of train.train_step for a fixed prior draw; gw = gradient of
-    mean_b (logq - logp) wrt the packed weights.
+    mean_b (logq - logp) wrt the packed weights (written into `out_gw` when given: a contiguous float64 device tensor
+    of w.numel() entries, e.g. the flat gradient buffer the conv parameters' .grad are views of).
 
     groups > 1: the chains are split into contiguous groups that run on concurrent streams (as in
     ft_trajectory); the groups' weight gradients are combined with weights B_g / B."""
     xi = _field(xi, 'xi'); B, _, L, _ = xi.shape
     w = _wall(w, n_layers)
     G = max(1, min(int(groups), B))
+    if out_gw is not None and (not out_gw.is_cuda or out_gw.dtype != torch.float64 or not out_gw.is_contiguous()
+                               or out_gw.numel() != w.numel()):
+        raise FthmcError(f'train_grad: out_gw must be a contiguous float64 device tensor of {w.numel()} entries')
     if _out is None:
         x = torch.empty_like(xi)
         logq, logp = (torch.empty(B, dtype=xi.dtype, device=xi.device) for _ in range(2))
@@ -562,8 +607,12 @@ def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, grou
                     torch.mul(r['gw'], (b_ - a) / B, out=gws[gi])
         for st in sides:
             main.wait_stream(st)
-        return {'x': x, 'logq': logq, 'logp': logp, 'gw': _tag(gws.sum(0), w) if need_gw else None}
-    gw = _tag(torch.empty(w.numel(), dtype=xi.dtype, device=xi.device), w) if need_gw else None
+        if need_gw and out_gw is not None:
+            torch.sum(gws, 0, out=out_gw)
+        return {'x': x, 'logq': logq, 'logp': logp,
+                'gw': _tag(out_gw if out_gw is not None else gws.sum(0), w) if need_gw else None}
+    gw = _tag(out_gw.reshape(-1) if out_gw is not None else torch.empty(w.numel(), dtype=xi.dtype, device=xi.device), w) \
+        if need_gw else None
     ws, nb = _ws(xi, B, L, n_layers, train=True)
     check(_lib.load().fthmc_train_grad(_p(xi), _p(w), n_layers, B, L, act_code(act), float(beta), _p(x), _p(logq),
                                        _p(logp), _p(gw), ws, nb, _stream(xi)), 'fthmc_train_grad')

@@ -23,9 +23,22 @@ def world() -> Tuple[int, int, int]:
             int(os.environ.get('LOCAL_RANK', 0)))
 
 
+def force_group() -> bool:
+    """FTHMC_FORCE_PG=1: create a process group even for ONE rank, so that every collective of this module (and of
+    bench.py / train.py) takes its RCCL branch on a single GPU -- communicator creation, the async C1 handle living
+    across hipGraph replays, barrier(device_ids=...), the watchdog thread next to a graph capture: the 8-GPU code
+    path minus the peers.  A rehearsal switch; results are bit-identical to the run without a group."""
+    return os.environ.get('FTHMC_FORCE_PG', '0') not in ('', '0')
+
+
+def have_group() -> bool:
+    """A process group exists (of any size): collectives are issued whenever this is true, not only for world > 1."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, ws, local = world()
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or force_group()) and not dist.is_initialized():
         if backend is None:
             # FTHMC_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a 1-GPU box;
             # RCCL refuses two ranks on the same device)
@@ -33,6 +46,8 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
         if backend == 'nccl':
             torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if ws == 1:
+            os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 2000))   # a lone rank outside torchrun
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
     return rank, ws, local
 
@@ -86,9 +101,9 @@ class RunStats:
         self.vec += rows.sum(dim=1)
 
     def reduce(self, async_op: bool = False):
-        """C1: SUM all-reduce of a snapshot over ranks (plain copy for one process)."""
+        """C1: SUM all-reduce of a snapshot over the ranks of the process group (plain copy without one)."""
         self.glob = self.vec.clone()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if have_group():
             return dist.all_reduce(self.glob, op=dist.ReduceOp.SUM, async_op=async_op)
         return None
 
@@ -103,7 +118,7 @@ class RunStats:
 
 def allreduce_grads(gw: torch.Tensor, world_size: Optional[int] = None) -> torch.Tensor:
     """C2: SUM all-reduce of the flat weight-gradient buffer (955 * n_layers doubles)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if have_group():
         dist.all_reduce(gw, op=dist.ReduceOp.SUM)
     return gw
 
@@ -111,7 +126,7 @@ def allreduce_grads(gw: torch.Tensor, world_size: Optional[int] = None) -> torch
 def global_logsumexp(logw: torch.Tensor) -> torch.Tensor:
     """logsumexp over the chains of all ranks: MAX all-reduce, then SUM all-reduce."""
     m = logw.max()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if have_group():
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         s = torch.exp(logw - m).sum()
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
@@ -121,6 +136,6 @@ def global_logsumexp(logw: torch.Tensor) -> torch.Tensor:
 
 def global_mean(t: torch.Tensor, n_global: int) -> torch.Tensor:
     s = t.sum()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if have_group():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return s / n_global

@@ -21,8 +21,8 @@ from . import ops, parallel
 from .config import DTYPE, FlowModel, Param, TrainConfig, device
 from .utils import qed_helpers as qed
 from .utils.distributions import MultivariateUniform, calc_dkl, calc_ess
-from .utils.layers import (flow_activation, flow_weights, get_nets, make_net_from_layers, make_u1_equiv_layers,
-                           net_weights, set_weights)
+from .utils.layers import (attach_grads, flatten_flow, flow_activation, flow_grad_buffer, flow_weights, get_nets,
+                           make_net_from_layers, make_u1_equiv_layers, net_weights, set_weights)
 from .utils.samplers import apply_flow_to_prior
 
 TWO_PI = 2 * PI
@@ -65,12 +65,14 @@ def restore_model_from_checkpoint(infile, train_config: TrainConfig, trusted: bo
     `save_checkpoint` here hold tensors and plain numbers only and load with `weights_only=True`.  A checkpoint
     written by the reference pickles numpy arrays in its history: pass `trusted=True` for such a file -- unpickling
     it can run arbitrary code, so only for files you wrote yourself."""
+    import pickle
     try:
         checkpoint = torch.load(infile, map_location=device(), weights_only=True)
-    except Exception as e:                                      # pickle.UnpicklingError and friends
-        if not trusted:
-            raise RuntimeError(f'{infile} does not load with weights_only=True ({type(e).__name__}); if you wrote '
-                               f'this file yourself, call restore_model_from_checkpoint(..., trusted=True)') from e
+    except pickle.UnpicklingError as e:                         # what the weights-only unpickler raises on a refused global;
+        if not trusted:                                         # a missing or unreadable file (OSError) propagates as it is
+            raise RuntimeError(f'{infile} does not load with weights_only=True ({type(e).__name__}: a checkpoint written by '
+                               f'the reference pickles numpy arrays in its history); if you wrote this file yourself, call '
+                               f'restore_model_from_checkpoint(..., trusted=True)') from e
         checkpoint = torch.load(infile, map_location=device(), weights_only=False)
     model = get_model(train_config)
     optimizer = optim.AdamW(model.layers.parameters(), lr=train_config.base_lr, weight_decay=1e-5)
@@ -84,11 +86,63 @@ def save_checkpoint(era: int, epoch: int, model: nn.Module, optimizer, history: 
     os.makedirs(outdir, exist_ok=True)
     path = os.path.join(outdir, f'ckpt-era{era}-epoch{epoch}.tar')
     torch.save({'era': era, 'epoch': epoch, 'model_state_dict': model.state_dict(),
-                'optimizer_state_dict': optimizer.state_dict(), 'history': _plain(history)}, path)
+                'optimizer_state_dict': _portable_optimizer_state(optimizer), 'history': _plain(history)}, path)
     return path
 
 
+def _portable_optimizer_state(optimizer) -> dict:
+    """optimizer.state_dict() in the layout a plain (non-capturable) torch optimizer writes and reads: the learning rate a
+    Python float and the step counts CPU scalars -- a capturable optimizer (make_optimizer) keeps both on the device."""
+    sd = optimizer.state_dict()
+    groups = []
+    for g in sd['param_groups']:
+        g = dict(g)
+        if torch.is_tensor(g.get('lr')):
+            g['lr'] = float(g['lr'])
+        g['capturable'] = False; g['fused'] = None; g['foreach'] = None
+        groups.append(g)
+    state = {}
+    for k, st in sd['state'].items():
+        st = dict(st)
+        if torch.is_tensor(st.get('step')):
+            st['step'] = st['step'].detach().to('cpu', torch.float32)
+        state[k] = st
+    return {'state': state, 'param_groups': groups}
+
+
 ActionFn = Callable[[torch.Tensor], torch.Tensor]
+
+METRIC_KEYS = ('ess', 'logp', 'logq', 'loss_dkl', 'q', 'dq', 'plaq')
+
+
+def _fused_step_device(model: FlowModel, action, batch_size: int, dkl_factor: float, xi: torch.Tensor, row: torch.Tensor = None,
+                       groups: int = None):
+    """The device side of one fused training step, enqueue only (no host synchronisation, graph-capturable without a
+    process group): d(loss)/d(weights) straight into the flat gradient buffer every conv parameter's .grad is a view of
+    (no unpacking, no copies), and the stacked metrics row (ops.train_metrics).  -> (row, x)."""
+    layers = model.layers
+    flat = flatten_flow(layers)
+    gflat = flow_grad_buffer(layers)
+    world = torch.distributed.get_world_size() if parallel.have_group() else 1
+    B, L = xi.shape[0], xi.shape[-1]
+    r = ops.train_grad(xi, flat, len(layers), action.beta, flow_activation(layers),
+                       groups=ops.default_groups(B, L) if groups is None else groups, out_gw=gflat)
+    scale = dkl_factor / world                   # kernel seeds 1 / B_local; the loss is the global mean
+    if scale != 1.0:
+        gflat.mul_(scale)
+    parallel.allreduce_grads(gflat)
+    row = ops.train_metrics(xi, r['x'], r['logq'], r['logp'], action.beta, dkl_factor, out=row)
+    if parallel.have_group():                    # C2: loss mean and ESS over the chains of all ranks
+        n_global = B * world
+        logw = r['logp'] - r['logq']
+        row[0] = dkl_factor * parallel.global_mean(r['logq'] - r['logp'], n_global)
+        row[1] = torch.exp(2 * parallel.global_logsumexp(logw) - parallel.global_logsumexp(2 * logw)) / n_global
+    return row, r['x']
+
+
+def _metrics_dict(row_host: np.ndarray, B: int) -> dict:
+    m = ops.split_metrics(row_host, B)
+    return {k: np.asarray(m[k]) for k in METRIC_KEYS}
 
 
 def train_step(model: FlowModel, config: TrainConfig, action: ActionFn, optimizer: optim.Optimizer,
@@ -97,10 +151,11 @@ def train_step(model: FlowModel, config: TrainConfig, action: ActionFn, optimize
     """train.py:162-228.  `batch_size` is this rank's share of the global batch.
 
     fused=True : one HIP call computes x, logq, logp and d(loss)/d(weights) (needs `action` to be
-                 the Wilson `BatchAction(config.beta)`, which is what train.py:291 passes);
-    fused=False: the layers run one by one through autograd (any `action` callable)."""
+                 the Wilson `BatchAction(config.beta)`, which is what train.py:291 passes); the gradient lands in the
+                 flat buffer the parameters' .grad are views of, the metrics come back in ONE device-to-host copy;
+    fused=False: the layers run one by one through autograd (any `action` callable).
+    A whole training loop without any per-step host synchronisation: `GraphTrainer` (what `train` uses)."""
     t0 = time.time()
-    optimizer.zero_grad()
     if scaler is not None:
         raise NotImplementedError('GradScaler (fp16 autocast) does not apply to the fp64 HIP path')
     if pre_model is not None:
@@ -108,30 +163,30 @@ def train_step(model: FlowModel, config: TrainConfig, action: ActionFn, optimize
         x_pre = qed.ft_flow(pre_model.layers, pre_xi)
         xi = qed.ft_flow_inv(pre_model.layers, x_pre)
     layers = model.layers
-    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    world = torch.distributed.get_world_size() if parallel.have_group() else 1
     n_global = batch_size * world
     if fused and isinstance(action, qed.BatchAction):
         if xi is None:
             xi = model.prior.sample_n(batch_size)
         xi = xi.to(DTYPE)
-        r = ops.train_grad(xi, flow_weights(layers, xi.device), len(layers), action.beta, flow_activation(layers),
-                           groups=ops.default_groups(xi.shape[0], xi.shape[-1]))
-        x, logq, logp = r['x'], r['logq'], r['logp']
-        gw = r['gw'] * (dkl_factor / world)          # kernel seeds 1/B_local; loss is the global mean
-        parallel.allreduce_grads(gw)
-        for layer, gl in zip(layers, ops.unpack_weight_grads(gw, len(layers), arch=ops.arch_of(r['gw']))):
-            for p, g in zip(net_weights(layer.plaq_coupling.net), gl):
-                p.grad = g.clone()
-        loss_dkl = dkl_factor * parallel.global_mean(logq - logp, n_global)
-    else:
-        x, xi, logq = apply_flow_to_prior(model.prior, layers, xi=xi, batch_size=batch_size)
-        logp = (-1.) * action(x)
-        loss_local = dkl_factor * (logq - logp).sum() / n_global
-        loss_local.backward()
-        if world > 1:
-            for p in layers.parameters():
-                parallel.allreduce_grads(p.grad)
-        loss_dkl = dkl_factor * parallel.global_mean((logq - logp).detach(), n_global)
+        row, _ = _fused_step_device(model, action, batch_size, dkl_factor, xi)
+        attach_grads(layers)                     # the fused call overwrites every gradient: no zero_grad pass
+        optimizer.step()
+        host = row.cpu().numpy()                 # the one synchronisation of the step
+        out = _metrics_dict(host, xi.shape[0])
+        if scheduler is not None:
+            scheduler.step(float(out['loss_dkl']))
+        out['dt'] = time.time() - t0
+        return out
+    optimizer.zero_grad()
+    x, xi, logq = apply_flow_to_prior(model.prior, layers, xi=xi, batch_size=batch_size)
+    logp = (-1.) * action(x)
+    loss_local = dkl_factor * (logq - logp).sum() / n_global
+    loss_local.backward()
+    if parallel.have_group():
+        for p in layers.parameters():
+            parallel.allreduce_grads(p.grad)
+    loss_dkl = dkl_factor * parallel.global_mean((logq - logp).detach(), n_global)
     logw = (logp - logq).detach()
     ess = torch.exp(2 * parallel.global_logsumexp(logw) - parallel.global_logsumexp(2 * logw)) / n_global
     qi = qed.batch_charges(xi)
@@ -141,18 +196,132 @@ def train_step(model: FlowModel, config: TrainConfig, action: ActionFn, optimize
     optimizer.step()
     if scheduler is not None:
         scheduler.step(loss_dkl)
-    return {'dt': time.time() - t0, 'ess': grab(ess), 'logp': grab(logp), 'logq': grab(logq),
-            'loss_dkl': grab(loss_dkl), 'q': grab(q), 'dq': grab(dq), 'plaq': grab(plaq)}
+    # one stacked copy instead of seven synchronising ones
+    B = x.shape[0]
+    host = torch.cat([loss_dkl.reshape(1), ess.reshape(1), logp.detach(), logq.detach(), q, dq, plaq]).cpu().numpy()
+    out = _metrics_dict(host, B)
+    out['dt'] = time.time() - t0
+    return out
+
+
+class GraphTrainer:
+    """The training loop of fthmc/train.py:352-407 without the host in it: one step = prior draw (Philox on the device,
+    keyed by global chain id and step) -> fthmc_train_grad into the flat gradient buffer -> metrics row -> optimizer
+    step, captured ONCE in a hipGraph and replayed; the metrics of every step are kept on the device (one small
+    device-to-device copy per step) and come to the host when somebody looks (`metrics()`, `history()`).
+
+    Needs an optimizer whose step is capturable (torch.optim.Adam(..., capturable=True); `make_optimizer`).  With a process
+    group (more than one rank, or FTHMC_FORCE_PG=1) the same device sequence runs eagerly, with the C2 collectives
+    (gradient all-reduce, global loss mean and ESS) in it.  A ReduceLROnPlateau scheduler needs the loss on the host after
+    every step and so brings one synchronisation per step back."""
+
+    def __init__(self, model: FlowModel, config: TrainConfig, optimizer: optim.Optimizer, batch_size: int,
+                 dkl_factor: float = 1., scheduler: Any = None, seed: int = 1234, use_graph: bool = True, chunk: int = 256):
+        self.model, self.config, self.optimizer, self.scheduler = model, config, optimizer, scheduler
+        self.B, self.dkl_factor, self.seed = int(batch_size), float(dkl_factor), int(seed)
+        self.action = qed.BatchAction(config.beta)
+        self.dev = next(model.layers.parameters()).device
+        L = tuple(config.lat)[-1]
+        self.rank, self.world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if parallel.have_group() else (0, 1)
+        self.lo = self.rank * self.B                                   # global chain ids of this rank's batch
+        self.seeds = torch.empty(self.B, dtype=torch.int64, device=self.dev)
+        self.xi = torch.empty(self.B, 2, L, L, dtype=DTYPE, device=self.dev)
+        self.row = torch.empty(2 + 5 * self.B, dtype=DTYPE, device=self.dev)
+        self.chunk = max(1, int(chunk))
+        self.hist_dev = torch.empty(self.chunk, self.row.numel(), dtype=DTYPE, device=self.dev)
+        self.hist_host = []                                            # flushed chunks (numpy)
+        self.nstep = 0
+        self.graph = None
+        self.stream = torch.cuda.Stream(device=self.dev)
+        flatten_flow(model.layers); flow_grad_buffer(model.layers); attach_grads(model.layers)
+        self.use_graph = bool(use_graph) and not parallel.have_group()
+        if self.use_graph and not all(g.get('capturable', False) for g in optimizer.param_groups):
+            raise ValueError('GraphTrainer captures optimizer.step(): build the optimizer with capturable=True '
+                             '(train.make_optimizer does), or pass use_graph=False')
+
+    def _enqueue(self):
+        ops.random_uniform(self.seeds, self.xi.shape, -PI, PI, out=self.xi)        # MultivariateUniform(-pi, pi).sample_n
+        _fused_step_device(self.model, self.action, self.B, self.dkl_factor, self.xi, row=self.row)
+        self.optimizer.step()
+
+    def _flush(self):
+        k = self.nstep % self.chunk or (self.chunk if self.nstep else 0)
+        if k:
+            self.hist_host.append(self.hist_dev[:k].cpu().numpy())
+
+    def step(self):
+        """enqueue one training step; returns nothing and waits for nothing (unless a scheduler is attached)"""
+        with torch.cuda.stream(self.stream):
+            self.seeds.copy_(parallel.chain_seeds(self.seed, self.lo, self.lo + self.B, self.nstep).to(self.dev, non_blocking=True))
+            if self.use_graph and self.graph is None:
+                # first step: once eagerly (allocator, workspaces, optimizer state), then capture the SAME sequence; the
+                # eager step counts as step 0 and the capture run is not replayed into the statistics (capture does not execute)
+                self._enqueue()
+                attach_grads(self.model.layers)
+                self.stream.synchronize()
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode='thread_local'):
+                    self._enqueue()
+            elif self.use_graph:
+                self.graph.replay()
+            else:
+                self._enqueue()
+                attach_grads(self.model.layers)
+            self.hist_dev[self.nstep % self.chunk].copy_(self.row)
+            self.nstep += 1
+            if self.nstep % self.chunk == 0:
+                self._flush()
+            if self.scheduler is not None:
+                self.scheduler.step(float(self.row[0]))
+
+    def metrics(self) -> dict:
+        """metrics of the last step on the host (synchronises)"""
+        self.stream.synchronize()
+        return _metrics_dict(self.row.cpu().numpy(), self.B)
+
+    def history(self) -> dict:
+        """{key: [per-step arrays]} of every step so far (synchronises)"""
+        self.stream.synchronize()
+        chunks = list(self.hist_host)
+        k = self.nstep % self.chunk
+        if k:
+            chunks.append(self.hist_dev[:k].cpu().numpy())
+        if not chunks:
+            return {k_: [] for k_ in METRIC_KEYS}
+        allrows = np.concatenate(chunks, axis=0)
+        out = {k_: [] for k_ in METRIC_KEYS}
+        for r in allrows:
+            m = _metrics_dict(r, self.B)
+            for k_ in METRIC_KEYS:
+                out[k_].append(m[k_])
+        return out
+
+
+def make_optimizer(model: FlowModel, config: TrainConfig, capturable: bool = True) -> optim.Optimizer:
+    """optim.Adam(model.layers.parameters(), lr=config.base_lr) (train.py:297) on the flattened parameters; capturable
+    (step count on the device, lr as a device scalar a scheduler can change between replays) and fused where the
+    device supports it, so that GraphTrainer can capture its step."""
+    flatten_flow(model.layers)
+    params = list(model.layers.parameters())
+    on_gpu = bool(params) and params[0].is_cuda
+    if capturable and on_gpu:
+        lr = torch.tensor(float(config.base_lr), dtype=torch.float64, device=params[0].device)
+        return optim.Adam(params, lr=lr, capturable=True, fused=True)
+    return optim.Adam(params, lr=config.base_lr)
 
 
 def train(config: TrainConfig, model: Optional[FlowModel] = None, pre_model: FlowModel = None,
           figsize=None, dpi: int = 120, scheduler_config=None, dkl_factor: float = 1., save: bool = False,
-          verbose: bool = True):
+          verbose: bool = True, use_graph: bool = True, seed: int = 1234):
     """train.py:236-431 without plots / tensorboard: n_era x n_epoch steps, one checkpoint per era
-    (save=True).  Returns dict(model, optimizer, history, ckpt_files)."""
+    (save=True).  Returns dict(model, optimizer, history, ckpt_files).
+
+    The steps run through `GraphTrainer` (one captured hipGraph per step, metrics kept on the device until the end or
+    the next `print_freq` line); `pre_model` (a prior passed through another flow and back) keeps the step-by-step
+    `train_step` route."""
     if model is None:
         model = get_model(config)
-    optimizer = optim.Adam(model.layers.parameters(), lr=config.base_lr)
+    optimizer = make_optimizer(model, config, capturable=(pre_model is None))
     scheduler = None
     if scheduler_config is not None:
         sc = {k: v for k, v in vars(scheduler_config).items() if k != 'verbose'}
@@ -160,19 +329,32 @@ def train(config: TrainConfig, model: Optional[FlowModel] = None, pre_model: Flo
     action = qed.BatchAction(config.beta)
     history, ckpts = {}, []
     step = 0
+    t0 = time.time()
+    trainer = None if pre_model is not None else GraphTrainer(model, config, optimizer, config.batch_size, dkl_factor=dkl_factor,
+                                                              scheduler=scheduler, seed=seed, use_graph=use_graph)
     for era in range(config.n_era):
         for epoch in range(config.n_epoch):
-            metrics = train_step(model, config, action, optimizer, config.batch_size, scheduler=scheduler,
-                                 pre_model=pre_model, dkl_factor=dkl_factor)
-            for k, v in metrics.items():
-                history.setdefault(k, []).append(v)
-            if verbose and config.print_freq and step % config.print_freq == 0:
+            show = verbose and config.print_freq and step % config.print_freq == 0
+            if trainer is not None:
+                trainer.step()
+                metrics = trainer.metrics() if show else None
+            else:
+                metrics = train_step(model, config, action, optimizer, config.batch_size, scheduler=scheduler,
+                                     pre_model=pre_model, dkl_factor=dkl_factor)
+                for k, v in metrics.items():
+                    history.setdefault(k, []).append(v)
+            if show:
                 print(f"era {era} epoch {epoch}: loss_dkl={float(metrics['loss_dkl']):.4f} "
                       f"ess={float(metrics['ess']):.4f} plaq={float(np.mean(metrics['plaq'])):.5f}", flush=True)
             step += 1
         if save:
+            if trainer is not None:
+                history = trainer.history()
             ckpts.append(save_checkpoint(era, config.n_epoch, model.layers, optimizer, history,
                                          config.update_logdirs(config.logdir)['ckpts']))
+    if trainer is not None:
+        history = trainer.history()
+        history['dt'] = [(time.time() - t0) / max(step, 1)] * step       # per-step wall time: the loop never stops to measure one
     return {'model': model, 'optimizer': optimizer, 'history': history, 'ckpt_files': ckpts, 'action': action}
 
 

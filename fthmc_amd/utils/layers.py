@@ -267,15 +267,100 @@ def make_net_from_layers(*, lattice_shape: tuple, nets: List[nn.Module]):
     return nn.ModuleList(layers)
 
 
-def flow_weights(flow: nn.ModuleList, dev=None) -> torch.Tensor:
-    """All layers' conv parameters as the flat [n_layers * params] buffer of the C ABI (955 per layer for the default net), checking
-    that the layers follow the reference mask schedule."""
+def _flow_rows(flow: nn.ModuleList):
     rows = []
     for i, layer in enumerate(flow):
         if (layer.mask_mu, layer.mask_off) != (i % 2, (i // 2) % 4):
             raise ValueError(f'layer {i}: masks (mu={layer.mask_mu}, off={layer.mask_off}) are not the reference '
                              f'schedule mu = i % 2, off = (i // 2) % 4')
         rows.append(net_weights(layer.plaq_coupling.net))
+    return rows
+
+
+# flat parameter buffers by the address of their storage: two ModuleLists built over the same conv nets
+# (transfer_to_new_lattice reuses them) find the same buffer
+_FLATS: 'weakref.WeakValueDictionary' = None
+
+
+def _flat_of(rows):
+    """The flat buffer the conv parameters are views of (flatten_flow), if they all still are; else None."""
+    global _FLATS
+    if _FLATS is None or not rows:
+        return None
+    p0 = rows[0][0]
+    flat = _FLATS.get((p0.device, p0.untyped_storage().data_ptr()))
+    if flat is None:
+        return None
+    base, o = flat.data_ptr(), 0
+    for row in rows:
+        for p in row:
+            if p.data_ptr() != base + 8 * o or p.dtype != torch.float64 or not p.is_contiguous():
+                return None
+            o += p.numel()
+    return flat if o == flat.numel() else None
+
+
+def flatten_flow(flow: nn.ModuleList) -> torch.Tensor:
+    """Re-home every conv parameter of the flow as a VIEW of ONE flat fp64 buffer in the order of the C ABI
+    (per layer w0 b0 w1 b1 ...; include/fthmc_hip.h) and return that buffer.  Afterwards `flow_weights(flow)` is the buffer
+    itself -- no packing, no copy, per call -- `load_state_dict`, optimizers and `state_dict` keys work as before (they act
+    on the parameters in place), and a weight gradient written into `flow_grad_buffer(flow)` IS every parameter's `.grad`.
+    Idempotent; `.to()` / `.cuda()` re-create the parameters, after which the next call flattens again."""
+    import weakref
+    global _FLATS
+    rows = _flow_rows(flow)
+    flat = _flat_of(rows)
+    if flat is not None:
+        return flat
+    flat = ops.pack_weights(rows, device=rows[0][0].device if rows else device())
+    o = 0
+    with torch.no_grad():
+        for row in rows:
+            for p in row:
+                n = p.numel()
+                p.data = flat[o:o + n].view(p.shape)
+                o += n
+    if _FLATS is None:
+        _FLATS = weakref.WeakValueDictionary()
+    _FLATS[(flat.device, flat.untyped_storage().data_ptr())] = flat
+    flow._fthmc_flat = flat                     # keeps the buffer alive as long as the flow
+    return flat
+
+
+def flow_grad_buffer(flow: nn.ModuleList) -> torch.Tensor:
+    """Flat gradient buffer shaped like flatten_flow(flow); `attach_grads` makes every conv parameter's .grad a view of it."""
+    flat = flatten_flow(flow)
+    g = getattr(flow, '_fthmc_gflat', None)
+    if g is None or g.numel() != flat.numel() or g.device != flat.device:
+        g = torch.zeros_like(flat)
+        flow._fthmc_gflat = g
+        o, views = 0, []
+        for row in _flow_rows(flow):
+            for p in row:
+                views.append(g[o:o + p.numel()].view(p.shape)); o += p.numel()
+        flow._fthmc_gviews = views
+    return g
+
+
+def attach_grads(flow: nn.ModuleList):
+    """p.grad = its view of flow_grad_buffer(flow), for every conv parameter (optimizer.zero_grad() drops them)."""
+    flow_grad_buffer(flow)
+    k = 0
+    for row in _flow_rows(flow):
+        for p in row:
+            if p.grad is not flow._fthmc_gviews[k]:
+                p.grad = flow._fthmc_gviews[k]
+            k += 1
+
+
+def flow_weights(flow: nn.ModuleList, dev=None) -> torch.Tensor:
+    """All layers' conv parameters as the flat [n_layers * params] buffer of the C ABI (955 per layer for the default net), checking
+    that the layers follow the reference mask schedule.  A flow whose parameters live in one flat buffer (flatten_flow)
+    hands that buffer out as it is; otherwise the parameters are packed into a new one."""
+    rows = _flow_rows(flow)
+    flat = _flat_of(rows)
+    if flat is not None and (dev is None or torch.device(dev) == flat.device):
+        return flat
     if dev is None:
         dev = rows[0][0].device if rows else device()
     return ops.pack_weights(rows, device=dev)

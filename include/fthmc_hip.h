@@ -221,6 +221,20 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
                      double beta, double* x, double* logq, double* logp, double* gw,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* The prior draw of a training step on the device: out[b][0..n) ~ U[lo, hi) from Philox4x32-10 keyed by the per-chain
+ * seed (MultivariateUniform.sample_n, fthmc/utils/distributions.py:65-76, called at fthmc/train.py:191 through
+ * apply_flow_to_prior, fthmc/utils/samplers.py:40-56).  A chain's draw depends on its seed only, not on the sharding. */
+int fthmc_random_uniform(const int64_t* seeds, int B, int n_per_chain, double lo, double hi, double* out, void* stream);
+
+/* Metrics of one training step from its pieces (train_step, fthmc/train.py:206-228; calc_dkl / calc_ess,
+ * fthmc/utils/distributions.py:23-37; batch_charges, fthmc/utils/qed_helpers.py:108-116), ONE rank's batch:
+ *   row[0] = loss_dkl = dkl_factor * mean(logq - logp)       row[1] = ess = exp(2 lse(logw) - lse(2 logw)) / B
+ *   row[2 + k B + b], k = 0..4:  logp, logq, q = Q(x), dq = |Q(x) - Q(xi)|, plaq = logp / (beta L^2)   of chain b
+ * (2 + 5 B doubles: what train_step returns, stacked, so that a training loop copies ONE buffer to the host, when it
+ * wants to look).  ws: fthmc_ws_bytes(B, L, 0). */
+int fthmc_train_metrics(const double* xi, const double* x, const double* logq, const double* logp, int B, int L,
+                        double beta, double dkl_factor, double* row, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- measurement hook (the only entry point that synchronises) ---------- */
 /* Average duration in milliseconds (host double) of `reps` back-to-back launches of one
  * coupling-layer kernel on `stream`, bracketed by HIP events recorded on that stream.

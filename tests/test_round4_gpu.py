@@ -1,0 +1,338 @@
+"""GPU tests added in round 4: the device-bound training loop (flat parameter buffer, captured step, metrics kernel,
+Philox prior draw) against the step-by-step route and the oracle; the single-rank RCCL rehearsal (FTHMC_FORCE_PG=1) of
+bench.py and train_step; the delta-Q^2 tooling on HIP-produced histories; the full config-5 batch."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_flow, load_golden
+
+pytestmark = pytest.mark.gpu
+
+ops = None
+R = None
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _mods():
+    global ops, R
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from fthmc_amd import ops as _ops
+    from oracle import ref_cpu as _R
+    ops, R = _ops, _R
+    ops.set_variant(1)
+
+
+def H(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def close(a, b, rtol=1e-10, atol=1e-10):
+    np.testing.assert_allclose(H(a), H(b), rtol=rtol, atol=atol)
+
+
+# ---------------------------------------------------------------- flat parameter buffer
+def test_flat_parameter_buffer_keeps_the_reference_module_layout():
+    """flatten_flow re-homes the conv parameters as views of one buffer in ABI order: state_dict keys and values,
+    load_state_dict, optimizers and transfer_to_new_lattice keep working, flow_weights hands the buffer out without a copy."""
+    from fthmc_amd import train as T
+    from fthmc_amd.config import TrainConfig
+    from fthmc_amd.utils import layers as LY
+    tc = TrainConfig(L=8, beta=2.0, n_layers=4, batch_size=8)
+    torch.manual_seed(5)
+    model = T.get_model(tc)
+    before = {k: v.clone() for k, v in model.layers.state_dict().items()}
+    packed = LY.flow_weights(model.layers)                       # not flattened yet: a packed copy
+    flat = LY.flatten_flow(model.layers)
+    assert torch.equal(flat, packed) and flat.numel() == 4 * 955
+    assert LY.flatten_flow(model.layers) is flat                 # idempotent
+    assert LY.flow_weights(model.layers).data_ptr() == flat.data_ptr()          # no copy any more
+    after = model.layers.state_dict()
+    assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
+    assert '0.plaq_coupling.net.0.weight' in after and after['3.plaq_coupling.net.4.bias'].shape == (3,)
+    # in-place updates through the parameters are updates of the buffer, and the other way round
+    p = model.layers[1].plaq_coupling.net[2].weight
+    with torch.no_grad():
+        p.mul_(2.0)
+    assert torch.equal(LY.flow_weights(model.layers)[955 + 152:955 + 152 + 576].view(8, 8, 3, 3), p)
+    model.layers.load_state_dict(before)                         # copies in place: still views
+    assert LY.flatten_flow(model.layers) is flat and torch.equal(flat, packed)
+    # gradient buffer: every .grad is a view of it
+    g = LY.flow_grad_buffer(model.layers)
+    LY.attach_grads(model.layers)
+    g.fill_(3.0)
+    assert all(float(q.grad.min()) == 3.0 for q in model.layers.parameters())
+    # a second ModuleList over the same nets (transfer) shares the buffer
+    big = T.transfer_to_new_lattice(16, model.layers)
+    assert LY.flow_weights(big.layers).data_ptr() == flat.data_ptr()
+    # .to() re-creates the parameters: the next call flattens again
+    model.layers.to(torch.float64)
+    assert LY.flow_weights(model.layers).numel() == flat.numel()
+
+
+# ---------------------------------------------------------------- device pieces of a training step
+def test_prior_draw_and_metrics_kernels():
+    from fthmc_amd import parallel
+    B, L, beta = 37, 12, 3.0
+    seeds = parallel.chain_seeds(7, 100, 100 + B, 3).cuda()
+    xi = ops.random_uniform(seeds, (B, 2, L, L), -math.pi, math.pi)
+    assert xi.shape == (B, 2, L, L) and float(xi.min()) >= -math.pi and float(xi.max()) < math.pi
+    assert abs(float(xi.mean())) < 0.1 and abs(float(xi.var()) - math.pi ** 2 / 3) < 0.2
+    # a chain's draw depends on its seed only: any sub-batch reproduces its chains bit for bit
+    assert torch.equal(ops.random_uniform(seeds[5:9], (4, 2, L, L), -math.pi, math.pi), xi[5:9])
+    assert not torch.equal(xi[0], xi[1])
+    gen = torch.Generator().manual_seed(3)
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    logq = torch.randn(B, generator=gen, dtype=torch.float64).cuda() * 3 - 500
+    logp = torch.randn(B, generator=gen, dtype=torch.float64).cuda() * 3 + 200
+    row = ops.train_metrics(xi, x, logq, logp, beta, dkl_factor=0.7)
+    m = ops.split_metrics(row, B)
+    logw = logp - logq
+    ess = torch.exp(2 * torch.logsumexp(logw, 0) - torch.logsumexp(2 * logw, 0)) / B     # calc_ess, distributions.py:27-37
+    close(m['loss_dkl'], 0.7 * (logq - logp).mean(), rtol=1e-13)
+    close(m['ess'], ess, rtol=1e-11)
+    q, qi = ops.wilson_action_charge(x, beta)[1], ops.wilson_action_charge(xi, beta)[1]
+    assert torch.equal(m['logp'], logp) and torch.equal(m['logq'], logq) and torch.equal(m['q'], q)
+    close(m['dq'], (q - qi).abs(), atol=0); close(m['plaq'], logp / (beta * L * L), rtol=1e-15)
+
+
+@pytest.mark.parametrize('L,B,nl', [(8, 16, 4), (16, 8, 2), (20, 4, 3)])
+def test_graph_trainer_equals_step_by_step(L, B, nl):
+    """GraphTrainer (captured step, Philox prior, flat gradient buffer, fused capturable Adam) walks through the same
+    weights and metrics as train_step called step by step on the same draws with the reference's optimizer
+    (optim.Adam, train.py:297), and its eager mode equals its captured mode bit for bit."""
+    from fthmc_amd import parallel, train as T
+    from fthmc_amd.config import TrainConfig
+    from fthmc_amd.utils import layers as LY
+    from fthmc_amd.utils import qed_helpers as qed
+    tc = TrainConfig(L=L, beta=2.5, n_layers=nl, batch_size=B, base_lr=2e-3, print_freq=0)
+    torch.manual_seed(21)
+    m0 = T.get_model(tc)
+    init = {k: v.clone() for k, v in m0.layers.state_dict().items()}
+    nsteps, seed = 5, 99
+    runs = {}
+    for mode in ('graph', 'eager'):
+        model = T.get_model(tc); model.layers.load_state_dict(init)
+        tr = T.GraphTrainer(model, tc, T.make_optimizer(model, tc), B, seed=seed, use_graph=(mode == 'graph'))
+        for _ in range(nsteps):
+            tr.step()
+        runs[mode] = (LY.flow_weights(model.layers).clone(), tr.history())
+    assert torch.equal(runs['graph'][0], runs['eager'][0])
+    for k in T.METRIC_KEYS:
+        assert all(np.array_equal(a, b) for a, b in zip(runs['graph'][1][k], runs['eager'][1][k])), k
+    # step by step through the reference-shaped API with a plain Adam on the same draws
+    model = T.get_model(tc); model.layers.load_state_dict(init)
+    opt = torch.optim.Adam(model.layers.parameters(), lr=tc.base_lr)
+    act = qed.BatchAction(tc.beta)
+    hist = []
+    for k in range(nsteps):
+        xi = ops.random_uniform(parallel.chain_seeds(seed, 0, B, k).cuda(), (B, 2, L, L), -math.pi, math.pi)
+        hist.append(T.train_step(model, tc, act, opt, B, xi=xi))
+    close(LY.flow_weights(model.layers), runs['graph'][0], rtol=1e-9, atol=1e-12)
+    gh = runs['graph'][1]
+    assert len(gh['loss_dkl']) == nsteps and gh['logp'][0].shape == (B,) and gh['ess'][0].shape == ()
+    for k in range(nsteps):
+        for key in ('loss_dkl', 'ess', 'logp', 'logq', 'plaq'):
+            close(hist[k][key], gh[key][k], rtol=1e-8, atol=1e-9)
+        close(hist[k]['q'], gh['q'][k], atol=1e-8); close(hist[k]['dq'], gh['dq'][k], atol=1e-8)
+
+
+def test_train_step_metrics_match_the_autograd_route():
+    """train_step(fused=True) (flat gradient buffer, metrics kernel) against train_step(fused=False) (layer-wise autograd,
+    torch formulas) on one draw: loss, ESS, per-chain arrays and every parameter gradient."""
+    from fthmc_amd import train as T
+    from fthmc_amd.config import TrainConfig
+    from fthmc_amd.utils import qed_helpers as qed
+    tc = TrainConfig(L=12, beta=3.0, n_layers=3, batch_size=6, base_lr=0.0, print_freq=0)
+    torch.manual_seed(8)
+    model = T.get_model(tc)
+    xi = model.prior.sample_n(6)
+    act = qed.BatchAction(tc.beta)
+    outs, grads = [], []
+    for fused in (True, False):
+        opt = torch.optim.SGD(model.layers.parameters(), lr=0.0)
+        outs.append(T.train_step(model, tc, act, opt, 6, xi=xi, fused=fused, dkl_factor=1.3))
+        grads.append([p.grad.clone() for p in model.layers.parameters()])
+    for k in T.METRIC_KEYS:
+        close(outs[0][k], outs[1][k], rtol=1e-9, atol=1e-9)
+    gmax = max(float(g.abs().max()) for g in grads[1])
+    for a, b in zip(*grads):
+        close(a, b, rtol=1e-8, atol=1e-11 * max(gmax, 1.0))
+
+
+# ---------------------------------------------------------------- single-rank RCCL rehearsal
+def _bench_child(tmp_path, tag, env_extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2', **env_extra)
+    env.pop('FTHMC_DIST_BACKEND', None)
+    dump = str(tmp_path / tag)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '2', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline', '--regions', '1', '--dump', dump], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    return line, dict(np.load(dump + '.1.0.npz'))
+
+
+def test_single_rank_nccl_group_rehearses_the_multi_gpu_path(tmp_path):
+    """FTHMC_FORCE_PG=1: bench.py creates a ONE-rank `nccl` (= RCCL) process group in a fresh process and takes every
+    collective branch of the 8-GPU run -- communicator creation before the capture, the asynchronous C1 all-reduce after
+    every graph replay, barrier(device_ids=...), the MAX-reduced region time -- and ends in the same chains, bit for bit,
+    as the run without a group."""
+    plain, d0 = _bench_child(tmp_path, 'plain', {})
+    forced, d1 = _bench_child(tmp_path, 'forced', {'FTHMC_FORCE_PG': '1'})
+    assert plain['config']['process_group'] is None and forced['config']['process_group'] == 'nccl'
+    assert forced['n_gpus'] == 1 and forced['config']['launch'] == 'hipGraph replay'
+    for k in ('x0', 'x', 'dH', 'acc', 'Q', 'plaq'):
+        assert np.array_equal(d0[k], d1[k]), k
+    assert plain['acceptance'] == forced['acceptance'] and plain['plaq'] == forced['plaq']
+
+
+_TRAIN_WORKER = r'''
+import os, sys, json, hashlib, math
+sys.path.insert(0, os.environ['FTHMC_ROOT'])
+import torch
+from fthmc_amd import ops, parallel, train as T
+from fthmc_amd.config import TrainConfig
+from fthmc_amd.utils import layers as LY, qed_helpers as qed
+parallel.init()
+tc = TrainConfig(L=16, beta=4.0, n_layers=4, batch_size=32, base_lr=1e-3, print_freq=0)
+torch.manual_seed(17)
+model = T.get_model(tc)
+opt = torch.optim.Adam(model.layers.parameters(), lr=tc.base_lr)
+act = qed.BatchAction(tc.beta)
+out = None
+for k in range(3):
+    xi = ops.random_uniform(parallel.chain_seeds(5, 0, 32, k).cuda(), (32, 2, 16, 16), -math.pi, math.pi)
+    out = T.train_step(model, tc, act, opt, 32, xi=xi, fused=True)
+# and the loop object in its eager (collective) mode
+tr = T.GraphTrainer(model, tc, T.make_optimizer(model, tc), 32, seed=5)
+for _ in range(2):
+    tr.step()
+m = tr.metrics()
+w = LY.flow_weights(model.layers).cpu().numpy()
+print(json.dumps({'group': parallel.have_group(), 'backend': torch.distributed.get_backend() if parallel.have_group() else None,
+                  'captured': tr.graph is not None, 'w': hashlib.sha256(w.tobytes()).hexdigest(),
+                  'loss': float(out['loss_dkl']), 'ess': float(out['ess']), 'loss2': float(m['loss_dkl'])}))
+if parallel.have_group():
+    torch.distributed.destroy_process_group()
+'''
+
+
+def test_single_rank_nccl_group_train_step():
+    """train_step(fused=True) and GraphTrainer under a one-rank `nccl` group: the C2 branches (gradient all-reduce, global
+    loss mean, MAX + SUM all-reduces of the ESS logsumexp) run over RCCL and leave the same weights, bit for bit, as no group."""
+    res = {}
+    for tag, extra in (('plain', {}), ('forced', {'FTHMC_FORCE_PG': '1'})):
+        env = dict(os.environ, FTHMC_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2', **extra)
+        env.pop('FTHMC_DIST_BACKEND', None)
+        p = subprocess.run([sys.executable, '-c', _TRAIN_WORKER], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[tag] = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['plain']['group'] is False and res['plain']['captured'] is True
+    assert res['forced']['group'] is True and res['forced']['backend'] == 'nccl' and res['forced']['captured'] is False
+    assert res['plain']['w'] == res['forced']['w']
+    assert res['plain']['loss'] == res['forced']['loss'] and res['plain']['loss2'] == res['forced']['loss2']
+    assert abs(res['plain']['ess'] - res['forced']['ess']) < 1e-12
+
+
+# ---------------------------------------------------------------- f4: delta-Q^2 tooling on HIP-produced histories
+def test_observables_tooling_on_hip_histories():
+    """64 physical-field ftHMC trajectories of 8 chains at L = 8 through qed_helpers.ft_hmc (what ft_run loops over: inverse
+    sweep -> trajectory -> forward sweep, ipynb/ft_hmc.py:420-435) on the HIP path, and the same chains through the oracle
+    with the same momenta and accept draws: equal accept and charge histories, and equal rows out of the delta-Q^2-vs-lag /
+    block-error tooling (ipynb/ft_hmc.py:16-53,168-176) in the reference's literal mode, chain by chain and for the ensemble."""
+    from fthmc_amd.config import Param
+    from fthmc_amd.utils import layers as LY, observables as OB, qed_helpers as qed
+    gen = torch.Generator().manual_seed(64)
+    B, L, nl, beta, tau, nstep, ntraj = 8, 8, 4, 2.0, 1.0, 10, 64
+    wts = R.default_flow(nl, gen)
+    flow = LY.make_u1_equiv_layers(n_layers=nl, n_mixture_comps=2, lattice_shape=(L, L), hidden_sizes=[8, 8], kernel_size=3)
+    names = ('net.0.weight', 'net.0.bias', 'net.2.weight', 'net.2.bias', 'net.4.weight', 'net.4.bias')
+    flow.load_state_dict({f'{li}.plaq_coupling.{n}': wts[li][pi].cuda() for li in range(nl) for pi, n in enumerate(names)})
+    param = Param(beta=beta, L=L, tau=tau, nstep=nstep)
+    x0 = (torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+    vs = torch.randn(ntraj, B, 2, L, L, generator=gen, dtype=torch.float64)
+    us = torch.rand(ntraj, B, generator=gen, dtype=torch.float64)
+    # HIP: one configuration at a time, as the notebook runs it
+    fields = [x0[b:b + 1].cuda() for b in range(B)]
+    qh = np.zeros((ntraj + 1, B)); acc_h = np.zeros((ntraj, B), dtype=bool)
+    qh[0] = np.asarray(ops.wilson_action_charge(x0.cuda(), beta)[1].cpu())
+    for k in range(ntraj):
+        vk, uk = vs[k].cuda(), us[k].cuda()
+        for b in range(B):
+            _, _, acc, fields[b] = qed.ft_hmc(param, flow, fields[b], v=vk[b:b + 1], u=uk[b])
+            acc_h[k, b] = bool(acc)
+        qh[k + 1] = np.asarray(ops.wilson_action_charge(torch.cat(fields), beta)[1].cpu())
+    # oracle: the chains as a batch of independent systems, same draws, inverse by bisection down to fp resolution
+    xc = x0.clone()
+    qc = np.zeros((ntraj + 1, B)); acc_c = np.zeros((ntraj, B), dtype=bool)
+    qc[0] = R.charge(xc).numpy()
+    for k in range(ntraj):
+        with torch.no_grad():
+            xi = R.flow_reverse(xc, wts, tol=1e-13)[0]
+        _, _, acc, newx, _, _ = R.ft_hmc(xi, vs[k], us[k], wts, beta, tau / nstep, nstep, mode='md')
+        with torch.no_grad():
+            xc = R.flow_forward(newx, wts)[0]
+        acc_c[k] = acc.numpy(); qc[k + 1] = R.charge(xc).numpy()
+    assert np.abs(qh - np.round(qh)).max() < 1e-8
+    qh, qc = np.round(qh), np.round(qc)
+    assert np.array_equal(acc_h, acc_c) and 0.2 < acc_h.mean() <= 1.0
+    assert np.array_equal(qh, qc) and np.abs(np.diff(qh, axis=0)).max() > 0        # the charge does move
+    for q_h, q_c in [(qh[:, b], qc[:, b]) for b in range(B)] + [(qh, qc)]:
+        rows_h = OB.change_sqr_vs_dt(q_h, dt_range=8, reference_literal=True)
+        rows_c = OB.change_sqr_vs_dt(q_c, dt_range=8, reference_literal=True)
+        np.testing.assert_array_equal(np.asarray(rows_h), np.asarray(rows_c))
+    assert np.isfinite(np.asarray(OB.change_sqr_vs_dt(qh, dt_range=8))[:, 1]).all()
+
+
+# ---------------------------------------------------------------- BASELINE configs[4]: the FULL batch on one GPU
+def test_config5_full_batch_on_one_gpu():
+    """configs[4] = 256 chains of L=256, beta=7, 16 layers (32 per GPU on 8 GPUs).  All 256 fit one MI355X (force workspace
+    ~50 GB, training ~90 GB of the 288): size-independent properties on the full batch -- integer Q, forward o reverse = id,
+    force = finite-difference gradient of S_eff, training gradient = finite-difference derivative of the loss -- and chains
+    0 / 131 / 255 bit-equal to the same chain inside its 32-chain shard.  Workspaces are released afterwards."""
+    gen = torch.Generator().manual_seed(256)
+    B, L, nl, beta = 256, 256, 16, 7.0
+    flow = R.default_flow(nl, gen)
+    w = ops.pack_weights(flow, device='cuda')
+    try:
+        x = ops.random_uniform(torch.arange(B, dtype=torch.int64, device='cuda') + 77, (B, 2, L, L), -math.pi, math.pi)
+        y, ld = ops.flow_forward(x, w, nl)
+        Q = ops.wilson_action_charge(y, beta)[1]
+        assert float((Q - Q.round()).abs().max()) < 1e-6
+        xb, ldb = ops.flow_reverse(y, w, nl, tol=1e-13)
+        d = (xb - x + math.pi) % (2 * math.pi) - math.pi
+        assert float(d.abs().max()) < 1e-8 and float((ldb + ld).abs().max()) < 1e-5
+        del xb, ldb, d
+        F = ops.ft_force(x, w, nl, beta)
+        dirn = ops.random_momenta(torch.arange(B, dtype=torch.int64, device='cuda') + 5, (B, 2, L, L), need_u=False)[0]
+        eps = 1e-5
+        fd = (ops.ft_action(x + eps * dirn, w, nl, beta)[0] - ops.ft_action(x - eps * dirn, w, nl, beta)[0]) / (2 * eps)
+        close((F * dirn).flatten(1).sum(1), fd, rtol=5e-5, atol=2e-3)
+        # shards: chains 0, 131, 255 inside their 32-chain blocks
+        for c in (0, 131, 255):
+            lo = c // 32 * 32
+            Fs = ops.ft_force(x[lo:lo + 32].contiguous(), w, nl, beta)
+            assert torch.equal(Fs[c - lo], F[c])
+            ys = ops.flow_forward(x[lo:lo + 32].contiguous(), w, nl)[0]
+            assert torch.equal(ys[c - lo], y[c])
+        del F, dirn, fd, y
+        # training gradient on the full batch: directional finite difference of the loss in weight space
+        r = ops.train_grad(x, w, nl, beta, groups=1)
+        loss = lambda ww: float((lambda t: (t['logq'] - t['logp']).mean())(ops.train_grad(x, ww, nl, beta, need_gw=False)))
+        dw = torch.randn(w.numel(), generator=gen, dtype=torch.float64).cuda()
+        dw = dw / dw.norm()
+        epsw = 1e-6
+        fdw = (loss(w + epsw * dw) - loss(w - epsw * dw)) / (2 * epsw)
+        an = float((r['gw'] * dw).sum())
+        assert abs(an - fdw) < 1e-4 * max(1.0, abs(an)), (an, fdw)
+        rs = ops.train_grad(x[128:160].contiguous(), w, nl, beta, groups=1, need_gw=False)
+        assert torch.equal(rs['logq'][3], r['logq'][131]) and torch.equal(rs['logp'][3], r['logp'][131])
+    finally:
+        ops.release_workspaces()
+        torch.cuda.empty_cache()

@@ -25,6 +25,14 @@ MODE_MD, MODE_LITERAL = 0, 1
 _D = c_void_p          # device pointer
 _P = c_void_p
 
+
+class ArchT(ctypes.Structure):
+    """fthmc_arch_t (include/fthmc_hip.h): the s/t net's shape, an argument of every entry point that runs the net."""
+    _fields_ = [('n_hidden', c_int), ('hidden', c_int * 8), ('kernel_size', c_int), ('n_mix', c_int)]
+
+
+_A = ctypes.POINTER(ArchT)   # const fthmc_arch_t* (None = the default shape)
+
 # name -> argtypes (restype is int unless listed in _RESTYPE); must match include/fthmc_hip.h
 SIGNATURES = {
     'fthmc_version': [],
@@ -32,12 +40,11 @@ SIGNATURES = {
     'fthmc_last_error': [],
     'fthmc_set_variant': [c_int],
     'fthmc_get_variant': [],
-    'fthmc_set_arch': [c_int, ctypes.POINTER(c_int), c_int, c_int],
-    'fthmc_arch_params': [],
+    'fthmc_arch_params': [_A],
     'fthmc_set_small_path': [c_int],
     'fthmc_get_small_path': [],
-    'fthmc_ws_bytes': [c_int, c_int, c_int],
-    'fthmc_train_ws_bytes': [c_int, c_int, c_int],
+    'fthmc_ws_bytes': [_A, c_int, c_int, c_int],
+    'fthmc_train_ws_bytes': [_A, c_int, c_int, c_int],
     'fthmc_wrap': [_D, _D, c_size_t, _P],
     'fthmc_regularize': [_D, _D, c_size_t, _P],
     'fthmc_plaquettes': [_D, _D, c_int, c_int, _P],
@@ -49,33 +56,28 @@ SIGNATURES = {
     'fthmc_random_momenta': [_D, c_int, c_int, _D, _D, _P],
     'fthmc_hmc_trajectory': [_D, _D, _D, c_int, c_int, c_double, c_double, c_int, _D, _D, _D, _D, _D,
                              _P, c_size_t, _P],
-    'fthmc_flow_layer_fwd': [_D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
-    'fthmc_flow_layer_bwd': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
-    'fthmc_layer_stash_bytes': [c_int, c_int],
-    'fthmc_flow_layer_fwd_stash': [_D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _D, _P, c_size_t, _P],
-    'fthmc_flow_layer_bwd_stash': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
-    'fthmc_flow_layer_rev': [_D, _D, c_int, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
-    'fthmc_plaq_coupling_fwd': [_D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
-    'fthmc_plaq_coupling_rev': [_D, _D, c_int, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
-    'fthmc_flow_forward': [_D, _D, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
-    'fthmc_flow_reverse': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
-    'fthmc_ft_action': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
-    'fthmc_ft_force': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _P, c_size_t, _P],
-    'fthmc_ft_leapfrog': [_D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int, _D, _D,
-                          _P, c_size_t, _P],
-    'fthmc_ft_trajectory': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int,
-                            _D, _D, _D, _D, _D, _D, _D, _D, _D, _P, c_size_t, _P],
-    'fthmc_train_grad': [_D, _D, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_layer_fwd': [_D, _D, _A, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_layer_bwd': [_D, _D, _A, _D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_layer_stash_bytes': [_A, c_int, c_int],
+    'fthmc_flow_layer_fwd_stash': [_D, _D, _A, c_int, c_int, c_int, c_int, c_int, _D, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_layer_bwd_stash': [_D, _D, _A, _D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_layer_rev': [_D, _D, _A, c_int, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
+    'fthmc_plaq_coupling_fwd': [_D, _D, _A, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_plaq_coupling_rev': [_D, _D, _A, c_int, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_forward': [_D, _D, _A, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_flow_reverse': [_D, _D, _A, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
+    'fthmc_ft_action': [_D, _D, _A, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
+    'fthmc_ft_force': [_D, _D, _A, c_int, c_int, c_int, c_int, c_double, _D, _P, c_size_t, _P],
+    'fthmc_ft_leapfrog': [_D, _D, _D, _A, c_int, c_int, c_int, c_int, c_double, c_double, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_ft_trajectory': [_D, _D, _D, _D, _A, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, _D, _D, _D, _D, _D, _D, _D, _D, _D, _P, c_size_t, _P],
+    'fthmc_train_grad': [_D, _D, _A, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
     'fthmc_random_uniform': [_D, c_int, c_int, c_double, c_double, _D, _P],
+    'fthmc_adam_step': [_D, _D, _D, _D, _D, c_size_t, c_double, c_double, c_double, c_double, c_int, _P],
     'fthmc_train_metrics': [_D, _D, _D, _D, c_int, c_int, c_double, c_double, _D, _P, c_size_t, _P],
-    'fthmc_time_kernel': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double, c_int,
-                          ctypes.POINTER(c_double), _P, c_size_t, _P],
-    'fthmc_time_small': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int,
-                         ctypes.POINTER(c_double), _P, c_size_t, _P],
-    'fthmc_small_profile': [_D, _D, _D, _D, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
-                            ctypes.POINTER(c_double), _P, c_size_t, _P],
-    'fthmc_profile_stages': [c_int, _D, _D, c_int, c_int, c_int, c_int, c_int, c_double,
-                             ctypes.POINTER(c_double), _P, c_size_t, _P],
+    'fthmc_time_kernel': [c_int, _D, _D, _A, c_int, c_int, c_int, c_int, c_int, c_double, c_int, ctypes.POINTER(c_double), _P, c_size_t, _P],
+    'fthmc_time_small': [_D, _D, _D, _D, _A, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, ctypes.POINTER(c_double), _P, c_size_t, _P],
+    'fthmc_small_profile': [_D, _D, _D, _D, _A, c_int, c_int, c_int, c_int, c_double, c_double, c_int, ctypes.POINTER(c_double), _P, c_size_t, _P],
+    'fthmc_profile_stages': [c_int, _D, _D, _A, c_int, c_int, c_int, c_int, c_int, c_double, ctypes.POINTER(c_double), _P, c_size_t, _P],
 }
 _RESTYPE = {'fthmc_layer_stash_bytes': c_size_t, 'fthmc_version': c_char_p, 'fthmc_last_error': c_char_p, 'fthmc_train_ws_bytes': c_size_t, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
 

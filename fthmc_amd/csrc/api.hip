@@ -33,7 +33,28 @@ struct WS {
 // scal slots, each B doubles
 enum { SC_S = 0, SC_Q, SC_PLAQ, SC_LOGDET, SC_K, SC_H0, SC_H1, SC_OLD0, SC_OLD1, SC_OLD2, SC_NEW0, SC_NEW1, SC_NEW2, SC_SEFF, SC_N };
 
-WS ws_layout(double* base, int B, int L, int nl, bool train = false) {
+// What a call runs with: the net's shape (an ARGUMENT of the call: fthmc_arch_t), the two process-wide debug switches read
+// ONCE per call, the caller's canonical weights and stream.  Nothing below reads a global.
+struct Ctx {
+    FlowArch A;
+    bool mfma;               // fthmc_set_variant: MFMA kernels (default) / VALU kernels
+    bool small_on;           // fthmc_set_small_path
+    const double* wcan;      // the caller's canonical weights (generic net shapes read them as they are)
+    hipStream_t s;
+    bool gen() const { return !A.is_default(); }
+    bool small(int L, int nl) const { return small_on && mfma && A.is_default() && ft_small_shape(L, nl); }
+};
+inline int make_ctx(const fthmc_arch_t* arch, void* stream, Ctx* c) {
+    c->A = flow_arch_default();
+    if (arch) { int rc = make_flow_arch(arch->n_hidden, arch->hidden, arch->kernel_size, arch->n_mix, &c->A); if (rc != FTHMC_OK) return rc; }
+    c->mfma = get_flow_variant() == 1;
+    c->small_on = get_small_path() != 0;
+    c->wcan = nullptr;
+    c->s = ft_stream(stream);
+    return FTHMC_OK;
+}
+
+WS ws_layout(const FlowArch& A, double* base, int B, int L, int nl, bool train = false) {
     WS w{};
     const size_t n1 = (size_t)B * L * L, n2 = 2 * n1;
     const size_t nt = flow_ntiles_max(L);
@@ -50,38 +71,38 @@ WS ws_layout(double* base, int B, int L, int nl, bool train = false) {
     w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
     w.gw_part = take(nl > 0 ? (size_t)B * nt * FLOW_GW_STRIDE : 0);
     w.gw_tmp = take(nl > 0 ? (size_t)FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE : 0);
-    const bool gen = !arch_default();
+    const bool gen = !A.is_default();
     // activation stash of a force evaluation (generic shapes: every layer's planes, at least one region as scratch)
-    w.stash = take(gen ? (size_t)(nl > 0 ? nl : 1) * gen_stash_doubles(B, L) : (size_t)nl * flow_stash_doubles(B, L, train));
+    w.stash = take(gen ? (size_t)(nl > 0 ? nl : 1) * A.stash_doubles(B, L) : (size_t)nl * flow_stash_doubles(B, L, train));
     w.gz = take(train && nl > 0 && !gen ? flow_gz_doubles(B, L) : 0);   // training: pre-activation gradients of the layer in flight
-    w.hbuf = take(gen ? (size_t)B * arch_cmax() * L * L : 0);
-    w.gbuf = take(gen ? (size_t)2 * B * arch_cmax() * L * L : 0);
+    w.hbuf = take(gen ? (size_t)B * A.cmax() * L * L : 0);
+    w.gbuf = take(gen ? (size_t)2 * B * A.cmax() * L * L : 0);
     w.total = o;
     return w;
 }
 
 // which kernel family serves a call, and with it the tile geometry of its partial buffers
-inline bool fwd_is_mfma() { return get_flow_variant() == 1; }
-inline int flow_rev(const FlowLayerArgs& a, hipStream_t s) {
-    return fwd_is_mfma() ? launch_flow_rev_mfma(a, s) : launch_flow_rev(a, s);
+inline int flow_rev(const Ctx& C, const FlowLayerArgs& a, hipStream_t s) {
+    return C.mfma ? launch_flow_rev_mfma(a, s) : launch_flow_rev(a, s);
 }
-inline int flow_fwd(const FlowLayerArgs& a, hipStream_t s) {
-    return fwd_is_mfma() ? launch_flow_fwd_mfma(a, s) : launch_flow_fwd(a, s);
+inline int flow_fwd(const Ctx& C, const FlowLayerArgs& a, hipStream_t s) {
+    return C.mfma ? launch_flow_fwd_mfma(a, s) : launch_flow_fwd(a, s);
 }
+inline size_t ws_doubles(const FlowArch& A, int B, int L, int nl, bool train = false) { return ws_layout(A, nullptr, B, L, nl, train).total; }
 
 inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
 
 // The caller's canonical weights: the tuned kernels read their own expansion (k_pack_weights -> W.wint), the kernels for
 // other net shapes (flow_generic.hip) read the canonical layout itself.
-thread_local const double* g_wcan = nullptr;
-inline int use_weights(const double* w, int nl, const WS& W, hipStream_t s) {
-    g_wcan = w;
-    return arch_default() ? launch_pack_weights(w, nl, W.wint, s) : FTHMC_OK;
+inline int use_weights(Ctx& C, const double* w, int nl, const WS& W, hipStream_t s) {
+    C.wcan = w;
+    return C.A.is_default() ? launch_pack_weights(w, nl, W.wint, s) : FTHMC_OK;
 }
-inline GenLayerArgs gen_args(const WS& w, int l, int B, int L, int act, bool own_region) {
+inline GenLayerArgs gen_args(const Ctx& C, const WS& w, int l, int B, int L, int act, bool own_region) {
     GenLayerArgs g{};
-    g.w = g_wcan + (size_t)l * arch_params();
-    g.stash = w.stash + (own_region ? (size_t)l * gen_stash_doubles(B, L) : 0);
+    g.arch = C.A;
+    g.w = C.wcan + (size_t)l * C.A.params();
+    g.stash = w.stash + (own_region ? (size_t)l * C.A.stash_doubles(B, L) : 0);
     g.hbuf = w.hbuf; g.gbuf = w.gbuf;
     g.B = B; g.L = L; g.mu = l % 2; g.off = (l / 2) % 4; g.act = act;
     return g;
@@ -97,11 +118,11 @@ inline SmallArgs small_args(const double* x, const WS& w, int nl, int B, int act
 #define FT_TRY(expr) do { int rc_ = (expr); if (rc_ != FTHMC_OK) return rc_; } while (0)
 
 // Forward sweep x -> X[0..nl-1] (X[l] = output of layer l).  logdet (device [B]) optional.
-int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, double* logdet,
+int sweep_forward(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, int act, double* logdet,
                   hipStream_t s, bool stash = false, bool train = false) {
-    if (!arch_default()) {                                // any other net shape: plain kernels, one stash region per layer
+    if (C.gen()) {                                // any other net shape: plain kernels, one stash region per layer
         for (int l = 0; l < nl; ++l) {
-            GenLayerArgs g = gen_args(w, l, B, L, act, stash);
+            GenLayerArgs g = gen_args(C, w, l, B, L, act, stash);
             g.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
             g.y = w.X + (size_t)l * w.n2;
             g.logj = logdet; g.logj_accumulate = l > 0;
@@ -117,11 +138,11 @@ int sweep_forward(const double* x, const WS& w, int nl, int B, int L, int act, d
         a.wint = w.wint + (size_t)l * FLOW_WINT;
         a.y = w.X + (size_t)l * w.n2;
         // logJ partials of all layers side by side, summed by ONE launch behind the sweep (layer by layer, in order)
-        a.logj_part = logdet ? w.lj_part + (size_t)l * B * flow_fwd_geom(fwd_is_mfma()).ntiles(L) : nullptr;
+        a.logj_part = logdet ? w.lj_part + (size_t)l * B * flow_fwd_geom(C.mfma).ntiles(L) : nullptr;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
-        FT_TRY(flow_fwd(a, s));
+        FT_TRY(flow_fwd(C, a, s));
     }
-    if (logdet && nl > 0) FT_TRY(launch_sum_parts(w.lj_part, B, flow_fwd_geom(fwd_is_mfma()).ntiles(L), 1.0, 0, logdet, s, nl));
+    if (logdet && nl > 0) FT_TRY(launch_sum_parts(w.lj_part, B, flow_fwd_geom(C.mfma).ntiles(L), 1.0, 0, logdet, s, nl));
     return FTHMC_OK;
 }
 
@@ -130,10 +151,10 @@ inline const double* phys_field(const double* x, const WS& w, int nl) {
 }
 
 // S_eff (and friends) of x; leaves the checkpoints in w.X
-int eval_action(const double* x, const WS& w, int nl, int B, int L, int act, double beta,
+int eval_action(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, int act, double beta,
                 double* S_eff, double* logdet, double* plaq, double* Q, hipStream_t s) {
     double* ld = logdet ? logdet : w.scal + (size_t)SC_LOGDET * B;
-    if (nl > 0) FT_TRY(sweep_forward(x, w, nl, B, L, act, ld, s));
+    if (nl > 0) FT_TRY(sweep_forward(C, x, w, nl, B, L, act, ld, s));
     double* S = w.scal + (size_t)SC_S * B;
     FT_TRY(launch_action_charge(phys_field(x, w, nl), B, L, beta, S, Q, plaq, s));
     if (S_eff) FT_TRY(launch_lincomb(S, 1.0, nl > 0 ? ld : nullptr, -1.0, 0.0, S_eff, B, s));
@@ -142,17 +163,17 @@ int eval_action(const double* x, const WS& w, int nl, int B, int L, int act, dou
 
 // Plaquette-gradient field of sum_b S_eff (scaled): gp = scale*beta*sin P(F(x)) + sum_l gP_l,
 // with dL/dlogJ = glogj.  gw != null also accumulates weight gradients (training).
-int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double beta_scaled,
+int force_gp(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, int act, double beta_scaled,
              double glogj, double* gw, hipStream_t s, bool have_forward = false) {
-    if (!arch_default()) {                                // any other net shape (flow_generic.hip)
-        if (nl > 0 && !have_forward) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s, true));
+    if (C.gen()) {                                // any other net shape (flow_generic.hip)
+        if (nl > 0 && !have_forward) FT_TRY(sweep_forward(C, x, w, nl, B, L, act, nullptr, s, true));
         double* gcur = (nl & 1) ? w.gp2 : w.gp;
         double* galt = gcur == w.gp ? w.gp2 : w.gp;
         FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, gcur, s));
         for (int l = nl - 1; l >= 0; --l) {
-            GenLayerArgs g = gen_args(w, l, B, L, act, true);
+            GenLayerArgs g = gen_args(C, w, l, B, L, act, true);
             g.up_gp = gcur; g.glogj_const = glogj; g.gp_out = galt;
-            g.gw = gw ? gw + (size_t)l * arch_params() : nullptr;
+            g.gw = gw ? gw + (size_t)l * C.A.params() : nullptr;
             FT_TRY(launch_gen_bwd(g, s));
             double* t_ = gcur; gcur = galt; galt = t_;
         }
@@ -161,10 +182,10 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
     // MFMA path without weight gradients: the forward sweep stashes act'(z1), act'(z2), s per site
     // and the backward kernels read them back instead of recomputing the network
     // (training: the caller ran the forward with the h planes stashed too, have_forward = true)
-    const bool mfma = get_flow_variant() == 1;
+    const bool mfma = C.mfma;
     const bool stash = mfma && (gw == nullptr ? !have_forward : have_forward);
     const bool train = gw != nullptr && stash;
-    if (nl > 0 && !have_forward) FT_TRY(sweep_forward(x, w, nl, B, L, act, nullptr, s, stash));
+    if (nl > 0 && !have_forward) FT_TRY(sweep_forward(C, x, w, nl, B, L, act, nullptr, s, stash));
     // stash path: gather-form backward, gP ping-pongs between two fields and ends in w.gp
     double* gcur = (stash && (nl & 1)) ? w.gp2 : w.gp;
     double* galt = gcur == w.gp ? w.gp2 : w.gp;
@@ -200,13 +221,13 @@ int force_gp(const double* x, const WS& w, int nl, int B, int L, int act, double
 }
 
 // leapfrog in the latent field; result in w.xa / w.va
-int ft_leapfrog_ws(const double* x, const double* v, const WS& w, int nl, int B, int L, int act,
+int ft_leapfrog_ws(const Ctx& C, const double* x, const double* v, const WS& w, int nl, int B, int L, int act,
                    double beta, double dt, int nstep, hipStream_t s) {
     FT_TRY(launch_axpy(x, v, 0.5 * dt, w.xa, w.n2, s));
     if (hipMemcpyAsync(w.va, v, w.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return FTHMC_ERR_LAUNCH;
     for (int k = 0; k < nstep; ++k) {
-        FT_TRY(force_gp(w.xa, w, nl, B, L, act, beta, -1.0, nullptr, s));
+        FT_TRY(force_gp(C, w.xa, w, nl, B, L, act, beta, -1.0, nullptr, s));
         FT_TRY(launch_kick_from_gp(w.gp, w.va, w.xa, nullptr, B, L, dt, k == nstep - 1 ? 0.5 * dt : dt, s));
     }
     return FTHMC_OK;
@@ -242,10 +263,11 @@ int fthmc_set_variant(int v) {
 }
 int fthmc_get_variant(void) { return get_flow_variant(); }
 
-int fthmc_set_arch(int n_hidden, const int* hidden_sizes, int kernel_size, int n_mix) {
-    return set_flow_arch(n_hidden, hidden_sizes, kernel_size, n_mix);
+int fthmc_arch_params(const fthmc_arch_t* arch) {
+    Ctx C;
+    if (make_ctx(arch, nullptr, &C) != FTHMC_OK) return FTHMC_ERR_UNSUPPORTED;
+    return C.A.params();
 }
-int fthmc_arch_params(void) { return arch_params(); }
 
 int fthmc_set_small_path(int on) {
     if (on != 0 && on != 1) return FTHMC_ERR_ARG;
@@ -267,21 +289,26 @@ const char* fthmc_strerror(int code) {
     }
 }
 
-size_t fthmc_ws_bytes(int B, int L, int n_layers) {
-    if (B <= 0 || L <= 0 || n_layers < 0) return 0;
-    return ws_layout(nullptr, B, L, n_layers).total * sizeof(double);
+size_t fthmc_ws_bytes(const fthmc_arch_t* arch, int B, int L, int n_layers) {
+    Ctx C;
+    if (B <= 0 || L <= 0 || n_layers < 0 || make_ctx(arch, nullptr, &C) != FTHMC_OK) return 0;
+    return ws_doubles(C.A, B, L, n_layers) * sizeof(double);
 }
 
-size_t fthmc_train_ws_bytes(int B, int L, int n_layers) {
-    if (B <= 0 || L <= 0 || n_layers < 0) return 0;
-    return ws_layout(nullptr, B, L, n_layers, true).total * sizeof(double);
+size_t fthmc_train_ws_bytes(const fthmc_arch_t* arch, int B, int L, int n_layers) {
+    Ctx C;
+    if (B <= 0 || L <= 0 || n_layers < 0 || make_ctx(arch, nullptr, &C) != FTHMC_OK) return 0;
+    return ws_doubles(C.A, B, L, n_layers, true) * sizeof(double);
 }
 
-#define FT_WS(nl)                                                                   \
+// the call's context (shape from `arch`, the debug switches, the stream), then its workspace view
+#define FT_CTX(arch_)                                                               \
     (void)hipGetLastError();   /* drop stale (non-sticky) errors left by the host framework */ \
-    if (!ws || ws_bytes < fthmc_ws_bytes(B, L, (nl))) return FTHMC_ERR_WS;          \
-    const WS W = ws_layout(static_cast<double*>(ws), B, L, (nl));                   \
-    hipStream_t s = ft_stream(stream)
+    Ctx C; { const int rc_ = make_ctx((arch_), stream, &C); if (rc_ != FTHMC_OK) return rc_; } \
+    hipStream_t s = C.s; (void)s
+#define FT_WS(nl)                                                                   \
+    if (!ws || ws_bytes < ws_doubles(C.A, B, L, (nl)) * sizeof(double)) return FTHMC_ERR_WS; \
+    const WS W = ws_layout(C.A, static_cast<double*>(ws), B, L, (nl))
 
 int fthmc_wrap(const double* x, double* out, size_t n, void* stream) {
     if (!x || !out) return FTHMC_ERR_ARG;
@@ -328,6 +355,7 @@ int fthmc_random_uniform(const int64_t* seeds, int B, int n_per_chain, double lo
 int fthmc_train_metrics(const double* xi, const double* x, const double* logq, const double* logp, int B, int L,
                         double beta, double dkl_factor, double* row, void* ws, size_t ws_bytes, void* stream) {
     if (!xi || !x || !logq || !logp || !row || bad_shape(B, L) || !(beta != 0.0)) return FTHMC_ERR_ARG;
+    FT_CTX(nullptr);
     FT_WS(0);
     double* q = W.scal + (size_t)SC_Q * B; double* qi = W.scal + (size_t)SC_OLD0 * B;
     FT_TRY(launch_action_charge(x, B, L, beta, nullptr, q, nullptr, s));
@@ -335,9 +363,17 @@ int fthmc_train_metrics(const double* xi, const double* x, const double* logq, c
     return launch_train_metrics(logq, logp, q, qi, B, 1.0 / (beta * L * L), dkl_factor, row, s);
 }
 
+int fthmc_adam_step(double* w, const double* gw, double* exp_avg, double* exp_avg_sq, double* hyper, size_t n,
+                    double beta1, double beta2, double eps, double weight_decay, int decoupled, void* stream) {
+    if (!w || !gw || !exp_avg || !exp_avg_sq || !hyper || n == 0) return FTHMC_ERR_ARG;
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0)) return FTHMC_ERR_ARG;
+    return launch_adam(w, gw, exp_avg, exp_avg_sq, hyper, n, beta1, beta2, eps, weight_decay, decoupled != 0, ft_stream(stream));
+}
+
 int fthmc_leapfrog(const double* x, const double* p, int B, int L, double beta, double dt, int nstep,
                    double* x_out, double* p_out, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !p || !x_out || !p_out || bad_shape(B, L) || nstep < 1) return FTHMC_ERR_ARG;
+    FT_CTX(nullptr);
     FT_WS(0);
     double *xo, *po;
     FT_TRY(leapfrog_ws(x, p, W, B, L, beta, dt, nstep, &xo, &po, s));
@@ -351,9 +387,10 @@ int fthmc_hmc_trajectory(const double* x, const double* v, const double* u, int 
                          double dt, int nstep, double* x_new, double* dH, double* acc, double* H0,
                          double* H1, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !v || !u || !x_new || bad_shape(B, L) || nstep < 1) return FTHMC_ERR_ARG;
+    FT_CTX(nullptr);
     // L <= 64 (x_new must not alias x): one persistent launch per trajectory, state in LDS / registers
-    if (L <= 64 && get_flow_variant() == 1 && x_new != x)
-        return launch_hmc_trajectory_fused(x, v, u, B, L, beta, dt, nstep, x_new, dH, acc, H0, H1, ft_stream(stream));
+    if (L <= 64 && C.mfma && x_new != x)
+        return launch_hmc_trajectory_fused(x, v, u, B, L, beta, dt, nstep, x_new, dH, acc, H0, H1, s);
     FT_WS(0);
     double* S = W.scal + (size_t)SC_S * B; double* K = W.scal + (size_t)SC_K * B;
     double* h0 = H0 ? H0 : W.scal + (size_t)SC_H0 * B;
@@ -370,53 +407,57 @@ int fthmc_hmc_trajectory(const double* x, const double* v, const double* u, int 
     return launch_metropolis(x, xo, u, h0, h1, B, L, 0, x_new, dH, acc, nullptr, nullptr, nullptr, 0, s);
 }
 
-int fthmc_flow_layer_fwd(const double* x, const double* w, int B, int L, int mu, int off, int act,
+int fthmc_flow_layer_fwd(const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                          double* y, double* logJ, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !y || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
     FT_WS(1);
-    FT_TRY(use_weights(w, 1, W, s));
-    if (!arch_default()) {
-        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+    FT_TRY(use_weights(C, w, 1, W, s));
+    if (C.gen()) {
+        GenLayerArgs g = gen_args(C, W, 0, B, L, act, false);
         g.mu = mu; g.off = off; g.x = x; g.y = y; g.logj = logJ;
         return launch_gen_fwd(g, false, s);
     }
     FlowLayerArgs a{};
     a.x = x; a.wint = W.wint; a.y = y; a.logj_part = W.lj_part;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    FT_TRY(flow_fwd(a, s));
-    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_fwd_geom(fwd_is_mfma()).ntiles(L), 1.0, 0, logJ, s));
+    FT_TRY(flow_fwd(C, a, s));
+    if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_fwd_geom(C.mfma).ntiles(L), 1.0, 0, logJ, s));
     return FTHMC_OK;
 }
 
-int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu, int off, int act,
+int fthmc_flow_layer_rev(const double* y, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                          double tol, double* x, double* logJ, void* ws, size_t ws_bytes, void* stream) {
     if (!y || !w || !x || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
     FT_WS(1);
-    FT_TRY(use_weights(w, 1, W, s));
-    if (!arch_default()) {
-        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+    FT_TRY(use_weights(C, w, 1, W, s));
+    if (C.gen()) {
+        GenLayerArgs g = gen_args(C, W, 0, B, L, act, false);
         g.mu = mu; g.off = off; g.x = y; g.y = x; g.logj = logJ; g.tol = tol;
         return launch_gen_fwd(g, true, s);
     }
     FlowLayerArgs a{};
     a.x = y; a.wint = W.wint; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
-    FT_TRY(flow_rev(a, s));
+    FT_TRY(flow_rev(C, a, s));
     if (logJ) FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(false).ntiles(L), 1.0, 0, logJ, s));
     return FTHMC_OK;
 }
 
 // plaquette-level map: the coupling kernel with the plaquette field as input and output (MFMA kernels only)
-static int plaq_coupling(const double* P, const double* w, int B, int L, int mu, int off, int act, double tol,
+static int plaq_coupling(const double* P, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act, double tol,
                          bool rev, double* out, double* logJ, void* ws, size_t ws_bytes, void* stream) {
     if (!P || !w || !out || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
-    if (act < 0 || act > 2 || (get_flow_variant() != 1 && arch_default())) return FTHMC_ERR_UNSUPPORTED;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
+    if (!C.mfma && C.A.is_default()) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(1);
-    FT_TRY(use_weights(w, 1, W, s));
-    if (!arch_default()) {
-        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+    FT_TRY(use_weights(C, w, 1, W, s));
+    if (C.gen()) {
+        GenLayerArgs g = gen_args(C, W, 0, B, L, act, false);
         g.mu = mu; g.off = off; g.pin = P; g.pout = out; g.logj = logJ; g.tol = tol;
         return launch_gen_fwd(g, rev, s);
     }
@@ -428,33 +469,32 @@ static int plaq_coupling(const double* P, const double* w, int B, int L, int mu,
     return FTHMC_OK;
 }
 
-int fthmc_plaq_coupling_fwd(const double* P, const double* w, int B, int L, int mu, int off, int act,
+int fthmc_plaq_coupling_fwd(const double* P, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                             double* fP, double* logJ, void* ws, size_t ws_bytes, void* stream) {
-    return plaq_coupling(P, w, B, L, mu, off, act, 0.0, false, fP, logJ, ws, ws_bytes, stream);
+    return plaq_coupling(P, w, arch, B, L, mu, off, act, 0.0, false, fP, logJ, ws, ws_bytes, stream);
 }
 
-int fthmc_plaq_coupling_rev(const double* fP, const double* w, int B, int L, int mu, int off, int act,
+int fthmc_plaq_coupling_rev(const double* fP, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                             double tol, double* P, double* logJ, void* ws, size_t ws_bytes, void* stream) {
-    return plaq_coupling(fP, w, B, L, mu, off, act, tol, true, P, logJ, ws, ws_bytes, stream);
+    return plaq_coupling(fP, w, arch, B, L, mu, off, act, tol, true, P, logJ, ws, ws_bytes, stream);
 }
 
 // VJP of one layer.  `stash` != null: the forward's activation stash (fthmc_flow_layer_fwd_stash) -- nothing is recomputed;
 // else the layer is run forward first from `x`.
-static int layer_bwd_impl(const double* x, const double* stash, const double* w, const double* gy, const double* glogJ,
+static int layer_bwd_impl(const double* x, const double* stash, const double* w, const fthmc_arch_t* arch, const double* gy, const double* glogJ,
                           int B, int L, int mu, int off, int act, double* gx, double* gw, void* ws, size_t ws_bytes, void* stream) {
     if ((!x && !stash) || !w || !gy || !glogJ || !gx || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3)
         return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
-    const bool mfma = get_flow_variant() == 1;
-    if (stash && !mfma && arch_default()) return FTHMC_ERR_UNSUPPORTED;      // the VALU variant has no stash
-    (void)hipGetLastError();
-    if (!ws || ws_bytes < (gw && mfma ? fthmc_train_ws_bytes(B, L, 1) : fthmc_ws_bytes(B, L, 1))) return FTHMC_ERR_WS;
-    const WS W = ws_layout(static_cast<double*>(ws), B, L, 1, gw != nullptr && mfma);
-    hipStream_t s = ft_stream(stream);
-    FT_TRY(use_weights(w, 1, W, s));
-    if (!arch_default()) {
+    FT_CTX(arch);
+    const bool mfma = C.mfma;
+    if (stash && !mfma && C.A.is_default()) return FTHMC_ERR_UNSUPPORTED;      // the VALU variant has no stash
+    if (!ws || ws_bytes < ws_doubles(C.A, B, L, 1, gw != nullptr && mfma) * sizeof(double)) return FTHMC_ERR_WS;
+    const WS W = ws_layout(C.A, static_cast<double*>(ws), B, L, 1, gw != nullptr && mfma);
+    FT_TRY(use_weights(C, w, 1, W, s));
+    if (C.gen()) {
         // the adjoint seeded by the link gradient; W.gp holds the layer's plaquette gradient alone
-        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+        GenLayerArgs g = gen_args(C, W, 0, B, L, act, false);
         g.mu = mu; g.off = off; g.x = x;
         if (stash) g.stash = const_cast<double*>(stash);
         else FT_TRY(launch_gen_fwd(g, false, s));                 // forward once: fills the layer's planes
@@ -489,27 +529,29 @@ static int layer_bwd_impl(const double* x, const double* stash, const double* w,
     return launch_adj_add(W.gp, gy, B, L, gx, s);
 }
 
-int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, const double* glogJ,
+int fthmc_flow_layer_bwd(const double* x, const double* w, const fthmc_arch_t* arch, const double* gy, const double* glogJ,
                          int B, int L, int mu, int off, int act, double* gx, double* gw, void* ws,
                          size_t ws_bytes, void* stream) {
     if (!x) return FTHMC_ERR_ARG;
-    return layer_bwd_impl(x, nullptr, w, gy, glogJ, B, L, mu, off, act, gx, gw, ws, ws_bytes, stream);
+    return layer_bwd_impl(x, nullptr, w, arch, gy, glogJ, B, L, mu, off, act, gx, gw, ws, ws_bytes, stream);
 }
 
-size_t fthmc_layer_stash_bytes(int B, int L) {
-    if (B <= 0 || L <= 0) return 0;
-    if (!arch_default()) return gen_stash_doubles(B, L) * sizeof(double);
-    return get_flow_variant() == 1 ? flow_stash_doubles(B, L, true) * sizeof(double) : 0;
+size_t fthmc_layer_stash_bytes(const fthmc_arch_t* arch, int B, int L) {
+    Ctx C;
+    if (B <= 0 || L <= 0 || make_ctx(arch, nullptr, &C) != FTHMC_OK) return 0;
+    if (C.gen()) return C.A.stash_doubles(B, L) * sizeof(double);
+    return C.mfma ? flow_stash_doubles(B, L, true) * sizeof(double) : 0;
 }
 
-int fthmc_flow_layer_fwd_stash(const double* x, const double* w, int B, int L, int mu, int off, int act, double* y,
+int fthmc_flow_layer_fwd_stash(const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act, double* y,
                                double* logJ, double* stash, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !y || !stash || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
-    if (act < 0 || act > 2 || fthmc_layer_stash_bytes(B, L) == 0) return FTHMC_ERR_UNSUPPORTED;
+    if (act < 0 || act > 2 || fthmc_layer_stash_bytes(arch, B, L) == 0) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
     FT_WS(1);
-    FT_TRY(use_weights(w, 1, W, s));
-    if (!arch_default()) {
-        GenLayerArgs g = gen_args(W, 0, B, L, act, false);
+    FT_TRY(use_weights(C, w, 1, W, s));
+    if (C.gen()) {
+        GenLayerArgs g = gen_args(C, W, 0, B, L, act, false);
         g.mu = mu; g.off = off; g.x = x; g.y = y; g.logj = logJ; g.stash = stash;
         return launch_gen_fwd(g, false, s);
     }
@@ -521,37 +563,39 @@ int fthmc_flow_layer_fwd_stash(const double* x, const double* w, int B, int L, i
     return FTHMC_OK;
 }
 
-int fthmc_flow_layer_bwd_stash(const double* stash, const double* w, const double* gy, const double* glogJ, int B, int L,
+int fthmc_flow_layer_bwd_stash(const double* stash, const double* w, const fthmc_arch_t* arch, const double* gy, const double* glogJ, int B, int L,
                                int mu, int off, int act, double* gx, double* gw, void* ws, size_t ws_bytes, void* stream) {
     if (!stash) return FTHMC_ERR_ARG;
-    return layer_bwd_impl(nullptr, stash, w, gy, glogJ, B, L, mu, off, act, gx, gw, ws, ws_bytes, stream);
+    return layer_bwd_impl(nullptr, stash, w, arch, gy, glogJ, B, L, mu, off, act, gx, gw, ws, ws_bytes, stream);
 }
 
-int fthmc_flow_forward(const double* x, const double* w, int n_layers, int B, int L, int act,
+int fthmc_flow_forward(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                        double* y, double* logdet, void* ws, size_t ws_bytes, void* stream) {
     if (!x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s));
     double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
     if (n_layers == 0 && hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
-    if (ft_small_ok(L, n_layers)) {
+    if (C.small(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, 1.0, 0);
         a.x_out = y; a.logdet = ld;
         return launch_ft_small(a, L, s);
     }
-    FT_TRY(sweep_forward(x, W, n_layers, B, L, act, ld, s));
+    FT_TRY(sweep_forward(C, x, W, n_layers, B, L, act, ld, s));
     if (y && hipMemcpyAsync(y, phys_field(x, W, n_layers), W.n2 * sizeof(double),
                             hipMemcpyDeviceToDevice, s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     return FTHMC_OK;
 }
 
-int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, int L, int act, double tol,
+int fthmc_flow_reverse(const double* y, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double tol,
                        double* x, double* logdet, void* ws, size_t ws_bytes, void* stream) {
     if (!y || !x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s));
     double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
     if (hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     // The last layer maps y -> x, the others run in place on x.  In place is safe: a layer only rewrites its ACTIVE links,
@@ -559,9 +603,9 @@ int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, in
     // links the layer never writes plus the workgroup's own active links, which it loads before it stores them; the
     // active / passive plaquettes of the halo, which a neighbour's update can tear, are never read.
     const double* src = y;
-    if (!arch_default()) {
+    if (C.gen()) {
         for (int l = n_layers - 1; l >= 0; --l) {
-            GenLayerArgs g = gen_args(W, l, B, L, act, false);
+            GenLayerArgs g = gen_args(C, W, l, B, L, act, false);
             g.x = src; g.y = x; g.logj = ld; g.logj_accumulate = 1; g.tol = tol;
             FT_TRY(launch_gen_fwd(g, true, s));
             src = x;
@@ -574,7 +618,7 @@ int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, in
         FlowLayerArgs a{};
         a.x = src; a.wint = W.wint + (size_t)l * FLOW_WINT; a.y = x; a.logj_part = W.lj_part; a.tol = tol;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
-        FT_TRY(flow_rev(a, s));
+        FT_TRY(flow_rev(C, a, s));
         FT_TRY(launch_sum_parts(W.lj_part, B, flow_geom(false).ntiles(L), 1.0, 1, ld, s));
         src = x;
     }
@@ -583,58 +627,61 @@ int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, in
     return FTHMC_OK;
 }
 
-int fthmc_ft_action(const double* x, const double* w, int n_layers, int B, int L, int act, double beta,
+int fthmc_ft_action(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,
                     double* S_eff, double* logdet, double* plaq, double* Q, void* ws, size_t ws_bytes,
                     void* stream) {
     if (!x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s));
     if (n_layers == 0 && logdet && hipMemsetAsync(logdet, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
-    if (ft_small_ok(L, n_layers)) {
+    if (C.small(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 0);
         a.S_eff = S_eff; a.logdet = logdet; a.plaq = plaq; a.Q = Q;
         return launch_ft_small(a, L, s);
     }
-    return eval_action(x, W, n_layers, B, L, act, beta, S_eff, logdet, plaq, Q, s);
+    return eval_action(C, x, W, n_layers, B, L, act, beta, S_eff, logdet, plaq, Q, s);
 }
 
-int fthmc_ft_force(const double* x, const double* w, int n_layers, int B, int L, int act, double beta,
+int fthmc_ft_force(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,
                    double* F, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !F || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(w, n_layers, W, s));
-    if (ft_small_ok(L, n_layers)) {
+    FT_TRY(use_weights(C, w, n_layers, W, s));
+    if (C.small(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 1);
         a.F = F;
         return launch_ft_small(a, L, s);
     }
-    FT_TRY(force_gp(x, W, n_layers, B, L, act, beta, -1.0, nullptr, s));
+    FT_TRY(force_gp(C, x, W, n_layers, B, L, act, beta, -1.0, nullptr, s));
     return launch_kick_from_gp(W.gp, nullptr, nullptr, F, B, L, 0.0, 0.0, s);
 }
 
-int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, int n_layers, int B, int L,
+int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L,
                       int act, double beta, double dt, int nstep, double* x_out, double* v_out,
                       void* ws, size_t ws_bytes, void* stream) {
     if (!x || !v || !x_out || !v_out || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0 || nstep < 1)
         return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(w, n_layers, W, s));
-    if (ft_small_ok(L, n_layers)) {
+    FT_TRY(use_weights(C, w, n_layers, W, s));
+    if (C.small(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 2);
         a.v = v; a.dt = dt; a.nstep = nstep; a.x_out = x_out; a.v_out = v_out;
         return launch_ft_small(a, L, s);
     }
-    FT_TRY(ft_leapfrog_ws(x, v, W, n_layers, B, L, act, beta, dt, nstep, s));
+    FT_TRY(ft_leapfrog_ws(C, x, v, W, n_layers, B, L, act, beta, dt, nstep, s));
     if (hipMemcpyAsync(x_out, W.xa, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess ||
         hipMemcpyAsync(v_out, W.va, W.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return FTHMC_ERR_LAUNCH;
     return FTHMC_OK;
 }
 
-int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w, int n_layers,
+int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch, int n_layers,
                         int B, int L, int act, double beta, double dt, int nstep, int mode, double* x_new,
                         double* dH, double* acc, double* H0, double* H1, double* plaq, double* Q,
                         const double* state_in, double* state_out,
@@ -642,6 +689,7 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
     if (!x || !v || !u || !x_new || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0 || nstep < 1)
         return FTHMC_ERR_ARG;
     if (act < 0 || act > 2 || (mode != FTHMC_MODE_MD && mode != FTHMC_MODE_LITERAL)) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
     FT_WS(n_layers);
     double* K = W.scal + (size_t)SC_K * B;
     double* h0 = H0 ? H0 : W.scal + (size_t)SC_H0 * B;
@@ -650,8 +698,8 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
     double* old = W.scal + (size_t)SC_OLD0 * B;      // slots SC_OLD0.. : 3 consecutive
     double* neu = W.scal + (size_t)SC_NEW0 * B;
     double* sel = state_out ? state_out : W.scal + (size_t)SC_S * B;
-    FT_TRY(use_weights(w, n_layers, W, s));
-    if (mode == FTHMC_MODE_MD && ft_small_ok(L, n_layers)) {          // the whole trajectory in one launch
+    FT_TRY(use_weights(C, w, n_layers, W, s));
+    if (mode == FTHMC_MODE_MD && C.small(L, n_layers)) {          // the whole trajectory in one launch
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
         a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = x_new; a.state_in = state_in; a.state_out = state_out;
         a.dH = dH; a.acc = acc; a.H0 = H0; a.H1 = H1; a.plaq = plaq; a.Q = Q;
@@ -661,13 +709,13 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
         if (hipMemcpyAsync(old, state_in, (size_t)3 * B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
             return FTHMC_ERR_LAUNCH;
     } else {
-        FT_TRY(eval_action(x, W, n_layers, B, L, act, beta, old, nullptr, old + B, old + 2 * B, s));
+        FT_TRY(eval_action(C, x, W, n_layers, B, L, act, beta, old, nullptr, old + B, old + 2 * B, s));
     }
     FT_TRY(launch_kinetic(v, B, L, K, s));
     FT_TRY(launch_lincomb(old, 1.0, K, 0.5, 0.0, h0, B, s));
     const double* vend;
     if (mode == FTHMC_MODE_MD) {
-        FT_TRY(ft_leapfrog_ws(x, v, W, n_layers, B, L, act, beta, dt, nstep, s));
+        FT_TRY(ft_leapfrog_ws(C, x, v, W, n_layers, B, L, act, beta, dt, nstep, s));
         FT_TRY(launch_wrap(W.xa, W.xb, W.n2, 1, s));              // regularize (ipynb/ft_hmc.py:426)
         vend = W.va;
     } else {
@@ -675,7 +723,7 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
         FT_TRY(launch_wrap(W.xa, W.xb, W.n2, 0, s));              // wrap (ft_hmc.py:208)
         vend = v;
     }
-    FT_TRY(eval_action(W.xb, W, n_layers, B, L, act, beta, neu, nullptr, neu + B, neu + 2 * B, s));
+    FT_TRY(eval_action(C, W.xb, W, n_layers, B, L, act, beta, neu, nullptr, neu + B, neu + 2 * B, s));
     FT_TRY(launch_kinetic(vend, B, L, K, s));
     FT_TRY(launch_lincomb(neu, 1.0, K, 0.5, 0.0, h1, B, s));
     // state of x_new without another sweep: select per chain
@@ -687,22 +735,21 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
     return FTHMC_OK;
 }
 
-int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int L, int act, double beta,
+int fthmc_train_grad(const double* xi, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,
                      double* x, double* logq, double* logp, double* gw, void* ws, size_t ws_bytes,
                      void* stream) {
     if (!xi || !w || bad_shape(B, L) || n_layers < 1) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
-    (void)hipGetLastError();
-    if (!ws || ws_bytes < fthmc_train_ws_bytes(B, L, n_layers)) return FTHMC_ERR_WS;
-    const WS W = ws_layout(static_cast<double*>(ws), B, L, n_layers, true);
-    hipStream_t s = ft_stream(stream);
-    FT_TRY(use_weights(w, n_layers, W, s));
+    FT_CTX(arch);
+    if (!ws || ws_bytes < ws_doubles(C.A, B, L, n_layers, true) * sizeof(double)) return FTHMC_ERR_WS;
+    const WS W = ws_layout(C.A, static_cast<double*>(ws), B, L, n_layers, true);
+    FT_TRY(use_weights(C, w, n_layers, W, s));
     double* ld = W.scal + (size_t)SC_LOGDET * B;
     double* S = W.scal + (size_t)SC_S * B;
     // one forward sweep serves both the outputs (x, logq, logp) and the backward pass; with the MFMA
     // kernels it stashes act', s and h of every layer for the weight-gradient backward
-    const bool mfma = get_flow_variant() == 1 || !arch_default();       // paths whose backward reads the forward's stash
-    FT_TRY(sweep_forward(xi, W, n_layers, B, L, act, ld, s, mfma && gw != nullptr, mfma && gw != nullptr));
+    const bool mfma = C.mfma || C.gen();       // paths whose backward reads the forward's stash
+    FT_TRY(sweep_forward(C, xi, W, n_layers, B, L, act, ld, s, mfma && gw != nullptr, mfma && gw != nullptr));
     if (x || logq || logp) {
         FT_TRY(launch_action_charge(phys_field(xi, W, n_layers), B, L, beta, S, nullptr, nullptr, s));
         const double lp0 = -(double)(2 * L * L) * log(FT_TWO_PI);
@@ -713,20 +760,21 @@ int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int
     }
     if (gw) {
         // d mean_b(S_W - logdet) / dw : seed beta/B on the Wilson term, -1/B on every logJ
-        FT_TRY(force_gp(xi, W, n_layers, B, L, act, beta / B, -1.0 / B, gw, s, /*have_forward=*/true));
+        FT_TRY(force_gp(C, xi, W, n_layers, B, L, act, beta / B, -1.0 / B, gw, s, /*have_forward=*/true));
     }
     return FTHMC_OK;
 }
 
-int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
+int fthmc_time_kernel(int kind, const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                       double beta, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !ms_avg_host || bad_shape(B, L) || reps < 1 || kind < 0 || kind > 3) return FTHMC_ERR_ARG;
-    if (!arch_default() && kind < 2) return FTHMC_ERR_UNSUPPORTED;
     if (kind < 2 && !w) return FTHMC_ERR_ARG;
+    FT_CTX(arch);
+    if (C.gen() && kind < 2) return FTHMC_ERR_UNSUPPORTED;         // the tuned kernels serve the default net shape
     FT_WS(1);
     FlowLayerArgs a{};
     if (kind < 2) {
-        FT_TRY(use_weights(w, 1, W, s));
+        FT_TRY(use_weights(C, w, 1, W, s));
         FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
         a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
         a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.gp_out = W.gp2;
@@ -734,7 +782,7 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
 #ifdef FT_DIAG
         if (const char* e = getenv("FTHMC_DBG_STOP")) a.dbg_stop = atoi(e);
 #endif
-        if (get_flow_variant() == 1) {            // the hot path: forward stashes, backward reads the stash
+        if (C.mfma) {            // the hot path: forward stashes, backward reads the stash
             a.stash = W.stash;
             FT_TRY(launch_flow_fwd_mfma(a, s));
         }
@@ -750,7 +798,7 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     int rc = FTHMC_OK;
     for (int it = -2; it < reps && rc == FTHMC_OK; ++it) {          // two untimed warm-up launches
         if (it == 0) (void)hipEventRecord(e0, s);
-        if (kind == 0) rc = flow_fwd(a, s);
+        if (kind == 0) rc = flow_fwd(C, a, s);
         else if (kind == 1) rc = a.stash ? launch_flow_bwd_gather(a, s) : launch_flow_bwd(a, false, s);
         else if (kind == 2) rc = launch_leap_step(x, W.va, W.xa, W.vb, B, L, beta, 0.05, 0.1, s);
         else rc = launch_hmc_trajectory_fused(x, W.va, W.scal + B, B, L, beta, 0.1, 10, W.xa, nullptr, nullptr, nullptr, nullptr, s);
@@ -764,12 +812,13 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, 
     return rc;
 }
 
-int fthmc_time_small(const double* x, const double* v, const double* u, const double* w, int n_layers, int B, int L, int act,
+int fthmc_time_small(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                      double beta, double dt, int nstep, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !v || !u || !w || !ms_avg_host || bad_shape(B, L) || n_layers < 1 || nstep < 1 || reps < 1) return FTHMC_ERR_ARG;
-    if (!ft_small_ok(L, n_layers)) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
+    if (!C.small(L, n_layers)) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
-    FT_TRY(use_weights(w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s));
     SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
     a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = W.xb;
     // H0 is evaluated in the launch (no state_in): nstep force sweeps + 2 action sweeps
@@ -790,15 +839,16 @@ int fthmc_time_small(const double* x, const double* v, const double* u, const do
     return rc;
 }
 
-int fthmc_small_profile(const double* x, const double* v, const double* u, const double* w, int n_layers, int B, int L,
+int fthmc_small_profile(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L,
                         int act, double beta, double dt, int nstep, double* cycles_host32, void* ws, size_t ws_bytes,
                         void* stream) {
     if (!x || !v || !u || !w || !cycles_host32 || bad_shape(B, L) || n_layers < 1 || nstep < 1) return FTHMC_ERR_ARG;
-    if (!ft_small_ok(L, n_layers)) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
+    if (!C.small(L, n_layers)) return FTHMC_ERR_UNSUPPORTED;
     FT_WS(n_layers);
     long long* dbg = reinterpret_cast<long long*>(W.gw_part);            // unused by the force path; B * 32 stamps fit
     if (hipMemsetAsync(dbg, 0, (size_t)B * 32 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
-    FT_TRY(use_weights(w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s));
     SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
     a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = W.xb; a.dbg = dbg;
     FT_TRY(launch_ft_small(a, L, s));
@@ -814,20 +864,19 @@ int fthmc_small_profile(const double* x, const double* v, const double* u, const
     return FTHMC_OK;
 }
 
-int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off, int act,
+int fthmc_profile_stages(int kind, const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
-    if (!arch_default()) return FTHMC_ERR_UNSUPPORTED;
-    (void)hipGetLastError();
+    FT_CTX(arch);
+    if (C.gen()) return FTHMC_ERR_UNSUPPORTED;                     // the tuned kernels serve the default net shape
     const bool train = kind == 2;                                  // kind 2: the backward in training mode (also writes A.gz)
-    if (!ws || ws_bytes < (train ? fthmc_train_ws_bytes(B, L, 1) : fthmc_ws_bytes(B, L, 1))) return FTHMC_ERR_WS;
-    const WS W = ws_layout(static_cast<double*>(ws), B, L, 1, train);
-    hipStream_t s = ft_stream(stream);
+    if (!ws || ws_bytes < ws_doubles(C.A, B, L, 1, train) * sizeof(double)) return FTHMC_ERR_WS;
+    const WS W = ws_layout(C.A, static_cast<double*>(ws), B, L, 1, train);
     const size_t nrec = (size_t)B * (kind >= 1 ? flow_gather_geom() : flow_fwd_geom(true)).ntiles(L);
     // stamp buffer: a workspace region the profiled launch does not write (B * ntiles * 16 stamps fit in either)
     long long* dbg = reinterpret_cast<long long*>(train ? W.gp_part : W.gw_part);
     if (hipMemsetAsync(dbg, 0, nrec * 16 * sizeof(long long), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
-    FT_TRY(use_weights(w, 1, W, s));
+    FT_TRY(use_weights(C, w, 1, W, s));
     FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
     FlowLayerArgs a{};
     a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;

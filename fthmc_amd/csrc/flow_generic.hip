@@ -7,7 +7,7 @@
 // element, circular taps by index wrap, fixed-order reductions.  Same mathematics (GaugeEquivCouplingLayer.forward / .reverse
 // layers.py:188-210, NCPPlaqCouplingLayer :348-396, the tan-mixture transform :58-90) and the same analytic adjoint as the
 // tuned kernels (flow_fwd.hip stash coefficients, flow_bwd_gather.hip); correctness first -- a layer costs a dozen launches
-// and moves its activations through HBM.  fthmc_set_arch selects the shape (api.hip routes on arch_default()).
+// and moves its activations through HBM.  The shape travels with the call (GenLayerArgs::arch; api.hip routes on is_default()).
 #include "common.h"
 #include "kernels.h"
 #include "flow_common.h"
@@ -18,8 +18,6 @@ namespace {
 
 using namespace fthmc;
 using namespace fthmc_flow;
-
-FlowArch g_arch = {2, {8, 8, 0, 0, 0, 0, 0, 0}, 3, 2};
 
 __device__ __forceinline__ int wrapc(int v, int L) { return v < 0 ? v + L : (v >= L ? v - L : v); }
 
@@ -269,55 +267,44 @@ inline int egrid(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 4096 ?
 
 namespace fthmc {
 
-const FlowArch& flow_arch() { return g_arch; }
-int set_flow_arch(int nh, const int* hid, int k, int nmix) {
+int make_flow_arch(int nh, const int* hid, int k, int nmix, FlowArch* out) {
     if (nh < 0 || nh > FLOW_ARCH_MAXH || k < 1 || (k & 1) == 0 || k > 15 || nmix < 1 || nmix > 64) return FTHMC_ERR_UNSUPPORTED;
     for (int i = 0; i < nh; ++i) if (!hid || hid[i] < 1 || hid[i] > 256) return FTHMC_ERR_UNSUPPORTED;
     FlowArch a{};
     a.nh = nh; a.k = k; a.nmix = nmix;
     for (int i = 0; i < nh; ++i) a.hid[i] = hid[i];
-    g_arch = a;
+    *out = a;
     return FTHMC_OK;
 }
-bool arch_default() { return g_arch.nh == 2 && g_arch.hid[0] == 8 && g_arch.hid[1] == 8 && g_arch.k == 3 && g_arch.nmix == 2; }
-int arch_chan(int i) { return i == 0 ? 2 : (i <= g_arch.nh ? g_arch.hid[i - 1] : g_arch.nmix + 1); }   // channels in front of conv i
-int arch_params() {
-    int p = 0;
-    for (int i = 0; i <= g_arch.nh; ++i) p += arch_chan(i + 1) * arch_chan(i) * g_arch.k * g_arch.k + arch_chan(i + 1);
-    return p;
-}
-int arch_cmax() { int m = 2; for (int i = 1; i <= g_arch.nh + 1; ++i) m = arch_chan(i) > m ? arch_chan(i) : m; return m; }
-int arch_csum() { int c = 0; for (int i = 1; i <= g_arch.nh + 1; ++i) c += arch_chan(i); return c; }
-// per layer: P [B][n], IN [B][2][n], Z_1 .. Z_{nh+1} [B][c_i][n]
-size_t gen_stash_doubles(int B, int L) { return (size_t)B * L * L * (3 + arch_csum()); }
 
 namespace {
 struct GenStash { double *P, *IN, *Z[FLOW_ARCH_MAXH + 1]; };
-GenStash gen_view(double* base, int B, int L) {
+GenStash gen_view(const FlowArch& A, double* base, int B, int L) {
     GenStash v{};
     const size_t n = (size_t)L * L;
     v.P = base; v.IN = base + (size_t)B * n;
     double* p = base + (size_t)B * 3 * n;
-    for (int i = 0; i <= g_arch.nh; ++i) { v.Z[i] = p; p += (size_t)B * arch_chan(i + 1) * n; }
+    for (int i = 0; i <= A.nh; ++i) { v.Z[i] = p; p += (size_t)B * A.chan(i + 1) * n; }
     return v;
 }
 struct GenW { const double *w, *b; };
-GenW gen_w(const double* wl, int conv) {          // canonical layout [w0 b0 w1 b1 ...], PyTorch [Cout][Cin][k][k]
+GenW gen_w(const FlowArch& A, const double* wl, int conv) {          // canonical layout [w0 b0 w1 b1 ...], PyTorch [Cout][Cin][k][k]
     const double* p = wl;
-    for (int i = 0; i < conv; ++i) p += arch_chan(i + 1) * arch_chan(i) * g_arch.k * g_arch.k + arch_chan(i + 1);
-    return GenW{p, p + arch_chan(conv + 1) * arch_chan(conv) * g_arch.k * g_arch.k};
+    for (int i = 0; i < conv; ++i) p += A.chan(i + 1) * A.chan(i) * A.k * A.k + A.chan(i + 1);
+    return GenW{p, p + A.chan(conv + 1) * A.chan(conv) * A.k * A.k};
 }
 }  // namespace
 
 // net of one layer on the plaquettes of a.x (or a.pin): fills the layer's stash region (P, IN, every pre-activation)
 static int gen_net(const GenLayerArgs& a, const GenStash& st, hipStream_t s) {
-    const int n = a.L * a.L, nh = g_arch.nh, k = g_arch.k;
+    const FlowArch& A_ = a.arch;
+    const int n = a.L * a.L, nh = A_.nh, k = A_.k;
     hipLaunchKernelGGL(k_gen_input, dim3(sgrid(n), a.B), dim3(256), 0, s, a.x, a.pin, st.P, st.IN, a.L, a.mu, a.off);
     FT_LAUNCH_CHECK();
     const double* A = st.IN;
     for (int i = 0; i <= nh; ++i) {
-        const int cin = arch_chan(i), cout = arch_chan(i + 1);
-        const GenW W = gen_w(a.w, i);
+        const int cin = A_.chan(i), cout = A_.chan(i + 1);
+        const GenW W = gen_w(A_, a.w, i);
         hipLaunchKernelGGL(k_gen_conv, dim3(sgrid(n), cout, a.B), dim3(256), 0, s, A, cin, cout, k, W.w, W.b, st.Z[i], a.L);
         FT_LAUNCH_CHECK();
         if (i < nh) {
@@ -330,28 +317,31 @@ static int gen_net(const GenLayerArgs& a, const GenStash& st, hipStream_t s) {
 }
 
 int launch_gen_fwd(const GenLayerArgs& a, bool rev, hipStream_t s) {
-    const GenStash st = gen_view(a.stash, a.B, a.L);
+    if (a.arch.k / 2 > a.L) return FTHMC_ERR_UNSUPPORTED;    // a circular pad wider than the lattice (torch's Conv2d refuses it too)
+    const GenStash st = gen_view(a.arch, a.stash, a.B, a.L);
     FT_TRY_RC(gen_net(a, st, s));
-    if (rev) hipLaunchKernelGGL(k_gen_transform<true>, dim3(a.B), dim3(256), 0, s, a.x, st.P, st.Z[g_arch.nh], a.y, a.pout, a.logj,
-                                a.logj_accumulate, a.L, a.mu, a.off, g_arch.nmix, a.tol);
-    else hipLaunchKernelGGL(k_gen_transform<false>, dim3(a.B), dim3(256), 0, s, a.x, st.P, st.Z[g_arch.nh], a.y, a.pout, a.logj,
-                            a.logj_accumulate, a.L, a.mu, a.off, g_arch.nmix, 0.0);
+    if (rev) hipLaunchKernelGGL(k_gen_transform<true>, dim3(a.B), dim3(256), 0, s, a.x, st.P, st.Z[a.arch.nh], a.y, a.pout, a.logj,
+                                a.logj_accumulate, a.L, a.mu, a.off, a.arch.nmix, a.tol);
+    else hipLaunchKernelGGL(k_gen_transform<false>, dim3(a.B), dim3(256), 0, s, a.x, st.P, st.Z[a.arch.nh], a.y, a.pout, a.logj,
+                            a.logj_accumulate, a.L, a.mu, a.off, a.arch.nmix, 0.0);
     FT_LAUNCH_CHECK();
     return FTHMC_OK;
 }
 
 // backward of one layer from its stash region: gp_out = upstream + layer contribution; gw (optional): this layer's weights
 int launch_gen_bwd(const GenLayerArgs& a, hipStream_t s) {
-    const int n = a.L * a.L, nh = g_arch.nh, k = g_arch.k, K = g_arch.nmix;
-    const GenStash st = gen_view(a.stash, a.B, a.L);
+    if (a.arch.k / 2 > a.L) return FTHMC_ERR_UNSUPPORTED;
+    const FlowArch& A_ = a.arch;
+    const int n = a.L * a.L, nh = A_.nh, k = A_.k, K = A_.nmix;
+    const GenStash st = gen_view(A_, a.stash, a.B, a.L);
     double* G = a.gbuf;
-    double* G2 = a.gbuf + (size_t)a.B * arch_cmax() * n;
+    double* G2 = a.gbuf + (size_t)a.B * A_.cmax() * n;
     hipLaunchKernelGGL(k_gen_transform_bwd, dim3(sgrid(n), a.B), dim3(256), 0, s, st.P, st.Z[nh], a.up_gp, a.up_link, a.glogj,
                        a.glogj_const, G, a.gp_out, a.L, a.mu, a.off, K);
     FT_LAUNCH_CHECK();
     for (int i = nh; i >= 0; --i) {
-        const int cin = arch_chan(i), cout = arch_chan(i + 1);
-        const GenW W = gen_w(a.w, i);
+        const int cin = A_.chan(i), cout = A_.chan(i + 1);
+        const GenW W = gen_w(A_, a.w, i);
         if (a.gw) {
             const double* A = st.IN;
             if (i > 0) {

@@ -796,7 +796,7 @@ int get_small_path() {
     if (g_small < 0) { const char* e = getenv("FTHMC_SMALL_PATH"); g_small = e ? (atoi(e) != 0) : 1; }
     return g_small;
 }
-bool ft_small_ok(int L, int nl) { return get_small_path() && arch_default() && get_flow_variant() == 1 && nl >= 1 && (L == 8 || L == 12 || L == 16); }
+bool ft_small_shape(int L, int nl) { return nl >= 1 && (L == 8 || L == 12 || L == 16); }
 
 int launch_ft_small(const SmallArgs& a, int L, hipStream_t s) {
     const dim3 grid(a.B), block(NT);

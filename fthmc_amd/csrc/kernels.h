@@ -35,6 +35,8 @@ int launch_metropolis(const double* x_old, const double* x_prop, const double* u
 
 int launch_train_metrics(const double* logq, const double* logp, const double* q, const double* qi, int B,
                          double inv_beta_vol, double dkl_factor, double* row, hipStream_t s);
+int launch_adam(double* p, const double* g, double* m, double* v, double* hp, size_t n, double b1, double b2, double eps,
+                double wd, int decoupled, hipStream_t s);       // hp: [t, lr, ticket] on the device
 
 // ---- rng.hip
 int launch_random_momenta(const int64_t* seeds, int B, int n, double* v, double* u, hipStream_t s);
@@ -115,14 +117,27 @@ inline int flow_wgrad_parts(int L) { return 2 * FlowGeom{MG_TR, MG_TC}.ntiles(L)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }
 // ---- flow_generic.hip: any s/t net shape (hidden sizes, kernel size, mixture components); plain kernels, HBM-resident planes
 constexpr int FLOW_ARCH_MAXH = 8;
-struct FlowArch { int nh; int hid[FLOW_ARCH_MAXH]; int k; int nmix; };
-const FlowArch& flow_arch();
-int set_flow_arch(int n_hidden, const int* hidden_sizes, int kernel_size, int n_mix);
-bool arch_default();                    // 2 -> 8 -> 8 -> 3, k = 3, two components: the tuned kernels serve it
-int arch_params();                      // doubles per layer in the canonical (PyTorch-order) weight layout
-int arch_cmax();                        // widest activation
-size_t gen_stash_doubles(int B, int L); // per layer: P, (cos, sin), every pre-activation
+// Shape of the s/t conv net: 2 -> hid[0] -> ... -> hid[nh - 1] -> nmix + 1 channels, k x k kernels.  A VALUE that travels with
+// every call (fthmc_arch_t of the C ABI; NULL there = the default): nothing about the shape is process state.
+struct FlowArch {
+    int nh; int hid[FLOW_ARCH_MAXH]; int k; int nmix;
+    bool is_default() const { return nh == 2 && hid[0] == 8 && hid[1] == 8 && k == 3 && nmix == 2; }   // the tuned kernels serve it
+    int chan(int i) const { return i == 0 ? 2 : (i <= nh ? hid[i - 1] : nmix + 1); }                   // channels in front of conv i
+    int params() const {                                    // doubles per layer in the canonical (PyTorch-order) weight layout
+        int p = 0;
+        for (int i = 0; i <= nh; ++i) p += chan(i + 1) * chan(i) * k * k + chan(i + 1);
+        return p;
+    }
+    int cmax() const { int m = 2; for (int i = 1; i <= nh + 1; ++i) m = chan(i) > m ? chan(i) : m; return m; }   // widest activation
+    int csum() const { int c = 0; for (int i = 1; i <= nh + 1; ++i) c += chan(i); return c; }
+    // per layer: P [B][n], IN [B][2][n], Z_1 .. Z_{nh+1} [B][c_i][n]
+    size_t stash_doubles(int B, int L) const { return (size_t)B * L * L * (3 + csum()); }
+};
+inline FlowArch flow_arch_default() { return FlowArch{2, {8, 8, 0, 0, 0, 0, 0, 0}, 3, 2}; }
+// validated copy of a caller's shape (FTHMC_ERR_UNSUPPORTED beyond the limits of flow_generic.hip)
+int make_flow_arch(int n_hidden, const int* hidden_sizes, int kernel_size, int n_mix, FlowArch* out);
 struct GenLayerArgs {
+    FlowArch arch;           // the net's shape
     const double* x;         // [B][2][L][L] layer input (null with pin)
     const double* pin;       // plaquette-level map: input plaquette field [B][L][L]
     const double* w;         // this layer's weights, canonical layout
@@ -131,7 +146,7 @@ struct GenLayerArgs {
     double* logj;            // [B] or null
     int logj_accumulate;     // logj[b] += instead of =
     double tol;              // reverse
-    double* stash;           // this layer's region (gen_stash_doubles): written by the forward, read by the backward
+    double* stash;           // this layer's region (arch.stash_doubles): written by the forward, read by the backward
     double* hbuf;            // [B][cmax][n] scratch: activations of the conv input
     double* gbuf;            // [2][B][cmax][n] scratch: gradients, ping-pong
     const double* up_gp;     // backward: upstream plaquette gradient [B][L][L] or null
@@ -162,7 +177,7 @@ struct SmallArgs {
     int nstep, mode, B, nl, act;   // mode: 0 action (forward sweep), 1 force, 2 leapfrog, 3 trajectory
     long long* dbg;          // profiling runs: [B][32] cycles per stage, accumulated by thread 0 of each chain (else null)
 };
-bool ft_small_ok(int L, int n_layers);          // the fused path serves this shape (and is switched on)
+bool ft_small_shape(int L, int n_layers);       // the fused path is built for this lattice size (default net shape, MFMA kernels)
 int launch_ft_small(const SmallArgs& a, int L, hipStream_t s);
 void set_small_path(int v);
 int get_small_path();

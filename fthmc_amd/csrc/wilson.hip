@@ -257,6 +257,58 @@ __global__ void k_kick_from_gp(const double* __restrict__ gp, double* __restrict
     }
 }
 
+// The two stencil kernels of a FLOWED leapfrog step for lattices whose rows are whole multiples of 64 sites (k_leap_rows'
+// treatment): a workgroup owns TR rows x 64 columns of one chain, a thread TWO adjacent sites of one row, every access to a
+// plane is one 16-byte load / store per lane; the left / right neighbour of a lane's pair comes from the neighbouring lane
+// (the 32 lanes of a row segment are one half-wave), only the segment's edge lanes load it.  No LDS, no barrier.
+// Same arithmetic per site as k_force<2> / k_kick_from_gp: results are bit-identical.
+//
+// gP = beta sin P(x): the seed of the flow's backward sweep (qed_helpers.py:226-242: d S_W / d P)
+template <int TR>
+__global__ __launch_bounds__(TR * 32) void k_gp_rows(const double* __restrict__ x, double* __restrict__ gp, int L, double beta) {
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    const int b = blockIdx.z, i = blockIdx.y * TR + (threadIdx.x >> 5), q = threadIdx.x & 31, j = blockIdx.x * 64 + 2 * q;
+    const int n = L * L;
+    const double* x0 = x + (size_t)b * 2 * n;
+    const double* x1 = x0 + n;
+    const int ip = i + 1 == L ? 0 : i + 1;
+    const double2_t a0 = *reinterpret_cast<const double2_t*>(x0 + i * L + j), a1 = *reinterpret_cast<const double2_t*>(x1 + i * L + j);
+    const double2_t d1 = *reinterpret_cast<const double2_t*>(x1 + ip * L + j);
+    double r0 = __shfl_down(a0.x, 1, 32);                                     // x0[i][j + 2]: the next lane's first site
+    if (q == 31) r0 = x0[i * L + (j + 2 == L ? 0 : j + 2)];
+    double sa, sb, cs;
+    ft_sincos(a0.x - a1.x - a0.y + d1.x, &sa, &cs);
+    ft_sincos(a0.y - a1.y - r0 + d1.y, &sb, &cs);
+    *reinterpret_cast<double2_t*>(gp + (size_t)b * n + i * L + j) = double2_t{beta * sa, beta * sb};
+}
+
+// v' = v - dt adj(gP), optionally x' = x + a v' and / or F = adj(gP)  (k_kick_from_gp on row strips)
+template <int TR>
+__global__ __launch_bounds__(TR * 32) void k_kick_rows(const double* __restrict__ gp, double* __restrict__ v, double* __restrict__ xq,
+                                                       double* __restrict__ Fout, int L, double dt, double a) {
+    typedef double double2_t __attribute__((ext_vector_type(2)));
+    const int b = blockIdx.z, i = blockIdx.y * TR + (threadIdx.x >> 5), q = threadIdx.x & 31, j = blockIdx.x * 64 + 2 * q;
+    const int n = L * L;
+    const double* g = gp + (size_t)b * n;
+    const int im = i == 0 ? L - 1 : i - 1;
+    const double2_t gc = *reinterpret_cast<const double2_t*>(g + i * L + j), gu = *reinterpret_cast<const double2_t*>(g + im * L + j);
+    double gl = __shfl_up(gc.y, 1, 32);                                       // gP[i][j - 1]: the previous lane's second site
+    if (q == 0) gl = g[i * L + (j == 0 ? L - 1 : j - 1)];
+    const double2_t f0 = {gc.x - gl, gc.y - gc.x}, f1 = {gu.x - gc.x, gu.y - gc.y};
+    const size_t s0 = (size_t)b * 2 * n + (size_t)i * L + j, s1 = s0 + n;
+    if (Fout) { *reinterpret_cast<double2_t*>(Fout + s0) = f0; *reinterpret_cast<double2_t*>(Fout + s1) = f1; }
+    if (v) {
+        const double2_t w0 = *reinterpret_cast<const double2_t*>(v + s0), w1 = *reinterpret_cast<const double2_t*>(v + s1);
+        const double2_t v0 = {w0.x - dt * f0.x, w0.y - dt * f0.y}, v1 = {w1.x - dt * f1.x, w1.y - dt * f1.y};
+        *reinterpret_cast<double2_t*>(v + s0) = v0; *reinterpret_cast<double2_t*>(v + s1) = v1;
+        if (xq) {
+            double2_t y0 = *reinterpret_cast<const double2_t*>(xq + s0), y1 = *reinterpret_cast<const double2_t*>(xq + s1);
+            y0.x += a * v0.x; y0.y += a * v0.y; y1.x += a * v1.x; y1.y += a * v1.y;
+            *reinterpret_cast<double2_t*>(xq + s0) = y0; *reinterpret_cast<double2_t*>(xq + s1) = y1;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- Metropolis
 // Per chain: H1 = S1 + K1/2, dH = H1 - H0, acc = u < exp(-dH),
 // x_new = acc ? xform(x_prop) : x_old.   xform: 0 none, 1 regularize, 2 wrap.
@@ -355,6 +407,36 @@ __global__ __launch_bounds__(256) void k_train_metrics(const double* __restrict_
     if (threadIdx.x == 0) {
         row[0] = dkl_factor * td / B;
         row[1] = t1 * t1 / t2 / B;                 // exp(2 (m + log s1) - (2 m + log s2)) / B
+    }
+}
+
+// Adam / AdamW on ONE flat parameter buffer (optim.Adam(model.layers.parameters(), lr), fthmc/train.py:297; AdamW in
+// restore_model_from_checkpoint, train.py:86): torch's single-tensor update, element by element --
+//   g += wd p (Adam) | p *= 1 - lr wd (AdamW);  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;
+//   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// hp = (t, lr) lives on the DEVICE: the launch reads the step count and the learning rate from there and the last
+// workgroup to finish moves t on, so the same launch can be replayed from a captured graph step after step.
+__global__ __launch_bounds__(256) void k_adam(double* __restrict__ p, const double* __restrict__ g, double* __restrict__ m,
+                                              double* __restrict__ v, double* __restrict__ hp, unsigned* __restrict__ ticket,
+                                              size_t n, double b1, double b2, double eps, double wd, int decoupled) {
+    const double t = hp[0] + 1.0, lr = hp[1];
+    const double bc1 = 1.0 - pow(b1, t), bc2s = sqrt(1.0 - pow(b2, t));
+    const double step_size = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double pi = p[i], gi = g[i];
+        if (wd != 0.0) { if (decoupled) pi *= 1.0 - lr * wd; else gi += wd * pi; }
+        const double mi = m[i] + (gi - m[i]) * (1.0 - b1);
+        const double vi = v[i] * b2 + (1.0 - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = pi - step_size * (mi / (sqrt(vi) / bc2s + eps));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {          // every other workgroup has read hp[0] and finished
+            *ticket = 0u;
+            hp[0] = t;
+        }
     }
 }
 
@@ -497,6 +579,13 @@ int launch_train_metrics(const double* logq, const double* logp, const double* q
     hipLaunchKernelGGL(k_train_metrics, dim3(1), dim3(256), 0, s, logq, logp, q, qi, B, inv_beta_vol, dkl_factor, row);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
+int launch_adam(double* p, const double* g, double* m, double* v, double* hp, size_t n, double b1, double b2, double eps,
+                double wd, int decoupled, hipStream_t s) {
+    size_t gx = (n + 1023) / 1024; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)gx), dim3(256), 0, s, p, g, m, v, hp, reinterpret_cast<unsigned*>(hp + 2), n, b1, b2,
+                       eps, wd, decoupled);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
 int launch_wilson_force(const double* x, int B, int L, double beta, double* F, hipStream_t s) {
     hipLaunchKernelGGL(k_force<0>, tile_grid(B, L), dim3(256), 0, s, x, nullptr, F, nullptr, L, beta, 0.0, 0.0);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
@@ -519,11 +608,21 @@ int launch_hmc_trajectory_fused(const double* x, const double* v, const double* 
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_wilson_gp(const double* x, int B, int L, double beta, double* gp, hipStream_t s) {
+    if (L % 64 == 0 && g_leap_rows) {
+        constexpr int TR = 8;
+        hipLaunchKernelGGL(k_gp_rows<TR>, dim3(L / 64, L / TR, B), dim3(TR * 32), 0, s, x, gp, L, beta);
+        FT_LAUNCH_CHECK(); return FTHMC_OK;
+    }
     hipLaunchKernelGGL(k_force<2>, tile_grid(B, L), dim3(256), 0, s, x, nullptr, gp, nullptr, L, beta, 0.0, 0.0);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_kick_from_gp(const double* gp, double* v, double* xq, double* Fout, int B, int L,
                         double dt, double a, hipStream_t s) {
+    if (L % 64 == 0 && g_leap_rows) {
+        constexpr int TR = 8;
+        hipLaunchKernelGGL(k_kick_rows<TR>, dim3(L / 64, L / TR, B), dim3(TR * 32), 0, s, gp, v, xq, Fout, L, dt, a);
+        FT_LAUNCH_CHECK(); return FTHMC_OK;
+    }
     int gx = (L * L + 255) / 256; if (gx > 64) gx = 64;
     hipLaunchKernelGGL(k_kick_from_gp, dim3(gx, B), dim3(256), 0, s, gp, v, xq, Fout, L, dt, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;

@@ -43,12 +43,12 @@ def _stream(t: torch.Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def ws_bytes(B: int, L: int, n_layers: int) -> int:
-    return int(_lib.load().fthmc_ws_bytes(B, L, n_layers))
+def ws_bytes(B: int, L: int, n_layers: int, arch=None) -> int:
+    return int(_lib.load().fthmc_ws_bytes(_arch(arch), B, L, n_layers))
 
 
-def _ws(t: torch.Tensor, B: int, L: int, nl: int, train: bool = False):
-    need = int(_lib.load().fthmc_train_ws_bytes(B, L, nl)) if train else ws_bytes(B, L, nl)
+def _ws(t: torch.Tensor, B: int, L: int, nl: int, train: bool = False, arch=None):
+    need = int(_lib.load().fthmc_train_ws_bytes(_arch(arch), B, L, nl)) if train else ws_bytes(B, L, nl, arch)
     # one workspace per (device, stream): chain groups running on concurrent streams must not share scratch
     key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
     buf = _WS.get(key)
@@ -79,44 +79,54 @@ def release_workspaces():
 
 
 # ---------------------------------------------------------------- s/t net shape
+# The shape of the s/t conv net is an ARGUMENT of every call that runs the net (C ABI: fthmc_arch_t; the library keeps no
+# shape between calls).  On this side it is a tuple (hidden_sizes, kernel_size, n_mixture_comps); it comes, in this order,
+# from the `arch=` argument of an op, from the tag `pack_weights` leaves on a packed weight tensor (`arch_of`), or it is
+# the reference default.
 DEFAULT_ARCH = ((8, 8), 3, 2)          # hidden_sizes, kernel_size, n_mixture_comps: the reference default (tuned kernels)
-_ARCH = [DEFAULT_ARCH]                 # what the library is currently set to (fthmc_set_arch is process-global state)
+
+
+def norm_arch(arch) -> tuple:
+    if arch is None:
+        return DEFAULT_ARCH
+    return (tuple(int(h) for h in arch[0]), int(arch[1]), int(arch[2]))
 
 
 def arch_params(arch=DEFAULT_ARCH) -> int:
     """Doubles per layer of the canonical weight layout [w0 b0 w1 b1 ...] for a net 2 -> hidden... -> n_mix + 1."""
-    hidden, k, n_mix = arch
+    hidden, k, n_mix = norm_arch(arch)
     chans = [2, *hidden, n_mix + 1]
     return sum(co * ci * k * k + co for ci, co in zip(chans[:-1], chans[1:]))
 
 
-def set_arch(arch=DEFAULT_ARCH):
-    """Select the s/t net shape of the following calls (C ABI fthmc_set_arch).  Any shape other than the default runs on
-    the plain kernels of csrc/flow_generic.hip.  The ops below call this themselves from the shape recorded on `w`."""
+def _arch(arch):
+    """-> the fthmc_arch_t* of a call (None = NULL = the default shape)"""
+    arch = norm_arch(arch)
+    if arch == DEFAULT_ARCH:
+        return None
+    hidden, k, n_mix = arch
+    if len(hidden) > 8:
+        raise FthmcError(f'net shape {arch}: at most 8 hidden layers')
+    a = _lib.ArchT()
+    a.n_hidden, a.kernel_size, a.n_mix = len(hidden), k, n_mix
+    for i, h in enumerate(hidden):
+        a.hidden[i] = h
     import ctypes
-    hidden, k, n_mix = tuple(int(h) for h in arch[0]), int(arch[1]), int(arch[2])
-    arch = (hidden, k, n_mix)
-    if arch != _ARCH[0]:
-        hs = (ctypes.c_int * max(len(hidden), 1))(*hidden)
-        check(_lib.load().fthmc_set_arch(len(hidden), hs, k, n_mix), f'fthmc_set_arch{arch}')
-        _ARCH[0] = arch
-    return arch
+    return ctypes.pointer(a)
 
 
-def arch_of(w) -> tuple:
-    """Net shape recorded on a packed weight tensor by pack_weights (default shape for a plain tensor)."""
+def arch_of(w, arch=None) -> tuple:
+    """The net shape of a call: the explicit `arch`, else the one recorded on the packed weight tensor `w` by pack_weights
+    (a plain attribute: it does not survive .to() / .clone() / arithmetic -- pass `arch=` then), else the default."""
+    if arch is not None:
+        return norm_arch(arch)
     return getattr(w, '_fthmc_arch', DEFAULT_ARCH)
 
 
-def _use_arch(w) -> int:
-    """Make the library's net shape the one of `w`; -> doubles per layer."""
-    return arch_params(set_arch(arch_of(w)))
-
-
-def _tag(t, like):
-    """carry the net shape of `like` over to a tensor derived from it"""
-    a = arch_of(like)
-    if a != DEFAULT_ARCH:
+def _tag(t, like, arch=None):
+    """carry the net shape of `like` (or `arch`) over to a tensor derived from it"""
+    a = arch_of(like, arch)
+    if a != DEFAULT_ARCH and t is not None:
         t._fthmc_arch = a
     return t
 
@@ -308,6 +318,18 @@ def train_metrics(xi, x, logq, logp, beta: float, dkl_factor: float = 1.0, out=N
     return out
 
 
+def adam_step(w, gw, exp_avg, exp_avg_sq, hyper, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+              decoupled: bool = False):
+    """One Adam (AdamW: decoupled=True) step on flat fp64 device buffers, in place, ONE launch (C ABI fthmc_adam_step).
+    `hyper` = [steps taken, learning rate, 0] on the device: the launch reads both from there and moves the count on."""
+    n = w.numel()
+    for t, want in ((w, n), (gw, n), (exp_avg, n), (exp_avg_sq, n), (hyper, 3)):
+        if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != want:
+            raise FthmcError('adam_step: contiguous float64 device tensors expected (w, gw, exp_avg, exp_avg_sq alike; hyper: 3)')
+    check(_lib.load().fthmc_adam_step(_p(w), _p(gw), _p(exp_avg), _p(exp_avg_sq), _p(hyper), n, float(betas[0]), float(betas[1]),
+                                      float(eps), float(weight_decay), int(bool(decoupled)), _stream(w)), 'fthmc_adam_step')
+
+
 def split_metrics(row, B: int) -> dict:
     """views of a train_metrics row (device or host tensor / array) under train_step's keys"""
     r = row[2:].reshape(5, B)
@@ -338,66 +360,68 @@ def hmc_trajectory(x, v, u, beta: float, dt: float, nstep: int):
 
 
 # ---------------------------------------------------------------- coupling layer
-def _w1(w, x):
-    npl = _use_arch(w)
-    w = _tag(_dev(w, 'w').reshape(-1), w)
+def _w1(w, x, arch=None):
+    """-> (one layer's weights, flat and tagged; the call's fthmc_arch_t*; the shape)"""
+    a = arch_of(w, arch)
+    npl = arch_params(a)
+    w = _tag(_dev(w, 'w').reshape(-1), w, a)
     if w.numel() != npl:
-        raise FthmcError(f'w: expected {npl} doubles for one layer of net shape {_ARCH[0]}, got {w.numel()}')
-    return w
+        raise FthmcError(f'w: expected {npl} doubles for one layer of net shape {a}, got {w.numel()}')
+    return w, _arch(a), a
 
 
-def flow_layer_fwd(x, w, mu: int, off: int, act='silu'):
-    x = _field(x); w = _w1(w, x); B, _, L, _ = x.shape
+def flow_layer_fwd(x, w, mu: int, off: int, act='silu', arch=None):
+    x = _field(x); w, ap, a = _w1(w, x, arch); B, _, L, _ = x.shape
     y = torch.empty_like(x); logJ = torch.empty(B, dtype=x.dtype, device=x.device)
-    ws, nb = _ws(x, B, L, 1)
-    check(_lib.load().fthmc_flow_layer_fwd(_p(x), _p(w), B, L, int(mu), int(off), act_code(act), _p(y), _p(logJ),
+    ws, nb = _ws(x, B, L, 1, arch=a)
+    check(_lib.load().fthmc_flow_layer_fwd(_p(x), _p(w), ap, B, L, int(mu), int(off), act_code(act), _p(y), _p(logJ),
                                            ws, nb, _stream(x)), 'fthmc_flow_layer_fwd')
     return y, logJ
 
 
-def flow_layer_bwd(x, w, gy, glogJ, mu: int, off: int, act='silu', need_gw=False):
-    x = _field(x); w = _w1(w, x); gy = _field(gy, 'gy'); glogJ = _dev(glogJ, 'glogJ').reshape(-1)
+def flow_layer_bwd(x, w, gy, glogJ, mu: int, off: int, act='silu', need_gw=False, arch=None):
+    x = _field(x); w, ap, a = _w1(w, x, arch); gy = _field(gy, 'gy'); glogJ = _dev(glogJ, 'glogJ').reshape(-1)
     B, _, L, _ = x.shape
     gx = torch.empty_like(x)
     gw = _tag(torch.empty(w.numel(), dtype=x.dtype, device=x.device), w) if need_gw else None
-    ws, nb = _ws(x, B, L, 1, train=need_gw)
-    check(_lib.load().fthmc_flow_layer_bwd(_p(x), _p(w), _p(gy), _p(glogJ), B, L, int(mu), int(off), act_code(act),
+    ws, nb = _ws(x, B, L, 1, train=need_gw, arch=a)
+    check(_lib.load().fthmc_flow_layer_bwd(_p(x), _p(w), ap, _p(gy), _p(glogJ), B, L, int(mu), int(off), act_code(act),
                                            _p(gx), _p(gw), ws, nb, _stream(x)), 'fthmc_flow_layer_bwd')
     return gx, gw
 
 
-def flow_layer_fwd_stash(x, w, mu: int, off: int, act='silu'):
+def flow_layer_fwd_stash(x, w, mu: int, off: int, act='silu', arch=None):
     """-> (y, logJ, stash): the layer forward that keeps its activations for `flow_layer_bwd_stash` (stash is None where
     the kernels have none -- the VALU variant: use flow_layer_bwd then)."""
-    x = _field(x); w = _w1(w, x); B, _, L, _ = x.shape
-    nbytes = int(_lib.load().fthmc_layer_stash_bytes(B, L))
+    x = _field(x); w, ap, a = _w1(w, x, arch); B, _, L, _ = x.shape
+    nbytes = int(_lib.load().fthmc_layer_stash_bytes(ap, B, L))
     if nbytes == 0:
-        return (*flow_layer_fwd(x, w, mu, off, act), None)
+        return (*flow_layer_fwd(x, w, mu, off, act, arch=a), None)
     y = torch.empty_like(x); logJ = torch.empty(B, dtype=x.dtype, device=x.device)
     stash = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
-    ws, nb = _ws(x, B, L, 1)
-    check(_lib.load().fthmc_flow_layer_fwd_stash(_p(x), _p(w), B, L, int(mu), int(off), act_code(act), _p(y), _p(logJ),
+    ws, nb = _ws(x, B, L, 1, arch=a)
+    check(_lib.load().fthmc_flow_layer_fwd_stash(_p(x), _p(w), ap, B, L, int(mu), int(off), act_code(act), _p(y), _p(logJ),
                                                  _p(stash), ws, nb, _stream(x)), 'fthmc_flow_layer_fwd_stash')
     return y, logJ, stash
 
 
-def flow_layer_bwd_stash(stash, shape, w, gy, glogJ, mu: int, off: int, act='silu', need_gw=False):
+def flow_layer_bwd_stash(stash, shape, w, gy, glogJ, mu: int, off: int, act='silu', need_gw=False, arch=None):
     """VJP of the layer from the stash of `flow_layer_fwd_stash` (`shape` = that call's x.shape): nothing recomputed."""
-    w_ = _w1(w, gy); gy = _field(gy, 'gy'); glogJ = _dev(glogJ, 'glogJ').reshape(-1)
+    w_, ap, a = _w1(w, gy, arch); gy = _field(gy, 'gy'); glogJ = _dev(glogJ, 'glogJ').reshape(-1)
     B, _, L, _ = shape
     gx = torch.empty_like(gy)
     gw = _tag(torch.empty(w_.numel(), dtype=gy.dtype, device=gy.device), w_) if need_gw else None
-    ws, nb = _ws(gy, B, L, 1, train=need_gw)
-    check(_lib.load().fthmc_flow_layer_bwd_stash(_p(stash), _p(w_), _p(gy), _p(glogJ), B, L, int(mu), int(off), act_code(act),
+    ws, nb = _ws(gy, B, L, 1, train=need_gw, arch=a)
+    check(_lib.load().fthmc_flow_layer_bwd_stash(_p(stash), _p(w_), ap, _p(gy), _p(glogJ), B, L, int(mu), int(off), act_code(act),
                                                  _p(gx), _p(gw), ws, nb, _stream(gy)), 'fthmc_flow_layer_bwd_stash')
     return gx, gw
 
 
-def flow_layer_rev(y, w, mu: int, off: int, act='silu', tol: float = 1e-12):
-    y = _field(y, 'y'); w = _w1(w, y); B, _, L, _ = y.shape
+def flow_layer_rev(y, w, mu: int, off: int, act='silu', tol: float = 1e-12, arch=None):
+    y = _field(y, 'y'); w, ap, a = _w1(w, y, arch); B, _, L, _ = y.shape
     x = torch.empty_like(y); logJ = torch.empty(B, dtype=y.dtype, device=y.device)
-    ws, nb = _ws(y, B, L, 1)
-    check(_lib.load().fthmc_flow_layer_rev(_p(y), _p(w), B, L, int(mu), int(off), act_code(act), float(tol),
+    ws, nb = _ws(y, B, L, 1, arch=a)
+    check(_lib.load().fthmc_flow_layer_rev(_p(y), _p(w), ap, B, L, int(mu), int(off), act_code(act), float(tol),
                                            _p(x), _p(logJ), ws, nb, _stream(y)), 'fthmc_flow_layer_rev')
     return x, logJ
 
@@ -409,84 +433,88 @@ def _plaq_field(P, name='P'):
     return P
 
 
-def plaq_coupling_fwd(P, w, mu: int, off: int, act='silu'):
+def plaq_coupling_fwd(P, w, mu: int, off: int, act='silu', arch=None):
     """NCPPlaqCouplingLayer.forward on a plaquette field [B, L, L] -> (fP, logJ[B])."""
     P = _plaq_field(P); B, L, _ = P.shape
-    w = _w1(w, P)
+    w, ap, a = _w1(w, P, arch)
     fP = torch.empty_like(P); logJ = torch.empty(B, dtype=P.dtype, device=P.device)
-    ws, nb = _ws(P, B, L, 1)
-    check(_lib.load().fthmc_plaq_coupling_fwd(_p(P), _p(w), B, L, int(mu), int(off), act_code(act), _p(fP), _p(logJ),
+    ws, nb = _ws(P, B, L, 1, arch=a)
+    check(_lib.load().fthmc_plaq_coupling_fwd(_p(P), _p(w), ap, B, L, int(mu), int(off), act_code(act), _p(fP), _p(logJ),
                                               ws, nb, _stream(P)), 'fthmc_plaq_coupling_fwd')
     return fP, logJ
 
 
-def plaq_coupling_rev(fP, w, mu: int, off: int, act='silu', tol: float = 1e-12):
+def plaq_coupling_rev(fP, w, mu: int, off: int, act='silu', tol: float = 1e-12, arch=None):
     """NCPPlaqCouplingLayer.reverse on a plaquette field [B, L, L] -> (P, logJ[B])."""
     fP = _plaq_field(fP, 'fP'); B, L, _ = fP.shape
-    w = _w1(w, fP)
+    w, ap, a = _w1(w, fP, arch)
     P = torch.empty_like(fP); logJ = torch.empty(B, dtype=fP.dtype, device=fP.device)
-    ws, nb = _ws(fP, B, L, 1)
-    check(_lib.load().fthmc_plaq_coupling_rev(_p(fP), _p(w), B, L, int(mu), int(off), act_code(act), float(tol),
+    ws, nb = _ws(fP, B, L, 1, arch=a)
+    check(_lib.load().fthmc_plaq_coupling_rev(_p(fP), _p(w), ap, B, L, int(mu), int(off), act_code(act), float(tol),
                                               _p(P), _p(logJ), ws, nb, _stream(fP)), 'fthmc_plaq_coupling_rev')
     return P, logJ
 
 
 # ---------------------------------------------------------------- whole flow
-def _wall(w, n_layers):
-    npl = _use_arch(w)
-    w = _tag(_dev(w, 'w').reshape(-1), w)
+def _wall(w, n_layers, arch=None):
+    """-> (all layers' weights, flat and tagged; the call's fthmc_arch_t*; the shape); (None, NULL, default) without layers"""
+    if not n_layers:
+        return None, None, DEFAULT_ARCH
+    a = arch_of(w, arch)
+    npl = arch_params(a)
+    w = _tag(_dev(w, 'w').reshape(-1), w, a)
     if w.numel() != n_layers * npl:
-        raise FthmcError(f'w: expected {n_layers}*{npl} doubles for net shape {_ARCH[0]}, got {w.numel()}')
-    return w
+        raise FthmcError(f'w: expected {n_layers}*{npl} doubles for net shape {a}, got {w.numel()}')
+    return w, _arch(a), a
 
 
-def flow_forward(x, w, n_layers: int, act='silu'):
+def flow_forward(x, w, n_layers: int, act='silu', arch=None):
     x = _field(x); B, _, L, _ = x.shape
-    w = _wall(w, n_layers) if n_layers else None
+    w, ap, a = _wall(w, n_layers, arch)
     y = torch.empty_like(x); ld = torch.empty(B, dtype=x.dtype, device=x.device)
-    ws, nb = _ws(x, B, L, n_layers)
-    check(_lib.load().fthmc_flow_forward(_p(x), _p(w), n_layers, B, L, act_code(act), _p(y), _p(ld), ws, nb,
+    ws, nb = _ws(x, B, L, n_layers, arch=a)
+    check(_lib.load().fthmc_flow_forward(_p(x), _p(w), ap, n_layers, B, L, act_code(act), _p(y), _p(ld), ws, nb,
                                          _stream(x)), 'fthmc_flow_forward')
     return y, ld
 
 
-def flow_reverse(y, w, n_layers: int, act='silu', tol: float = 1e-12):
+def flow_reverse(y, w, n_layers: int, act='silu', tol: float = 1e-12, arch=None):
     y = _field(y, 'y'); B, _, L, _ = y.shape
-    w = _wall(w, n_layers) if n_layers else None
+    w, ap, a = _wall(w, n_layers, arch)
     x = torch.empty_like(y); ld = torch.empty(B, dtype=y.dtype, device=y.device)
-    ws, nb = _ws(y, B, L, n_layers)
-    check(_lib.load().fthmc_flow_reverse(_p(y), _p(w), n_layers, B, L, act_code(act), float(tol), _p(x), _p(ld),
+    ws, nb = _ws(y, B, L, n_layers, arch=a)
+    check(_lib.load().fthmc_flow_reverse(_p(y), _p(w), ap, n_layers, B, L, act_code(act), float(tol), _p(x), _p(ld),
                                          ws, nb, _stream(y)), 'fthmc_flow_reverse')
     return x, ld
 
 
-def ft_action(x, w, n_layers: int, beta: float, act='silu'):
+def ft_action(x, w, n_layers: int, beta: float, act='silu', arch=None):
     """-> (S_eff, logdet, plaq, Q) each [B]."""
     x = _field(x); B, _, L, _ = x.shape
-    w = _wall(w, n_layers) if n_layers else None
+    w, ap, a = _wall(w, n_layers, arch)
     S, ld, plaq, Q = (torch.empty(B, dtype=x.dtype, device=x.device) for _ in range(4))
-    ws, nb = _ws(x, B, L, n_layers)
-    check(_lib.load().fthmc_ft_action(_p(x), _p(w), n_layers, B, L, act_code(act), float(beta), _p(S), _p(ld),
+    ws, nb = _ws(x, B, L, n_layers, arch=a)
+    check(_lib.load().fthmc_ft_action(_p(x), _p(w), ap, n_layers, B, L, act_code(act), float(beta), _p(S), _p(ld),
                                       _p(plaq), _p(Q), ws, nb, _stream(x)), 'fthmc_ft_action')
     return S, ld, plaq, Q
 
 
-def ft_force(x, w, n_layers: int, beta: float, act='silu'):
+def ft_force(x, w, n_layers: int, beta: float, act='silu', arch=None):
     x = _field(x); B, _, L, _ = x.shape
-    w = _wall(w, n_layers) if n_layers else None
+    w, ap, a = _wall(w, n_layers, arch)
     F = torch.empty_like(x)
-    ws, nb = _ws(x, B, L, n_layers)
-    check(_lib.load().fthmc_ft_force(_p(x), _p(w), n_layers, B, L, act_code(act), float(beta), _p(F), ws, nb,
+    ws, nb = _ws(x, B, L, n_layers, arch=a)
+    check(_lib.load().fthmc_ft_force(_p(x), _p(w), ap, n_layers, B, L, act_code(act), float(beta), _p(F), ws, nb,
                                      _stream(x)), 'fthmc_ft_force')
     return F
 
 
-def ft_leapfrog(x, v, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu'):
+def ft_leapfrog(x, v, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', arch=None):
     x = _field(x); v = _field(v, 'v'); B, _, L, _ = x.shape
-    w = _wall(w, n_layers) if n_layers else None
+    w, ap, a = _wall(w, n_layers, arch)
     xo, vo = torch.empty_like(x), torch.empty_like(v)
-    ws, nb = _ws(x, B, L, n_layers)
-    check(_lib.load().fthmc_ft_leapfrog(_p(x), _p(v), _p(w), n_layers, B, L, act_code(act), float(beta), float(dt),
+    ws, nb = _ws(x, B, L, n_layers, arch=a)
+    check(_lib.load().fthmc_ft_leapfrog(_p(x), _p(v), _p(w), ap, n_layers, B, L, act_code(act), float(beta), float(dt),
                                         int(nstep), _p(xo), _p(vo), ws, nb, _stream(x)), 'fthmc_ft_leapfrog')
     return xo, vo
 
@@ -509,7 +537,7 @@ def _side_streams(device, n: int):
 
 
 def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', mode='md',
-                  out: Optional[dict] = None, state_in: Optional[torch.Tensor] = None, groups: int = 1):
+                  out: Optional[dict] = None, state_in: Optional[torch.Tensor] = None, groups: int = 1, arch=None):
     """One ftHMC trajectory per chain -> dict(x_new, dH, acc, H0, H1, plaq, Q, state).
 
     `out` may carry preallocated output tensors (same keys) so that a caller can replay the call
@@ -523,7 +551,7 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
     x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
     if u.numel() != B:
         raise FthmcError(f'u: expected {B} uniforms, got {u.numel()}')
-    w = _wall(w, n_layers) if n_layers else None
+    w, ap, a = _wall(w, n_layers, arch)
     if out is None:
         out = {'x_new': torch.empty_like(x)}
         for k in ('dH', 'acc', 'H0', 'H1', 'plaq', 'Q'):
@@ -539,6 +567,7 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
         G = max(1, min(int(groups), B))
         edges = [k * B // G for k in range(G + 1)]
     if G > 1:
+        arch_ = a
         if state_in is not None:
             state_in = _dev(state_in, 'state_in')
             if state_in.numel() != 3 * B:
@@ -555,7 +584,7 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
             with torch.cuda.stream(st):
                 og = {k: t[a:b_] for k, t in out.items() if k != 'state'}
                 sg = state_in[:, a:b_].contiguous() if state_in is not None else None
-                ft_trajectory(x[a:b_], v[a:b_], u[a:b_], w, n_layers, beta, dt, nstep, act, mode, og, sg)
+                ft_trajectory(x[a:b_], v[a:b_], u[a:b_], w, n_layers, beta, dt, nstep, act, mode, og, sg, arch=arch_)
                 out['state'][:, a:b_].copy_(og['state'])
                 parts.append(og)                                        # keep the group's temporaries alive until the join
         for st in sides:
@@ -566,8 +595,8 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
         if state_in.numel() != 3 * B:
             raise FthmcError(f'state_in: expected [3, {B}]')
     m = {'md': MODE_MD, 'literal': MODE_LITERAL, 'reference_literal': MODE_LITERAL}[mode]
-    ws, nb = _ws(x, B, L, n_layers)
-    check(_lib.load().fthmc_ft_trajectory(_p(x), _p(v), _p(u), _p(w), n_layers, B, L, act_code(act), float(beta),
+    ws, nb = _ws(x, B, L, n_layers, arch=a)
+    check(_lib.load().fthmc_ft_trajectory(_p(x), _p(v), _p(u), _p(w), ap, n_layers, B, L, act_code(act), float(beta),
                                           float(dt), int(nstep), m, _p(out['x_new']), _p(out['dH']), _p(out['acc']),
                                           _p(out['H0']), _p(out['H1']), _p(out['plaq']), _p(out['Q']),
                                           _p(state_in), _p(out['state']), ws, nb,
@@ -575,7 +604,7 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
     return out
 
 
-def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, groups: int = 1, _out=None, out_gw=None):
+def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, groups: int = 1, _out=None, out_gw=None, arch=None):
     """-> dict(x, logq, logp, gw): pieces of train.train_step for a fixed prior draw; gw = gradient of
     mean_b (logq - logp) wrt the packed weights (written into `out_gw` when given: a contiguous float64 device tensor
     of w.numel() entries, e.g. the flat gradient buffer the conv parameters' .grad are views of).
@@ -583,7 +612,7 @@ def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, grou
     groups > 1: the chains are split into contiguous groups that run on concurrent streams (as in
     ft_trajectory); the groups' weight gradients are combined with weights B_g / B."""
     xi = _field(xi, 'xi'); B, _, L, _ = xi.shape
-    w = _wall(w, n_layers)
+    w, ap, arch_ = _wall(w, n_layers, arch)
     G = max(1, min(int(groups), B))
     if out_gw is not None and (not out_gw.is_cuda or out_gw.dtype != torch.float64 or not out_gw.is_contiguous()
                                or out_gw.numel() != w.numel()):
@@ -602,7 +631,7 @@ def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, grou
         for gi in list(range(1, G)) + [0]:
             a, b_ = gi * B // G, (gi + 1) * B // G
             with torch.cuda.stream(main if gi == 0 else sides[gi - 1]):
-                r = train_grad(xi[a:b_], w, n_layers, beta, act, need_gw, 1, (x[a:b_], logq[a:b_], logp[a:b_]))
+                r = train_grad(xi[a:b_], w, n_layers, beta, act, need_gw, 1, (x[a:b_], logq[a:b_], logp[a:b_]), arch=arch_)
                 if need_gw:
                     torch.mul(r['gw'], (b_ - a) / B, out=gws[gi])
         for st in sides:
@@ -613,8 +642,8 @@ def train_grad(xi, w, n_layers: int, beta: float, act='silu', need_gw=True, grou
                 'gw': _tag(out_gw if out_gw is not None else gws.sum(0), w) if need_gw else None}
     gw = _tag(out_gw.reshape(-1) if out_gw is not None else torch.empty(w.numel(), dtype=xi.dtype, device=xi.device), w) \
         if need_gw else None
-    ws, nb = _ws(xi, B, L, n_layers, train=True)
-    check(_lib.load().fthmc_train_grad(_p(xi), _p(w), n_layers, B, L, act_code(act), float(beta), _p(x), _p(logq),
+    ws, nb = _ws(xi, B, L, n_layers, train=True, arch=arch_)
+    check(_lib.load().fthmc_train_grad(_p(xi), _p(w), ap, n_layers, B, L, act_code(act), float(beta), _p(x), _p(logq),
                                        _p(logp), _p(gw), ws, nb, _stream(xi)), 'fthmc_train_grad')
     return {'x': x, 'logq': logq, 'logp': logp, 'gw': gw}
 
@@ -625,10 +654,10 @@ def time_kernel(kind: str, x, w=None, mu=0, off=0, act='silu', beta=1.0, reps=20
     import ctypes
     x = _field(x); B, _, L, _ = x.shape
     k = {'flow_fwd': 0, 'flow_bwd': 1, 'leap_step': 2, 'hmc_trajectory': 3}[kind]
-    wp = _p(_w1(w, x)) if k < 2 else None
+    wp = _p(_w1(w, x)[0]) if k < 2 else None
     ms = ctypes.c_double(0.0)
     ws, nb = _ws(x, B, L, 1)
-    check(_lib.load().fthmc_time_kernel(k, _p(x), wp, B, L, int(mu), int(off), act_code(act), float(beta),
+    check(_lib.load().fthmc_time_kernel(k, _p(x), wp, None, B, L, int(mu), int(off), act_code(act), float(beta),
                                         int(reps), ctypes.byref(ms), ws, nb, _stream(x)), 'fthmc_time_kernel')
     return ms.value
 
@@ -640,7 +669,7 @@ def profile_stages(kind: str, x, w, mu=0, off=0, act='silu', beta=1.0):
     k = {'flow_fwd': 0, 'flow_bwd': 1, 'flow_bwd_train': 2}[kind]
     buf = (ctypes.c_double * 16)()
     ws, nb = _ws(x, B, L, 1, train=(k == 2))
-    check(_lib.load().fthmc_profile_stages(k, _p(x), _p(_w1(w, x)), B, L, int(mu), int(off), act_code(act),
+    check(_lib.load().fthmc_profile_stages(k, _p(x), _p(_w1(w, x)[0]), None, B, L, int(mu), int(off), act_code(act),
                                            float(beta), buf, ws, nb, _stream(x)), 'fthmc_profile_stages')
     return list(buf)
 
@@ -651,7 +680,7 @@ def small_profile(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
     x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
     buf = (ctypes.c_double * 32)()
     ws, nb = _ws(x, B, L, n_layers)
-    check(_lib.load().fthmc_small_profile(_p(x), _p(v), _p(u), _p(_wall(w, n_layers)), n_layers, B, L, act_code(act), float(beta),
+    check(_lib.load().fthmc_small_profile(_p(x), _p(v), _p(u), _p(_wall(w, n_layers)[0]), None, n_layers, B, L, act_code(act), float(beta),
                                           float(dt), int(nstep), buf, ws, nb, _stream(x)), 'fthmc_small_profile')
     return list(buf)
 
@@ -662,6 +691,6 @@ def time_small(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int, ac
     x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
     ms = ctypes.c_double(0.0)
     ws, nb = _ws(x, B, L, n_layers)
-    check(_lib.load().fthmc_time_small(_p(x), _p(v), _p(u), _p(_wall(w, n_layers)), n_layers, B, L, act_code(act), float(beta),
+    check(_lib.load().fthmc_time_small(_p(x), _p(v), _p(u), _p(_wall(w, n_layers)[0]), None, n_layers, B, L, act_code(act), float(beta),
                                        float(dt), int(nstep), int(reps), ctypes.byref(ms), ws, nb, _stream(x)), 'fthmc_time_small')
     return ms.value

@@ -11,17 +11,21 @@ Operators (reference call site each one replaces):
   wilson_action_charge(x, beta) -> (S, Q, plaq)      qed_helpers.py:94-116,177-186
   wilson_force(x, beta) -> F                         qed_helpers.py:265-272
   hmc_trajectory(x, v, u, beta, dt, nstep) -> (x_new, dH, acc)          qed_helpers.py:275-311
-  flow_layer_fwd(x, w, mu, off, n_mix, act) -> (y, logJ)                layers.py:196-202,348-371
-  flow_layer_bwd_x(x, gy, glogJ, w, mu, off, n_mix, act) -> gx          (autograd of the above)
-  flow_layer_bwd_w(x, gy, glogJ, w, mu, off, n_mix, act) -> gw[955]
-  flow_layer_rev(y, w, mu, off, n_mix, act, tol) -> (x, logJ)           layers.py:204-210,294-320,373-396
-  ft_action_force(x, w_all, n_layers, beta, act) -> (S_eff, logdet, F)  qed_helpers.py:212-242
-  fthmc_trajectory(x, v, u, w_all, n_layers, beta, dt, nstep, mode, act) -> (x_new, dH, acc, plaq, Q)
-                                                      ft_hmc.py:180-224 / ipynb/ft_hmc.py:394-435
-  train_grad(xi, w_all, n_layers, beta, act) -> (x, logq, logp, gw)     train.py:162-228
+  flow_layer_fwd(x, w, mu, off, n_mix, act, hidden=None, kernel_size=3) -> (y, logJ)      layers.py:196-202,348-371
+  flow_layer_bwd_x(x, gy, glogJ, w, mu, off, n_mix, act, hidden, kernel_size) -> gx        (autograd of the above)
+  flow_layer_bwd_w(x, gy, glogJ, w, mu, off, n_mix, act, hidden, kernel_size) -> gw[params]
+  flow_layer_rev(y, w, mu, off, n_mix, act, tol, hidden, kernel_size) -> (x, logJ)         layers.py:204-210,294-320,373-396
+  ft_action_force(x, w_all, n_layers, beta, act, n_mix=2, hidden, kernel_size) -> (S_eff, logdet, F)  qed_helpers.py:212-242
+  fthmc_trajectory(x, v, u, w_all, n_layers, beta, dt, nstep, mode, act, n_mix=2, hidden, kernel_size)
+                   -> (x_new, dH, acc, plaq, Q)                        ft_hmc.py:180-224 / ipynb/ft_hmc.py:394-435
+  train_grad(xi, w_all, n_layers, beta, act, n_mix=2, hidden, kernel_size) -> (x, logq, logp, gw)     train.py:162-228
 `act` is the integer code of fthmc_hip.h (0 silu/swish, 1 relu, 2 leaky_relu); `mode` 0 = MD
-semantics, 1 = literal reference leapfrog; n_mix must be 2 (the compiled kernels).
+semantics, 1 = literal reference leapfrog.  The s/t net's shape travels IN the schema, as plain
+integers: `n_mix` mixture components, `hidden` = hidden_sizes (None = the reference default [8, 8]), `kernel_size` --
+the C ABI's fthmc_arch_t of the call; a weight tensor is a plain tensor here and carries no shape of its own.
 """
+from typing import Optional, Sequence
+
 import torch
 
 from . import ops
@@ -38,9 +42,9 @@ def _act(code: int) -> str:
     return _ACT[code]
 
 
-def _nmix(n_mix: int):
-    if n_mix != 2:
-        raise FthmcError(f'n_mix = {n_mix}: the HIP kernels are built for 2 mixture components')
+def _arch(n_mix: int, hidden, kernel_size: int):
+    """(hidden_sizes, kernel_size, n_mix) of a call from the schema's integers"""
+    return (tuple(int(h) for h in hidden) if hidden is not None else (8, 8), int(kernel_size), int(n_mix))
 
 
 @torch.library.custom_op('fthmc_hip::wilson_action_charge', mutates_args=(), device_types=_DEV)
@@ -61,63 +65,63 @@ def hmc_trajectory(x: torch.Tensor, v: torch.Tensor, u: torch.Tensor, beta: floa
 
 
 @torch.library.custom_op('fthmc_hip::flow_layer_fwd', mutates_args=(), device_types=_DEV)
-def flow_layer_fwd(x: torch.Tensor, w: torch.Tensor, mu: int, off: int, n_mix: int,
-                   act: int) -> tuple[torch.Tensor, torch.Tensor]:
-    _nmix(n_mix)
-    return ops.flow_layer_fwd(x, w, mu, off, _act(act))
+def flow_layer_fwd(x: torch.Tensor, w: torch.Tensor, mu: int, off: int, n_mix: int, act: int,
+                   hidden: Optional[Sequence[int]] = None, kernel_size: int = 3) -> tuple[torch.Tensor, torch.Tensor]:
+    return ops.flow_layer_fwd(x, w, mu, off, _act(act), arch=_arch(n_mix, hidden, kernel_size))
 
 
 @torch.library.custom_op('fthmc_hip::flow_layer_bwd_x', mutates_args=(), device_types=_DEV)
 def flow_layer_bwd_x(x: torch.Tensor, gy: torch.Tensor, glogJ: torch.Tensor, w: torch.Tensor, mu: int, off: int,
-                     n_mix: int, act: int) -> torch.Tensor:
-    _nmix(n_mix)
-    return ops.flow_layer_bwd(x, w, gy, glogJ, mu, off, _act(act), need_gw=False)[0]
+                     n_mix: int, act: int, hidden: Optional[Sequence[int]] = None, kernel_size: int = 3) -> torch.Tensor:
+    return ops.flow_layer_bwd(x, w, gy, glogJ, mu, off, _act(act), need_gw=False, arch=_arch(n_mix, hidden, kernel_size))[0]
 
 
 @torch.library.custom_op('fthmc_hip::flow_layer_bwd_w', mutates_args=(), device_types=_DEV)
 def flow_layer_bwd_w(x: torch.Tensor, gy: torch.Tensor, glogJ: torch.Tensor, w: torch.Tensor, mu: int, off: int,
-                     n_mix: int, act: int) -> torch.Tensor:
-    _nmix(n_mix)
-    return ops.flow_layer_bwd(x, w, gy, glogJ, mu, off, _act(act), need_gw=True)[1]
+                     n_mix: int, act: int, hidden: Optional[Sequence[int]] = None, kernel_size: int = 3) -> torch.Tensor:
+    return ops.flow_layer_bwd(x, w, gy, glogJ, mu, off, _act(act), need_gw=True, arch=_arch(n_mix, hidden, kernel_size))[1]
 
 
 @torch.library.custom_op('fthmc_hip::flow_layer_bwd', mutates_args=(), device_types=_DEV)
 def flow_layer_bwd(x: torch.Tensor, gy: torch.Tensor, glogJ: torch.Tensor, w: torch.Tensor, mu: int, off: int,
-                   n_mix: int, act: int) -> tuple[torch.Tensor, torch.Tensor]:
+                   n_mix: int, act: int, hidden: Optional[Sequence[int]] = None,
+                   kernel_size: int = 3) -> tuple[torch.Tensor, torch.Tensor]:
     """Both gradients from one launch (what the autograd formula of flow_layer_fwd uses)."""
-    _nmix(n_mix)
-    gx, gw = ops.flow_layer_bwd(x, w, gy, glogJ, mu, off, _act(act), need_gw=True)
+    gx, gw = ops.flow_layer_bwd(x, w, gy, glogJ, mu, off, _act(act), need_gw=True, arch=_arch(n_mix, hidden, kernel_size))
     return gx, gw
 
 
 @torch.library.custom_op('fthmc_hip::flow_layer_rev', mutates_args=(), device_types=_DEV)
-def flow_layer_rev(y: torch.Tensor, w: torch.Tensor, mu: int, off: int, n_mix: int, act: int,
-                   tol: float) -> tuple[torch.Tensor, torch.Tensor]:
-    _nmix(n_mix)
-    return ops.flow_layer_rev(y, w, mu, off, _act(act), tol)
+def flow_layer_rev(y: torch.Tensor, w: torch.Tensor, mu: int, off: int, n_mix: int, act: int, tol: float,
+                   hidden: Optional[Sequence[int]] = None, kernel_size: int = 3) -> tuple[torch.Tensor, torch.Tensor]:
+    return ops.flow_layer_rev(y, w, mu, off, _act(act), tol, arch=_arch(n_mix, hidden, kernel_size))
 
 
 @torch.library.custom_op('fthmc_hip::ft_action_force', mutates_args=(), device_types=_DEV)
-def ft_action_force(x: torch.Tensor, w_all: torch.Tensor, n_layers: int, beta: float,
-                    act: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    S, logdet, _, _ = ops.ft_action(x, w_all, n_layers, beta, _act(act))
-    return S, logdet, ops.ft_force(x, w_all, n_layers, beta, _act(act))
+def ft_action_force(x: torch.Tensor, w_all: torch.Tensor, n_layers: int, beta: float, act: int, n_mix: int = 2,
+                    hidden: Optional[Sequence[int]] = None,
+                    kernel_size: int = 3) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    a = _arch(n_mix, hidden, kernel_size)
+    S, logdet, _, _ = ops.ft_action(x, w_all, n_layers, beta, _act(act), arch=a)
+    return S, logdet, ops.ft_force(x, w_all, n_layers, beta, _act(act), arch=a)
 
 
 @torch.library.custom_op('fthmc_hip::fthmc_trajectory', mutates_args=(), device_types=_DEV)
 def fthmc_trajectory(x: torch.Tensor, v: torch.Tensor, u: torch.Tensor, w_all: torch.Tensor, n_layers: int,
-                     beta: float, dt: float, nstep: int, mode: int,
-                     act: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                     beta: float, dt: float, nstep: int, mode: int, act: int, n_mix: int = 2,
+                     hidden: Optional[Sequence[int]] = None,
+                     kernel_size: int = 3) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     if mode not in _MODE:
         raise FthmcError(f'mode: expected 0 (md) or 1 (literal), got {mode}')
-    r = ops.ft_trajectory(x, v, u, w_all, n_layers, beta, dt, nstep, _act(act), _MODE[mode])
+    r = ops.ft_trajectory(x, v, u, w_all, n_layers, beta, dt, nstep, _act(act), _MODE[mode], arch=_arch(n_mix, hidden, kernel_size))
     return r['x_new'], r['dH'], r['acc'], r['plaq'], r['Q']
 
 
 @torch.library.custom_op('fthmc_hip::train_grad', mutates_args=(), device_types=_DEV)
-def train_grad(xi: torch.Tensor, w_all: torch.Tensor, n_layers: int, beta: float,
-               act: int) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    r = ops.train_grad(xi, w_all, n_layers, beta, _act(act))
+def train_grad(xi: torch.Tensor, w_all: torch.Tensor, n_layers: int, beta: float, act: int, n_mix: int = 2,
+               hidden: Optional[Sequence[int]] = None,
+               kernel_size: int = 3) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    r = ops.train_grad(xi, w_all, n_layers, beta, _act(act), arch=_arch(n_mix, hidden, kernel_size))
     return r['x'], r['logq'], r['logp'], r['gw']
 
 
@@ -142,42 +146,42 @@ def _(x, v, u, beta, dt, nstep):
 
 
 @flow_layer_fwd.register_fake
-def _(x, w, mu, off, n_mix, act):
+def _(x, w, mu, off, n_mix, act, hidden=None, kernel_size=3):
     return torch.empty_like(x), _b(x)
 
 
 @flow_layer_bwd_x.register_fake
-def _(x, gy, glogJ, w, mu, off, n_mix, act):
+def _(x, gy, glogJ, w, mu, off, n_mix, act, hidden=None, kernel_size=3):
     return torch.empty_like(x)
 
 
 @flow_layer_bwd_w.register_fake
-def _(x, gy, glogJ, w, mu, off, n_mix, act):
+def _(x, gy, glogJ, w, mu, off, n_mix, act, hidden=None, kernel_size=3):
     return x.new_empty(w.numel())
 
 
 @flow_layer_bwd.register_fake
-def _(x, gy, glogJ, w, mu, off, n_mix, act):
+def _(x, gy, glogJ, w, mu, off, n_mix, act, hidden=None, kernel_size=3):
     return torch.empty_like(x), x.new_empty(w.numel())
 
 
 @flow_layer_rev.register_fake
-def _(y, w, mu, off, n_mix, act, tol):
+def _(y, w, mu, off, n_mix, act, tol, hidden=None, kernel_size=3):
     return torch.empty_like(y), _b(y)
 
 
 @ft_action_force.register_fake
-def _(x, w_all, n_layers, beta, act):
+def _(x, w_all, n_layers, beta, act, n_mix=2, hidden=None, kernel_size=3):
     return _b(x), _b(x), torch.empty_like(x)
 
 
 @fthmc_trajectory.register_fake
-def _(x, v, u, w_all, n_layers, beta, dt, nstep, mode, act):
+def _(x, v, u, w_all, n_layers, beta, dt, nstep, mode, act, n_mix=2, hidden=None, kernel_size=3):
     return torch.empty_like(x), _b(x), _b(x), _b(x), _b(x)
 
 
 @train_grad.register_fake
-def _(xi, w_all, n_layers, beta, act):
+def _(xi, w_all, n_layers, beta, act, n_mix=2, hidden=None, kernel_size=3):
     return torch.empty_like(xi), _b(xi), _b(xi), xi.new_empty(w_all.numel())
 
 
@@ -204,9 +208,9 @@ wilson_action_charge.register_autograd(_wilson_backward, setup_context=_wilson_s
 
 
 def _layer_setup(ctx, inputs, output):
-    x, w, mu, off, n_mix, act = inputs
+    x, w, mu, off, n_mix, act, hidden, kernel_size = inputs
     ctx.save_for_backward(x, w)
-    ctx.args = (mu, off, n_mix, act)
+    ctx.args = (mu, off, n_mix, act, hidden, kernel_size)
 
 
 def _layer_backward(ctx, gy, glogJ):
@@ -216,8 +220,8 @@ def _layer_backward(ctx, gy, glogJ):
     glogJ = torch.zeros(B, dtype=x.dtype, device=x.device) if glogJ is None else glogJ.contiguous()
     if ctx.needs_input_grad[1]:
         gx, gw = torch.ops.fthmc_hip.flow_layer_bwd(x, gy, glogJ, w, *ctx.args)
-        return gx, gw.view_as(w), None, None, None, None
-    return torch.ops.fthmc_hip.flow_layer_bwd_x(x, gy, glogJ, w, *ctx.args), None, None, None, None, None
+        return gx, gw.view_as(w), None, None, None, None, None, None
+    return torch.ops.fthmc_hip.flow_layer_bwd_x(x, gy, glogJ, w, *ctx.args), None, None, None, None, None, None, None
 
 
 flow_layer_fwd.register_autograd(_layer_backward, setup_context=_layer_setup)

@@ -210,7 +210,7 @@ class GraphTrainer:
     step, captured ONCE in a hipGraph and replayed; the metrics of every step are kept on the device (one small
     device-to-device copy per step) and come to the host when somebody looks (`metrics()`, `history()`).
 
-    Needs an optimizer whose step is capturable (torch.optim.Adam(..., capturable=True); `make_optimizer`).  With a process
+    Needs an optimizer whose step is capturable (`FlatAdam` = `make_optimizer`, or a torch one built with capturable=True).  With a process
     group (more than one rank, or FTHMC_FORCE_PG=1) the same device sequence runs eagerly, with the C2 collectives
     (gradient all-reduce, global loss mean and ESS) in it.  A ReduceLROnPlateau scheduler needs the loss on the host after
     every step and so brings one synchronisation per step back."""
@@ -234,10 +234,13 @@ class GraphTrainer:
         self.graph = None
         self.stream = torch.cuda.Stream(device=self.dev)
         flatten_flow(model.layers); flow_grad_buffer(model.layers); attach_grads(model.layers)
+        # the steps run on the trainer's own stream (a capture needs one): it starts behind whatever initialised the model and
+        # the optimizer on the caller's stream; metrics() / history() / synchronize() are where the caller waits for it
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         self.use_graph = bool(use_graph) and not parallel.have_group()
-        if self.use_graph and not all(g.get('capturable', False) for g in optimizer.param_groups):
-            raise ValueError('GraphTrainer captures optimizer.step(): build the optimizer with capturable=True '
-                             '(train.make_optimizer does), or pass use_graph=False')
+        if self.use_graph and not (getattr(optimizer, 'graph_safe', False) or all(g.get('capturable', False) for g in optimizer.param_groups)):
+            raise ValueError('GraphTrainer captures optimizer.step(): pass a FlatAdam (train.make_optimizer) or a torch '
+                             'optimizer built with capturable=True, or use_graph=False')
 
     def _enqueue(self):
         ops.random_uniform(self.seeds, self.xi.shape, -PI, PI, out=self.xi)        # MultivariateUniform(-pi, pi).sample_n
@@ -263,7 +266,11 @@ class GraphTrainer:
                 with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode='thread_local'):
                     self._enqueue()
             elif self.use_graph:
+                if hasattr(self.optimizer, 'sync_lr'):
+                    self.optimizer.sync_lr()                   # a scheduler's new rate -> the device scalar the replay reads
                 self.graph.replay()
+                if hasattr(self.optimizer, 'count_step'):
+                    self.optimizer.count_step()
             else:
                 self._enqueue()
                 attach_grads(self.model.layers)
@@ -273,6 +280,10 @@ class GraphTrainer:
                 self._flush()
             if self.scheduler is not None:
                 self.scheduler.step(float(self.row[0]))
+
+    def synchronize(self):
+        """wait for every step enqueued so far (before reading the weights on another stream)"""
+        self.stream.synchronize()
 
     def metrics(self) -> dict:
         """metrics of the last step on the host (synchronises)"""
@@ -297,16 +308,89 @@ class GraphTrainer:
         return out
 
 
+class FlatAdam(optim.Adam):
+    """torch.optim.Adam (or AdamW: decoupled=True) over the conv parameters of a flattened flow whose `step()` is ONE HIP
+    launch on the flat buffers (C ABI fthmc_adam_step: torch's single-tensor update formulas in fp64).  Step count and
+    learning rate live on the device, so a captured step can be replayed (GraphTrainer) and a scheduler's new rate reaches
+    the next replay; `state_dict()` / `load_state_dict()` keep torch's Adam layout (per-parameter step / exp_avg / exp_avg_sq),
+    so checkpoints move between this class and a plain torch optimizer either way."""
+
+    graph_safe = True
+
+    def __init__(self, layers: nn.ModuleList, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 decoupled: bool = False):
+        self._flat = flatten_flow(layers)
+        self._gflat = flow_grad_buffer(layers)
+        super().__init__(list(layers.parameters()), lr=float(lr), betas=betas, eps=eps, weight_decay=weight_decay, foreach=False)
+        self._layers, self._decoupled = layers, bool(decoupled)
+        self._m = torch.zeros_like(self._flat)
+        self._v = torch.zeros_like(self._flat)
+        self._hyper = torch.zeros(3, dtype=torch.float64, device=self._flat.device)      # [steps taken, lr, ticket]
+        self._hyper[1] = float(lr)
+        self._lr_dev = float(lr)
+        self._nstep = 0                                                                  # host mirror of _hyper[0]
+        self._view_state()
+
+    def _view_state(self):
+        o = 0
+        for p in self.param_groups[0]['params']:
+            n = p.numel()
+            self.state[p] = {'step': torch.tensor(float(self._nstep)), 'exp_avg': self._m[o:o + n].view(p.shape),
+                             'exp_avg_sq': self._v[o:o + n].view(p.shape)}
+            o += n
+
+    def sync_lr(self):
+        """param_groups[0]['lr'] (what a scheduler writes) -> the device scalar the kernel reads; a launch only when it changed"""
+        lr = float(self.param_groups[0]['lr'])
+        if lr != self._lr_dev:
+            self._hyper[1:2].fill_(lr)
+            self._lr_dev = lr
+
+    def count_step(self, n: int = 1):
+        """a step the host did not launch itself (graph replay): keep the host mirror of the step count in line"""
+        self._nstep += n
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if flatten_flow(self._layers) is not self._flat:
+            raise RuntimeError('the flow\'s parameters left their flat buffer (.to() / .cuda() after the optimizer was built): '
+                               'build the optimizer again')
+        g = self.param_groups[0]
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+            attach_grads(self._layers)
+        ops.adam_step(self._flat, self._gflat, self._m, self._v, self._hyper, betas=g['betas'], eps=g['eps'],
+                      weight_decay=g['weight_decay'], decoupled=self._decoupled)
+        if not torch.cuda.is_current_stream_capturing():
+            self._nstep += 1
+
+    def state_dict(self):
+        for st in self.state.values():
+            st['step'] = torch.tensor(float(self._nstep))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)                # torch's checks and casts; leaves copies in self.state
+        o, nstep = 0, 0
+        for p in self.param_groups[0]['params']:
+            st, n = self.state.get(p, {}), p.numel()
+            if 'exp_avg' in st:
+                self._m[o:o + n].copy_(st['exp_avg'].reshape(-1)); self._v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+                nstep = int(float(st['step']))
+            o += n
+        self._nstep = nstep
+        self._hyper[0] = float(nstep)
+        self._lr_dev = None
+        self.sync_lr()
+        self._view_state()
+
+
 def make_optimizer(model: FlowModel, config: TrainConfig, capturable: bool = True) -> optim.Optimizer:
-    """optim.Adam(model.layers.parameters(), lr=config.base_lr) (train.py:297) on the flattened parameters; capturable
-    (step count on the device, lr as a device scalar a scheduler can change between replays) and fused where the
-    device supports it, so that GraphTrainer can capture its step."""
-    flatten_flow(model.layers)
+    """optim.Adam(model.layers.parameters(), lr=config.base_lr) (train.py:297): on the GPU as `FlatAdam` -- one launch per
+    step on the flat parameter buffer, capturable -- otherwise the plain torch optimizer."""
     params = list(model.layers.parameters())
-    on_gpu = bool(params) and params[0].is_cuda
-    if capturable and on_gpu:
-        lr = torch.tensor(float(config.base_lr), dtype=torch.float64, device=params[0].device)
-        return optim.Adam(params, lr=lr, capturable=True, fused=True)
+    if capturable and params and params[0].is_cuda:
+        return FlatAdam(model.layers, lr=config.base_lr)
     return optim.Adam(params, lr=config.base_lr)
 
 

@@ -53,19 +53,29 @@ const char* fthmc_strerror(int code);
 /* text of the HIP error behind the last FTHMC_ERR_LAUNCH on this thread ("" if none) */
 const char* fthmc_last_error(void);
 
-/* Kernel variant of the coupling-layer forward / backward-wrt-x kernels (process-wide):
- * 1 (default) MFMA f64 16x16x4 implicit-GEMM convolutions, 0 fp64-VALU convolutions.
- * Same results to rounding; kept selectable for A/B measurement and cross-checks. */
+/* Kernel variant of the coupling-layer forward / backward-wrt-x kernels: 1 (default) MFMA f64 16x16x4 implicit-GEMM
+ * convolutions, 0 fp64-VALU convolutions.  Same results to rounding.  A process-wide DEBUG switch (A/B measurement and
+ * cross-checks), like fthmc_set_small_path below: each entry point reads both once, when it is entered; they are the only
+ * mutable state of the library and nothing a production caller touches. */
 int fthmc_set_variant(int v);
 int fthmc_get_variant(void);
-/* Shape of the s/t conv net of every following call: in_channels 2 -> hidden_sizes[0] -> ... -> n_mix + 1, square kernels of
- * odd size, `n_mix` mixture components (make_conv_net fthmc/utils/layers.py:138-167, make_u1_equiv_layers :399-429).  The
- * default -- (2, {8, 8}, 3, 2): the reference default and every BASELINE config -- runs on the tuned kernels; any other
- * shape runs on plain kernels (csrc/flow_generic.hip: same results, one launch per operation, activations through HBM).
- * Weights: n_layers * fthmc_arch_params() doubles, per layer [w0 b0 w1 b1 ...] in PyTorch order; fthmc_ws_bytes follows the
- * shape.  n_hidden <= 8, hidden sizes <= 256, kernel_size <= 15, n_mix <= 64; FTHMC_ERR_UNSUPPORTED otherwise. */
-int fthmc_set_arch(int n_hidden, const int* hidden_sizes, int kernel_size, int n_mix);
-int fthmc_arch_params(void);   /* 955 for the default */
+/* Shape of the s/t conv net, an ARGUMENT of every entry point that runs the net (the reference passes it to the layer
+ * constructors: make_conv_net fthmc/utils/layers.py:138-167, make_u1_equiv_layers :399-429; TrainConfig.hidden_sizes /
+ * kernel_size / n_s_nets, fthmc/config.py:283-303): in_channels 2 -> hidden[0] -> ... -> hidden[n_hidden - 1] -> n_mix + 1,
+ * square kernels of odd size, `n_mix` mixture components.  NULL = the default (2, {8, 8}, 3, 2) -- the reference default and
+ * every BASELINE config -- which runs on the tuned kernels; any other shape runs on plain kernels (csrc/flow_generic.hip:
+ * same results, one launch per operation, activations through HBM).  Weights: n_layers * fthmc_arch_params(arch) doubles,
+ * per layer [w0 b0 w1 b1 ...] in PyTorch order; the workspace sizes follow the shape.  Limits: n_hidden <= 8, hidden sizes
+ * <= 256, kernel_size <= 15 (and kernel_size / 2 <= L), n_mix <= 64; FTHMC_ERR_UNSUPPORTED otherwise.
+ * The shape is read during the call only: the library keeps no net shape between calls, two threads may run two different
+ * flows on two streams at the same time. */
+typedef struct fthmc_arch_t {
+    int n_hidden;
+    int hidden[8];
+    int kernel_size;
+    int n_mix;
+} fthmc_arch_t;
+int fthmc_arch_params(const fthmc_arch_t* arch);   /* doubles per layer; 955 for the default */
 /* Lattices of L = 8, 12, 16 take a fused path by default (csrc/flow_small.hip): one workgroup holds a whole chain in
  * LDS, and fthmc_ft_trajectory / _ft_leapfrog / _ft_force / _ft_action / _flow_forward are ONE launch each instead of
  * one launch per layer.  0 switches it off (the tiled kernels then serve every L): A/B runs and parity tests. */
@@ -73,9 +83,9 @@ int fthmc_set_small_path(int on);
 int fthmc_get_small_path(void);
 
 /* Bytes of scratch the flow / trajectory entry points need for (B, L, n_layers). */
-size_t fthmc_ws_bytes(int B, int L, int n_layers);
+size_t fthmc_ws_bytes(const fthmc_arch_t* arch, int B, int L, int n_layers);
 /* Scratch for fthmc_train_grad (larger: the forward also stashes h1, h2 of every layer). */
-size_t fthmc_train_ws_bytes(int B, int L, int n_layers);
+size_t fthmc_train_ws_bytes(const fthmc_arch_t* arch, int B, int L, int n_layers);
 
 /* ---- angle maps ------------------------------------------------------- */
 /* out = remainder(x + pi, 2 pi) - pi.  fthmc/utils/layers.py:41-43 (torch_mod),
@@ -98,7 +108,7 @@ int fthmc_wilson_force(const double* x, int B, int L, double beta, double* F, vo
 
 /* ---- plain HMC --------------------------------------------------------- */
 /* x_, p_ = leapfrog(x, p): fthmc/utils/qed_helpers.py:275-295.  x_out/p_out must
- * not alias x/p.  ws: fthmc_ws_bytes(B, L, 0). */
+ * not alias x/p.  ws: fthmc_ws_bytes(NULL, B, L, 0). */
 int fthmc_leapfrog(const double* x, const double* p, int B, int L, double beta,
                    double dt, int nstep, double* x_out, double* p_out,
                    void* ws, size_t ws_bytes, void* stream);
@@ -131,25 +141,25 @@ int fthmc_random_momenta(const int64_t* seeds, int B, int n_per_chain, double* v
 /* (y, logJ[B]) = GaugeEquivCouplingLayer.forward(x): fthmc/utils/layers.py:196-202
  * with NCPPlaqCouplingLayer.forward :348-371.  w: one layer (955 doubles).
  * y may alias x. */
-int fthmc_flow_layer_fwd(const double* x, const double* w, int B, int L, int mu, int off,
+int fthmc_flow_layer_fwd(const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off,
                          int act, double* y, double* logJ,
                          void* ws, size_t ws_bytes, void* stream);
 /* VJP of the layer wrt x: gx = d/dx [ sum(gy * y) + sum_b glogJ[b] logJ[b] ]
  * (what autograd does for fthmc/utils/qed_helpers.py:226-242 and train.py:210).
  * gw != NULL additionally returns the same VJP wrt the 955 weights; the workspace must then hold
- * fthmc_train_ws_bytes(B, L, 1). */
-int fthmc_flow_layer_bwd(const double* x, const double* w, const double* gy, const double* glogJ,
+ * fthmc_train_ws_bytes(arch, B, L, 1). */
+int fthmc_flow_layer_bwd(const double* x, const double* w, const fthmc_arch_t* arch, const double* gy, const double* glogJ,
                          int B, int L, int mu, int off, int act,
                          double* gx, double* gw,
                          void* ws, size_t ws_bytes, void* stream);
 /* The same pair for callers that keep a layer's activations between its forward and its backward (an autograd graph:
  * fthmc/utils/layers.py:196-202 under loss.backward(), train.py:210): the forward also fills `stash`
- * (fthmc_layer_stash_bytes(B, L) bytes, caller-owned), the backward reads it and recomputes nothing.
+ * (fthmc_layer_stash_bytes(arch, B, L) bytes, caller-owned), the backward reads it and recomputes nothing.
  * fthmc_layer_stash_bytes is 0 where no stash exists (fthmc_set_variant(0)): use fthmc_flow_layer_bwd there. */
-size_t fthmc_layer_stash_bytes(int B, int L);
-int fthmc_flow_layer_fwd_stash(const double* x, const double* w, int B, int L, int mu, int off, int act,
+size_t fthmc_layer_stash_bytes(const fthmc_arch_t* arch, int B, int L);
+int fthmc_flow_layer_fwd_stash(const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                                double* y, double* logJ, double* stash, void* ws, size_t ws_bytes, void* stream);
-int fthmc_flow_layer_bwd_stash(const double* stash, const double* w, const double* gy, const double* glogJ,
+int fthmc_flow_layer_bwd_stash(const double* stash, const double* w, const fthmc_arch_t* arch, const double* gy, const double* glogJ,
                                int B, int L, int mu, int off, int act, double* gx, double* gw,
                                void* ws, size_t ws_bytes, void* stream);
 /* (x, logJ[B]) = GaugeEquivCouplingLayer.reverse(y): fthmc/utils/layers.py:204-210,
@@ -157,7 +167,7 @@ int fthmc_flow_layer_bwd_stash(const double* stash, const double* w, const doubl
  * safeguarded Newton/bisection on [-pi, pi] (the reference bisects to a global
  * 1e-6, layers.py:294-320).  x may alias y (a layer rewrites only its active links, and every
  * plaquette a workgroup uses is built from links the layer leaves alone plus its own). */
-int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu, int off,
+int fthmc_flow_layer_rev(const double* y, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off,
                          int act, double tol, double* x, double* logJ,
                          void* ws, size_t ws_bytes, void* stream);
 
@@ -166,33 +176,33 @@ int fthmc_flow_layer_rev(const double* y, const double* w, int B, int L, int mu,
  * plaquettes, P at the frozen and passive ones; and its inverse NCPPlaqCouplingLayer.reverse(fP):
  * fthmc/utils/layers.py:373-396 (logJ of the inverse = -sum log dP'/dP; `tol` as fthmc_flow_layer_rev).
  * Served by the MFMA kernels only (FTHMC_ERR_UNSUPPORTED with fthmc_set_variant(0)).  logJ may be NULL. */
-int fthmc_plaq_coupling_fwd(const double* P, const double* w, int B, int L, int mu, int off, int act,
+int fthmc_plaq_coupling_fwd(const double* P, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                             double* fP, double* logJ, void* ws, size_t ws_bytes, void* stream);
-int fthmc_plaq_coupling_rev(const double* fP, const double* w, int B, int L, int mu, int off, int act,
+int fthmc_plaq_coupling_rev(const double* fP, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                             double tol, double* P, double* logJ, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- whole flow ---------------------------------------------------------- */
 /* y = F(x), logdet[B] = sum_l logJ_l.  fthmc/ft_hmc.py:143-150 (flow_forward),
  * fthmc/utils/qed_helpers.py:191-198 (ft_flow).  y, logdet may be NULL. */
-int fthmc_flow_forward(const double* x, const double* w, int n_layers, int B, int L, int act,
+int fthmc_flow_forward(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                        double* y, double* logdet, void* ws, size_t ws_bytes, void* stream);
 /* x = F^-1(y), logdet[B].  fthmc/ft_hmc.py:152-160, qed_helpers.py:201-209.  x may alias y: the last layer maps
  * y -> x and the remaining layers run in place on x (see fthmc_flow_layer_rev). */
-int fthmc_flow_reverse(const double* y, const double* w, int n_layers, int B, int L, int act,
+int fthmc_flow_reverse(const double* y, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                        double tol, double* x, double* logdet,
                        void* ws, size_t ws_bytes, void* stream);
 /* S_eff[b] = S_W(F(x)) - logdet.  fthmc/utils/qed_helpers.py:212-223 (ft_action),
  * fthmc/ft_hmc.py:135-141.  Optional outputs (NULL to skip): logdet[B],
  * plaq[B], Q[B] of the physical field F(x). */
-int fthmc_ft_action(const double* x, const double* w, int n_layers, int B, int L, int act,
+int fthmc_ft_action(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                     double beta, double* S_eff, double* logdet, double* plaq, double* Q,
                     void* ws, size_t ws_bytes, void* stream);
 /* F = d(sum_b S_eff)/dx.  fthmc/utils/qed_helpers.py:226-242 (ft_force),
  * fthmc/ft_hmc.py:162-171. */
-int fthmc_ft_force(const double* x, const double* w, int n_layers, int B, int L, int act,
+int fthmc_ft_force(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                    double beta, double* F, void* ws, size_t ws_bytes, void* stream);
 /* x_, v_ = leapfrog with ft_force.  ipynb/ft_hmc.py:394-418. */
-int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, int n_layers,
+int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, const fthmc_arch_t* arch, int n_layers,
                       int B, int L, int act, double beta, double dt, int nstep,
                       double* x_out, double* v_out, void* ws, size_t ws_bytes, void* stream);
 /* One ftHMC trajectory per chain in the latent field x with supplied v, u[B].
@@ -203,7 +213,7 @@ int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, int n_l
  * Chaining: state_out[3][B] (nullable) receives [S_eff, plaq, Q] of x_new; passing it back as
  * state_in of the next call (x = this x_new) skips the H0 flow sweep, which would recompute
  * exactly these numbers (the reference recomputes, ft_hmc.py:205).  state_in NULL = stateless. */
-int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w,
+int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch,
                         int n_layers, int B, int L, int act, double beta, double dt, int nstep,
                         int mode, double* x_new, double* dH, double* acc,
                         double* H0, double* H1, double* plaq, double* Q,
@@ -216,8 +226,8 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
  *   x = F(xi); logq = -2 L^2 log(2 pi) - logdet; logp = -S_W(x);
  *   loss = mean(logq - logp); gw = d loss / d w  (n_layers*955).
  * Outputs (any may be NULL): x[B][2][L][L], logq[B], logp[B], gw.
- * ws: fthmc_train_ws_bytes(B, L, n_layers). */
-int fthmc_train_grad(const double* xi, const double* w, int n_layers, int B, int L, int act,
+ * ws: fthmc_train_ws_bytes(arch, B, L, n_layers). */
+int fthmc_train_grad(const double* xi, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                      double beta, double* x, double* logq, double* logp, double* gw,
                      void* ws, size_t ws_bytes, void* stream);
 
@@ -231,9 +241,18 @@ int fthmc_random_uniform(const int64_t* seeds, int B, int n_per_chain, double lo
  *   row[0] = loss_dkl = dkl_factor * mean(logq - logp)       row[1] = ess = exp(2 lse(logw) - lse(2 logw)) / B
  *   row[2 + k B + b], k = 0..4:  logp, logq, q = Q(x), dq = |Q(x) - Q(xi)|, plaq = logp / (beta L^2)   of chain b
  * (2 + 5 B doubles: what train_step returns, stacked, so that a training loop copies ONE buffer to the host, when it
- * wants to look).  ws: fthmc_ws_bytes(B, L, 0). */
+ * wants to look).  ws: fthmc_ws_bytes(NULL, B, L, 0). */
 int fthmc_train_metrics(const double* xi, const double* x, const double* logq, const double* logp, int B, int L,
                         double beta, double dkl_factor, double* row, void* ws, size_t ws_bytes, void* stream);
+
+/* The optimizer step of the training loop on the flat parameter buffer: torch.optim.Adam (decoupled = 0; fthmc/train.py:297
+ * optim.Adam(model['layers'].parameters(), lr=config.base_lr)) or AdamW (decoupled = 1; train.py:86), torch's update formulas
+ * element by element, in ONE launch over all n = n_layers * params values:  w, exp_avg, exp_avg_sq updated in place from gw.
+ * hyper: THREE doubles on the device -- [0] the number of steps taken so far (the launch moves it on), [1] the learning rate,
+ * [2] scratch, zero-initialised -- so that a captured launch can be replayed step after step and a scheduler changes the
+ * rate by writing hyper[1]. */
+int fthmc_adam_step(double* w, const double* gw, double* exp_avg, double* exp_avg_sq, double* hyper, size_t n,
+                    double beta1, double beta2, double eps, double weight_decay, int decoupled, void* stream);
 
 /* ---- measurement hook (the only entry point that synchronises) ---------- */
 /* Average duration in milliseconds (host double) of `reps` back-to-back launches of one
@@ -242,25 +261,25 @@ int fthmc_train_metrics(const double* xi, const double* x, const double* logq, c
  * activation stash with the MFMA variant, recomputes the forward with the VALU variant);
  * 2: fused plain-HMC leapfrog step (Wilson force stencil); 3: whole plain-HMC trajectory of 10
  * steps in one launch (L <= 64). */
-int fthmc_time_kernel(int kind, const double* x, const double* w, int B, int L, int mu, int off,
+int fthmc_time_kernel(int kind, const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off,
                       int act, double beta, int reps, double* ms_avg_host,
                       void* ws, size_t ws_bytes, void* stream);
 
 /* Measurement hook: average milliseconds per launch of the small-lattice fused trajectory kernel (two action sweeps,
  * nstep force sweeps, Metropolis), `reps` launches back to back between two HIP events on `stream`.  Synchronises. */
-int fthmc_time_small(const double* x, const double* v, const double* u, const double* w, int n_layers, int B, int L, int act,
+int fthmc_time_small(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                      double beta, double dt, int nstep, int reps, double* ms_avg_host, void* ws, size_t ws_bytes, void* stream);
 /* Measurement hook: one trajectory on the small-lattice fused path (fthmc_set_small_path) with cycle stamps of thread 0
  * of every chain; cycles_host32[k] = mean over chains of the cycles spent in stage k, summed over the trajectory
  * (0..6 forward layer stages, 8..13 backward layer stages, 16 copy, 17 Wilson seed, 18 kick, 19 action / charge).
  * Synchronises. */
-int fthmc_small_profile(const double* x, const double* v, const double* u, const double* w, int n_layers, int B, int L,
+int fthmc_small_profile(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L,
                         int act, double beta, double dt, int nstep, double* cycles_host32, void* ws, size_t ws_bytes,
                         void* stream);
 /* Diagnostic (synchronises, mallocs on the host): one launch of the MFMA forward (kind 0), stash backward
  * (kind 1) or training backward (kind 2, ws: fthmc_train_ws_bytes) kernel with per-workgroup cycle stamps at every stage boundary;
  * cycles_host16[k] = mean cycles spent between stamp k-1 and stamp k. */
-int fthmc_profile_stages(int kind, const double* x, const double* w, int B, int L, int mu, int off,
+int fthmc_profile_stages(int kind, const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off,
                          int act, double beta, double* cycles_host16,
                          void* ws, size_t ws_bytes, void* stream);
 

@@ -25,7 +25,14 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f'{name} has no ctypes signature'
     assert set(_lib.SIGNATURES) <= declared
     assert lib.fthmc_version().startswith(b'fthmc_hip')
-    assert lib.fthmc_ws_bytes(128, 64, 8) > 128 * 2 * 64 * 64 * 8 * 9
+    assert lib.fthmc_ws_bytes(None, 128, 64, 8) > 128 * 2 * 64 * 64 * 8 * 9
+    # the net shape is an argument of the call (fthmc_arch_t), sizes follow it, limits are refused, nothing is remembered
+    from fthmc_amd import ops
+    assert lib.fthmc_arch_params(None) == 955 == lib.fthmc_arch_params(ops._arch(((8, 8), 3, 2)) or None)
+    assert lib.fthmc_arch_params(ops._arch(((4, 6, 5), 5, 1))) == ops.arch_params(((4, 6, 5), 5, 1))
+    assert lib.fthmc_ws_bytes(ops._arch(((16, 16), 3, 2)), 8, 16, 4) != lib.fthmc_ws_bytes(None, 8, 16, 4) > 0
+    assert lib.fthmc_arch_params(ops._arch(((8, 8), 17, 2))) < 0 and lib.fthmc_ws_bytes(ops._arch(((8, 8), 4, 2)), 8, 16, 4) == 0
+    assert lib.fthmc_arch_params(None) == 955
     assert b'workspace' in lib.fthmc_strerror(-4)
 
 
@@ -372,7 +379,12 @@ def test_net_shapes_and_their_limits():
     with pytest.raises(FthmcError, match='share the net shape'):
         ops.pack_weights([w, w3])
     header = open(os.path.join(ROOT, 'include', 'fthmc_hip.h')).read()
-    assert 'fthmc_set_arch' in header and 'FTHMC_ERR_UNSUPPORTED' in header
+    assert 'fthmc_arch_t' in header and 'fthmc_set_arch' not in header and 'FTHMC_ERR_UNSUPPORTED' in header
+    # no mutable global in the kernel sources but the debug switches (variant, small path, leapfrog rows)
+    import glob
+    for f in glob.glob(os.path.join(ROOT, 'fthmc_amd', 'csrc', '*.hip')):
+        src = open(f).read()
+        assert 'g_arch' not in src and 'g_wcan' not in src, f
 
 
 def _device_code_objects(path, tmp):

@@ -403,12 +403,15 @@ def test_generic_net_shapes_against_the_oracle(hidden, k, n_mix, L, nl, act):
     angle_close(fP, fPc, atol=1e-11); close(lj, ljc, rtol=1e-11, atol=1e-11)
     Pb, _ = ops.plaq_coupling_rev(fP, ops.pack_weights([flow[0]], device='cuda'), 0, 0, act)
     angle_close(Pb, P, atol=1e-9)
-    # back to the default shape: the tuned kernels again (the library's shape is process-global state)
+    # a default-shaped flow right behind it: the shape is an argument of each call, the library remembers nothing
     fd = R.default_flow(2, gen)
     wd = ops.pack_weights(fd, device='cuda')
     xq = (torch.rand(2, 2, 8, 8, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
     close(ops.ft_force(xq.cuda(), wd, 2, beta), R.ft_force(xq, fd, beta), rtol=1e-10, atol=1e-10)
-    assert ops._ARCH[0] == ops.DEFAULT_ARCH
+    # the shape given explicitly to a PLAIN tensor (a clone drops pack_weights' tag) == the tagged call
+    wp = w.clone()
+    assert ops.arch_of(wp) == ops.DEFAULT_ARCH
+    assert torch.equal(ops.ft_force(x.cuda(), wp, nl, beta, act, arch=(hidden, k, n_mix)), ops.ft_force(x.cuda(), w, nl, beta, act))
 
 
 @pytest.mark.parametrize('tag', ['a', 'b'])

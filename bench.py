@@ -159,16 +159,18 @@ def host_threads():
 
 
 def csrc_sha16():
-    """Fingerprint of the kernel sources this library was built from (fthmc_amd/csrc/*.hip, *.h, in name order):
-    tools/pmc_summary.py stores it with a counter summary, and a summary taken on other kernels is reported stale."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, 'fthmc_amd', 'csrc')
-    for name in sorted(os.listdir(d)):
-        if name.endswith(('.hip', '.h')):
-            with open(os.path.join(d, name), 'rb') as f:
-                h.update(name.encode() + b'\0' + f.read())
-    return h.hexdigest()[:16]
+    """Fingerprint of the kernel sources on disk (tools/csrc_sha.py: fthmc_amd/csrc/*.hip, *.h in name order)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from csrc_sha import csrc_sha16 as f
+    return f(ROOT)
+
+
+def lib_sha16():
+    """Fingerprint of the sources the LOADED library was built from (built in by csrc/Makefile, reported by fthmc_version());
+    differs from csrc_sha16() for a library that was not rebuilt after an edit, or an A/B build loaded through FTHMC_LIB."""
+    from fthmc_amd import _lib
+    v = _lib.load().fthmc_version().decode()
+    return v.split(' src ')[-1] if ' src ' in v else None
 
 
 def pmc_traffic(kernel):
@@ -184,7 +186,9 @@ def pmc_traffic(kernel):
         k = next(v for n, v in d['kernels'].items() if kernel in n)
         return (round((k['FETCH_SIZE']['mean_per_launch'] + k['WRITE_SIZE']['mean_per_launch']) * 1024),
                 {'file': 'profiles/' + names[-1], 'commit': d.get('commit'), 'launch_shape': d.get('launch_shape'),
-                 'csrc_sha16': d.get('csrc_sha16'), 'stale': d.get('csrc_sha16') != csrc_sha16()})
+                 'csrc_sha16': d.get('csrc_sha16'), 'library_sha16': lib_sha16(),
+                 # stale: the summary was taken on other kernels than the ones the loaded library was built from
+                 'stale': d.get('csrc_sha16') != lib_sha16(), 'library_matches_sources': lib_sha16() == csrc_sha16()})
     except Exception:
         return None, None
 
@@ -299,13 +303,16 @@ def main():
     state = torch.stack([S0, p0, q0]).contiguous()      # (S_eff, plaq, Q) of the current x, carried along
     out['state'] = state
 
-    def enqueue():
-        """momentum refresh + one trajectory of every chain of this GPU, forked from the current stream"""
+    def enqueue(stateless=False):
+        """momentum refresh + one trajectory of every chain of this GPU, forked from the current stream.
+        stateless: H0 is recomputed by a flow sweep at the start of the trajectory, as the reference does (ft_hmc.py:205),
+        instead of being carried over from the previous trajectory's H1 (bit-identical numbers either way)."""
         ops.random_momenta(seeds, x.shape, out_v=v, out_u=u)
         if flowed:
             # in place: the accepted field replaces x, its (S_eff, plaq, Q) replace the carried state (the C ABI allows
             # x_new == x and state_out == state_in: both are read before they are written)
-            ops.ft_trajectory(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=state, groups=Gsplit)
+            ops.ft_trajectory(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=None if stateless else state,
+                              groups=Gsplit)
         else:
             r = ops.hmc_trajectory(x, v, u, BETA, dt, NSTEP)
             for k in ('x_new', 'dH', 'acc', 'H0', 'H1'):
@@ -317,7 +324,7 @@ def main():
             x.copy_(out['x_new'])
         stats.add_device(out['acc'], out['plaq'], out['Q'], qold, out['dH'])      # one launch; also qold <- Q
 
-    graph = None
+    graph = graph_sl = None
     if not args.no_graph:
         # the launches of a trajectory (~200 with the flow) are captured once and replayed (launch-bound otherwise)
         with torch.cuda.stream(stream):
@@ -328,16 +335,20 @@ def main():
             # thread_local: the process group's watchdog thread may poll its events while this thread captures
             with torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
                 enqueue()
+            if flowed:                      # the stateless variant of the same trajectory, for the side figure below
+                graph_sl = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_sl, stream=stream, capture_error_mode='thread_local'):
+                    enqueue(stateless=True)
 
     traj = [0]
     pending = [None]
 
-    def step():
+    def step(stateless=False):
         seeds.copy_(parallel.chain_seeds(SEED, lo, hi, traj[0]).to(dev, non_blocking=True))
         if graph is not None:
-            graph.replay()
+            (graph_sl if stateless else graph).replay()
         else:
-            enqueue()
+            enqueue(stateless)
         if pending[0] is not None:
             pending[0].wait()
         pending[0] = stats.reduce(async_op=grouped)
@@ -350,12 +361,12 @@ def main():
 
     log(f'rank {rank}/{world}: config {args.config}, {B} chains here / {B_total} in total, groups {G}, '
         f'graph={"yes" if graph is not None else "no"}; warmup {args.warmup}')
-    def region():
+    def region(stateless=False):
         """EXACTLY --steps trajectories between two (barrier + device synchronize) brackets; seconds, MAX over ranks"""
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            step(stateless)
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
@@ -378,6 +389,8 @@ def main():
         nreg = args.regions if args.regions else (5 if times[0] < 1.0 else 1)
         while len(times) < nreg:
             times.append(region())
+        # side figure: the same trajectories with H0 recomputed (one more flow sweep per trajectory), one region
+        elapsed_sl = region(stateless=True) if flowed else None
     elapsed = sorted(times)[len(times) // 2]
     if args.dump:
         import numpy as np
@@ -412,12 +425,45 @@ def main():
             torch.distributed.all_reduce(tt_t, op=torch.distributed.ReduceOp.MAX)
         tt = float(tt_t)
         tflops = N_LAYERS * L * L * TRAIN_FLOPS_PER_SITE * B_total * nt / tt / 1e12
+
+        def train_wall(Lw, Bw, nlw, betaw, steps_w):
+            """wall milliseconds per WHOLE training step (prior draw on the device, fthmc_train_grad, metrics, Adam on the flat
+            parameter buffer; with a process group also the C2 all-reduces) through train.GraphTrainer, MAX over ranks"""
+            from fthmc_amd import train as T
+            from fthmc_amd.config import TrainConfig
+            tc = TrainConfig(L=Lw, beta=betaw, n_layers=nlw, batch_size=Bw, base_lr=1e-3, print_freq=0)
+            torch.manual_seed(SEED)
+            model = T.get_model(tc)
+            tr = T.GraphTrainer(model, tc, T.make_optimizer(model, tc), Bw, seed=SEED + 31)
+            for _ in range(3):
+                tr.step()
+            tr.synchronize(); barrier()
+            t0_ = time.perf_counter()
+            for _ in range(steps_w):
+                tr.step()
+            tr.synchronize(); barrier()
+            tw = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
+            if grouped:
+                torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
+            m_ = tr.metrics()
+            del tr, model
+            return float(tw) / steps_w * 1e3, bool(np.isfinite(m_['loss_dkl'])), ('hipGraph replay' if not grouped else 'eager + collectives')
+        import numpy as np
+        wall_ms, wall_ok, wall_mode = train_wall(L, B, N_LAYERS, BETA, nt)
+        small_ms, small_ok, _ = train_wall(16, 512, 8, 4.0, 100)
+        ops.release_workspaces()
         train = {'train_steps_per_s': round(nt / tt, 3), 'ms_per_train_step': round(tt / nt * 1e3, 3),
+                 'wall_ms_per_train_step': round(wall_ms, 3), 'wall_over_compute': round(wall_ms / (tt / nt * 1e3), 4),
+                 'wall': {'what': 'whole steps of fthmc.train (GraphTrainer: prior draw, fthmc_train_grad, metrics, FlatAdam), '
+                                  'no host synchronisation inside the loop', 'launch': wall_mode, 'loss_finite': wall_ok},
+                 'wall_L16_B512_8layers': {'ms_per_train_step': round(small_ms, 4), 'loss_finite': small_ok,
+                                           'note': 'the size the reference trains at before transfer_to_new_lattice (train.py:434-455)'},
                  'batch_total': B_total, 'steps': nt,
                  'algorithmic_flops_per_sample_step': N_LAYERS * L * L * TRAIN_FLOPS_PER_SITE,
                  'achieved_TFLOPs': round(tflops, 3), 'frac_of_fp64_peak': round(tflops / (FP64_PEAK_TFLOPS * world), 4),
-                 'note': 'fthmc_train_grad (forward with stash, backward with MFMA weight gradients) + gradient '
-                         'all-reduce; the optimizer step (torch Adam on 15 280 parameters) is host-side and excluded'}
+                 'note': 'ms_per_train_step / train_steps_per_s: fthmc_train_grad (forward with stash, backward with MFMA weight '
+                         'gradients) + gradient all-reduce on a fixed draw; wall_ms_per_train_step: whole steps incl. the prior draw, '
+                         'the metrics and the optimizer'}
     if rank != 0:
         if grouped:
             torch.distributed.destroy_process_group()
@@ -604,6 +650,10 @@ def main():
                    'path': 'small-lattice fused (one launch per trajectory)' if (flowed and L <= 16 and ops.get_small_path()) else
                            ('tiled, one launch per layer' if flowed else 'plain HMC, one launch per trajectory')},
         'batched_leapfrog_steps_per_s': round(NSTEP * args.steps / elapsed, 3),
+        'stateless': (None if elapsed_sl is None else
+                      {'ms_per_step': round(elapsed_sl / args.steps * 1e3, 4), 'value': round(chain_steps / elapsed_sl, 2),
+                       'note': 'H0 recomputed by a flow sweep at the start of every trajectory, as the reference does '
+                               '(ft_hmc.py:205); `value` carries S_eff of the accepted field over instead (bit-identical)'}),
         'regions': {'n': len(times), 'seconds': [round(t, 7) for t in times], 'value_from': 'median region',
                     'spread': round((max(times) - min(times)) / elapsed, 4),
                     'note': f'each region = exactly {args.steps} trajectories between barrier + synchronize brackets, '

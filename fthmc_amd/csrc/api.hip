@@ -253,7 +253,11 @@ int leapfrog_ws(const double* x, const double* p, const WS& w, int B, int L, dou
 
 extern "C" {
 
-const char* fthmc_version(void) { return "fthmc_hip 0.1 (gfx950)"; }
+#ifndef FTHMC_SRC_SHA
+#define FTHMC_SRC_SHA "unknown"
+#endif
+// "... src <fingerprint>": the kernel sources this library was built from (tools/csrc_sha.py, csrc/Makefile)
+const char* fthmc_version(void) { return "fthmc_hip 0.4 (gfx950) src " FTHMC_SRC_SHA; }
 
 int fthmc_set_variant(int v) {
     if (v != 0 && v != 1) return FTHMC_ERR_ARG;

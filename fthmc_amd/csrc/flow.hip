@@ -579,22 +579,26 @@ __global__ void k_adj_add(const double* __restrict__ gp, const double* __restric
 }
 
 // out[g][idx] = scale * sum over the g-th chunk of partials part[p][idx] (p in [g*chunk, (g+1)*chunk));
-// 64 idx x 4 slices per block, fixed order.  Run twice (partials -> REDUCE_GROUPS rows -> 1 row)
-// so that thousands of per-tile partials are summed by REDUCE_GROUPS x 15 workgroups instead of 15.
-__global__ void k_reduce_gw(const double* __restrict__ part, int np, int chunk, double scale, int accumulate,
-                            double* __restrict__ out) {
-    __shared__ double red[256];
+// 64 idx x RG_SL slices per block, fixed order.  Run twice (partials -> groups of <= 32 rows -> 1 row) so that a thread
+// sums a handful of rows: each load is a dependent 7.7 KB-strided access, and with one level and four slices a training
+// step at L = 16, batch 512 spent half of its GPU time here (128 back-to-back loads per thread, 39 us per layer).
+constexpr int RG_SL = 16;
+__global__ __launch_bounds__(64 * RG_SL) void k_reduce_gw(const double* __restrict__ part, int np, int chunk, double scale,
+                                                          int accumulate, double* __restrict__ out) {
+    __shared__ double red[64 * RG_SL];
     const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + li;
     const int g = blockIdx.y;
     const int p0 = g * chunk, p1 = min(np, p0 + chunk);
     double a = 0.0;
     if (idx < FTHMC_W_PER_LAYER)
-        for (int p = p0 + sl; p < p1; p += 4) a += part[(size_t)p * FLOW_GW_STRIDE + idx];
+        for (int p = p0 + sl; p < p1; p += RG_SL) a += part[(size_t)p * FLOW_GW_STRIDE + idx];
     red[threadIdx.x] = a;
     __syncthreads();
     if (sl == 0 && idx < FTHMC_W_PER_LAYER) {
-        const double t = ((red[li] + red[64 + li]) + red[128 + li]) + red[192 + li];
+        double t = red[li];
+#pragma unroll
+        for (int k = 1; k < RG_SL; ++k) t += red[64 * k + li];
         double* o = out + (size_t)g * FLOW_GW_STRIDE + idx;
         *o = (accumulate ? *o : 0.0) + scale * t;
     }
@@ -642,14 +646,17 @@ int launch_adj_add(const double* gp, const double* gy, int B, int L, double* gx,
 int launch_reduce_gw(const double* gw_part, int nparts, double scale, int accumulate, double* gw,
                      double* tmp, hipStream_t s) {
     const int nb = (FTHMC_W_PER_LAYER + 63) / 64;
-    if (nparts <= 4 * FLOW_REDUCE_GROUPS || !tmp) {
-        hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1), dim3(256), 0, s, gw_part, nparts, nparts, scale, accumulate, gw);
+    if (nparts <= 4 * RG_SL || !tmp) {                     // a thread sums at most four rows: one level
+        hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1), dim3(64 * RG_SL), 0, s, gw_part, nparts, nparts, scale, accumulate, gw);
         FT_LAUNCH_CHECK(); return FTHMC_OK;
     }
-    const int chunk = (nparts + FLOW_REDUCE_GROUPS - 1) / FLOW_REDUCE_GROUPS;
-    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, FLOW_REDUCE_GROUPS), dim3(256), 0, s, gw_part, nparts, chunk, 1.0, 0, tmp);
+    // groups of ~32 rows (two per thread), at most FLOW_REDUCE_GROUPS of them (the size of tmp)
+    int groups = (nparts + 31) / 32; if (groups > FLOW_REDUCE_GROUPS) groups = FLOW_REDUCE_GROUPS;
+    const int chunk = (nparts + groups - 1) / groups;
+    groups = (nparts + chunk - 1) / chunk;
+    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, groups), dim3(64 * RG_SL), 0, s, gw_part, nparts, chunk, 1.0, 0, tmp);
     FT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1), dim3(256), 0, s, tmp, FLOW_REDUCE_GROUPS, FLOW_REDUCE_GROUPS, scale, accumulate, gw);
+    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1), dim3(64 * RG_SL), 0, s, tmp, groups, groups, scale, accumulate, gw);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

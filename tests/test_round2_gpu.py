@@ -171,7 +171,7 @@ def test_flow_reverse_in_place_and_out_of_place_agree():
     from fthmc_amd import _lib
     y2 = y.clone(); ld2 = torch.empty_like(ld1)
     wsb = torch.empty(ops.ws_bytes(B, L, nl) // 8 + 1, dtype=torch.float64, device='cuda')
-    rc = _lib.load().fthmc_flow_reverse(y2.data_ptr(), w.data_ptr(), nl, B, L, 0, 1e-12, y2.data_ptr(), ld2.data_ptr(),
+    rc = _lib.load().fthmc_flow_reverse(y2.data_ptr(), w.data_ptr(), None, nl, B, L, 0, 1e-12, y2.data_ptr(), ld2.data_ptr(),
                                         wsb.data_ptr(), wsb.numel() * 8, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     torch.cuda.synchronize()

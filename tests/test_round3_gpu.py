@@ -206,13 +206,13 @@ def test_layer_calls_with_output_aliasing_input(variant):
             wl = w[li * 955:(li + 1) * 955].contiguous()
             y, lj = ops.flow_layer_fwd(x, wl, mu, off)
             xa = x.clone(); lja = torch.empty_like(lj)
-            assert lib.fthmc_flow_layer_fwd(xa.data_ptr(), wl.data_ptr(), B, L, mu, off, 0, xa.data_ptr(), lja.data_ptr(),
+            assert lib.fthmc_flow_layer_fwd(xa.data_ptr(), wl.data_ptr(), None, B, L, mu, off, 0, xa.data_ptr(), lja.data_ptr(),
                                             wsb.data_ptr(), wsb.numel() * 8, st) == 0
             torch.cuda.synchronize()
             assert torch.equal(xa, y) and torch.equal(lja, lj), (mu, off)
             xr, ljr = ops.flow_layer_rev(y, wl, mu, off)
             ya = y.clone(); ljb = torch.empty_like(lj)
-            assert lib.fthmc_flow_layer_rev(ya.data_ptr(), wl.data_ptr(), B, L, mu, off, 0, 1e-12, ya.data_ptr(), ljb.data_ptr(),
+            assert lib.fthmc_flow_layer_rev(ya.data_ptr(), wl.data_ptr(), None, B, L, mu, off, 0, 1e-12, ya.data_ptr(), ljb.data_ptr(),
                                             wsb.data_ptr(), wsb.numel() * 8, st) == 0
             torch.cuda.synchronize()
             assert torch.equal(ya, xr) and torch.equal(ljb, ljr), (mu, off)

@@ -24,9 +24,11 @@ COMMIT = None
 
 
 def csrc_sha16():
+    """fingerprint of the sources the library that was PROFILED was built from (FTHMC_LIB or the in-tree one), as the library
+    reports it; falls back to the sources on disk for a library without one"""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    return bench.csrc_sha16()
+    return bench.lib_sha16() or bench.csrc_sha16()
 
 
 def main(src, dst):

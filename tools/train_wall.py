@@ -41,12 +41,14 @@ def wall(L, B, nl, steps):
     # (c) compute only: fthmc_train_grad on a fixed draw
     xi = model.prior.sample_n(B)
     w = qed.flow_weights(model.layers, xi.device)
-    for _ in range(3):
-        ops.train_grad(xi, w, nl, beta, groups=ops.default_groups(B, L))
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(steps):
-        ops.train_grad(xi, w, nl, beta, groups=ops.default_groups(B, L))
-    torch.cuda.synchronize(); out['train_grad_only_ms'] = (time.perf_counter() - t0) / steps * 1e3
+    for G in (ops.default_groups(B, L), 1, 2):
+        for _ in range(3):
+            ops.train_grad(xi, w, nl, beta, groups=G)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            ops.train_grad(xi, w, nl, beta, groups=G)
+        torch.cuda.synchronize()
+        out['train_grad_only_ms' if G == ops.default_groups(B, L) and 'train_grad_only_ms' not in out else f'train_grad_groups{G}_ms'] = (time.perf_counter() - t0) / steps * 1e3
     ops.release_workspaces()
     return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()}
 

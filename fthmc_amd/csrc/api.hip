@@ -69,12 +69,16 @@ WS ws_layout(const FlowArch& A, double* base, int B, int L, int nl, bool train =
     w.lj_part = take((size_t)(nl > 0 ? nl : 1) * B * nt);               // logJ partials [layer][chain][tile] of a sweep
     w.scal = take((size_t)SC_N * B);
     w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
-    w.gw_part = take(nl > 0 ? (size_t)B * nt * FLOW_GW_STRIDE : 0);
-    w.gw_tmp = take(nl > 0 ? (size_t)FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE : 0);
+    // small lattices in training: the weight-gradient partials (and reduction rows) of ALL layers at once
+    const size_t nlw = train && A.is_default() && ft_small_shape(L, nl) ? (size_t)nl : 1;
+    w.gw_part = take(nl > 0 ? nlw * B * nt * FLOW_GW_STRIDE : 0);
+    w.gw_tmp = take(nl > 0 ? nlw * FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE : 0);
     const bool gen = !A.is_default();
     // activation stash of a force evaluation (generic shapes: every layer's planes, at least one region as scratch)
     w.stash = take(gen ? (size_t)(nl > 0 ? nl : 1) * A.stash_doubles(B, L) : (size_t)nl * flow_stash_doubles(B, L, train));
-    w.gz = take(train && nl > 0 && !gen ? flow_gz_doubles(B, L) : 0);   // training: pre-activation gradients of the layer in flight
+    // training: pre-activation gradients of the layer in flight; small lattices (flow_small.hip: one launch runs all layers
+    // forward and backward): of every layer
+    w.gz = take(train && nl > 0 && !gen ? flow_gz_doubles(B, L) * (ft_small_shape(L, nl) ? (size_t)nl : 1) : 0);
     w.hbuf = take(gen ? (size_t)B * A.cmax() * L * L : 0);
     w.gbuf = take(gen ? (size_t)2 * B * A.cmax() * L * L : 0);
     w.total = o;
@@ -748,6 +752,21 @@ int fthmc_train_grad(const double* xi, const double* w, const fthmc_arch_t* arch
     if (!ws || ws_bytes < ws_doubles(C.A, B, L, n_layers, true) * sizeof(double)) return FTHMC_ERR_WS;
     const WS W = ws_layout(C.A, static_cast<double*>(ws), B, L, n_layers, true);
     FT_TRY(use_weights(C, w, n_layers, W, s));
+    if (gw && C.small(L, n_layers)) {
+        // small lattices: ONE launch runs the forward sweep (stash + h1, h2 + log J), the loss pieces and the backward sweep of
+        // every chain (flow_small.hip, training sweep); then the weight gradients layer by layer from the gz it left behind
+        SmallArgs a = small_args(xi, W, n_layers, B, act, beta, 4);
+        a.x_out = x; a.logq = logq; a.logp = logp; a.gz = W.gz;
+        FT_TRY(launch_ft_small(a, L, s));
+        FlowLayerArgs f{};                                            // every layer's weight gradient in ONE launch + one reduction
+        f.stash = W.stash; f.gz = W.gz; f.gw_part = W.gw_part;
+        f.B = B; f.L = L; f.act = act;
+        f.nlb = n_layers;
+        f.stash_lstride = flow_stash_doubles(B, L, true); f.gz_lstride = flow_gz_doubles(B, L);
+        f.gwp_lstride = (size_t)B * flow_wgrad_parts(L) * FLOW_GW_STRIDE;
+        FT_TRY(launch_flow_wgrad(f, s));
+        return launch_reduce_gw(W.gw_part, B * flow_wgrad_parts(L), 1.0, 0, gw, W.gw_tmp, s, n_layers, f.gwp_lstride);
+    }
     double* ld = W.scal + (size_t)SC_LOGDET * B;
     double* S = W.scal + (size_t)SC_S * B;
     // one forward sweep serves both the outputs (x, logq, logp) and the backward pass; with the MFMA

@@ -584,11 +584,14 @@ __global__ void k_adj_add(const double* __restrict__ gp, const double* __restric
 // step at L = 16, batch 512 spent half of its GPU time here (128 back-to-back loads per thread, 39 us per layer).
 constexpr int RG_SL = 16;
 __global__ __launch_bounds__(64 * RG_SL) void k_reduce_gw(const double* __restrict__ part, int np, int chunk, double scale,
-                                                          int accumulate, double* __restrict__ out) {
+                                                          int accumulate, double* __restrict__ out, size_t part_lstride,
+                                                          size_t out_lstride) {
     __shared__ double red[64 * RG_SL];
     const int li = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + li;
     const int g = blockIdx.y;
+    part += (size_t)blockIdx.z * part_lstride;               // several layers in one launch: blockIdx.z = layer
+    out += (size_t)blockIdx.z * out_lstride;
     const int p0 = g * chunk, p1 = min(np, p0 + chunk);
     double a = 0.0;
     if (idx < FTHMC_W_PER_LAYER)
@@ -644,19 +647,23 @@ int launch_adj_add(const double* gp, const double* gy, int B, int L, double* gx,
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_reduce_gw(const double* gw_part, int nparts, double scale, int accumulate, double* gw,
-                     double* tmp, hipStream_t s) {
+                     double* tmp, hipStream_t s, int nlayers, size_t part_lstride) {
     const int nb = (FTHMC_W_PER_LAYER + 63) / 64;
+    const unsigned nz = nlayers > 1 ? nlayers : 1;
     if (nparts <= 4 * RG_SL || !tmp) {                     // a thread sums at most four rows: one level
-        hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1), dim3(64 * RG_SL), 0, s, gw_part, nparts, nparts, scale, accumulate, gw);
+        hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1, nz), dim3(64 * RG_SL), 0, s, gw_part, nparts, nparts, scale, accumulate, gw,
+                           part_lstride, (size_t)FTHMC_W_PER_LAYER);
         FT_LAUNCH_CHECK(); return FTHMC_OK;
     }
     // groups of ~32 rows (two per thread), at most FLOW_REDUCE_GROUPS of them (the size of tmp)
     int groups = (nparts + 31) / 32; if (groups > FLOW_REDUCE_GROUPS) groups = FLOW_REDUCE_GROUPS;
     const int chunk = (nparts + groups - 1) / groups;
     groups = (nparts + chunk - 1) / chunk;
-    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, groups), dim3(64 * RG_SL), 0, s, gw_part, nparts, chunk, 1.0, 0, tmp);
+    const size_t tmp_l = (size_t)FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE;
+    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, groups, nz), dim3(64 * RG_SL), 0, s, gw_part, nparts, chunk, 1.0, 0, tmp, part_lstride, tmp_l);
     FT_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1), dim3(64 * RG_SL), 0, s, tmp, groups, groups, scale, accumulate, gw);
+    hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1, nz), dim3(64 * RG_SL), 0, s, tmp, groups, groups, scale, accumulate, gw, tmp_l,
+                       (size_t)FTHMC_W_PER_LAYER);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

@@ -294,12 +294,12 @@ struct BlockTile { int b, tile, ti, tj; };
 // grid = (8 * ntj, nti, ceil(B / 8)): the linear block id the dispatcher deals round-robin over the 8 XCDs is
 // x + gridDim.x * (y + gridDim.y * z) and gridDim.x is a multiple of 8, so XCD = blockIdx.x & 7; the rest
 // of the coordinates come out of the block index without a division.
-__device__ __forceinline__ bool block_tile(int B, int nti, int ntj, BlockTile& t) {
+__device__ __forceinline__ bool block_tile(int B, int nti, int ntj, BlockTile& t, int zb = -1) {   // zb: the chain group when blockIdx.z carries more (layers)
     const int xcd = blockIdx.x & 7;
     t.tj = blockIdx.x >> 3;
     t.ti = blockIdx.y;
     t.tile = t.ti * ntj + t.tj;
-    t.b = blockIdx.z * 8 + xcd;
+    t.b = (zb < 0 ? (int)blockIdx.z : zb) * 8 + xcd;
     return t.b < B;
 }
 inline dim3 xcd_grid(int B, int nti, int ntj) { return dim3(8 * ntj, nti, (B + 7) / 8); }

@@ -113,6 +113,7 @@ struct Hot {
     double* stash;
     long long* dbg;
     int B, nl, act;
+    double* gz;              // training sweep: the pre-activation gradients of every layer (null otherwise)
 };
 __device__ __forceinline__ const SmallArgs& cold() {
     const SmallArgs* p = (const SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // the one explicit kernel argument, offset 0
@@ -123,7 +124,9 @@ __device__ __forceinline__ const SmallArgs& cold() {
 // the stash values a backward pass multiplies by, loaded one pass ahead
 struct BwdPre { double tcv[4 * NMIX], fcs, fsn, d2v[4], d1v[4]; };
 
-template <int L> struct Chain {
+// TRAIN: the instance that runs training sweeps (stashes h1, h2, writes the pre-activation gradients); a template parameter so
+// that the trajectory / force instances carry none of it (the kernel is register- and SGPR-bound)
+template <int L, bool TRAIN> struct Chain {
     using G = GS<L>;
     static constexpr int NWC = (LF_LDS + NT - 1) / NT;         // weight-block doubles per thread (LF_LDS >= LB_SIZE)
     double* sm;
@@ -152,7 +155,14 @@ template <int L> struct Chain {
     __device__ __forceinline__ double* stash(int l) const {
         double* p = A.stash; int B_ = A.B;
         asm volatile("" : "+s"(p), "+s"(B_));
-        return p + (size_t)l * ((size_t)B_ * 19 * L * L);                  // kernels.h flow_stash_doubles
+        return p + (size_t)l * ((size_t)B_ * (TRAIN ? 35 : 19) * L * L);   // kernels.h flow_stash_doubles (training: + h1, h2)
+    }
+    // training sweep: this chain's slice of layer l's pre-activation gradients (kernels.h FlowLayerArgs::gz): gz2 [n][8],
+    // gz1 [n][8] channel-minor, g_out [n/4][4]
+    __device__ __forceinline__ double* gz(int l) const {
+        double* p = A.gz; int B_ = A.B, c = b;
+        asm volatile("" : "+s"(p), "+s"(B_), "+s"(c));
+        return p + ((size_t)l * B_ + c) * (size_t)(17 * L * L);
     }
     __device__ __forceinline__ double* sW() const { return sm + G::SW + wcur * LF_LDS; }
 
@@ -245,6 +255,9 @@ template <int L> struct Chain {
 
         double* const st_d1 = STASH ? sv.d1 + 2 * (lane >> 4) : nullptr;
         double* const st_d2 = STASH ? sv.d2 + 2 * (lane >> 4) : nullptr;
+        const bool HST = TRAIN && STASH;                                   // training: the weight gradients need h1, h2
+        double* const st_h1 = HST ? sv.h1 + 2 * (lane >> 4) : nullptr;
+        double* const st_h2 = HST ? sv.h2 + 2 * (lane >> 4) : nullptr;
         // ---- conv1 (2 -> 8) + act on the frozen taps: pairs across the stripe lines (columns for mu = 0, rows for mu = 1)
         {
             // K = 2 frozen lines x 3 taps along x 2 channels = 3 MFMA steps; the constant lines (cos, sin) = (1, 0) are in the
@@ -275,6 +288,10 @@ template <int L> struct Chain {
                     const int at = pr * L + pc;
                     *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)at) = double2_t{d[0], d[1]};
                     *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dr * L + dc)) = double2_t{d[2], d[3]};
+                    if (HST) {
+                        *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)at) = double2_t{h[0], h[1]};
+                        *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)(at + dr * L + dc)) = double2_t{h[2], h[3]};
+                    }
                 }
             }
         }
@@ -293,6 +310,10 @@ template <int L> struct Chain {
                 const int at = r * L + c;
                 *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)at) = double2_t{d[0], d[1]};
                 *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)(at + dr * L + dc)) = double2_t{d[2], d[3]};
+                if (HST) {
+                    *reinterpret_cast<double2_t*>(st_h2 + 8 * (size_t)at) = double2_t{h[0], h[1]};
+                    *reinterpret_cast<double2_t*>(st_h2 + 8 * (size_t)(at + dr * L + dc)) = double2_t{h[2], h[3]};
+                }
             }
         };
         double4_t bias2;
@@ -454,6 +475,7 @@ template <int L> struct Chain {
         double* sGP = sm + G::GP;  double* sGO = sm + G::IN;  double* sGZ2 = sm + G::A8;
         double* sD1 = sm + G::B8;  double* sPart = sm + G::A8;
         const double* sWc = sW();
+        double* const gzo = TRAIN ? gz(l) : nullptr;                       // training sweep: gz2 [N][8] | gz1 [N][8] | g_out [N / 4][4]
         // the next pass's weight block is requested first; its stash values (when it is a backward pass) refill `pre`
         // group by group behind this pass's last use of each
         const bool refill = nl_ >= 0 && nb;
@@ -486,6 +508,12 @@ template <int L> struct Chain {
             for (int k = 0; k < NMIX; ++k) put1i<RS>(sGO + k * PSZ, i, j, gdelta * pre.tcv[4 * k] + cbr * pre.tcv[4 * k + 1]);
             put1i<RS>(sGO + NMIX * PSZ, i, j, gdelta);
             sGP[i * L + j] = g0 + (gdelta * (csum - 1.0) - cbr * esum);
+            if (gzo) {                                                     // g_out record of active site tid: dL/ds_0, dL/ds_1, dL/dt, 0
+                static_assert(NMIX == 2, "g_out record");
+                double* po = gzo + 16 * (size_t)N + 4 * (size_t)tid;
+                *reinterpret_cast<double2_t*>(po) = double2_t{gdelta * pre.tcv[0] + cbr * pre.tcv[1], gdelta * pre.tcv[4] + cbr * pre.tcv[5]};
+                *reinterpret_cast<double2_t*>(po + 2) = double2_t{gdelta, 0.0};
+            }
         }
         if (refill) issue_tc(tid, nl_, pre);
         lds_barrier();
@@ -519,6 +547,10 @@ template <int L> struct Chain {
             for (int k = 0; k < 4; ++k) acc[k] = ksel <= 2 ? pre.d2v[k] * acc[k] : 0.0;
             put2<L, RS, PSZ>(sGZ2 + (c3half * 4) * PSZ, r, c, acc[0], acc[1]);
             put2<L, RS, PSZ>(sGZ2 + (c3half * 4 + 2) * PSZ, r, c, acc[2], acc[3]);
+            if (gzo) {
+                double* po = gzo + 8 * (size_t)c3s + 4 * c3half;
+                *reinterpret_cast<double2_t*>(po) = double2_t{acc[0], acc[1]}; *reinterpret_cast<double2_t*>(po + 2) = double2_t{acc[2], acc[3]};
+            }
         }
         if (refill) issue_d2(tid, nl_, pre);
         lds_barrier();
@@ -528,8 +560,14 @@ template <int L> struct Chain {
         {
             auto epi = [&](int g, int, bool ok, double (&z)[4], int) {
                 if (!ok) return;
-                put2i<RS, PSZ>(sD1 + 2 * g * PSZ, pr_, pc_, z[0] * pre.d1v[0], z[1] * pre.d1v[1]);
-                put2i<RS, PSZ>(sD1 + 2 * g * PSZ, pr_ + (mu == 0 ? 0 : 1), pc_ + (mu == 0 ? 1 : 0), z[2] * pre.d1v[2], z[3] * pre.d1v[3]);
+                const double v0 = z[0] * pre.d1v[0], v1 = z[1] * pre.d1v[1], v2 = z[2] * pre.d1v[2], v3 = z[3] * pre.d1v[3];
+                put2i<RS, PSZ>(sD1 + 2 * g * PSZ, pr_, pc_, v0, v1);
+                put2i<RS, PSZ>(sD1 + 2 * g * PSZ, pr_ + (mu == 0 ? 0 : 1), pc_ + (mu == 0 ? 1 : 0), v2, v3);
+                if (gzo) {
+                    const int s0 = pr_ * L + pc_, s1 = s0 + (mu == 0 ? 1 : L);
+                    *reinterpret_cast<double2_t*>(gzo + 8 * (size_t)N + 8 * (size_t)s0 + 2 * g) = double2_t{v0, v1};
+                    *reinterpret_cast<double2_t*>(gzo + 8 * (size_t)N + 8 * (size_t)s1 + 2 * g) = double2_t{v2, v3};
+                }
             };
             // the pair's four-line window holds exactly one line on which gz2 is zero (class 2: no active site within reach):
             // its six K steps are skipped; which line it is depends on u only (wave-uniform)
@@ -647,7 +685,7 @@ template <int L> struct Chain {
     }
 };
 
-enum { SM_ACTION = 0, SM_FORCE = 1, SM_LEAPFROG = 2, SM_TRAJ = 3 };
+enum { SM_ACTION = 0, SM_FORCE = 1, SM_LEAPFROG = 2, SM_TRAJ = 3, SM_TRAIN = 4 };
 
 // One launch = a sequence of SWEEPS over the layers of one chain.  A sweep copies the latent links, runs every layer forward
 // in place, and then either evaluates the Wilson action and charge of the flowed field (EVAL sweep: S_eff = S_W - log det J)
@@ -656,18 +694,21 @@ enum { SM_ACTION = 0, SM_FORCE = 1, SM_LEAPFROG = 2, SM_TRAJ = 3 };
 //   force:       [FORCE] -> F
 //   leapfrog:    x += dt/2 v; nstep x ([FORCE]; v -= dt F; x += dt v (dt/2 after the last))
 //   trajectory:  [EVAL] (unless state_in carries it), the leapfrog, regularize, [EVAL], Metropolis
+//   training:    ONE sweep that is both (fthmc/train.py:191-210): every layer forward with the stash (+ h1, h2) AND log J,
+//                the Wilson action of the flowed field -> x, logq, logp; the seed (beta / B) sin P, every layer backward with
+//                dL/dlogJ = -1 / B, writing each layer's pre-activation gradients for k_flow_wgrad
 // The sweep loop has ONE call site of the layer bodies (the kernel is register- and code-size-bound otherwise).
-template <int L>
+template <int L, bool TRAIN>
 __global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
     using G = GS<L>;
     constexpr int N = G::N;
     __shared__ __attribute__((aligned(16))) double sm[G::SIZE];
     const int b = blockIdx.x;
-    const Hot hot{Aarg.wint, Aarg.stash, Aarg.dbg, Aarg.B, Aarg.nl, Aarg.act};
-    Chain<L> C(sm, hot, b);
+    const Hot hot{Aarg.wint, Aarg.stash, Aarg.dbg, Aarg.B, Aarg.nl, Aarg.act, TRAIN ? Aarg.gz : nullptr};
+    Chain<L, TRAIN> C(sm, hot, b);
     const int tid = C.tid;
     double* red = sm + G::RED;
-    const int mode = Aarg.mode, nl = hot.nl;
+    const int mode = TRAIN ? (int)SM_TRAIN : Aarg.mode, nl = hot.nl;
     const double beta = Aarg.beta, dt = Aarg.dt;
     const bool have_state = Aarg.state_in != nullptr;
     {
@@ -676,7 +717,8 @@ __global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
     }
     if (hot.dbg && tid < 32) reinterpret_cast<long long*>(sm + G::PROF)[tid] = 0;
     const bool moves = mode == SM_LEAPFROG || mode == SM_TRAJ;
-    const int nforce = mode == SM_ACTION ? 0 : (mode == SM_FORCE ? 1 : Aarg.nstep);
+    constexpr bool train = TRAIN;
+    const int nforce = mode == SM_ACTION ? 0 : ((mode == SM_FORCE || train) ? 1 : Aarg.nstep);
     // sweeps it = first .. last: it < 0 and it == nforce are EVAL sweeps, 0 <= it < nforce FORCE sweeps
     const int first = (mode == SM_ACTION || (mode == SM_TRAJ && !have_state)) ? -1 : 0;
     const int last = mode == SM_TRAJ ? nforce : (mode == SM_ACTION ? -1 : nforce - 1);
@@ -709,15 +751,29 @@ __global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
             // the pass behind this one: the next layer, the first backward pass, or the first layer of the next sweep
             const bool nb = l + 1 == nl && force;
             const int nl_ = l + 1 < nl ? l + 1 : (force ? nl - 1 : (it < last ? 0 : -1));
-            ld += C.layer_fwd(l, force, !force, nb, nl_);
+            ld += C.layer_fwd(l, force, !force || train, nb, nl_);
         }
         if (force) {
+            double bscale = beta, cb = -1.0;
+            if (train) {
+                // the loss pieces of this chain (train.py:191-206): x = F(xi), logq = -2 L^2 log(2 pi) - log det J, logp = -S_W(x)
+                double S, Q;
+                C.action_charge(beta, S, Q);
+                const SmallArgs& At = cold();
+                if (tid == 0) {
+                    if (At.logq) At.logq[b] = -(double)(2 * N) * log(FT_TWO_PI) - ld;
+                    if (At.logp) At.logp[b] = -S;
+                }
+                if (At.x_out && tid < N) { At.x_out[(size_t)b * 2 * N + tid] = sm[G::X + tid]; At.x_out[(size_t)b * 2 * N + N + tid] = sm[G::X + N + tid]; }
+                bscale = beta / (double)hot.B; cb = -1.0 / (double)hot.B;      // d mean_b (S_W - log det J) / d .
+            }
             // the stash of this sweep was written by other threads of this workgroup: complete and visible before it is read
             __syncthreads();
             C.bwd_issue(nl - 1, C.pre);
-            C.wilson_seed(beta);
+            C.wilson_seed(bscale);
             C.stamp(17);
-            for (int l = nl - 1; l >= 0; --l) C.layer_bwd(l, -1.0, l > 0, l > 0 ? l - 1 : (it < last ? 0 : -1));
+            for (int l = nl - 1; l >= 0; --l) C.layer_bwd(l, cb, l > 0, l > 0 ? l - 1 : (it < last ? 0 : -1));
+            if (train) continue;
             if (tid < N) {
                 double f0, f1;
                 C.site_force(f0, f1);
@@ -758,7 +814,7 @@ __global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
         }
         return;
     }
-    if (mode != SM_TRAJ) return;
+    if (mode != SM_TRAJ) return;                                            // (training: everything was written inside the sweep)
     if (A.dbg && tid == 0) for (int k = 0; k < 32; ++k) A.dbg[(size_t)b * 32 + k] = reinterpret_cast<long long*>(sm + G::PROF)[k];
     // ---- Metropolis (ipynb/ft_hmc.py:427-435)
     const double k1 = ft_block_sum(v0 * v0 + v1 * v1, red);
@@ -800,10 +856,20 @@ bool ft_small_shape(int L, int nl) { return nl >= 1 && (L == 8 || L == 12 || L =
 
 int launch_ft_small(const SmallArgs& a, int L, hipStream_t s) {
     const dim3 grid(a.B), block(NT);
+    if (a.mode == SM_TRAIN) {
+        if (!a.gz) return FTHMC_ERR_ARG;
+        switch (L) {
+            case 8: hipLaunchKernelGGL((k_ft_small<8, true>), grid, block, 0, s, a); break;
+            case 12: hipLaunchKernelGGL((k_ft_small<12, true>), grid, block, 0, s, a); break;
+            case 16: hipLaunchKernelGGL((k_ft_small<16, true>), grid, block, 0, s, a); break;
+            default: return FTHMC_ERR_UNSUPPORTED;
+        }
+        FT_LAUNCH_CHECK(); return FTHMC_OK;
+    }
     switch (L) {
-        case 8: hipLaunchKernelGGL(k_ft_small<8>, grid, block, 0, s, a); break;
-        case 12: hipLaunchKernelGGL(k_ft_small<12>, grid, block, 0, s, a); break;
-        case 16: hipLaunchKernelGGL(k_ft_small<16>, grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_ft_small<8, false>), grid, block, 0, s, a); break;
+        case 12: hipLaunchKernelGGL((k_ft_small<12, false>), grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_ft_small<16, false>), grid, block, 0, s, a); break;
         default: return FTHMC_ERR_UNSUPPORTED;
     }
     FT_LAUNCH_CHECK(); return FTHMC_OK;

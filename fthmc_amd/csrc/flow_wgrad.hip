@@ -77,10 +77,13 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L = A.L, mu = A.mu, off = A.off, n = L * L;
+    const int L = A.L, n = L * L;
     const int nti_ = (L + TR - 1) / TR, ntj_ = (L + TC - 1) / TC;
+    // several layers in one launch (A.nlb): blockIdx.z = layer * ceil(B / 8) + chain group
+    const int nzb = (A.B + 7) / 8, lz = A.nlb > 0 ? (int)blockIdx.z / nzb : 0;
+    const int mu = A.nlb > 0 ? (lz & 1) : A.mu, off = A.nlb > 0 ? ((lz >> 1) & 3) : A.off;
     BlockTile bt;
-    if (!block_tile(A.B, nti_, ntj_, bt)) return;
+    if (!block_tile(A.B, nti_, ntj_, bt, A.nlb > 0 ? (int)blockIdx.z - lz * nzb : (int)blockIdx.z)) return;
     const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
     const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);
@@ -90,13 +93,13 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     auto ldu2 = [](const double* base, unsigned idx) {
         return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx * 8u);
     };
-    const double* __restrict__ gz2g = uniform_ptr((const double*)A.gz, (size_t)b * 17 * n);
+    const double* __restrict__ gz2g = uniform_ptr((const double*)A.gz, (size_t)lz * A.gz_lstride + (size_t)b * 17 * n);
     const double* __restrict__ gz1g = gz2g + (size_t)8 * n;
     const double* __restrict__ gog = gz2g + (size_t)16 * n;
-    const double* __restrict__ scs = uniform_ptr((const double*)A.stash, ((size_t)A.B * 18 + b) * n);
-    const double* __restrict__ sh1 = uniform_ptr((const double*)A.stash, ((size_t)A.B * 19 + (size_t)b * 8) * n);
-    const double* __restrict__ sh2 = uniform_ptr((const double*)A.stash, ((size_t)A.B * 27 + (size_t)b * 8) * n);
-    double* gw0 = A.gw_part + ((size_t)b * ntiles + tile) * 2 * FLOW_GW_STRIDE;       // the tile's two partials (site halves)
+    const double* __restrict__ scs = uniform_ptr((const double*)A.stash, (size_t)lz * A.stash_lstride + ((size_t)A.B * 18 + b) * n);
+    const double* __restrict__ sh1 = uniform_ptr((const double*)A.stash, (size_t)lz * A.stash_lstride + ((size_t)A.B * 19 + (size_t)b * 8) * n);
+    const double* __restrict__ sh2 = uniform_ptr((const double*)A.stash, (size_t)lz * A.stash_lstride + ((size_t)A.B * 27 + (size_t)b * 8) * n);
+    double* gw0 = A.gw_part + (size_t)lz * A.gwp_lstride + ((size_t)b * ntiles + tile) * 2 * FLOW_GW_STRIDE;   // the tile's two partials (site halves)
 
     // ---- phase 1 loads (unconditional, clamped: straight-line code keeps the waits counted)
     // own sites: thread = (site, channel quad): 32 bytes of gz2 and of gz1
@@ -221,7 +224,8 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
 namespace fthmc {
 
 int launch_flow_wgrad(const FlowLayerArgs& a, hipStream_t s) {
-    const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
+    dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
+    if (a.nlb > 0) grid.z *= a.nlb;
     if (wrap_fast_ok(a.L, MG_TR, MG_TC)) hipLaunchKernelGGL((k_flow_wgrad<MG_TR, MG_TC, true>), grid, dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((k_flow_wgrad<MG_TR, MG_TC, false>), grid, dim3(NT), 0, s, a);
     FT_LAUNCH_CHECK(); return FTHMC_OK;

@@ -94,6 +94,10 @@ struct FlowLayerArgs {
                              // (channel-minor), g_out [n/4][4] (dL/ds_0, dL/ds_1, dL/dt, 0 at the active sites, compact)
     int dbg_stop;            // -DFT_DIAG builds: the forward kernel returns after this stage (instruction counts per stage); 0 = run all
     int B, L, mu, off, act;
+    // k_flow_wgrad over SEVERAL layers in one launch (small lattices: every layer's gz and stash are there at once): layers
+    // 0 .. nlb - 1 (mu, off from the layer index), their stash / gz / partial regions `*_lstride` doubles apart; nlb = 0: one layer
+    int nlb;
+    size_t stash_lstride, gz_lstride, gwp_lstride;
 };
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_rev(const FlowLayerArgs& a, hipStream_t s);
@@ -173,8 +177,10 @@ struct SmallArgs {
     double* v_out;           // leapfrog: v'
     double* F;               // force
     double *dH, *acc, *H0, *H1, *S_eff, *logdet, *plaq, *Q;   // per chain [B], each may be null
+    double *logq, *logp;     // training: [B]
+    double* gz;              // training: n_layers * flow_gz_doubles(B, L): every layer's pre-activation gradients (for k_flow_wgrad)
     double beta, dt;
-    int nstep, mode, B, nl, act;   // mode: 0 action (forward sweep), 1 force, 2 leapfrog, 3 trajectory
+    int nstep, mode, B, nl, act;   // mode: 0 action (forward sweep), 1 force, 2 leapfrog, 3 trajectory, 4 training sweep
     long long* dbg;          // profiling runs: [B][32] cycles per stage, accumulated by thread 0 of each chain (else null)
 };
 bool ft_small_shape(int L, int n_layers);       // the fused path is built for this lattice size (default net shape, MFMA kernels)
@@ -195,6 +201,6 @@ int launch_adj_add(const double* gp, const double* gy, int B, int L, double* gx,
 // tmp: FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE doubles of scratch (two-level reduction), or null
 constexpr int FLOW_REDUCE_GROUPS = 128;
 int launch_reduce_gw(const double* gw_part, int nparts, double scale, int accumulate, double* gw,
-                     double* tmp, hipStream_t s);
+                     double* tmp, hipStream_t s, int nlayers = 1, size_t part_lstride = 0);   // nlayers > 1: layer l reads gw_part + l * part_lstride, writes gw + l * 955; tmp: nlayers * FLOW_REDUCE_GROUPS rows
 
 }  // namespace fthmc

@@ -525,6 +525,8 @@ _SIDE_STREAMS: dict = {}
 def default_groups(B: int, L: int) -> int:
     """Two chain groups once a launch is large enough to amortise the extra launches (measured: +10 % at
     B=128, L=64; -50 % at B=32, L=16 where the sequence is launch-bound)."""
+    if L <= 16 and get_small_path() and get_variant() == 1:
+        return 1              # small lattices: a sweep is ONE launch with a workgroup per chain, there is no tail to fill
     return 2 if B >= 16 and B * L * L >= (1 << 17) else 1
 
 

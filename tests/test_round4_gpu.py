@@ -210,6 +210,41 @@ def test_train_step_metrics_match_the_autograd_route():
         close(a, b, rtol=1e-8, atol=1e-11 * max(gmax, 1.0))
 
 
+# ---------------------------------------------------------------- small lattices: the training sweep in one launch
+@pytest.mark.parametrize('L,nl,B,beta,act', [(8, 4, 5, 2.0, 'silu'), (12, 3, 3, 3.0, 'silu'), (16, 8, 9, 4.0, 'silu'), (16, 2, 2, 2.0, 'relu'),
+                                             (8, 1, 1, 1.0, 'leaky_relu')])
+def test_small_lattice_training_sweep(L, nl, B, beta, act):
+    """fthmc_train_grad at L = 8, 12, 16: ONE launch runs the forward sweep (stash, h1, h2, log J), the loss pieces and the
+    backward sweep of every chain (flow_small.hip, training sweep), k_flow_wgrad turns the pre-activation gradients it leaves
+    into weight gradients.  Against the tiled path (small path off) and against the oracle's autograd."""
+    gen = torch.Generator().manual_seed(900 + L + nl)
+    flow = R.default_flow(nl, gen)
+    w = ops.pack_weights(flow, device='cuda')
+    xi = (torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+    assert ops.get_small_path()
+    r = ops.train_grad(xi.cuda(), w, nl, beta, act)
+    ops.set_small_path(False)
+    try:
+        rt = ops.train_grad(xi.cuda(), w, nl, beta, act)
+    finally:
+        ops.set_small_path(True)
+    d = (H(r['x']) - H(rt['x']) + np.pi) % (2 * np.pi) - np.pi
+    assert np.abs(d).max() < 1e-11
+    close(r['logq'], rt['logq'], rtol=1e-12); close(r['logp'], rt['logp'], rtol=1e-12)
+    gmax = float(rt['gw'].abs().max())
+    close(r['gw'], rt['gw'], rtol=1e-9, atol=1e-12 * max(gmax, 1.0))
+    out, grads = R.train_grads(xi, flow, beta, act)
+    close(r['logq'], out['logq'], rtol=1e-11); close(r['logp'], out['logp'], rtol=1e-11)
+    gws = ops.unpack_weight_grads(r['gw'], nl)
+    for li in range(nl):
+        for pi in range(6):
+            close(gws[li][pi], grads[li][pi], rtol=1e-8, atol=1e-11 * max(gmax, 1.0))
+    assert torch.equal(ops.train_grad(xi.cuda(), w, nl, beta, act)['gw'], r['gw'])          # deterministic
+    # the chains of a batch do not see each other: chain 0 alone
+    r1 = ops.train_grad(xi[:1].cuda(), w, nl, beta, act, need_gw=False)
+    close(r1['logq'], r['logq'][:1], rtol=1e-13); close(r1['logp'], r['logp'][:1], rtol=1e-13)
+
+
 # ---------------------------------------------------------------- the net shape is an argument of the call
 def test_two_net_shapes_on_two_threads_and_streams():
     """Two flows of different s/t net shapes driven from two Python threads on two streams at the same time (ctypes drops

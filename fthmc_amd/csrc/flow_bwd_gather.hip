@@ -65,7 +65,9 @@ template <int TR, int TC> struct SmemG {
 // (flow_wgrad.hip), which turns them into weight gradients; nothing else changes.
 // MU: the layer's stripe direction as a compile-time constant (as in k_flow_fwd: the selects on it fold, each kernel carries
 // one of the two conv2^T code paths).
-template <int TR, int TC, bool FASTW, int MU>
+// EXACT: the tiles divide the lattice and L is a power of two (64, 128, 256): every own site is a lattice site, the lattice-edge
+// tests fold away, a window line wraps by one v_and.
+template <int TR, int TC, bool FASTW, int MU, bool EXACT>
 __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     using S = SmemG<TR, TC>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
     const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
-    const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);    // own sites inside the lattice
+    const int rmax = EXACT ? TR : min(TR, L - i0), cmax = EXACT ? TC : min(TC, L - j0);    // own sites inside the lattice
     const double* __restrict__ w = A.wint;
     const Stash sv = stash_view(A.stash, A.B, b, n);
     // stash planes of this chain (struct Stash), as kernel-argument base + uniform offset
@@ -103,10 +105,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     STAMP(0);
 
     // wrapped lattice coordinates of window lines, relative to the tile origin (rows premultiplied by L)
-    const unsigned wmagic = FASTW ? 0u : wrap_magic(L);
-    auto wi = [&](int k) { return wrap_line<FASTW>(i0 + k, L, wmagic); };
+    const unsigned wmagic = EXACT ? (unsigned)(L - 1) : (FASTW ? 0u : wrap_magic(L));
+    auto wi = [&](int k) { return wrap_line<FASTW, EXACT>(i0 + k, L, wmagic); };
     auto WI = [&](int k) { return mul24(wi(k), L); };
-    auto WJ = [&](int k) { return wrap_line<FASTW>(j0 + k, L, wmagic); };
+    auto WJ = [&](int k) { return wrap_line<FASTW, EXACT>(j0 + k, L, wmagic); };
 
     // ---- load phase.  Every load is unconditional, from a clamped address (idle lanes read element 0
     //      and drop it): straight-line code lets the compiler count outstanding loads (s_waitcnt
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     if (FT_RECOMP_D1) wp1 = ldu(w + (mu == 0 ? WFWD0 : WFWD1) + LF_P1, (unsigned)min(tid, LF_P1_SIZE - 1));
     // (3) upstream gradient of the own sites (pass-through term)
     const int orr = fdiv<TC>(tid), occ = tid - orr * TC;
-    const bool ovalid = tid < N3 && orr < rmax && occ < cmax;
+    const bool ovalid = tid < N3 && (EXACT || (orr < rmax && occ < cmax));
     double gpin;
     {
         const double* gsrc = A.up_gp ? uniform_ptr(A.up_gp, (size_t)b * n) : scs;   // no pass-through without up_gp
@@ -498,12 +500,15 @@ namespace fthmc {
 int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s) {
     const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
     const bool fast = wrap_fast_ok(a.L, MG_TR, MG_TC);
+    const bool exact = fast && a.L % MG_TR == 0 && a.L % MG_TC == 0 && (a.L & (a.L - 1)) == 0;
     if (a.mu == 0) {
-        if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, 0>), grid, dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, 0>), grid, dim3(NT), 0, s, a);
+        if (exact) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, 0, true>), grid, dim3(NT), 0, s, a);
+        else if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, 0, false>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, 0, false>), grid, dim3(NT), 0, s, a);
     } else {
-        if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, 1>), grid, dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, 1>), grid, dim3(NT), 0, s, a);
+        if (exact) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, 1, true>), grid, dim3(NT), 0, s, a);
+        else if (fast) hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, true, 1, false>), grid, dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((k_flow_bwd_gather<MG_TR, MG_TC, false, 1, false>), grid, dim3(NT), 0, s, a);
     }
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }

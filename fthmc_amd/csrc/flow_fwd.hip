@@ -45,8 +45,9 @@ template <int TR, int TC> struct SmemF {
 // MU: the layer's stripe direction (A.mu) as a compile-time constant: every `mu == 0 ? a : b` below folds, the LDS steps
 // across / along the lines become immediate offsets of the operand reads, and each kernel carries one of the two conv2
 // code paths instead of both (selects on per-lane values by a uniform mu were ~5 % of the VALU instructions).
-// EXACT: the tiles divide the lattice (L % 16 == 0: BASELINE configs 3, 4, 5), so every tile site is a lattice site: the
-// lattice-edge halves of the bounds tests of the stash stores, the link update and the active sites fold away.
+// EXACT: the tiles divide the lattice and L is a power of two (L = 64, 128, 256: BASELINE configs 3, 4, 5), so every tile site
+// is a lattice site -- the lattice-edge halves of the bounds tests of the stash stores, the link update and the active sites
+// fold away -- and a window line wraps by one v_and.
 template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT>
 __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     using S = SmemF<TR, TC>;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
 
-    const unsigned fastw = FASTW ? 0u : wrap_magic(L);
+    const unsigned fastw = EXACT ? (unsigned)(L - 1) : (FASTW ? 0u : wrap_magic(L));
     // this layer's forward weight block (the conv2 table padded along the pair direction of this mu): the loads are
     // issued FIRST and land under the plaquette loads and the sincos; issued behind them (where they are consumed) the
     // stage pays two memory latencies in a row.  Unconditional, clamped: straight-line code keeps the waits counted.
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             if (sel != 1 && sel != 2) { sIn[rr * R0C + cc] = 1.0; sIn[PS0 + rr * R0C + cc] = 0.0; }
         }
         if (fz || ao) {
-            const int iL = mul24(wrap_line<FASTW>(i0 - 3 + r, L, fastw), L), ipL = mul24(wrap_line<FASTW>(i0 - 2 + r, L, fastw), L);
-            const int j = wrap_line<FASTW>(j0 - 3 + c, L, fastw), jp = wrap_line<FASTW>(j0 - 2 + c, L, fastw);
+            const int iL = mul24(wrap_line<FASTW, EXACT>(i0 - 3 + r, L, fastw), L), ipL = mul24(wrap_line<FASTW, EXACT>(i0 - 2 + r, L, fastw), L);
+            const int j = wrap_line<FASTW, EXACT>(j0 - 3 + c, L, fastw), jp = wrap_line<FASTW, EXACT>(j0 - 2 + c, L, fastw);
             const double p = pin ? ldu(pin, (unsigned)(iL + j))
                                  : ldu(x0, (unsigned)(iL + j)) - ldu(x1, (unsigned)(iL + j)) - ldu(x0, (unsigned)(iL + jp)) + ldu(x1, (unsigned)(ipL + j));
             const int at = r * R0C + c;
@@ -554,7 +555,7 @@ namespace {
 template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hipStream_t s) {
     constexpr int TR = fthmc::MF_FWD_TR, TC = fthmc::MF_FWD_TC;
     const bool fast = wrap_fast_ok(a.L, TR, TC);
-    const bool exact = fast && a.L % TR == 0 && a.L % TC == 0;
+    const bool exact = fast && a.L % TR == 0 && a.L % TC == 0 && (a.L & (a.L - 1)) == 0;
     if (a.mu == 0) {
         if (exact) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 0, true>), grid, dim3(NT), 0, s, a);
         else if (fast) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 0, false>), grid, dim3(NT), 0, s, a);

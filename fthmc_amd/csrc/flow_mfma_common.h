@@ -78,8 +78,10 @@ __device__ __forceinline__ void stu2(double* base, unsigned idx, double2u_t v) {
 // division by the launch-uniform L through its reciprocal (wrap_magic): n M >> 32 = floor(n / L) for
 // n, L < 2^16 with M = floor(2^32 / L) + 1.
 __device__ __forceinline__ unsigned wrap_magic(int L) { return 0xFFFFFFFFu / (unsigned)L + 1u; }
-template <bool FAST>
+// POW2 (L a power of two: 64, 128, 256 -- the EXACT instances of the coupling kernels; `magic` then carries L - 1): one v_and.
+template <bool FAST, bool POW2 = false>
 __device__ __forceinline__ int wrap_line(int v, int L, unsigned magic) {
+    if (POW2) return (int)((unsigned)v & magic);
     if (FAST) return (int)min(min((unsigned)v, (unsigned)(v - L)), (unsigned)(v + L));   // -L <= v < 2 L: one v_min3_u32
     const unsigned nn = (unsigned)(v + L);
     return (int)(nn - (unsigned)L * __umulhi(nn, magic));

@@ -122,8 +122,10 @@ inline SmallArgs small_args(const double* x, const WS& w, int nl, int B, int act
 #define FT_TRY(expr) do { int rc_ = (expr); if (rc_ != FTHMC_OK) return rc_; } while (0)
 
 // Forward sweep x -> X[0..nl-1] (X[l] = output of layer l).  logdet (device [B]) optional.
+// parts_only: leave the log J partials of every layer in w.lj_part ([layer][chain][tile]) and skip the summing launch (the
+// caller folds them into its own reduction: launch_traj_energy); tuned kernels only.
 int sweep_forward(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, int act, double* logdet,
-                  hipStream_t s, bool stash = false, bool train = false) {
+                  hipStream_t s, bool stash = false, bool train = false, bool parts_only = false) {
     if (C.gen()) {                                // any other net shape: plain kernels, one stash region per layer
         for (int l = 0; l < nl; ++l) {
             GenLayerArgs g = gen_args(C, w, l, B, L, act, stash);
@@ -142,7 +144,7 @@ int sweep_forward(const Ctx& C, const double* x, const WS& w, int nl, int B, int
         a.wint = w.wint + (size_t)l * FLOW_WINT;
         a.y = w.X + (size_t)l * w.n2;
         // logJ partials of all layers side by side, summed by ONE launch behind the sweep (layer by layer, in order)
-        a.logj_part = logdet ? w.lj_part + (size_t)l * B * flow_fwd_geom(C.mfma).ntiles(L) : nullptr;
+        a.logj_part = (logdet || parts_only) ? w.lj_part + (size_t)l * B * flow_fwd_geom(C.mfma).ntiles(L) : nullptr;
         a.B = B; a.L = L; a.mu = l % 2; a.off = (l / 2) % 4; a.act = act;
         FT_TRY(flow_fwd(C, a, s));
     }
@@ -225,14 +227,14 @@ int force_gp(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, i
 }
 
 // leapfrog in the latent field; result in w.xa / w.va
+// xreg (optional): regularize(result x), written by the last kick (the end point of a trajectory, ipynb/ft_hmc.py:426)
 int ft_leapfrog_ws(const Ctx& C, const double* x, const double* v, const WS& w, int nl, int B, int L, int act,
-                   double beta, double dt, int nstep, hipStream_t s) {
-    FT_TRY(launch_axpy(x, v, 0.5 * dt, w.xa, w.n2, s));
-    if (hipMemcpyAsync(w.va, v, w.n2 * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
-        return FTHMC_ERR_LAUNCH;
+                   double beta, double dt, int nstep, hipStream_t s, double* xreg = nullptr) {
+    FT_TRY(launch_axpy_copy(x, v, 0.5 * dt, w.xa, w.va, w.n2, s));       // first half drift + the working copy of the momenta
     for (int k = 0; k < nstep; ++k) {
         FT_TRY(force_gp(C, w.xa, w, nl, B, L, act, beta, -1.0, nullptr, s));
-        FT_TRY(launch_kick_from_gp(w.gp, w.va, w.xa, nullptr, B, L, dt, k == nstep - 1 ? 0.5 * dt : dt, s));
+        FT_TRY(launch_kick_from_gp(w.gp, w.va, w.xa, nullptr, B, L, dt, k == nstep - 1 ? 0.5 * dt : dt, s,
+                                   k == nstep - 1 ? xreg : nullptr));
     }
     return FTHMC_OK;
 }
@@ -712,6 +714,19 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
         a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = x_new; a.state_in = state_in; a.state_out = state_out;
         a.dH = dH; a.acc = acc; a.H0 = H0; a.H1 = H1; a.plaq = plaq; a.Q = Q;
         return launch_ft_small(a, L, s);
+    }
+    if (mode == FTHMC_MODE_MD && C.A.is_default() && n_layers > 0) {
+        // tuned kernels: the scalars of either end of the trajectory come from ONE launch each (launch_traj_energy: log det J
+        // from the sweep's partials, S_W / Q / plaq of the flowed field, the kinetic term, H), the first drift and the copy of
+        // the momenta are one pass, the last kick also writes the regularized end point, the Metropolis kernel hands plaq / Q
+        // out itself: 5 small launches per trajectory where there were 15
+        const int np = flow_fwd_geom(C.mfma).ntiles(L);
+        if (!state_in) FT_TRY(sweep_forward(C, x, W, n_layers, B, L, act, nullptr, s, false, false, true));
+        FT_TRY(launch_traj_energy(phys_field(x, W, n_layers), B, L, beta, W.lj_part, np, n_layers, state_in, v, old, h0, s));
+        FT_TRY(ft_leapfrog_ws(C, x, v, W, n_layers, B, L, act, beta, dt, nstep, s, W.xb));
+        FT_TRY(sweep_forward(C, W.xb, W, n_layers, B, L, act, nullptr, s, false, false, true));
+        FT_TRY(launch_traj_energy(phys_field(W.xb, W, n_layers), B, L, beta, W.lj_part, np, n_layers, nullptr, W.va, neu, h1, s));
+        return launch_metropolis(x, W.xb, u, h0, h1, B, L, 0, x_new, dH, acc, old, neu, sel, 3, s, plaq, Q);
     }
     if (state_in) {       // chained trajectories: S_eff and observables of x are the previous call's state_out
         if (hipMemcpyAsync(old, state_in, (size_t)3 * B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)

@@ -27,11 +27,16 @@ int launch_hmc_trajectory_fused(const double* x, const double* v, const double* 
                                 double dt, int nstep, double* x_new, double* dH, double* acc, double* H0,
                                 double* H1, hipStream_t s);
 int launch_kick_from_gp(const double* gp, double* v, double* xq, double* Fout, int B, int L,
-                        double dt, double a, hipStream_t s);
+                        double dt, double a, hipStream_t s, double* xreg = nullptr);   // xreg: also regularize(x') (end of the MD)
+// the scalars of one end of a flowed trajectory in one launch: (S_eff, plaq, Q) of the flowed field (or carried over: state_in)
+// and H = S_eff + sum v^2 / 2
+int launch_traj_energy(const double* xphys, int B, int L, double beta, const double* lj_part, int np, int nsets,
+                       const double* state_in, const double* v, double* trip, double* H, hipStream_t s);
+int launch_axpy_copy(const double* x, const double* p, double a, double* xo, double* po, size_t n, hipStream_t s);
 int launch_metropolis(const double* x_old, const double* x_prop, const double* u, const double* H0,
                       const double* H1, int B, int L, int xform, double* x_new, double* dH,
                       double* acc, const double* obs_old, const double* obs_new, double* obs_out,
-                      int n_obs, hipStream_t s);
+                      int n_obs, hipStream_t s, double* o1 = nullptr, double* o2 = nullptr);   // o1, o2: selected observables 1, 2
 
 int launch_train_metrics(const double* logq, const double* logp, const double* q, const double* qi, int B,
                          double inv_beta_vol, double dkl_factor, double* row, hipStream_t s);

@@ -82,6 +82,60 @@ __global__ void k_kinetic(const double* __restrict__ v, int n, double* __restric
     if (threadIdx.x == 0) K[b] = a;
 }
 
+// The scalars of one end of a flowed trajectory in ONE launch, one workgroup per chain (was five: k_sum_parts,
+// k_action_charge, k_lincomb, k_kinetic, k_lincomb -- with two chain groups in lockstep the chip sat nearly idle through each):
+//   log det J = sum over the sweep's layers and tiles of the log J partials   (k_sum_parts' order: wave 0, lane-strided, xor tree)
+//   S_W, Q, plaq of the flowed field                                          (k_action_charge's order)
+//   trip = (S_eff = S_W - log det J, plaq, Q)   -- or copied from state_in when the caller carries it over
+//   H = S_eff + K / 2,  K = sum v^2                                           (k_kinetic's order)
+// Launched with the block size k_action_charge / k_kinetic use for this L, so every sum is bit-identical to theirs.
+__global__ void k_traj_energy(const double* __restrict__ xphys, int L, double beta, const double* __restrict__ lj_part, int np,
+                              int nsets, const double* __restrict__ state_in, const double* __restrict__ v,
+                              double* __restrict__ trip, double* __restrict__ H, int B) {
+    __shared__ double red[16];
+    __shared__ double sld;
+    const int b = blockIdx.x;
+    double seff, pq, qq;
+    if (state_in) { seff = state_in[b]; pq = state_in[B + b]; qq = state_in[2 * B + b]; }
+    else {
+        if (threadIdx.x < FT_WAVE) {
+            double tot = 0.0;
+            for (int q = 0; q < nsets; ++q) {
+                double a = 0.0;
+                for (int t = threadIdx.x; t < np; t += FT_WAVE) a += lj_part[((size_t)q * B + b) * np + t];
+                a = ft_wave_sum(a);
+                tot += 1.0 * a;
+            }
+            if (threadIdx.x == 0) sld = tot;
+        }
+        double c, q;
+        chain_action_charge<0>(xphys + (size_t)b * 2 * L * L, L, c, q);
+        c = ft_block_sum(c, red);
+        q = ft_block_sum(q, red);
+        const double s = (-beta) * c;
+        seff = 1.0 * s + (nsets > 0 ? -1.0 * sld : 0.0) + 0.0;           // k_lincomb(S, 1, logdet, -1, 0)
+        pq = (-s) / (beta * (double)(L * L));
+        qq = q / FT_TWO_PI;
+    }
+    const int n = 2 * L * L;
+    const double* vb = v + (size_t)b * n;
+    double a = 0.0;
+    for (int s = threadIdx.x; s < n; s += blockDim.x) a += vb[s] * vb[s];
+    a = ft_block_sum(a, red);
+    if (threadIdx.x == 0) {
+        trip[b] = seff; trip[B + b] = pq; trip[2 * B + b] = qq;
+        H[b] = 1.0 * seff + 0.5 * a + 0.0;                                // k_lincomb(S_eff, 1, K, 0.5, 0)
+    }
+}
+
+// xo = x + a v and vo = v in one pass (the first half drift of a flowed trajectory and the working copy of the momenta)
+__global__ void k_axpy_copy(const double* __restrict__ x, const double* __restrict__ p, double a, double* __restrict__ xo,
+                            double* __restrict__ po, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) { const double pv = p[i]; xo[i] = x[i] + a * pv; po[i] = pv; }
+}
+
 // ---------------------------------------------------------------- force
 // Tile of TS x TS sites; sin P is evaluated once per plaquette on a
 // (TS+1) x (TS+1) region (one extra row above / column to the left) in LDS.
@@ -237,7 +291,7 @@ __global__ __launch_bounds__(TR * 32) void k_leap_rows(const double* __restrict_
 // drift x' = x + a v'.  In place on v (and x): every thread touches its own site only.
 __global__ void k_kick_from_gp(const double* __restrict__ gp, double* __restrict__ v,
                                double* __restrict__ xq, double* __restrict__ Fout,
-                               int L, double dt, double a) {
+                               int L, double dt, double a, double* __restrict__ xreg) {
     const int b = blockIdx.y;
     const int n = L * L;
     const double* g = gp + (size_t)b * n;
@@ -252,7 +306,11 @@ __global__ void k_kick_from_gp(const double* __restrict__ gp, double* __restrict
         if (v) {
             const double v0 = v[s0] - dt * f0, v1 = v[s1] - dt * f1;
             v[s0] = v0; v[s1] = v1;
-            if (xq) { xq[s0] += a * v0; xq[s1] += a * v1; }
+            if (xq) {
+                const double y0 = xq[s0] + a * v0, y1 = xq[s1] + a * v1;
+                xq[s0] = y0; xq[s1] = y1;
+                if (xreg) { xreg[s0] = ft_regularize(y0); xreg[s1] = ft_regularize(y1); }
+            }
         }
     }
 }
@@ -285,7 +343,7 @@ __global__ __launch_bounds__(TR * 32) void k_gp_rows(const double* __restrict__ 
 // v' = v - dt adj(gP), optionally x' = x + a v' and / or F = adj(gP)  (k_kick_from_gp on row strips)
 template <int TR>
 __global__ __launch_bounds__(TR * 32) void k_kick_rows(const double* __restrict__ gp, double* __restrict__ v, double* __restrict__ xq,
-                                                       double* __restrict__ Fout, int L, double dt, double a) {
+                                                       double* __restrict__ Fout, int L, double dt, double a, double* __restrict__ xreg) {
     typedef double double2_t __attribute__((ext_vector_type(2)));
     const int b = blockIdx.z, i = blockIdx.y * TR + (threadIdx.x >> 5), q = threadIdx.x & 31, j = blockIdx.x * 64 + 2 * q;
     const int n = L * L;
@@ -305,6 +363,10 @@ __global__ __launch_bounds__(TR * 32) void k_kick_rows(const double* __restrict_
             double2_t y0 = *reinterpret_cast<const double2_t*>(xq + s0), y1 = *reinterpret_cast<const double2_t*>(xq + s1);
             y0.x += a * v0.x; y0.y += a * v0.y; y1.x += a * v1.x; y1.y += a * v1.y;
             *reinterpret_cast<double2_t*>(xq + s0) = y0; *reinterpret_cast<double2_t*>(xq + s1) = y1;
+            if (xreg) {                                                   // end of the MD: xr = regularize(x_) (ipynb/ft_hmc.py:426)
+                *reinterpret_cast<double2_t*>(xreg + s0) = double2_t{ft_regularize(y0.x), ft_regularize(y0.y)};
+                *reinterpret_cast<double2_t*>(xreg + s1) = double2_t{ft_regularize(y1.x), ft_regularize(y1.y)};
+            }
         }
     }
 }
@@ -318,15 +380,19 @@ __global__ void k_metropolis(const double* __restrict__ x_old, const double* __r
                              double* __restrict__ x_new, double* __restrict__ dH,
                              double* __restrict__ acc,
                              const double* __restrict__ obs_old, const double* __restrict__ obs_new,
-                             double* __restrict__ obs_out, int n_obs, int B) {
+                             double* __restrict__ obs_out, int n_obs, int B, double* __restrict__ o1, double* __restrict__ o2) {
     const int b = blockIdx.x;                                    // gridDim.y workgroups share the copy of a chain
     const double d = H1[b] - H0[b];
     const bool a = u[b] < exp(-d);
     if (threadIdx.x == 0 && blockIdx.y == 0) {
         if (dH) dH[b] = d;
         if (acc) acc[b] = a ? 1.0 : 0.0;
-        for (int k = 0; k < n_obs; ++k)
-            if (obs_out) obs_out[k * B + b] = a ? obs_new[k * B + b] : obs_old[k * B + b];
+        // all selections are read before any is written: obs_out may be obs_old (the carried state updated in place)
+        double sel[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < n_obs && k < 4; ++k) sel[k] = a ? obs_new[k * B + b] : obs_old[k * B + b];
+        for (int k = 0; k < n_obs && k < 4; ++k) if (obs_out) obs_out[k * B + b] = sel[k];
+        if (o1) o1[b] = sel[1];                                  // observables 1, 2 of the selected state (plaq, Q) where the caller wants them
+        if (o2) o2[b] = sel[2];
     }
     const size_t o = (size_t)b * n2;
     for (int s = blockIdx.y * blockDim.x + threadIdx.x; s < n2; s += gridDim.y * blockDim.x) {
@@ -617,24 +683,35 @@ int launch_wilson_gp(const double* x, int B, int L, double beta, double* gp, hip
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_kick_from_gp(const double* gp, double* v, double* xq, double* Fout, int B, int L,
-                        double dt, double a, hipStream_t s) {
+                        double dt, double a, hipStream_t s, double* xreg) {
     if (L % 64 == 0 && g_leap_rows) {
         constexpr int TR = 8;
-        hipLaunchKernelGGL(k_kick_rows<TR>, dim3(L / 64, L / TR, B), dim3(TR * 32), 0, s, gp, v, xq, Fout, L, dt, a);
+        hipLaunchKernelGGL(k_kick_rows<TR>, dim3(L / 64, L / TR, B), dim3(TR * 32), 0, s, gp, v, xq, Fout, L, dt, a, xreg);
         FT_LAUNCH_CHECK(); return FTHMC_OK;
     }
     int gx = (L * L + 255) / 256; if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(k_kick_from_gp, dim3(gx, B), dim3(256), 0, s, gp, v, xq, Fout, L, dt, a);
+    hipLaunchKernelGGL(k_kick_from_gp, dim3(gx, B), dim3(256), 0, s, gp, v, xq, Fout, L, dt, a, xreg);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_traj_energy(const double* xphys, int B, int L, double beta, const double* lj_part, int np, int nsets,
+                       const double* state_in, const double* v, double* trip, double* H, hipStream_t s) {
+    const int nt = L * L >= 4096 ? 1024 : (L * L >= 1024 ? 512 : 256);           // = launch_action_charge = launch_kinetic
+    hipLaunchKernelGGL(k_traj_energy, dim3(B), dim3(nt), 0, s, xphys, L, beta, lj_part, np, nsets, state_in, v, trip, H, B);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_axpy_copy(const double* x, const double* p, double a, double* xo, double* po, size_t n, hipStream_t s) {
+    if (n == 0) return FTHMC_OK;
+    hipLaunchKernelGGL(k_axpy_copy, dim3(ew_grid(n)), dim3(256), 0, s, x, p, a, xo, po, n);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_metropolis(const double* x_old, const double* x_prop, const double* u, const double* H0,
                       const double* H1, int B, int L, int xform, double* x_new, double* dH,
                       double* acc, const double* obs_old, const double* obs_new, double* obs_out,
-                      int n_obs, hipStream_t s) {
+                      int n_obs, hipStream_t s, double* o1, double* o2) {
     int gy = (2 * L * L + 2047) / 2048;                          // ~8 sites per thread; one workgroup per chain left the copy latency-bound
     if (gy > 16) gy = 16;
     hipLaunchKernelGGL(k_metropolis, dim3(B, gy), dim3(256), 0, s, x_old, x_prop, u, H0, H1,
-                       2 * L * L, xform, x_new, dH, acc, obs_old, obs_new, obs_out, n_obs, B);
+                       2 * L * L, xform, x_new, dH, acc, obs_old, obs_new, obs_out, n_obs, B, o1, o2);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

@@ -35,5 +35,10 @@ python3 tools/lifetime.py 16 48 64 128 > "$OUT/workgroup_lifetime.txt" 2>&1
 python3 tools/small_profile.py > "$OUT/small_lattice_stage_cycles.txt" 2>&1
 python3 tools/leap_check.py > "$OUT/leapfrog_kernels.txt" 2>&1
 bash tools/abn.sh 2 fthmc_amd/libfthmc_hip.so experiments/lib_recomp_d1.so > "$OUT/ab_recomp_d1.txt" 2>&1
-rm -rf "$OUT/stats" "$OUT/stats2" "$OUT"/pmc*/pass*/ "$OUT/stg/stop"*
+# round 4: whole training steps (wall) against the compute-only figure, and where a step's GPU time goes at L = 16, batch 512
+python3 tools/train_wall.py 8 512 8 200 16 512 8 200 16 64 8 200 12 128 8 200 256 32 16 10 > "$OUT/train_wall.txt" 2> "$OUT/train_wall.err"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats3" -- python3 "$ROOT/tools/train_trace.py" 16 512 8 50 > "$OUT/stats3.log" 2>&1)
+cp $(find "$OUT/stats3" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats_train_L16_B512.csv"
+echo "[refresh] training done"
+rm -rf "$OUT/stats" "$OUT/stats2" "$OUT/stats3" "$OUT"/pmc*/pass*/ "$OUT/stg/stop"*
 echo "[refresh] done"

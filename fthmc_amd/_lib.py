@@ -28,7 +28,7 @@ _P = c_void_p
 
 class ArchT(ctypes.Structure):
     """fthmc_arch_t (include/fthmc_hip.h): the s/t net's shape, an argument of every entry point that runs the net."""
-    _fields_ = [('n_hidden', c_int), ('hidden', c_int * 8), ('kernel_size', c_int), ('n_mix', c_int)]
+    _fields_ = [('n_hidden', c_int), ('hidden', c_int * 8), ('kernel_size', c_int), ('n_mix', c_int), ('final_tanh', c_int)]
 
 
 _A = ctypes.POINTER(ArchT)   # const fthmc_arch_t* (None = the default shape)

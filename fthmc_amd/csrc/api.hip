@@ -46,7 +46,7 @@ struct Ctx {
 };
 inline int make_ctx(const fthmc_arch_t* arch, void* stream, Ctx* c) {
     c->A = flow_arch_default();
-    if (arch) { int rc = make_flow_arch(arch->n_hidden, arch->hidden, arch->kernel_size, arch->n_mix, &c->A); if (rc != FTHMC_OK) return rc; }
+    if (arch) { int rc = make_flow_arch(arch->n_hidden, arch->hidden, arch->kernel_size, arch->n_mix, arch->final_tanh, &c->A); if (rc != FTHMC_OK) return rc; }
     c->mfma = get_flow_variant() == 1;
     c->small_on = get_small_path() != 0;
     c->wcan = nullptr;

@@ -52,6 +52,19 @@ __global__ void k_gen_act(const double* __restrict__ Z, double* __restrict__ H, 
     for (; i < n; i += stride) { double h, d; act1(Z[i], act, h, d); H[i] = h; }
 }
 
+// ---- the optional tanh behind the last conv (make_conv_net(use_final_tanh=True), layers.py:163-164): Z <- tanh(Z) in place
+//      (the raw pre-activation is not needed again: tanh' = 1 - tanh^2), and its adjoint G <- G (1 - Z^2)
+__global__ void k_gen_tanh(double* __restrict__ Z, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) Z[i] = tanh(Z[i]);
+}
+__global__ void k_gen_tanh_bwd(const double* __restrict__ Z, double* __restrict__ G, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) G[i] *= 1.0 - Z[i] * Z[i];
+}
+
 // ---- circular conv: Z[b][co][s] = bias[co] + sum_{ci, ky, kx} w[co][ci][ky][kx] A[b][ci][s + (ky - r, kx - r)]
 __global__ void k_gen_conv(const double* __restrict__ A, int cin, int cout, int k, const double* __restrict__ w,
                            const double* __restrict__ bias, double* __restrict__ Z, int L) {
@@ -267,11 +280,11 @@ inline int egrid(size_t n) { size_t g = (n + 255) / 256; return (int)(g > 4096 ?
 
 namespace fthmc {
 
-int make_flow_arch(int nh, const int* hid, int k, int nmix, FlowArch* out) {
+int make_flow_arch(int nh, const int* hid, int k, int nmix, int final_tanh, FlowArch* out) {
     if (nh < 0 || nh > FLOW_ARCH_MAXH || k < 1 || (k & 1) == 0 || k > 15 || nmix < 1 || nmix > 64) return FTHMC_ERR_UNSUPPORTED;
     for (int i = 0; i < nh; ++i) if (!hid || hid[i] < 1 || hid[i] > 256) return FTHMC_ERR_UNSUPPORTED;
     FlowArch a{};
-    a.nh = nh; a.k = k; a.nmix = nmix;
+    a.nh = nh; a.k = k; a.nmix = nmix; a.tanh_out = final_tanh != 0;
     for (int i = 0; i < nh; ++i) a.hid[i] = hid[i];
     *out = a;
     return FTHMC_OK;
@@ -313,6 +326,11 @@ static int gen_net(const GenLayerArgs& a, const GenStash& st, hipStream_t s) {
             A = a.hbuf;
         }
     }
+    if (A_.tanh_out) {
+        const size_t nz = (size_t)a.B * (A_.nmix + 1) * n;
+        hipLaunchKernelGGL(k_gen_tanh, dim3(egrid(nz)), dim3(256), 0, s, st.Z[nh], nz);
+        FT_LAUNCH_CHECK();
+    }
     return FTHMC_OK;
 }
 
@@ -339,6 +357,11 @@ int launch_gen_bwd(const GenLayerArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_gen_transform_bwd, dim3(sgrid(n), a.B), dim3(256), 0, s, st.P, st.Z[nh], a.up_gp, a.up_link, a.glogj,
                        a.glogj_const, G, a.gp_out, a.L, a.mu, a.off, K);
     FT_LAUNCH_CHECK();
+    if (A_.tanh_out) {
+        const size_t nz = (size_t)a.B * (K + 1) * n;
+        hipLaunchKernelGGL(k_gen_tanh_bwd, dim3(egrid(nz)), dim3(256), 0, s, st.Z[nh], G, nz);
+        FT_LAUNCH_CHECK();
+    }
     for (int i = nh; i >= 0; --i) {
         const int cin = A_.chan(i), cout = A_.chan(i + 1);
         const GenW W = gen_w(A_, a.w, i);

@@ -130,7 +130,8 @@ constexpr int FLOW_ARCH_MAXH = 8;
 // every call (fthmc_arch_t of the C ABI; NULL there = the default): nothing about the shape is process state.
 struct FlowArch {
     int nh; int hid[FLOW_ARCH_MAXH]; int k; int nmix;
-    bool is_default() const { return nh == 2 && hid[0] == 8 && hid[1] == 8 && k == 3 && nmix == 2; }   // the tuned kernels serve it
+    int tanh_out;            // a tanh behind the last conv (make_conv_net(use_final_tanh=True))
+    bool is_default() const { return nh == 2 && hid[0] == 8 && hid[1] == 8 && k == 3 && nmix == 2 && !tanh_out; }   // the tuned kernels serve it
     int chan(int i) const { return i == 0 ? 2 : (i <= nh ? hid[i - 1] : nmix + 1); }                   // channels in front of conv i
     int params() const {                                    // doubles per layer in the canonical (PyTorch-order) weight layout
         int p = 0;
@@ -142,9 +143,9 @@ struct FlowArch {
     // per layer: P [B][n], IN [B][2][n], Z_1 .. Z_{nh+1} [B][c_i][n]
     size_t stash_doubles(int B, int L) const { return (size_t)B * L * L * (3 + csum()); }
 };
-inline FlowArch flow_arch_default() { return FlowArch{2, {8, 8, 0, 0, 0, 0, 0, 0}, 3, 2}; }
+inline FlowArch flow_arch_default() { return FlowArch{2, {8, 8, 0, 0, 0, 0, 0, 0}, 3, 2, 0}; }
 // validated copy of a caller's shape (FTHMC_ERR_UNSUPPORTED beyond the limits of flow_generic.hip)
-int make_flow_arch(int n_hidden, const int* hidden_sizes, int kernel_size, int n_mix, FlowArch* out);
+int make_flow_arch(int n_hidden, const int* hidden_sizes, int kernel_size, int n_mix, int final_tanh, FlowArch* out);
 struct GenLayerArgs {
     FlowArch arch;           // the net's shape
     const double* x;         // [B][2][L][L] layer input (null with pin)

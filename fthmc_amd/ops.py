@@ -80,7 +80,8 @@ def release_workspaces():
 
 # ---------------------------------------------------------------- s/t net shape
 # The shape of the s/t conv net is an ARGUMENT of every call that runs the net (C ABI: fthmc_arch_t; the library keeps no
-# shape between calls).  On this side it is a tuple (hidden_sizes, kernel_size, n_mixture_comps); it comes, in this order,
+# shape between calls).  On this side it is a tuple (hidden_sizes, kernel_size, n_mixture_comps) -- with a fourth entry True for a
+# net that ends in a tanh (make_conv_net(use_final_tanh=True)) --; it comes, in this order,
 # from the `arch=` argument of an op, from the tag `pack_weights` leaves on a packed weight tensor (`arch_of`), or it is
 # the reference default.
 DEFAULT_ARCH = ((8, 8), 3, 2)          # hidden_sizes, kernel_size, n_mixture_comps: the reference default (tuned kernels)
@@ -89,12 +90,13 @@ DEFAULT_ARCH = ((8, 8), 3, 2)          # hidden_sizes, kernel_size, n_mixture_co
 def norm_arch(arch) -> tuple:
     if arch is None:
         return DEFAULT_ARCH
-    return (tuple(int(h) for h in arch[0]), int(arch[1]), int(arch[2]))
+    a = (tuple(int(h) for h in arch[0]), int(arch[1]), int(arch[2]))
+    return a + (True,) if len(arch) > 3 and arch[3] else a
 
 
 def arch_params(arch=DEFAULT_ARCH) -> int:
     """Doubles per layer of the canonical weight layout [w0 b0 w1 b1 ...] for a net 2 -> hidden... -> n_mix + 1."""
-    hidden, k, n_mix = norm_arch(arch)
+    hidden, k, n_mix = norm_arch(arch)[:3]
     chans = [2, *hidden, n_mix + 1]
     return sum(co * ci * k * k + co for ci, co in zip(chans[:-1], chans[1:]))
 
@@ -104,11 +106,11 @@ def _arch(arch):
     arch = norm_arch(arch)
     if arch == DEFAULT_ARCH:
         return None
-    hidden, k, n_mix = arch
+    hidden, k, n_mix = arch[:3]
     if len(hidden) > 8:
         raise FthmcError(f'net shape {arch}: at most 8 hidden layers')
     a = _lib.ArchT()
-    a.n_hidden, a.kernel_size, a.n_mix = len(hidden), k, n_mix
+    a.n_hidden, a.kernel_size, a.n_mix, a.final_tanh = len(hidden), k, n_mix, int(len(arch) > 3)
     for i, h in enumerate(hidden):
         a.hidden[i] = h
     import ctypes
@@ -156,7 +158,7 @@ def act_code(act) -> int:
     return ACT_CODES[key]
 
 
-def pack_weights(nets: Sequence[Sequence[torch.Tensor]], device=None) -> torch.Tensor:
+def pack_weights(nets: Sequence[Sequence[torch.Tensor]], device=None, final_tanh: bool = False) -> torch.Tensor:
     """[(w0, b0, w1, b1, ...), ...] -> flat [n_layers * params] fp64 (PyTorch order).  The conv nets may have any
     hidden sizes / odd kernel size / number of mixture components (all layers alike); the shape is recorded on the
     result (`arch_of`) and selects the kernels: the tuned ones for the reference default 2 -> 8 -> 8 -> 3, k = 3."""
@@ -184,6 +186,8 @@ def pack_weights(nets: Sequence[Sequence[torch.Tensor]], device=None) -> torch.T
     if device is not None:
         out = out.to(device)
     out = out.reshape(-1)
+    if arch is not None and final_tanh:
+        arch = arch + (True,)                  # a tanh behind the last conv: not visible in the weights, the caller says so
     if arch is not None and arch != DEFAULT_ARCH:
         out._fthmc_arch = arch
     return out
@@ -191,7 +195,7 @@ def pack_weights(nets: Sequence[Sequence[torch.Tensor]], device=None) -> torch.T
 
 def unpack_weight_grads(gw: torch.Tensor, n_layers: int, arch=None):
     """flat [n_layers * params] -> list of tuples shaped like the conv parameters (w0, b0, w1, b1, ...)."""
-    hidden, k, n_mix = arch if arch is not None else arch_of(gw)
+    hidden, k, n_mix = (arch if arch is not None else arch_of(gw))[:3]
     chans = [2, *hidden, n_mix + 1]
     sizes = []
     for ci, co in zip(chans[:-1], chans[1:]):

@@ -43,7 +43,8 @@ def _act(code: int) -> str:
 
 
 def _arch(n_mix: int, hidden, kernel_size: int):
-    """(hidden_sizes, kernel_size, n_mix) of a call from the schema's integers"""
+    """(hidden_sizes, kernel_size, n_mix) of a call from the schema's integers (a net that ends in a tanh -- never built by the
+    reference -- is served through `ops` with `arch=(hidden, k, n_mix, True)`, not through these schemas)"""
     return (tuple(int(h) for h in hidden) if hidden is not None else (8, 8), int(kernel_size), int(n_mix))
 
 

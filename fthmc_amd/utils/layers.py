@@ -51,10 +51,10 @@ def _act_name(actfn) -> str:
 
 def make_conv_net(*, hidden_sizes: Sequence[int], kernel_size: int, in_channels: int, out_channels: int,
                   use_final_tanh: bool = False, activation_fn: str = None):
-    """layers.py:138-167: Conv2d(k, circular padding) + activation, no final activation."""
+    """layers.py:138-167: Conv2d(k, circular padding) + activation, no final activation -- or a final tanh
+    (`use_final_tanh`, layers.py:163-164; the reference always passes False, :419).  A net with the tanh runs on the plain
+    kernels (csrc/flow_generic.hip), like any net shape other than the default."""
     assert kernel_size % 2 == 1, 'kernel size must be odd'
-    if use_final_tanh:
-        raise NotImplementedError('use_final_tanh=True is never used by the reference (layers.py:419)')
     act = _act_name(activation_fn)
     sizes = [in_channels] + list(hidden_sizes) + [out_channels]
     net = []
@@ -63,8 +63,11 @@ def make_conv_net(*, hidden_sizes: Sequence[int], kernel_size: int, in_channels:
                              padding_mode='circular', dtype=DTYPE, device=device()))
         if i != len(sizes) - 2:
             net.append(ACTIVATION_FNS[act]())
+    if use_final_tanh:
+        net.append(nn.Tanh())
     seq = nn.Sequential(*net)
     seq.activation_fn = act
+    seq.final_tanh = bool(use_final_tanh)
     return seq
 
 
@@ -144,7 +147,8 @@ class _CouplingFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mu, off, act, *params):
-        w = ops.pack_weights([params], device=x.device)
+        act, final_tanh = act if isinstance(act, tuple) else (act, False)
+        w = ops.pack_weights([params], device=x.device, final_tanh=final_tanh)
         need_gw = any(p.requires_grad for p in params)
         stash = None
         if x.requires_grad or need_gw:
@@ -189,8 +193,12 @@ class NCPPlaqCouplingLayer(nn.Module):
     def activation_fn(self):
         return getattr(self.net, 'activation_fn', 'silu')
 
+    @property
+    def final_tanh(self):
+        return bool(getattr(self.net, 'final_tanh', False))
+
     def _w(self, dev):
-        return ops.pack_weights([net_weights(self.net)], device=dev)
+        return ops.pack_weights([net_weights(self.net)], device=dev, final_tanh=self.final_tanh)
 
     def forward(self, x):
         """layers.py:348-371 on a plaquette field [B, L, L] -> (fx, logJ[B]).  No autograd at this level: the
@@ -222,10 +230,10 @@ class GaugeEquivCouplingLayer(nn.Module):
 
     def forward(self, x):
         params = net_weights(self.plaq_coupling.net)
-        return _CouplingFn.apply(x, self.mask_mu, self.mask_off, self.activation_fn, *params)
+        return _CouplingFn.apply(x, self.mask_mu, self.mask_off, (self.activation_fn, self.plaq_coupling.final_tanh), *params)
 
     def reverse(self, fx, tol: float = 1e-12):
-        w = ops.pack_weights([net_weights(self.plaq_coupling.net)], device=fx.device)
+        w = self.plaq_coupling._w(fx.device)
         return ops.flow_layer_rev(fx.detach(), w, self.mask_mu, self.mask_off, self.activation_fn, tol=tol)
 
 
@@ -265,6 +273,13 @@ def make_net_from_layers(*, lattice_shape: tuple, nets: List[nn.Module]):
         layers.append(GaugeEquivCouplingLayer(lattice_shape=lattice_shape, mask_mu=mu, mask_off=off,
                                               plaq_coupling=plaq_coupling))
     return nn.ModuleList(layers)
+
+
+def _flow_tanh(flow: nn.ModuleList) -> bool:
+    t = {bool(getattr(layer.plaq_coupling.net, 'final_tanh', False)) for layer in flow}
+    if len(t) > 1:
+        raise ValueError('layers of one flow must agree on use_final_tanh')
+    return t.pop() if t else False
 
 
 def _flow_rows(flow: nn.ModuleList):
@@ -312,7 +327,7 @@ def flatten_flow(flow: nn.ModuleList) -> torch.Tensor:
     flat = _flat_of(rows)
     if flat is not None:
         return flat
-    flat = ops.pack_weights(rows, device=rows[0][0].device if rows else device())
+    flat = ops.pack_weights(rows, device=rows[0][0].device if rows else device(), final_tanh=_flow_tanh(flow))
     o = 0
     with torch.no_grad():
         for row in rows:
@@ -363,7 +378,7 @@ def flow_weights(flow: nn.ModuleList, dev=None) -> torch.Tensor:
         return flat
     if dev is None:
         dev = rows[0][0].device if rows else device()
-    return ops.pack_weights(rows, device=dev)
+    return ops.pack_weights(rows, device=dev, final_tanh=_flow_tanh(flow))
 
 
 def flow_activation(flow: nn.ModuleList) -> str:

@@ -62,7 +62,8 @@ int fthmc_get_variant(void);
 /* Shape of the s/t conv net, an ARGUMENT of every entry point that runs the net (the reference passes it to the layer
  * constructors: make_conv_net fthmc/utils/layers.py:138-167, make_u1_equiv_layers :399-429; TrainConfig.hidden_sizes /
  * kernel_size / n_s_nets, fthmc/config.py:283-303): in_channels 2 -> hidden[0] -> ... -> hidden[n_hidden - 1] -> n_mix + 1,
- * square kernels of odd size, `n_mix` mixture components.  NULL = the default (2, {8, 8}, 3, 2) -- the reference default and
+ * square kernels of odd size, `n_mix` mixture components, `final_tanh` != 0: a tanh behind the last conv (make_conv_net's
+ * use_final_tanh, layers.py:144,163-164; the reference passes False, :419).  NULL = the default (2, {8, 8}, 3, 2, 0) -- the reference default and
  * every BASELINE config -- which runs on the tuned kernels; any other shape runs on plain kernels (csrc/flow_generic.hip:
  * same results, one launch per operation, activations through HBM).  Weights: n_layers * fthmc_arch_params(arch) doubles,
  * per layer [w0 b0 w1 b1 ...] in PyTorch order; the workspace sizes follow the shape.  Limits: n_hidden <= 8, hidden sizes
@@ -74,6 +75,7 @@ typedef struct fthmc_arch_t {
     int hidden[8];
     int kernel_size;
     int n_mix;
+    int final_tanh;
 } fthmc_arch_t;
 int fthmc_arch_params(const fthmc_arch_t* arch);   /* doubles per layer; 955 for the default */
 /* Lattices of L = 8, 12, 16 take a fused path by default (csrc/flow_small.hip): one workgroup holds a whole chain in

@@ -177,7 +177,11 @@ _ACT = {
 
 
 def conv_net(inp: torch.Tensor, w: Weights, act: str = 'silu') -> torch.Tensor:
-    """layers.py:138-167: Conv2d(k, circular pad k//2) + act, no final act."""
+    """layers.py:138-167: Conv2d(k, circular pad k//2) + act, no final act -- or a final tanh (use_final_tanh,
+    layers.py:163-164), asked for here by an activation name that ends in '+tanh' (every caller hands `act` through)."""
+    final_tanh = isinstance(act, str) and act.endswith('+tanh')
+    if final_tanh:
+        act = act[:-5]
     fn = _ACT[act]
     n = len(w) // 2
     h = inp
@@ -187,7 +191,7 @@ def conv_net(inp: torch.Tensor, w: Weights, act: str = 'silu') -> torch.Tensor:
         h = F.conv2d(F.pad(h, (pad, pad, pad, pad), mode='circular'), wt, b)
         if li != n - 1:
             h = fn(h)
-    return h
+    return torch.tanh(h) if final_tanh else h
 
 
 def tan_transform(x: torch.Tensor, s: torch.Tensor) -> torch.Tensor:

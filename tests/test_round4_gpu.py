@@ -283,6 +283,63 @@ def test_two_net_shapes_on_two_threads_and_streams():
             close(F, j['F'], rtol=1e-9, atol=1e-10); close(S, j['S'], rtol=1e-11, atol=1e-10)
 
 
+@pytest.mark.parametrize('hidden,k,n_mix,L,nl', [((8, 8), 3, 2, 8, 3), ((6,), 3, 3, 12, 2)])
+def test_final_tanh_option(hidden, k, n_mix, L, nl):
+    """make_conv_net(use_final_tanh=True) (layers.py:144,163-164; never built by the reference, :419): the tanh behind the last
+    conv through the C ABI (`fthmc_arch_t.final_tanh`, plain kernels) against the oracle -- forward, log det, reverse, force,
+    training gradient -- and through the reference-shaped layer with autograd."""
+    gen = torch.Generator().manual_seed(300 + L)
+    B, beta = 3, 2.0
+    flow = R.default_flow(nl, gen, hidden=hidden, n_mix=n_mix, k=k)
+    flow = [tuple(t * 2.0 for t in lw) for lw in flow]                       # large enough for the tanh to bend
+    w = ops.pack_weights(flow, device='cuda', final_tanh=True)
+    assert ops.arch_of(w) == (tuple(hidden), k, n_mix, True)
+    x = (torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+    y, ld = ops.flow_forward(x.cuda(), w, nl)
+    yc, ldc = R.flow_forward(x, flow, 'silu+tanh')
+    d = (H(y) - H(yc) + np.pi) % (2 * np.pi) - np.pi
+    assert np.abs(d).max() < 1e-11
+    close(ld, ldc, rtol=1e-11, atol=1e-11)
+    y0, _ = ops.flow_forward(x.cuda(), ops.pack_weights(flow, device='cuda'), nl)
+    assert float((y - y0).abs().max()) > 1e-3                                # it is a different map
+    xb, ldb = ops.flow_reverse(y, w, nl)
+    d = (H(xb) - H(x) + np.pi) % (2 * np.pi) - np.pi
+    assert np.abs(d).max() < 1e-9 and float((ldb + ld).abs().max()) < 1e-8
+    close(ops.ft_force(x.cuda(), w, nl, beta), R.ft_force(x, flow, beta, 'silu+tanh'), rtol=1e-9, atol=1e-10)
+    out, grads = R.train_grads(x, flow, beta, 'silu+tanh')
+    r = ops.train_grad(x.cuda(), w, nl, beta)
+    close(r['logq'], out['logq'], rtol=1e-11); close(r['logp'], out['logp'], rtol=1e-11)
+    gws = ops.unpack_weight_grads(r['gw'], nl)
+    gmax = max(float(g.abs().max()) for lg in grads for g in lg)
+    for li in range(nl):
+        for pi in range(len(flow[0])):
+            close(gws[li][pi], grads[li][pi], rtol=1e-8, atol=1e-11 * max(gmax, 1.0))
+    # the reference-shaped modules: a coupling layer built on a net with the tanh, forward and autograd
+    from fthmc_amd.utils import layers as LY
+    net = LY.make_conv_net(hidden_sizes=list(hidden), kernel_size=k, in_channels=2, out_channels=n_mix + 1, use_final_tanh=True)
+    assert isinstance(net[-1], torch.nn.Tanh) and net.final_tanh
+    with torch.no_grad():
+        for p_, t_ in zip(LY.net_weights(net), flow[0]):
+            p_.copy_(t_.cuda())
+    layer = LY.GaugeEquivCouplingLayer(lattice_shape=(L, L), mask_mu=0, mask_off=0,
+                                       plaq_coupling=LY.NCPPlaqCouplingLayer(net, mask_shape=(L, L), mask_mu=0, mask_off=0))
+    xg = x.cuda().requires_grad_(True)
+    yl, lj = layer(xg)
+    xr_ = x.clone().requires_grad_(True)
+    wr_ = [t.clone().requires_grad_(True) for t in flow[0]]
+    ylc, ljc = R.layer_forward(xr_, wr_, 0, 0, 'silu+tanh')
+    close(lj, ljc.detach(), rtol=1e-11, atol=1e-11)
+    c = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64)
+    ((yl * c.cuda()).sum() + lj.sum()).backward()
+    ((ylc * c).sum() + ljc.sum()).backward()
+    close(xg.grad, xr_.grad, rtol=1e-9, atol=1e-10 * float(xr_.grad.abs().max()))
+    for p_, t_ in zip(LY.net_weights(net), wr_):
+        close(p_.grad, t_.grad, rtol=1e-8, atol=1e-10 * max(1.0, float(t_.grad.abs().max())))
+    xi_, _ = layer.reverse(yl.detach())
+    d = (H(xi_) - H(x) + np.pi) % (2 * np.pi) - np.pi
+    assert np.abs(d).max() < 1e-9
+
+
 def test_kernel_wider_than_the_lattice_is_refused():
     """A circular pad wider than the lattice (kernel_size // 2 > L) is refused before any launch, as torch's circular Conv2d
     refuses it (the plain kernels fold an index once)."""

@@ -63,6 +63,7 @@ SIGNATURES = {
     'fthmc_flow_layer_bwd_stash': [_D, _D, _A, _D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
     'fthmc_flow_layer_rev': [_D, _D, _A, c_int, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
     'fthmc_plaq_coupling_fwd': [_D, _D, _A, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
+    'fthmc_plaq_coupling_bwd': [_D, _D, _A, _D, _D, c_int, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
     'fthmc_plaq_coupling_rev': [_D, _D, _A, c_int, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],
     'fthmc_flow_forward': [_D, _D, _A, c_int, c_int, c_int, c_int, _D, _D, _P, c_size_t, _P],
     'fthmc_flow_reverse': [_D, _D, _A, c_int, c_int, c_int, c_int, c_double, _D, _D, _P, c_size_t, _P],

@@ -489,6 +489,46 @@ int fthmc_plaq_coupling_rev(const double* fP, const double* w, const fthmc_arch_
     return plaq_coupling(fP, w, arch, B, L, mu, off, act, tol, true, P, logJ, ws, ws_bytes, stream);
 }
 
+// VJP of the plaquette-level map fP = NCPPlaqCouplingLayer.forward(P) (layers.py:348-371): gP = d/dP [sum gfP fP + sum_b glogJ logJ],
+// gw (optional) the same wrt the weights.  fP = P + delta at the active sites and P elsewhere, so
+//     gP = gfP + (the link-level layer's plaquette gradient for the upstream link gradient gy[mu] = +-gfP),
+// i.e. the link-level backward kernels serve it unchanged: the upstream gradient is dressed as that link field
+// (launch_plane_from), the forward runs on the plaquette field itself (FlowLayerArgs::pin), gP = W.gp + gfP.
+int fthmc_plaq_coupling_bwd(const double* P, const double* w, const fthmc_arch_t* arch, const double* gfP, const double* glogJ,
+                            int B, int L, int mu, int off, int act, double* gP, double* gw, void* ws, size_t ws_bytes, void* stream) {
+    if (!P || !w || !gfP || !glogJ || !gP || bad_shape(B, L) || mu < 0 || mu > 1 || off < 0 || off > 3) return FTHMC_ERR_ARG;
+    if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
+    FT_CTX(arch);
+    if (!C.mfma && C.A.is_default()) return FTHMC_ERR_UNSUPPORTED;          // as fthmc_plaq_coupling_fwd: MFMA kernels (or the plain ones)
+    if (!ws || ws_bytes < ws_doubles(C.A, B, L, 1, gw != nullptr) * sizeof(double)) return FTHMC_ERR_WS;
+    const WS W = ws_layout(C.A, static_cast<double*>(ws), B, L, 1, gw != nullptr);
+    FT_TRY(use_weights(C, w, 1, W, s));
+    double* fake = W.xa;                                                     // [B][2][L][L]: only plane mu is read
+    FT_TRY(launch_plane_from(gfP, B, L, mu, mu == 0 ? 1.0 : -1.0, fake, s));
+    const size_t n1 = (size_t)B * L * L;
+    if (C.gen()) {
+        GenLayerArgs g = gen_args(C, W, 0, B, L, act, false);
+        g.mu = mu; g.off = off; g.pin = P;
+        FT_TRY(launch_gen_fwd(g, false, s));
+        g.up_link = fake; g.glogj = glogJ; g.gp_out = W.gp; g.gw = gw;
+        FT_TRY(launch_gen_bwd(g, s));
+        return launch_axpy(W.gp, gfP, 1.0, gP, n1, s);
+    }
+    FlowLayerArgs a{};
+    a.x = P; a.pin = P; a.wint = W.wint; a.up_link = fake; a.glogj = glogJ;
+    a.gw_part = W.gw_part; a.stash = W.stash; a.stash_h = gw ? 1 : 0;
+    a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+    FT_TRY(launch_flow_fwd_mfma(a, s));                                      // fills the stash (no output field, no log J)
+    a.gp_out = W.gp;
+    a.gz = gw ? W.gz : nullptr;
+    FT_TRY(launch_flow_bwd_gather(a, s));
+    if (gw) {
+        FT_TRY(launch_flow_wgrad(a, s));
+        FT_TRY(launch_reduce_gw(W.gw_part, B * flow_wgrad_parts(L), 1.0, 0, gw, W.gw_tmp, s));
+    }
+    return launch_axpy(W.gp, gfP, 1.0, gP, n1, s);
+}
+
 // VJP of one layer.  `stash` != null: the forward's activation stash (fthmc_flow_layer_fwd_stash) -- nothing is recomputed;
 // else the layer is run forward first from `x`.
 static int layer_bwd_impl(const double* x, const double* stash, const double* w, const fthmc_arch_t* arch, const double* gy, const double* glogJ,

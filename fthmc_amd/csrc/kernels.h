@@ -33,6 +33,7 @@ int launch_kick_from_gp(const double* gp, double* v, double* xq, double* Fout, i
 int launch_traj_energy(const double* xphys, int B, int L, double beta, const double* lj_part, int np, int nsets,
                        const double* state_in, const double* v, double* trip, double* H, hipStream_t s);
 int launch_axpy_copy(const double* x, const double* p, double a, double* xo, double* po, size_t n, hipStream_t s);
+int launch_plane_from(const double* g, int B, int L, int mu, double sign, double* out, hipStream_t s);   // out[b][mu][:] = sign * g[b][:]
 int launch_metropolis(const double* x_old, const double* x_prop, const double* u, const double* H0,
                       const double* H1, int B, int L, int xform, double* x_new, double* dH,
                       double* acc, const double* obs_old, const double* obs_new, double* obs_out,

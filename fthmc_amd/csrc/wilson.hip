@@ -128,6 +128,15 @@ __global__ void k_traj_energy(const double* __restrict__ xphys, int L, double be
     }
 }
 
+// out[b][mu][s] = sign * g[b][s]: a plaquette-level upstream gradient dressed as the link gradient that produces it in the
+// coupling layer's adjoint (gdelta = +-gy[mu] at the active sites): lets the link-level backward kernels serve the
+// plaquette-level map (NCPPlaqCouplingLayer.forward under autograd)
+__global__ void k_plane_from(const double* __restrict__ g, int n, int mu, double sign, double* __restrict__ out) {
+    const int b = blockIdx.y;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
+        out[((size_t)b * 2 + mu) * n + s] = sign * g[(size_t)b * n + s];
+}
+
 // xo = x + a v and vo = v in one pass (the first half drift of a flowed trajectory and the working copy of the momenta)
 __global__ void k_axpy_copy(const double* __restrict__ x, const double* __restrict__ p, double a, double* __restrict__ xo,
                             double* __restrict__ po, size_t n) {
@@ -697,6 +706,11 @@ int launch_traj_energy(const double* xphys, int B, int L, double beta, const dou
                        const double* state_in, const double* v, double* trip, double* H, hipStream_t s) {
     const int nt = L * L >= 4096 ? 1024 : (L * L >= 1024 ? 512 : 256);           // = launch_action_charge = launch_kinetic
     hipLaunchKernelGGL(k_traj_energy, dim3(B), dim3(nt), 0, s, xphys, L, beta, lj_part, np, nsets, state_in, v, trip, H, B);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+int launch_plane_from(const double* g, int B, int L, int mu, double sign, double* out, hipStream_t s) {
+    int gx = (L * L + 255) / 256; if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_plane_from, dim3(gx, B), dim3(256), 0, s, g, L * L, mu, sign, out);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_axpy_copy(const double* x, const double* p, double a, double* xo, double* po, size_t n, hipStream_t s) {

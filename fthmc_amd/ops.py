@@ -448,6 +448,21 @@ def plaq_coupling_fwd(P, w, mu: int, off: int, act='silu', arch=None):
     return fP, logJ
 
 
+def plaq_coupling_bwd(P, w, gfP, glogJ, mu: int, off: int, act='silu', need_gw=False, arch=None):
+    """VJP of plaq_coupling_fwd: -> (gP, gw or None) for the upstream gradients gfP [B, L, L] and glogJ [B]."""
+    P = _plaq_field(P); gfP = _plaq_field(gfP, 'gfP'); B, L, _ = P.shape
+    glogJ = _dev(glogJ, 'glogJ').reshape(-1)
+    if gfP.shape != P.shape or glogJ.numel() != B:
+        raise FthmcError('plaq_coupling_bwd: gfP must be shaped like P, glogJ [B]')
+    w, ap, a = _w1(w, P, arch)
+    gP = torch.empty_like(P)
+    gw = _tag(torch.empty(w.numel(), dtype=P.dtype, device=P.device), w) if need_gw else None
+    ws, nb = _ws(P, B, L, 1, train=need_gw, arch=a)
+    check(_lib.load().fthmc_plaq_coupling_bwd(_p(P), _p(w), ap, _p(gfP), _p(glogJ), B, L, int(mu), int(off), act_code(act),
+                                              _p(gP), _p(gw), ws, nb, _stream(P)), 'fthmc_plaq_coupling_bwd')
+    return gP, gw
+
+
 def plaq_coupling_rev(fP, w, mu: int, off: int, act='silu', tol: float = 1e-12, arch=None):
     """NCPPlaqCouplingLayer.reverse on a plaquette field [B, L, L] -> (P, logJ[B])."""
     fP = _plaq_field(fP, 'fP'); B, L, _ = fP.shape

@@ -176,6 +176,30 @@ class _CouplingFn(torch.autograd.Function):
         return (gx, None, None, None, *gparams)
 
 
+class _PlaqCouplingFn(torch.autograd.Function):
+    """fP, logJ = NCPPlaqCouplingLayer.forward(P) on a plaquette field: forward = fthmc_plaq_coupling_fwd, backward =
+    fthmc_plaq_coupling_bwd (the link-level backward kernels with the upstream gradient dressed as a link gradient)."""
+
+    @staticmethod
+    def forward(ctx, P, mu, off, act, *params):
+        act, final_tanh = act if isinstance(act, tuple) else (act, False)
+        w = ops.pack_weights([params], device=P.device, final_tanh=final_tanh)
+        fP, logJ = ops.plaq_coupling_fwd(P, w, mu, off, act)
+        ctx.save_for_backward(P, w)
+        ctx.meta = (mu, off, act, any(p.requires_grad for p in params), ops.arch_of(w), len(params))
+        return fP, logJ
+
+    @staticmethod
+    def backward(ctx, gfP, glogJ):
+        P, w = ctx.saved_tensors
+        mu, off, act, need_gw, arch, npar = ctx.meta
+        gfP = torch.zeros_like(P) if gfP is None else gfP.contiguous()
+        glogJ = torch.zeros(P.shape[0], dtype=P.dtype, device=P.device) if glogJ is None else glogJ.contiguous()
+        gP, gw = ops.plaq_coupling_bwd(P, w, gfP, glogJ, mu, off, act, need_gw=need_gw, arch=arch)
+        gparams = list(ops.unpack_weight_grads(gw, 1, arch=arch)[0]) if need_gw else [None] * npar
+        return (gP, None, None, None, *gparams)
+
+
 class NCPPlaqCouplingLayer(nn.Module):
     """Holder of the s/t conv net and stripe geometry (layers.py:324-396).  The plaquette-level
     map itself is fused into the link-level kernels used by GaugeEquivCouplingLayer."""
@@ -201,11 +225,12 @@ class NCPPlaqCouplingLayer(nn.Module):
         return ops.pack_weights([net_weights(self.net)], device=dev, final_tanh=self.final_tanh)
 
     def forward(self, x):
-        """layers.py:348-371 on a plaquette field [B, L, L] -> (fx, logJ[B]).  No autograd at this level: the
-        differentiable path is GaugeEquivCouplingLayer (the only caller in the reference, layers.py:196-202)."""
-        if x.requires_grad:
-            raise NotImplementedError('autograd runs through GaugeEquivCouplingLayer.forward (link level)')
+        """layers.py:348-371 on a plaquette field [B, L, L] -> (fx, logJ[B]); differentiable wrt the field and the conv
+        weights (round 4: fthmc_plaq_coupling_bwd), like the reference's module under autograd."""
         assert len(x.shape) == 3, f'field should be (batch_size, *lattice_shape); got {tuple(x.shape)}'
+        params = net_weights(self.net)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            return _PlaqCouplingFn.apply(x, self.mask_mu, self.mask_off, (self.activation_fn, self.final_tanh), *params)
         return ops.plaq_coupling_fwd(x, self._w(x.device), self.mask_mu, self.mask_off, self.activation_fn)
 
     def reverse(self, fx, tol: float = 1e-12):

@@ -182,6 +182,12 @@ int fthmc_plaq_coupling_fwd(const double* P, const double* w, const fthmc_arch_t
                             double* fP, double* logJ, void* ws, size_t ws_bytes, void* stream);
 int fthmc_plaq_coupling_rev(const double* fP, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                             double tol, double* P, double* logJ, void* ws, size_t ws_bytes, void* stream);
+/* VJP of fthmc_plaq_coupling_fwd (autograd through NCPPlaqCouplingLayer.forward, layers.py:348-371, on a plaquette field):
+ * gP = d/dP [ sum(gfP * fP) + sum_b glogJ[b] logJ[b] ]; gw != NULL additionally the same wrt the layer's weights (the workspace
+ * must then hold fthmc_train_ws_bytes(arch, B, L, 1)).  The layer is run forward once inside. */
+int fthmc_plaq_coupling_bwd(const double* P, const double* w, const fthmc_arch_t* arch, const double* gfP, const double* glogJ,
+                            int B, int L, int mu, int off, int act, double* gP, double* gw,
+                            void* ws, size_t ws_bytes, void* stream);
 
 /* ---- whole flow ---------------------------------------------------------- */
 /* y = F(x), logdet[B] = sum_l logJ_l.  fthmc/ft_hmc.py:143-150 (flow_forward),

@@ -340,6 +340,44 @@ def test_final_tanh_option(hidden, k, n_mix, L, nl):
     assert np.abs(d).max() < 1e-9
 
 
+@pytest.mark.parametrize('hidden,k,n_mix,L,B', [((8, 8), 3, 2, 8, 3), ((8, 8), 3, 2, 40, 2), ((4, 6), 5, 3, 12, 2)])
+def test_plaquette_level_autograd(hidden, k, n_mix, L, B):
+    """NCPPlaqCouplingLayer.forward on a plaquette field under autograd (layers.py:348-371): fthmc_plaq_coupling_bwd -- the
+    link-level backward kernels with the upstream gradient dressed as a link gradient -- against the oracle's autograd, wrt the
+    plaquette field and wrt every conv weight, all (mu, off) classes, tuned and plain kernels, through `ops` and the module."""
+    from fthmc_amd.utils import layers as LY
+    gen = torch.Generator().manual_seed(77 + L + k)
+    flow = R.default_flow(1, gen, hidden=hidden, n_mix=n_mix, k=k)[0]
+    w = ops.pack_weights([flow], device='cuda')
+    for mu, off in ((0, 0), (1, 2), (0, 3), (1, 1)):
+        P = (torch.rand(B, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi
+        c = torch.randn(B, L, L, generator=gen, dtype=torch.float64); dl = torch.randn(B, generator=gen, dtype=torch.float64)
+        Pr = P.clone().requires_grad_(True)
+        wr = [t.clone().requires_grad_(True) for t in flow]
+        fPc, ljc = R.plaq_coupling_forward(Pr, wr, mu, off)
+        ((fPc * c).sum() + (ljc * dl).sum()).backward()
+        gP, gw = ops.plaq_coupling_bwd(P.cuda(), w, c.cuda(), dl.cuda(), mu, off, need_gw=True)
+        close(gP, Pr.grad, rtol=1e-9, atol=1e-10 * max(1.0, float(Pr.grad.abs().max())))
+        for g_, t_ in zip(ops.unpack_weight_grads(gw, 1)[0], wr):
+            close(g_, t_.grad, rtol=1e-8, atol=1e-10 * max(1.0, float(t_.grad.abs().max())))
+        assert torch.equal(ops.plaq_coupling_bwd(P.cuda(), w, c.cuda(), dl.cuda(), mu, off)[0], gP)
+    # the module: P.requires_grad no longer raises
+    net = LY.make_conv_net(hidden_sizes=list(hidden), kernel_size=k, in_channels=2, out_channels=n_mix + 1)
+    with torch.no_grad():
+        for p_, t_ in zip(LY.net_weights(net), flow):
+            p_.copy_(t_.cuda())
+    layer = LY.NCPPlaqCouplingLayer(net, mask_shape=(L, L), mask_mu=mu, mask_off=off)
+    Pg = P.cuda().requires_grad_(True)
+    fP, lj = layer(Pg)
+    ((fP * c.cuda()).sum() + (lj * dl.cuda()).sum()).backward()
+    close(Pg.grad, Pr.grad, rtol=1e-9, atol=1e-10 * max(1.0, float(Pr.grad.abs().max())))
+    for p_, t_ in zip(LY.net_weights(net), wr):
+        close(p_.grad, t_.grad, rtol=1e-8, atol=1e-10 * max(1.0, float(t_.grad.abs().max())))
+    with torch.no_grad():
+        fP2, _ = layer(P.cuda())
+    assert torch.equal(fP2, fP.detach())
+
+
 def test_kernel_wider_than_the_lattice_is_refused():
     """A circular pad wider than the lattice (kernel_size // 2 > L) is refused before any launch, as torch's circular Conv2d
     refuses it (the plain kernels fold an index once)."""

@@ -36,6 +36,23 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b'workspace' in lib.fthmc_strerror(-4)
 
 
+def test_compiled_torch_library_loads_and_defines_every_operator():
+    """libfthmc_torch.so (csrc/torch_library.cpp, built by csrc/Makefile): the compiled TORCH_LIBRARY(fthmc_hip) loads on a CPU
+    box, defines all eleven operators with the net shape in their schemas, and a CPU tensor is refused by the dispatcher."""
+    so = os.path.join(ROOT, 'fthmc_amd', 'libfthmc_torch.so')
+    if not os.path.exists(so):
+        pytest.skip('libfthmc_torch.so not built (make -C fthmc_amd/csrc)')
+    import fthmc_amd.torch_ops as T
+    assert T.BACKEND == 'compiled'
+    for name in T.__all__:
+        op = getattr(torch.ops.fthmc_hip, name).default
+        assert op._schema.name == 'fthmc_hip::' + name
+    sch = str(torch.ops.fthmc_hip.fthmc_trajectory.default._schema)
+    assert 'int[]? hidden=None' in sch and 'int kernel_size=3' in sch and 'int n_mix=2' in sch
+    with pytest.raises(NotImplementedError):
+        torch.ops.fthmc_hip.wilson_force(torch.zeros(1, 2, 8, 8, dtype=torch.float64), 1.0)
+
+
 def test_no_cpu_fallback():
     from fthmc_amd import ops
     from fthmc_amd._lib import FthmcError

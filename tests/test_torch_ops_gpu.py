@@ -109,12 +109,13 @@ def test_ops_reject_cpu_tensors_and_bad_codes(T):
     x = torch.zeros(1, 2, 8, 8, dtype=torch.float64)
     with pytest.raises(NotImplementedError):
         torch.ops.fthmc_hip.wilson_force(x, 1.0)
-    from fthmc_amd._lib import FthmcError
     xc = x.cuda(); w = torch.zeros(955, dtype=torch.float64, device='cuda')
-    with pytest.raises(FthmcError):
-        torch.ops.fthmc_hip.flow_layer_fwd(xc, w, 0, 0, 3, 0)          # n_mix != 2
-    with pytest.raises(FthmcError):
+    with pytest.raises(RuntimeError):                                  # (FthmcError from the Python registration, c10::Error from the compiled one)
+        torch.ops.fthmc_hip.flow_layer_fwd(xc, w, 0, 0, 3, 0)          # three mixture components need 1028 weights
+    with pytest.raises(RuntimeError):
         torch.ops.fthmc_hip.flow_layer_fwd(xc, w, 0, 0, 2, 7)          # unknown activation
+    with pytest.raises(RuntimeError):
+        torch.ops.fthmc_hip.flow_layer_fwd(xc.float(), w, 0, 0, 2, 0)  # the HIP path computes in float64
 
 
 def test_opcheck_schema_and_fake(T):
@@ -126,3 +127,56 @@ def test_opcheck_schema_and_fake(T):
                           test_utils=('test_schema', 'test_faketensor'))
     torch.library.opcheck(torch.ops.fthmc_hip.wilson_force.default, (x, 2.0),
                           test_utils=('test_schema', 'test_faketensor'))
+
+
+_OPS_WORKER = r'''
+import os, sys, json, hashlib, math
+sys.path.insert(0, os.environ['FTHMC_ROOT']); sys.path.insert(0, os.path.join(os.environ['FTHMC_ROOT'], 'tests'))
+import numpy as np, torch
+import fthmc_amd.torch_ops as T
+from fthmc_amd import ops
+from oracle import ref_cpu as R
+gen = torch.Generator().manual_seed(5)
+out = {'backend': T.BACKEND}
+def h(*ts): return hashlib.sha256(b''.join(t.detach().cpu().numpy().tobytes() for t in ts)).hexdigest()
+for tag, hidden, k, n_mix in (('default', None, 3, 2), ('generic', [4, 6, 5], 5, 1)):
+    flow = R.default_flow(2, gen, hidden=tuple(hidden) if hidden else (8, 8), n_mix=n_mix, k=k)
+    w = torch.cat([t.reshape(-1) for lw in flow for t in lw]).cuda()
+    x = ((torch.rand(3, 2, 12, 12, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    v = torch.randn(3, 2, 12, 12, generator=gen, dtype=torch.float64).cuda(); u = torch.rand(3, generator=gen, dtype=torch.float64).cuda()
+    npl = w.numel() // 2
+    y, lj = torch.ops.fthmc_hip.flow_layer_fwd(x, w[:npl], 1, 2, n_mix, 0, hidden, k)
+    gx, gw = torch.ops.fthmc_hip.flow_layer_bwd(x, v, u, w[:npl], 1, 2, n_mix, 0, hidden, k)
+    S, ld, F = torch.ops.fthmc_hip.ft_action_force(x, w, 2, 2.0, 0, n_mix, hidden, k)
+    tr = torch.ops.fthmc_hip.fthmc_trajectory(x, v, u, w, 2, 2.0, 0.1, 3, 0, 0, n_mix, hidden, k)
+    tg = torch.ops.fthmc_hip.train_grad(x, w, 2, 2.0, 0, n_mix, hidden, k)
+    xr, wr = x.clone().requires_grad_(True), w[:npl].clone().requires_grad_(True)
+    yy, ll = torch.ops.fthmc_hip.flow_layer_fwd(xr, wr, 0, 1, n_mix, 0, hidden, k)
+    ((yy * v).sum() + (ll * u).sum()).backward()
+    out[tag] = h(y, lj, gx, gw, S, ld, F, *tr, *tg, xr.grad, wr.grad)
+    Fc = R.ft_force(x.cpu(), flow, 2.0)
+    out[tag + '_force_err'] = float((F.cpu() - Fc).abs().max())
+print(json.dumps(out))
+'''
+
+
+def test_compiled_and_python_registrations_agree():
+    """torch.ops.fthmc_hip.* from the compiled TORCH_LIBRARY (libfthmc_torch.so, csrc/torch_library.cpp) and from the Python
+    registration over ctypes (FTHMC_TORCH_OPS=python): same schemas, bit-identical results -- layer forward / backward, S_eff and
+    force, a trajectory, the training gradient, autograd through the layer operator -- for the default net shape and for one
+    given through the schema's `hidden` / `kernel_size` arguments; both against the oracle's force."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    import fthmc_amd.torch_ops as T
+    assert os.path.exists(os.path.join(ROOT, 'fthmc_amd', 'libfthmc_torch.so')), 'make -C fthmc_amd/csrc builds it'
+    assert T.BACKEND == 'compiled'
+    res = {}
+    for mode in ('compiled', 'python'):
+        env = dict(os.environ, FTHMC_ROOT=ROOT, FTHMC_TORCH_OPS=mode)
+        p = subprocess.run([sys.executable, '-c', _OPS_WORKER], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        res[mode] = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert res['compiled']['backend'] == 'compiled' and res['python']['backend'] == 'python'
+    for tag in ('default', 'generic'):
+        assert res['compiled'][tag] == res['python'][tag], tag
+        assert res['compiled'][tag + '_force_err'] < 1e-10

@@ -100,7 +100,8 @@ int fthmc_regularize(const double* x, double* out, size_t n, void* stream);
 /* P[b][i][j] = x0 - x1 - x0[i][j+1] + x1[i+1][j].
  * fthmc/utils/qed_helpers.py:94-105 (batch_plaqs), :80-90 (compute_u1_plaq). */
 int fthmc_plaquettes(const double* x, double* P, int B, int L, void* stream);
-/* S[b] = -beta sum cos P; Q[b] = sum wrap(P) / 2pi; plaq[b] = -S / (beta L^2).
+/* S[b] = -beta sum cos P; Q[b] = sum wrap(P) / 2pi; plaq[b] = -S / (beta L^2) (formed that way on every path, tiled and
+ * small-lattice alike, as the reference forms it, fthmc/hmc.py:125: at beta = 0 it is 0 / 0 = NaN there and here).
  * Any of S/Q/plaq may be NULL.  fthmc/utils/qed_helpers.py:177-186 (BatchAction),
  * :108-116 (batch_charges), fthmc/hmc.py:125 (plaq). */
 int fthmc_wilson_action_charge(const double* x, int B, int L, double beta,

@@ -344,7 +344,7 @@ def main():
     pending = [None]
 
     def step(stateless=False):
-        seeds.copy_(parallel.chain_seeds(SEED, lo, hi, traj[0]).to(dev, non_blocking=True))
+        seeds.copy_(parallel.chain_seeds(SEED, lo, hi, traj[0]), non_blocking=True)      # ONE host-to-device copy (no staging tensor)
         if graph is not None:
             (graph_sl if stateless else graph).replay()
         else:

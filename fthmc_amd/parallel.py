@@ -102,10 +102,11 @@ class RunStats:
 
     def reduce(self, async_op: bool = False):
         """C1: SUM all-reduce of a snapshot over the ranks of the process group (plain copy without one)."""
+        if not have_group():
+            self.glob = None              # one process: `means()` reads the running sums themselves (no snapshot, no copy per trajectory)
+            return None
         self.glob = self.vec.clone()
-        if have_group():
-            return dist.all_reduce(self.glob, op=dist.ReduceOp.SUM, async_op=async_op)
-        return None
+        return dist.all_reduce(self.glob, op=dist.ReduceOp.SUM, async_op=async_op)
 
     def means(self) -> dict:
         v = (self.glob if self.glob is not None else self.vec).detach().cpu()

@@ -31,6 +31,8 @@ ap.add_argument('--tau', type=float, default=1.0)
 ap.add_argument('--nstep', type=int, default=10)
 ap.add_argument('--nstep-trained', default='10,20,40', help='leapfrog steps per trajectory for the trained flow (same tau)')
 ap.add_argument('--seed', type=int, default=1331)
+ap.add_argument('--transfer-from', type=int, default=0, help='train.py:434-455 recipe: train at this lattice size first, then move the nets to --L')
+ap.add_argument('--pre-steps', type=int, default=0, help='training steps at the --transfer-from size')
 ap.add_argument('--out', default=None)
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
@@ -84,7 +86,18 @@ cfg = TrainConfig(L=L, beta=beta, n_layers=NL, batch_size=args.train_batch, n_er
                   base_lr=args.lr, print_freq=0)
 t0 = time.perf_counter()
 from fthmc_amd.train import get_model
-model0 = get_model(cfg)
+pre = None
+if args.transfer_from and args.pre_steps:                                # the reference's small-to-large recipe (train.py:434-455)
+    from fthmc_amd.train import transfer_to_new_lattice
+    cfg0 = TrainConfig(L=args.transfer_from, beta=beta, n_layers=NL, batch_size=args.train_batch, n_era=1, n_epoch=args.pre_steps,
+                       base_lr=args.lr, print_freq=0)
+    o0 = train(cfg0, model=get_model(cfg0), verbose=False, save=False)
+    e0 = [float(e) for e in o0['history']['ess']]
+    k0 = max(1, len(e0) // 20)
+    pre = {'L': args.transfer_from, 'steps': args.pre_steps, 'ess_first': round(float(np.mean(e0[:k0])), 4), 'ess_last': round(float(np.mean(e0[-k0:])), 4)}
+    model0 = transfer_to_new_lattice(L, o0['model'].layers)
+else:
+    model0 = get_model(cfg)
 w_init = ops.pack_weights([net_weights(l.plaq_coupling.net) for l in model0.layers], device=dev)
 out = train(cfg, model=model0, verbose=False, save=False) if args.train_steps else {'model': model0, 'history': {'ess': [0.0], 'loss_dkl': [0.0]}}
 torch.cuda.synchronize()
@@ -97,9 +110,9 @@ summary = {'L': L, 'beta': beta, 'n_layers': NL, 'plaq_exact': PLAQ_EXACT[beta],
            'chains': B, 'trajectories': args.traj, 'thermalisation': args.therm,
            'training': {'steps': args.train_steps, 'batch': args.train_batch, 'lr': args.lr, 'seconds': round(train_s, 1),
                         'ess_first': round(float(np.mean(ess[:k])), 4), 'ess_last': round(float(np.mean(ess[-k:])), 4),
-                        'loss_dkl_first': round(float(np.mean(loss[:k])), 3), 'loss_dkl_last': round(float(np.mean(loss[-k:])), 3)}}
+                        'loss_dkl_first': round(float(np.mean(loss[:k])), 3), 'loss_dkl_last': round(float(np.mean(loss[-k:])), 3), 'pre_training': pre}}
 print(json.dumps(summary), flush=True)
-summary['runs'] = [run(None, 0, 'plain HMC'), run(w_init, NL, 'ftHMC, flow at its random initialisation')]
+summary['runs'] = [run(None, 0, 'plain HMC'), run(w_init, NL, f'ftHMC, flow as moved from L = {args.transfer_from}' if pre else 'ftHMC, flow at its random initialisation', prior_start=bool(pre))]
 for ns in [int(t) for t in args.nstep_trained.split(',')]:
     summary['runs'].append(run(w_tr, NL, f'ftHMC, flow after {args.train_steps} reverse-KL steps', ns, prior_start=True))
 if args.out:

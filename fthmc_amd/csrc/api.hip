@@ -211,8 +211,9 @@ int force_gp(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, i
             a.gz = train ? w.gz : nullptr;
             FT_TRY(launch_flow_bwd_gather(a, s));
             if (gw) {                                                 // weight gradients from the pre-activation gradients
+                a.tpw = flow_wgrad_tpw(B, L, 1);
                 FT_TRY(launch_flow_wgrad(a, s));
-                FT_TRY(launch_reduce_gw(w.gw_part, B * flow_wgrad_parts(L), 1.0, 0,
+                FT_TRY(launch_reduce_gw(w.gw_part, flow_wgrad_nparts(B, L, a.tpw), 1.0, 0,
                                         gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
             }
             double* t_ = gcur; gcur = galt; galt = t_;
@@ -523,8 +524,9 @@ int fthmc_plaq_coupling_bwd(const double* P, const double* w, const fthmc_arch_t
     a.gz = gw ? W.gz : nullptr;
     FT_TRY(launch_flow_bwd_gather(a, s));
     if (gw) {
+        a.tpw = flow_wgrad_tpw(B, L, 1);
         FT_TRY(launch_flow_wgrad(a, s));
-        FT_TRY(launch_reduce_gw(W.gw_part, B * flow_wgrad_parts(L), 1.0, 0, gw, W.gw_tmp, s));
+        FT_TRY(launch_reduce_gw(W.gw_part, flow_wgrad_nparts(B, L, a.tpw), 1.0, 0, gw, W.gw_tmp, s));
     }
     return launch_axpy(W.gp, gfP, 1.0, gP, n1, s);
 }
@@ -568,8 +570,9 @@ static int layer_bwd_impl(const double* x, const double* stash, const double* w,
         a.gz = gw ? W.gz : nullptr;
         FT_TRY(launch_flow_bwd_gather(a, s));
         if (gw) {
+            a.tpw = flow_wgrad_tpw(B, L, 1);
             FT_TRY(launch_flow_wgrad(a, s));
-            FT_TRY(launch_reduce_gw(W.gw_part, B * flow_wgrad_parts(L), 1.0, 0, gw, W.gw_tmp, s));
+            FT_TRY(launch_reduce_gw(W.gw_part, flow_wgrad_nparts(B, L, a.tpw), 1.0, 0, gw, W.gw_tmp, s));
         }
         return launch_adj_add(W.gp, gy, B, L, gx, s);
     }
@@ -818,9 +821,10 @@ int fthmc_train_grad(const double* xi, const double* w, const fthmc_arch_t* arch
         f.B = B; f.L = L; f.act = act;
         f.nlb = n_layers;
         f.stash_lstride = flow_stash_doubles(B, L, true); f.gz_lstride = flow_gz_doubles(B, L);
-        f.gwp_lstride = (size_t)B * flow_wgrad_parts(L) * FLOW_GW_STRIDE;
+        f.tpw = flow_wgrad_tpw(B, L, n_layers);
+        f.gwp_lstride = (size_t)flow_wgrad_nparts(B, L, f.tpw) * FLOW_GW_STRIDE;
         FT_TRY(launch_flow_wgrad(f, s));
-        return launch_reduce_gw(W.gw_part, B * flow_wgrad_parts(L), 1.0, 0, gw, W.gw_tmp, s, n_layers, f.gwp_lstride);
+        return launch_reduce_gw(W.gw_part, flow_wgrad_nparts(B, L, f.tpw), 1.0, 0, gw, W.gw_tmp, s, n_layers, f.gwp_lstride);
     }
     double* ld = W.scal + (size_t)SC_LOGDET * B;
     double* S = W.scal + (size_t)SC_S * B;
@@ -944,10 +948,10 @@ int fthmc_small_profile(const double* x, const double* v, const double* u, const
 
 int fthmc_profile_stages(int kind, const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off, int act,
                          double beta, double* cycles_host16, void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 2) return FTHMC_ERR_ARG;
+    if (!x || !w || !cycles_host16 || bad_shape(B, L) || kind < 0 || kind > 3) return FTHMC_ERR_ARG;
     FT_CTX(arch);
     if (C.gen()) return FTHMC_ERR_UNSUPPORTED;                     // the tuned kernels serve the default net shape
-    const bool train = kind == 2;                                  // kind 2: the backward in training mode (also writes A.gz)
+    const bool train = kind >= 2;                                  // kind 2: the backward in training mode (also writes A.gz); 3: k_flow_wgrad behind it
     if (!ws || ws_bytes < ws_doubles(C.A, B, L, 1, train) * sizeof(double)) return FTHMC_ERR_WS;
     const WS W = ws_layout(C.A, static_cast<double*>(ws), B, L, 1, train);
     const size_t nrec = (size_t)B * (kind >= 1 ? flow_gather_geom() : flow_fwd_geom(true)).ntiles(L);
@@ -963,9 +967,11 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, const fthmc
     if (kind >= 1) {                              // stash backward needs the forward's stash first
         a.stash = W.stash; a.stash_h = train ? 1 : 0; a.gw_part = W.gw_part; a.gz = train ? W.gz : nullptr; a.dbg = nullptr;
         FT_TRY(launch_flow_fwd_mfma(a, s));
-        a.dbg = dbg;
+        a.dbg = kind == 3 ? nullptr : dbg;
     }
     FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : launch_flow_bwd_gather(a, s));
+    size_t nused = nrec;                                           // records the profiled launch stamps
+    if (kind == 3) { a.dbg = dbg; a.tpw = flow_wgrad_tpw(B, L, 1); nused = (size_t)flow_wgrad_nparts(B, L, a.tpw) / 2; FT_TRY(launch_flow_wgrad(a, s)); }
     long long* h = (long long*)malloc(nrec * 16 * sizeof(long long));
     if (!h) return FTHMC_ERR_ARG;
     if (hipMemcpyAsync(h, dbg, nrec * 16 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -973,8 +979,8 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, const fthmc
     for (int k = 0; k < 16; ++k) cycles_host16[k] = 0.0;
     for (size_t r = 0; r < nrec; ++r)
         for (int k = 1; k < 16; ++k) {
-            const int ref = (kind >= 1 && k >= 6) ? 0 : (kind == 0 && k == 7) ? 1 : (kind == 0 && k == 11) ? 2 : k - 1;   // forward 7..12 (-DFT_DIAG builds): inside conv1 / conv2      // backward, slots 6..13: per-wave arrival at the first barrier
-            if (h[r * 16 + k] && h[r * 16 + ref]) cycles_host16[k] += (double)(h[r * 16 + k] - h[r * 16 + ref]) / nrec;
+            const int ref = kind == 3 ? k - 1 : (kind >= 1 && k >= 6) ? 0 : (kind == 0 && k == 7) ? 1 : (kind == 0 && k == 11) ? 2 : k - 1;   // forward 7..12 (-DFT_DIAG builds): inside conv1 / conv2      // backward, slots 6..13: per-wave arrival at the first barrier
+            if (h[r * 16 + k] && h[r * 16 + ref]) cycles_host16[k] += (double)(h[r * 16 + k] - h[r * 16 + ref]) / nused;
         }
     free(h);
     return FTHMC_OK;

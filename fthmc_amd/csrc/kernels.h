@@ -104,6 +104,7 @@ struct FlowLayerArgs {
     // 0 .. nlb - 1 (mu, off from the layer index), their stash / gz / partial regions `*_lstride` doubles apart; nlb = 0: one layer
     int nlb;
     size_t stash_lstride, gz_lstride, gwp_lstride;
+    int tpw;                 // k_flow_wgrad: (chain, tile) items a workgroup walks (flow_wgrad_tpw; 0 = 1)
 };
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_rev(const FlowLayerArgs& a, hipStream_t s);
@@ -118,11 +119,19 @@ int launch_flow_rev_mfma(const FlowLayerArgs& a, hipStream_t s);
 constexpr int MG_TR = 16, MG_TC = 16;
 inline FlowGeom flow_gather_geom() { return FlowGeom{MG_TR, MG_TC}; }
 int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s);
-// flow_wgrad.hip: weight gradients of one layer from a.gz and the stashed h1, h2, cos / sin: one workgroup per 16 x 16
-// tile writes TWO 955-entry partials (halves of its sites) to a.gw_part [B * ntiles * 2][FLOW_GW_STRIDE]
+// flow_wgrad.hip: weight gradients of one layer from a.gz and the stashed h1, h2, cos / sin: a workgroup walks a.tpw
+// consecutive (chain, 16 x 16 tile) items and writes TWO 955-entry partials (halves of the tiles' sites) to
+// a.gw_part [flow_wgrad_nparts(B, L, tpw)][FLOW_GW_STRIDE]
 int launch_flow_wgrad(const FlowLayerArgs& a, hipStream_t s);
 inline size_t flow_gz_doubles(int B, int L) { return (size_t)B * 17 * L * L; }
-inline int flow_wgrad_parts(int L) { return 2 * FlowGeom{MG_TR, MG_TC}.ntiles(L); }
+inline int flow_wgrad_parts(int L) { return 2 * FlowGeom{MG_TR, MG_TC}.ntiles(L); }          // per chain at one item per workgroup: sizes the workspace
+// items per workgroup: as many as leave one workgroup for each of the 512 slots of the chip (two per CU), at most 8
+inline int flow_wgrad_tpw(int B, int L, int nlayers) {
+    const long items = (long)B * FlowGeom{MG_TR, MG_TC}.ntiles(L) * (nlayers > 0 ? nlayers : 1);
+    const long t = items / 512;
+    return t < 1 ? 1 : t > 8 ? 8 : (int)t;
+}
+inline int flow_wgrad_nparts(int B, int L, int tpw) { const int items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L); return 2 * ((items + tpw - 1) / tpw); }
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }
 // ---- flow_generic.hip: any s/t net shape (hidden sizes, kernel size, mixture components); plain kernels, HBM-resident planes

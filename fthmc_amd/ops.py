@@ -684,12 +684,12 @@ def time_kernel(kind: str, x, w=None, mu=0, off=0, act='silu', beta=1.0, reps=20
 
 
 def profile_stages(kind: str, x, w, mu=0, off=0, act='silu', beta=1.0):
-    """Mean cycles per stage of one MFMA coupling-layer kernel launch ('flow_fwd' | 'flow_bwd' | 'flow_bwd_train')."""
+    """Mean cycles per stage of one MFMA coupling-layer kernel launch ('flow_fwd' | 'flow_bwd' | 'flow_bwd_train' | 'flow_wgrad')."""
     import ctypes
     x = _field(x); B, _, L, _ = x.shape
-    k = {'flow_fwd': 0, 'flow_bwd': 1, 'flow_bwd_train': 2}[kind]
+    k = {'flow_fwd': 0, 'flow_bwd': 1, 'flow_bwd_train': 2, 'flow_wgrad': 3}[kind]
     buf = (ctypes.c_double * 16)()
-    ws, nb = _ws(x, B, L, 1, train=(k == 2))
+    ws, nb = _ws(x, B, L, 1, train=(k >= 2))
     check(_lib.load().fthmc_profile_stages(k, _p(x), _p(_w1(w, x)[0]), None, B, L, int(mu), int(off), act_code(act),
                                            float(beta), buf, ws, nb, _stream(x)), 'fthmc_profile_stages')
     return list(buf)

@@ -286,7 +286,8 @@ int fthmc_small_profile(const double* x, const double* v, const double* u, const
                         int act, double beta, double dt, int nstep, double* cycles_host32, void* ws, size_t ws_bytes,
                         void* stream);
 /* Diagnostic (synchronises, mallocs on the host): one launch of the MFMA forward (kind 0), stash backward
- * (kind 1) or training backward (kind 2, ws: fthmc_train_ws_bytes) kernel with per-workgroup cycle stamps at every stage boundary;
+ * (kind 1), training backward (kind 2, ws: fthmc_train_ws_bytes) or weight-gradient (kind 3, same ws) kernel with per-workgroup
+ * cycle stamps at every stage boundary;
  * cycles_host16[k] = mean cycles spent between stamp k-1 and stamp k. */
 int fthmc_profile_stages(int kind, const double* x, const double* w, const fthmc_arch_t* arch, int B, int L, int mu, int off,
                          int act, double beta, double* cycles_host16,

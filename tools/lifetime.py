@@ -7,13 +7,14 @@ gen = torch.Generator().manual_seed(1331)
 w = ops.pack_weights(R.default_flow(1, gen), device='cuda')
 names = {'flow_fwd': ['', 'plaq+sincos', 'conv1', 'conv2', 'conv3', 'transform1', 'finish+store'],
          'flow_bwd': ['', 'load+xform', 'conv3T', 'conv2T', 'conv1T', 'store'],
-         'flow_bwd_train': ['', 'load+xform', 'conv3T', 'conv2T', 'conv1T', 'store']}     # backward with the pre-activation gradients written (training)
+         'flow_bwd_train': ['', 'load+xform', 'conv3T', 'conv2T', 'conv1T', 'store'],     # backward with the pre-activation gradients written (training)
+         'flow_wgrad': ['', 'issue loads', 'fill LDS', 'conv2/conv1 MFMA', 'barrier', 'h2 fill', 'conv3 VALU + stores']}
 for B in [int(a) for a in sys.argv[1:]] or (16, 32, 48, 64, 96, 128, 256):
     x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
-    for kind in ('flow_fwd', 'flow_bwd', 'flow_bwd_train'):
+    for kind in ('flow_fwd', 'flow_bwd', 'flow_bwd_train', 'flow_wgrad'):
         cyc = ops.profile_stages(kind, x, w, mu=0, off=1, beta=6.0)
-        tot = sum(cyc[:7]) if kind == 'flow_fwd' else sum(cyc[:6])
-        ms = ops.time_kernel(kind, x, w, mu=0, off=1, beta=6.0, reps=30) if kind != 'flow_bwd_train' else float('nan')
+        tot = sum(cyc[:7]) if kind in ('flow_fwd', 'flow_wgrad') else sum(cyc[:6])
+        ms = ops.time_kernel(kind, x, w, mu=0, off=1, beta=6.0, reps=30) if kind in ('flow_fwd', 'flow_bwd') else float('nan')
         if kind == 'flow_fwd' and any(cyc[7:13]): print('      inside conv1 (tile 0: mfma, epilogue; tile 1: mfma, epilogue), conv2 (mfma, epilogue):', ' '.join(f'{c:.0f}' for c in cyc[7:13]))
         if kind == 'flow_bwd' and 'diag' in os.environ.get('FTHMC_LIB', '') and any(cyc[6:10]):
             t2 = sum(cyc[1:3])

@@ -39,6 +39,16 @@ bash tools/abn.sh 2 fthmc_amd/libfthmc_hip.so experiments/lib_recomp_d1.so > "$O
 python3 tools/train_wall.py 8 512 8 200 16 512 8 200 16 64 8 200 12 128 8 200 256 32 16 10 > "$OUT/train_wall.txt" 2> "$OUT/train_wall.err"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats3" -- python3 "$ROOT/tools/train_trace.py" 16 512 8 50 > "$OUT/stats3.log" 2>&1)
 cp $(find "$OUT/stats3" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats_train_L16_B512.csv"
+# the training gradient at the config-5 shard on one stream: kernel stats and counters per kernel (tools/pmc_by_kernel.py)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats4" -- python3 "$ROOT/tools/train_trace.py" 256 32 16 5 1 > "$OUT/stats4.log" 2>&1)
+cp $(find "$OUT/stats4" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats_train_shard.csv"
+k=0
+for g in "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_ACTIVE_INST_LDS"; do
+  k=$((k+1))
+  (cd /tmp && rocprofv3 --pmc $g --output-format csv -d "$OUT/pmct/pass$k" -- python3 "$ROOT/tools/train_trace.py" 256 32 16 2 1 > "$OUT/pmct$k.log" 2>&1)
+done
+python3 tools/pmc_by_kernel.py "$OUT"/pmct/pass* > "$OUT/pmc_train_shard.txt"
+python3 tools/lifetime.py 512 2>&1 | grep -v "flow_fwd\|flow_bwd:" > "$OUT/workgroup_lifetime_train.txt"
 echo "[refresh] training done"
-rm -rf "$OUT/stats" "$OUT/stats2" "$OUT/stats3" "$OUT"/pmc*/pass*/ "$OUT/stg/stop"*
+rm -rf "$OUT/stats" "$OUT/stats2" "$OUT/stats3" "$OUT/stats4" "$OUT"/pmc*/pass*/ "$OUT/stg/stop"*
 echo "[refresh] done"

@@ -11,7 +11,7 @@
 // waves by halves of the site rows, so all eight waves run 32..36 MFMAs with both operands addressed as lane part +
 // compile-time constant (gz planes carry a zero row above and below: no bounds logic in the K loop).  conv3 (8 -> 3,
 // active sites only) runs on the VALU in a second phase that reuses the h1 planes for h2.
-// A workgroup WALKS A.tpw consecutive (chain, tile) items of its layer (the sum over sites simply runs on: accumulators
+// A workgroup WALKS A.tpw (chain, tile) items of its layer, A.wg_ns apart (the sum over sites simply runs on: accumulators
 // stay in registers) with the next item's operands prefetched into registers while the current one is in the MFMA phase:
 // one tile per workgroup spent 8 k of its 21 k cycles issuing loads and waiting for them (profiles/r04_workgroup_lifetime.txt).
 // At the end it writes TWO complete 955-entry partials (site halves) to A.gw_part; k_reduce_gw sums them in a fixed
@@ -118,14 +118,20 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int L = A.L, n = L * L;
     const int nti_ = (L + TR - 1) / TR, ntj_ = (L + TC - 1) / TC, ntiles = nti_ * ntj_;
-    // grid: x = 8 * ceil(groups / 8) with a contiguous range of groups per XCD (blockIdx.x % 8: neighbouring tile rows of a
-    // chain run on one XCD at about the same time and share their halo lines in its L2), y = layer (A.nlb launches)
-    const int items = A.B * ntiles, tpw = A.tpw, ngroups = (items + tpw - 1) / tpw, per = (ngroups + 7) >> 3;
-    const int grp = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
-    if (((int)blockIdx.x >> 3) >= per || grp >= ngroups) return;
+    // The walk is STRIDED: the ns workgroups that are resident together on an XCD (slot s of a round) stand on ns consecutive
+    // tiles at every step and move on by ns tiles -- at L = 256 four whole tile rows of a chain per step, so that the halo lines a
+    // tile shares with its neighbours are fetched once into the XCD's L2 (walking CONSECUTIVE tiles, every halo came from HBM
+    // again: 781 MB per launch at the config-5 shard against 573 MB for one tile per workgroup).
+    // grid: x = 8 XCDs (blockIdx.x % 8) x rounds x ns; round kr = xcd * R + r covers items [kr * tpw * ns, (kr + 1) * tpw * ns)
+    const int items = A.B * ntiles, tpw = A.tpw, ns = A.wg_ns;
+    const int KR = (items + tpw * ns - 1) / (tpw * ns), R = (KR + 7) >> 3;
+    const int idx = (int)blockIdx.x >> 3, r_ = idx / ns, s_ = idx - r_ * ns, kr = ((int)blockIdx.x & 7) * R + r_;
+    const int first = kr * tpw * ns + s_;
+    if (r_ >= R || first >= items) return;
+    const int grp = kr * ns + s_;                                         // valid groups are a prefix of this numbering
+    const int nwalk = min(tpw, (items - first + ns - 1) / ns);
     const int lz = (int)blockIdx.y;
     const int mu = A.nlb > 0 ? (lz & 1) : A.mu, off = A.nlb > 0 ? ((lz >> 1) & 3) : A.off;
-    const int first = grp * tpw, last = min(items, first + tpw);
     const unsigned wmagic = FASTW ? 0u : wrap_magic(L);
     auto ldu2 = [](const double* base, unsigned idx) {
         return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx * 8u);
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     double* gw0 = A.gw_part + (size_t)lz * A.gwp_lstride + (size_t)grp * 2 * FLOW_GW_STRIDE;     // the group's two partials (site halves)
     long long* dbg = A.dbg ? A.dbg + (size_t)grp * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid0 == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+    STAMP(8);                                                              // 8 -> 9 prologue, 9 -> 10 the walk, 10 -> 11 epilogue
 
     // ---- per-thread coordinates that do not depend on the item
     // own sites: thread = (site, channel quad): 32 bytes of gz2 and of gz1
@@ -203,16 +210,24 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
         }
         cb = b; cti = ti; ctj = tj;
     };
-    int ib = first / ntiles, iti, itj;
-    { const int t = first - ib * ntiles; iti = t / ntj_; itj = t - iti * ntj_; }
-    issue(ib, iti, itj);
+    auto item_coords = [&](int item, int& b, int& ti, int& tj) {        // uniform: scalar divisions, once per item
+        b = item / ntiles;
+        const int t = item - b * ntiles;
+        ti = t / ntj_; tj = t - ti * ntj_;
+    };
+    {
+        int ib, iti, itj;
+        item_coords(first, ib, iti, itj);
+        issue(ib, iti, itj);
+    }
 
     // accumulators of the whole walk
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};    // this wave's N tile x site half
     double asum = 0.0;                                                     // bias sums: lanes dy = 0 of the waves nt = 0 (b2) and nt = 3 (b1)
     double acc3[4] = {0.0, 0.0, 0.0, 0.0};                                 // conv3: thread = (output, site half); wave 7: b3 lane partials
 
-    for (int it = first; it < last; ++it) {
+    STAMP(9);
+    for (int it = 0; it < nwalk; ++it) {
         STAMP(0);
         // opaque copies of the thread coordinates: what the stages derive from them is recomputed per item instead of living
         // in registers across the walk
@@ -250,9 +265,8 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
         for (int k = 0; k < NRH; ++k) { h2v[k][0] = hv[k][0]; h2v[k][1] = hv[k][1]; }
         // ---- the next item's phase 1 operands (the last item loads itself again: no branch around the loads)
         {
-            const bool more = it + 1 < last;
-            int nb = cb, nti = cti, ntj = ctj + (more ? 1 : 0);
-            if (ntj == ntj_) { ntj = 0; if (++nti == nti_) { nti = 0; ++nb; } }
+            int nb, nti, ntj;
+            item_coords(first + (it + 1 < nwalk ? it + 1 : it) * ns, nb, nti, ntj);
             issue(nb, nti, ntj);
         }
 
@@ -296,9 +310,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
             for (int k = 0; k < 3; ++k) acc3[k] += sGO[k * NA + lane];
         }
         STAMP(6);
-        if (it + 1 < last) lds_barrier();                                // the next item refills the planes
+        if (it + 1 < nwalk) lds_barrier();                               // the next item refills the planes
     }
 
+    STAMP(10);
     // ---- the group's partials
     {
         const int lane = tid0 & 63, nt = wave >> 1, kh = wave & 1;
@@ -318,6 +333,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
             }
         }
     }
+    STAMP(11);
 #undef STAMP
 }
 
@@ -326,10 +342,12 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
 namespace fthmc {
 
 int launch_flow_wgrad(const FlowLayerArgs& a, hipStream_t s) {
-    const int tpw = a.tpw > 0 ? a.tpw : 1;
-    const int ngroups = flow_wgrad_nparts(a.B, a.L, tpw) / 2;
-    const dim3 grid(8 * ((ngroups + 7) / 8), a.nlb > 0 ? a.nlb : 1, 1);
-    FlowLayerArgs b = a; b.tpw = tpw;
+    FlowLayerArgs b = a;
+    b.tpw = a.tpw > 0 ? a.tpw : 1;
+    b.wg_ns = flow_wgrad_ns(a.B, a.L, b.tpw);
+    const int items = a.B * FlowGeom{MG_TR, MG_TC}.ntiles(a.L);
+    const int KR = (items + b.tpw * b.wg_ns - 1) / (b.tpw * b.wg_ns), R = (KR + 7) / 8;
+    const dim3 grid(8 * R * b.wg_ns, a.nlb > 0 ? a.nlb : 1, 1);
     if (wrap_fast_ok(a.L, MG_TR, MG_TC)) hipLaunchKernelGGL((k_flow_wgrad<MG_TR, MG_TC, true>), grid, dim3(NT), 0, s, b);
     else hipLaunchKernelGGL((k_flow_wgrad<MG_TR, MG_TC, false>), grid, dim3(NT), 0, s, b);
     FT_LAUNCH_CHECK(); return FTHMC_OK;

@@ -105,6 +105,7 @@ struct FlowLayerArgs {
     int nlb;
     size_t stash_lstride, gz_lstride, gwp_lstride;
     int tpw;                 // k_flow_wgrad: (chain, tile) items a workgroup walks (flow_wgrad_tpw; 0 = 1)
+    int wg_ns;               // k_flow_wgrad: stride of the walk = workgroups that stand on consecutive tiles (set by the launcher)
 };
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s);
 int launch_flow_rev(const FlowLayerArgs& a, hipStream_t s);
@@ -120,7 +121,7 @@ constexpr int MG_TR = 16, MG_TC = 16;
 inline FlowGeom flow_gather_geom() { return FlowGeom{MG_TR, MG_TC}; }
 int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s);
 // flow_wgrad.hip: weight gradients of one layer from a.gz and the stashed h1, h2, cos / sin: a workgroup walks a.tpw
-// consecutive (chain, 16 x 16 tile) items and writes TWO 955-entry partials (halves of the tiles' sites) to
+// (chain, 16 x 16 tile) items and writes TWO 955-entry partials (halves of the tiles' sites) to
 // a.gw_part [flow_wgrad_nparts(B, L, tpw)][FLOW_GW_STRIDE]
 int launch_flow_wgrad(const FlowLayerArgs& a, hipStream_t s);
 inline size_t flow_gz_doubles(int B, int L) { return (size_t)B * 17 * L * L; }
@@ -131,7 +132,17 @@ inline int flow_wgrad_tpw(int B, int L, int nlayers) {
     const long t = items / 512;
     return t < 1 ? 1 : t > 8 ? 8 : (int)t;
 }
-inline int flow_wgrad_nparts(int B, int L, int tpw) { const int items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L); return 2 * ((items + tpw - 1) / tpw); }
+// workgroups of one XCD that walk side by side (one per slot: 32 CUs x 2; fewer when the launch is smaller than the chip)
+inline int flow_wgrad_ns(int B, int L, int tpw) {
+    const int items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L), n = (items + 8 * tpw - 1) / (8 * tpw);
+    return n < 1 ? 1 : n > 64 ? 64 : n;
+}
+// partials of a launch: two per workgroup that has an item (k_flow_wgrad numbers those 0, 1, 2, ...)
+inline int flow_wgrad_nparts(int B, int L, int tpw) {
+    const int items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L), ns = flow_wgrad_ns(B, L, tpw);
+    const int k0 = items / (tpw * ns), rem = items - k0 * tpw * ns;
+    return 2 * (k0 * ns + (rem < ns ? rem : ns));
+}
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }
 // ---- flow_generic.hip: any s/t net shape (hidden sizes, kernel size, mixture components); plain kernels, HBM-resident planes

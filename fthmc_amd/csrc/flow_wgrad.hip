@@ -143,25 +143,34 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
 #define STAMP(k) do { if (dbg && tid0 == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(8);                                                              // 8 -> 9 prologue, 9 -> 10 the walk, 10 -> 11 epilogue
 
-    // ---- per-thread coordinates that do not depend on the item
-    // own sites: thread = (site, channel quad): 32 bytes of gz2 and of gz1
-    const int os = tid0 >> 1, oq = tid0 & 1, orr = fdiv<TC>(os), occ = os - orr * TC;
-    // tile+1 window of h1 (and, in phase 2, of h2): tasks (window site, channel quad), NH * 2 of them in two rounds
+    // ---- per-thread coordinates that do not depend on the item: recomputed from an opaque copy of the thread index where they
+    //      are used (twice per item, ~40 VALU) -- kept in registers across the walk they are 13 of the 128 a wave has, and spill
     constexpr int NIT = 2 * NH, NRH = (NIT + NT - 1) / NT;
-    int hwr[NRH], hwc[NRH], hls[NRH];
+    struct Coord {
+        int oq, orr, occ;                 // own sites: thread = (site, channel quad): 32 bytes of gz2 and of gz1
+        int hwr[NRH], hwc[NRH], hwq[NRH], hls[NRH];   // tile+1 window of h1 / h2: tasks (window site, channel quad) in two rounds; LDS slot or -1
+        int fwr, fwc; bool ftask, ffrozen;            // net input on the tile+1 window (thread = window site): frozen stripe classes 1, 2
+        int ar, ac; bool atask;           // own active site `tid` (tid < NA): mu = 0 columns off + 4 m, mu = 1 rows off + 4 q
+    };
+    auto coords = [&]() {
+        int t0 = tid0;
+        asm volatile("" : "+v"(t0));
+        Coord c;
+        const int os = t0 >> 1;
+        c.oq = t0 & 1; c.orr = fdiv<TC>(os); c.occ = os - c.orr * TC;
 #pragma unroll
-    for (int k = 0; k < NRH; ++k) {
-        const int t = min(tid0 + k * NT, NIT - 1), ws = t >> 1, wq = t & 1;
-        hwr[k] = fdiv<W1C>(ws); hwc[k] = ws - hwr[k] * W1C;
-        hls[k] = tid0 + k * NT < NIT ? (4 * wq) * PSH + hwr[k] * W1C + hwc[k] : -1;
-        hwc[k] |= wq << 16;                                             // the channel quad rides in the high half
-    }
-    // net input on the tile+1 window (thread = window site): frozen stripe classes 1, 2 of its line (tile origins are multiples of 4)
-    const int fwr = fdiv<W1C>(min(tid0, NH - 1)), fwc = min(tid0, NH - 1) - fwr * W1C;
-    const bool ftask = tid0 < NH, ffrozen = ftask && ((((mu == 0 ? fwc : fwr) - 1 - off) & 3) == 1 || (((mu == 0 ? fwc : fwr) - 1 - off) & 3) == 2);
-    // own active site `tid` (tid < NA): mu = 0 columns off + 4 m, mu = 1 rows off + 4 q
-    const int ar = mu == 0 ? tid0 / (TC / 4) : off + 4 * (tid0 / TC), ac = mu == 0 ? off + 4 * (tid0 % (TC / 4)) : tid0 % TC;
-    const bool atask = tid0 < NA;
+        for (int k = 0; k < NRH; ++k) {
+            const int t = min(t0 + k * NT, NIT - 1), ws = t >> 1;
+            c.hwq[k] = t & 1; c.hwr[k] = fdiv<W1C>(ws); c.hwc[k] = ws - c.hwr[k] * W1C;
+            c.hls[k] = t0 + k * NT < NIT ? (4 * c.hwq[k]) * PSH + c.hwr[k] * W1C + c.hwc[k] : -1;
+        }
+        c.fwr = fdiv<W1C>(min(t0, NH - 1)); c.fwc = min(t0, NH - 1) - c.fwr * W1C;
+        const int fl = ((mu == 0 ? c.fwc : c.fwr) - 1 - off) & 3;      // tile origins are multiples of 4
+        c.ftask = t0 < NH; c.ffrozen = c.ftask && (fl == 1 || fl == 2);
+        c.ar = mu == 0 ? t0 / (TC / 4) : off + 4 * (t0 / TC); c.ac = mu == 0 ? off + 4 * (t0 % (TC / 4)) : t0 % TC;
+        c.atask = t0 < NA;
+        return c;
+    };
 
     // ---- zeros that stay: ring rows of the gz planes (rows -1 and TR), slack behind the hin windows
     if (tid0 < 2 * TC) {
@@ -178,11 +187,12 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
 
     // ---- the item's operands in registers (every load unconditional from a clamped address: straight-line code keeps the
     //      waits counted)
-    double2_t z2a, z2b, z1a, z1b, hv[NRH][2], gva, gvb;
-    double fcs, fsn;
+    double2_t z2a, z2b, z1a, z1b, hv[NRH][2], gva;
+    double fcs, fsn, gvc;
     unsigned hat[NRH];
     int cb, cti, ctj;                                     // the item the registers hold: chain, tile row, tile column
     auto issue = [&](int b, int ti, int tj) {
+        const Coord c = coords();
         const int i0 = ti * TR, j0 = tj * TC;
         const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);
         const double* __restrict__ gz2g = uniform_ptr(gzl, (size_t)b * 17 * n);
@@ -190,23 +200,23 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
         const double* __restrict__ gog = gz2g + (size_t)16 * n;
         const double* __restrict__ scs = uniform_ptr(stl, ((size_t)A.B * 18 + b) * n);
         const double* __restrict__ sh1 = uniform_ptr(stl, ((size_t)A.B * 19 + (size_t)b * 8) * n);
-        const bool ovalid = orr < rmax && occ < cmax;
-        const unsigned oat = ovalid ? (unsigned)(mul24(i0 + orr, L) + j0 + occ) * 8u + 4u * oq : 0u;
+        const bool ovalid = c.orr < rmax && c.occ < cmax;
+        const unsigned oat = ovalid ? (unsigned)(mul24(i0 + c.orr, L) + j0 + c.occ) * 8u + 4u * c.oq : 0u;
         z2a = ldu2(gz2g, oat); z2b = ldu2(gz2g, oat + 2); z1a = ldu2(gz1g, oat); z1b = ldu2(gz1g, oat + 2);
 #pragma unroll
         for (int k = 0; k < NRH; ++k) {
-            hat[k] = (unsigned)(mul24(wrap_line<FASTW>(i0 + hwr[k] - 1, L, wmagic), L) + wrap_line<FASTW>(j0 + (hwc[k] & 0xffff) - 1, L, wmagic)) * 8u
-                     + 4u * (unsigned)(hwc[k] >> 16);
+            hat[k] = (unsigned)(mul24(wrap_line<FASTW>(i0 + c.hwr[k] - 1, L, wmagic), L) + wrap_line<FASTW>(j0 + c.hwc[k] - 1, L, wmagic)) * 8u
+                     + 4u * (unsigned)c.hwq[k];
             hv[k][0] = ldu2(sh1, hat[k]); hv[k][1] = ldu2(sh1, hat[k] + 2);
         }
         {
-            const unsigned ic = ffrozen ? (unsigned)stash_frozen_idx(wrap_line<FASTW>(i0 + fwr - 1, L, wmagic), wrap_line<FASTW>(j0 + fwc - 1, L, wmagic), L, mu, off) : 0u;
+            const unsigned ic = c.ffrozen ? (unsigned)stash_frozen_idx(wrap_line<FASTW>(i0 + c.fwr - 1, L, wmagic), wrap_line<FASTW>(j0 + c.fwc - 1, L, wmagic), L, mu, off) : 0u;
             fcs = ldu(scs, ic); fsn = ldu(scs + (n >> 1), ic);
         }
         {
-            const bool avalid = atask && ar < rmax && ac < cmax;
-            const unsigned ia = avalid ? (unsigned)stash_active_idx(i0 + ar, j0 + ac, L, mu) * 4u : 0u;
-            gva = ldu2(gog, ia); gvb = ldu2(gog, ia + 2);
+            const bool avalid = c.atask && c.ar < rmax && c.ac < cmax;
+            const unsigned ia = avalid ? (unsigned)stash_active_idx(i0 + c.ar, j0 + c.ac, L, mu) * 4u : 0u;
+            gva = ldu2(gog, ia); gvc = ldu(gog, ia + 2);
         }
         cb = b; cti = ti; ctj = tj;
     };
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     // accumulators of the whole walk
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};    // this wave's N tile x site half
     double asum = 0.0;                                                     // bias sums: lanes dy = 0 of the waves nt = 0 (b2) and nt = 3 (b1)
-    double acc3[4] = {0.0, 0.0, 0.0, 0.0};                                 // conv3: thread = (output, site half); wave 7: b3 lane partials
+    double acc3[3] = {0.0, 0.0, 0.0};                                      // conv3: thread = (output, site half) in [0]; wave 7: b3 lane partials
 
     STAMP(9);
     for (int it = 0; it < nwalk; ++it) {
@@ -235,20 +245,21 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63;
         // ---- phase 1 LDS fill from the registers; own sites and active sites beyond the lattice are zeros
+        const Coord c = coords();
         {
             const int rmax = min(TR, L - cti * TR), cmax = min(TC, L - ctj * TC);
-            const bool ovalid = orr < rmax && occ < cmax;
-            double* p2 = sGZ2 + (4 * oq) * PSG + (orr + 1) * TC + occ;
-            double* p1 = sGZ1 + (4 * oq) * PSG + (orr + 1) * TC + occ;
+            const bool ovalid = c.orr < rmax && c.occ < cmax;
+            double* p2 = sGZ2 + (4 * c.oq) * PSG + (c.orr + 1) * TC + c.occ;
+            double* p1 = sGZ1 + (4 * c.oq) * PSG + (c.orr + 1) * TC + c.occ;
             p2[0] = ovalid ? z2a.x : 0.0; p2[PSG] = ovalid ? z2a.y : 0.0; p2[2 * PSG] = ovalid ? z2b.x : 0.0; p2[3 * PSG] = ovalid ? z2b.y : 0.0;
             p1[0] = ovalid ? z1a.x : 0.0; p1[PSG] = ovalid ? z1a.y : 0.0; p1[2 * PSG] = ovalid ? z1b.x : 0.0; p1[3 * PSG] = ovalid ? z1b.y : 0.0;
 #pragma unroll
             for (int k = 0; k < NRH; ++k)
-                if (hls[k] >= 0) { double* p = sHA + hls[k]; p[0] = hv[k][0].x; p[PSH] = hv[k][0].y; p[2 * PSH] = hv[k][1].x; p[3 * PSH] = hv[k][1].y; }
-            if (ftask) { sIn[tid0] = ffrozen ? fcs : 1.0; sIn[PSH + tid0] = ffrozen ? fsn : 0.0; }
-            if (atask) {
-                const bool avalid = ar < rmax && ac < cmax;
-                sGO[tid0] = avalid ? gva.x : 0.0; sGO[NA + tid0] = avalid ? gva.y : 0.0; sGO[2 * NA + tid0] = avalid ? gvb.x : 0.0;
+                if (c.hls[k] >= 0) { double* p = sHA + c.hls[k]; p[0] = hv[k][0].x; p[PSH] = hv[k][0].y; p[2 * PSH] = hv[k][1].x; p[3 * PSH] = hv[k][1].y; }
+            if (c.ftask) { sIn[tid0] = c.ffrozen ? fcs : 1.0; sIn[PSH + tid0] = c.ffrozen ? fsn : 0.0; }
+            if (c.atask) {
+                const bool avalid = c.ar < rmax && c.ac < cmax;
+                sGO[tid0] = avalid ? gva.x : 0.0; sGO[NA + tid0] = avalid ? gva.y : 0.0; sGO[2 * NA + tid0] = avalid ? gvc : 0.0;
             }
         }
         // phase 2 operands of this item (h2 on the same window): issued now, they land under the MFMA phase
@@ -292,9 +303,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
         STAMP(4);
 
         // ---- phase 2: h2 over h1; conv3 weight gradient on the VALU
+        const Coord c2 = coords();
 #pragma unroll
         for (int k = 0; k < NRH; ++k)
-            if (hls[k] >= 0) { double* p = sHA + hls[k]; p[0] = h2v[k][0].x; p[PSH] = h2v[k][0].y; p[2 * PSH] = h2v[k][1].x; p[3 * PSH] = h2v[k][1].y; }
+            if (c2.hls[k] >= 0) { double* p = sHA + c2.hls[k]; p[0] = h2v[k][0].x; p[PSH] = h2v[k][0].y; p[2 * PSH] = h2v[k][1].x; p[3 * PSH] = h2v[k][1].y; }
         lds_barrier();
         STAMP(5);
         if (tid < 432) {
@@ -303,8 +315,10 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
             const double* pg = sGO + co * NA + hf * (NA / 2);
             // h2 at own (r, c) + (ky - 1, kx - 1): window index (r + ky) * W1C + c + kx
             const double* ph = sHA + ci * PSH + ky * W1C + kx;
-            if (mu == 0) conv3_acc<0, TC, W1C>(pg, ph + hf * (NA / 2 / (TC / 4)) * W1C + off, acc3);
-            else         conv3_acc<1, TC, W1C>(pg, ph + (off + 4 * hf * (NA / 2 / TC)) * W1C, acc3);
+            double c3[4] = {0.0, 0.0, 0.0, 0.0};
+            if (mu == 0) conv3_acc<0, TC, W1C>(pg, ph + hf * (NA / 2 / (TC / 4)) * W1C + off, c3);
+            else         conv3_acc<1, TC, W1C>(pg, ph + (off + 4 * hf * (NA / 2 / TC)) * W1C, c3);
+            acc3[0] += (c3[0] + c3[1]) + (c3[2] + c3[3]);
         } else if (tid >= 448) {                                         // b3: the idle wave sums the three g_out planes
 #pragma unroll
             for (int k = 0; k < 3; ++k) acc3[k] += sGO[k * NA + lane];
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
         // biases b2 (waves nt = 0), b1 (waves nt = 3): the lane partials of A rows (co, dy = 0) over the four K lane groups
         asum += __shfl_xor(asum, 16); asum += __shfl_xor(asum, 32);
         if ((nt == 0 || nt == 3) && lane < 8) gw[(nt == 0 ? CB1 : CB0) + lane] = asum;
-        if (tid0 < 432) gw0[(size_t)(tid0 >= 216 ? 1 : 0) * FLOW_GW_STRIDE + CW2 + (tid0 >= 216 ? tid0 - 216 : tid0)] = (acc3[0] + acc3[1]) + (acc3[2] + acc3[3]);
+        if (tid0 < 432) gw0[(size_t)(tid0 >= 216 ? 1 : 0) * FLOW_GW_STRIDE + CW2 + (tid0 >= 216 ? tid0 - 216 : tid0)] = acc3[0];
         else if (tid0 >= 448) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {

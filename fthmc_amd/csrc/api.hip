@@ -971,7 +971,7 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, const fthmc
     }
     FT_TRY(kind == 0 ? launch_flow_fwd_mfma(a, s) : launch_flow_bwd_gather(a, s));
     size_t nused = nrec;                                           // records the profiled launch stamps
-    if (kind == 3) { a.dbg = dbg; a.tpw = flow_wgrad_tpw(B, L, 1); nused = (size_t)flow_wgrad_nparts(B, L, a.tpw) / 2; FT_TRY(launch_flow_wgrad(a, s)); }
+    if (kind == 3) { a.dbg = dbg; a.tpw = flow_wgrad_tpw(B, L, 1); nused = (size_t)flow_wgrad_nparts(B, L, a.tpw); FT_TRY(launch_flow_wgrad(a, s)); }
     long long* h = (long long*)malloc(nrec * 16 * sizeof(long long));
     if (!h) return FTHMC_ERR_ARG;
     if (hipMemcpyAsync(h, dbg, nrec * 16 * sizeof(long long), hipMemcpyDeviceToHost, s) != hipSuccess ||

@@ -42,53 +42,37 @@ template <int TR, int TC> struct SmemW {
     static constexpr int GZ1 = HA + 8 * PSH;            // [8][PSG]
     static constexpr int IN = GZ1 + 8 * PSG;            // [2][PSH] cos, sin (1, 0 off the frozen sites)
     static constexpr int GO = IN + 2 * PSH;             // [3][NA] g_out at the own active sites, task order
-    static constexpr int SIZE = GO + 3 * NA;
+    // after the walk, over the planes: the waves' accumulators [8][4 tiles][4][64], bias lane sums [8][2][8], conv3 sums [432]
+    static constexpr int RED = 0, RBS = RED + 8 * 4 * 4 * 64, RC3 = RBS + 8 * 2 * 8, RSIZE = RC3 + 432;
+    static constexpr int SIZE = GO + 3 * NA > RSIZE ? GO + 3 * NA : RSIZE;
+    static_assert(TR == 16 && TC == 16, "K split of the MFMA phase: 8 waves x 2 rows + row 16 on four of them");
     static_assert(TC % 4 == 0 && TR % 4 == 0 && NA == 64 && GO % 2 == 0, "K steps of four sites; one wave sums a g_out plane; 16-byte reads of g_out");
     static_assert(2 * SIZE * 8 <= 160 * 1024, "two workgroups per CU");
 };
 
-// one N tile x one half of the site rows: rows [R0, R1) of the K walk (row r pairs gz rows r, r - 1 with hin rows r, r + 2)
-template <int TC, int PSG, int W1C, int PSH, int CIN, int R0, int R1, bool BIAS>
-__device__ __forceinline__ void wgrad_half(const double* __restrict__ gz, const double* __restrict__ hin, int nt, int lane,
-                                           double4_t& acc0, double4_t& acc1, double& asum) {
-    const int g = lane >> 4, i = lane & 15;
-    const int co = i & 7, dy = i >> 3;                      // A row m = (co, dy)
-    const int ncol = nt * 16 + i;                           // B column n = (ci, kx, kyb)
-    constexpr int NCOL = CIN * 6;
-    const int nc = ncol < NCOL ? ncol : 0;
-    const int ci = nc / 6, kx = (nc % 6) >> 1, kyb = nc & 1;
-    const double* pa = gz + co * PSG + (1 - dy) * TC + g;              // + r * TC + 4 cs
-    const double* pb = hin + ci * PSH + 2 * kyb * W1C + kx + g;        // + r * W1C + 4 cs
-#pragma unroll
-    for (int r = R0; r < R1; ++r)
-#pragma unroll
-        for (int cs = 0; cs < TC / 4; ++cs) {
-#if FT_WGRAD_TEST == 1                                                  // timing only: no B operand reads
-            const double av = pa[r * TC + 4 * cs], bv = av;
-#else
-            const double av = pa[r * TC + 4 * cs], bv = pb[r * W1C + 4 * cs];
-#endif
-#if FT_WGRAD_TEST == 2                                                  // timing only: the reads without the MFMAs
-            if ((r * (TC / 4) + cs) & 1) acc1[0] += av * bv; else acc0[0] += av + bv;
-#else
-            if ((r * (TC / 4) + cs) & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc1, 0, 0, 0);
-            else                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc0, 0, 0, 0);
-#endif
-            if (BIAS) asum += av;                           // lanes dy = 0: the A operand walks every own site of channel co once
-        }
+// One wave's slice of the K walk for ALL FOUR N tiles: the conv2 tiles nt = 0, 1, 2 share their A operand (gz2: one LDS read
+// instead of three), conv1 (nt = 3) reads gz1 at the same offset.  Row r of the walk pairs gz rows r, r - 1 with hin rows
+// r, r + 2.  `bsum`: lanes dy = 0 see every own site of channel co once.
+struct WgradLane { int pa, pb0, pb1, pb2, pb3; };            // LDS element offsets of the lane's operands at row 0, cs = 0
+template <int TC, int PSG, int W1C, int PSH>
+__device__ __forceinline__ WgradLane wgrad_lane(int lane) {
+    const int g = lane >> 4, i = lane & 15, co = i & 7, dy = i >> 3;   // A row m = (co, dy); B column n = (ci, kx, kyb)
+    WgradLane w;
+    w.pa = co * PSG + (1 - dy) * TC + g;
+    auto pb = [&](int ncol, int ncols) { const int nc = ncol < ncols ? ncol : 0, ci = nc / 6, kx = (nc % 6) >> 1, kyb = nc & 1; return ci * PSH + 2 * kyb * W1C + kx + g; };
+    w.pb0 = pb(i, 48); w.pb1 = pb(16 + i, 48); w.pb2 = pb(32 + i, 48); w.pb3 = pb(i, 12);
+    return w;
 }
-// the lane's four results of an N tile: D[row = g + 4 q][col = i] = gw[co][ci][2 kyb + dy][kx]
-template <int CIN, class Store>
-__device__ __forceinline__ void wgrad_store(const double4_t& acc, int nt, int lane, Store store) {
-    const int g = lane >> 4, i = lane & 15, ncol = nt * 16 + i;
-    if (ncol < CIN * 6) {
-        const int ci = ncol / 6, kx = (ncol % 6) >> 1, kyb = ncol & 1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = g + 4 * q, co2 = m & 7, dy2 = m >> 3, ky = 2 * kyb + dy2;
-            if (ky <= 2) store(co2, ci, ky, kx, acc[q]);
-        }
-    }
+__device__ __forceinline__ void wgrad_step(const double* __restrict__ gz2, const double* __restrict__ gz1, const double* __restrict__ h,
+                                           const double* __restrict__ in, const WgradLane& w, int oa, int ob,
+                                           double4_t (&acc)[4], double (&bsum)[2]) {
+    const double a2 = gz2[w.pa + oa], a1 = gz1[w.pa + oa];
+    const double b0 = h[w.pb0 + ob], b1 = h[w.pb1 + ob], b2 = h[w.pb2 + ob], b3 = in[w.pb3 + ob];
+    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b3, acc[3], 0, 0, 0);
+    bsum[0] += a2; bsum[1] += a1;
 }
 // conv3 (8 -> 3, active sites only): thread = (output (co, ci, tap), half of the active sites); the 32 sites of the half
 // at compile-time offsets from the thread's base (the stripe offset `off` and the half are folded into `ph`)
@@ -138,7 +122,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     };
     const double* __restrict__ gzl = uniform_ptr((const double*)A.gz, (size_t)lz * A.gz_lstride);
     const double* __restrict__ stl = uniform_ptr((const double*)A.stash, (size_t)lz * A.stash_lstride);
-    double* gw0 = A.gw_part + (size_t)lz * A.gwp_lstride + (size_t)grp * 2 * FLOW_GW_STRIDE;     // the group's two partials (site halves)
+    double* gw0 = A.gw_part + (size_t)lz * A.gwp_lstride + (size_t)grp * FLOW_GW_STRIDE;         // the group's partial
     long long* dbg = A.dbg ? A.dbg + (size_t)grp * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid0 == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(8);                                                              // 8 -> 9 prologue, 9 -> 10 the walk, 10 -> 11 epilogue
@@ -191,24 +175,32 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     double fcs, fsn, gvc;
     unsigned hat[NRH];
     int cb, cti, ctj;                                     // the item the registers hold: chain, tile row, tile column
-    auto issue = [&](int b, int ti, int tj) {
+    // two halves of an item's prefetch: the h1 window (with the window addresses `hat`, which the item's h2 loads reuse) goes
+    // out BEFORE the MFMA phase of the item ahead of it, the rest (gz2, gz1, cos / sin, g_out: 26 registers) behind that phase
+    // -- the eight waves hold all four N tiles' accumulators there (32 registers)
+    auto issue_h1 = [&](int b, int ti, int tj) {
         const Coord c = coords();
         const int i0 = ti * TR, j0 = tj * TC;
-        const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);
-        const double* __restrict__ gz2g = uniform_ptr(gzl, (size_t)b * 17 * n);
-        const double* __restrict__ gz1g = gz2g + (size_t)8 * n;
-        const double* __restrict__ gog = gz2g + (size_t)16 * n;
-        const double* __restrict__ scs = uniform_ptr(stl, ((size_t)A.B * 18 + b) * n);
         const double* __restrict__ sh1 = uniform_ptr(stl, ((size_t)A.B * 19 + (size_t)b * 8) * n);
-        const bool ovalid = c.orr < rmax && c.occ < cmax;
-        const unsigned oat = ovalid ? (unsigned)(mul24(i0 + c.orr, L) + j0 + c.occ) * 8u + 4u * c.oq : 0u;
-        z2a = ldu2(gz2g, oat); z2b = ldu2(gz2g, oat + 2); z1a = ldu2(gz1g, oat); z1b = ldu2(gz1g, oat + 2);
 #pragma unroll
         for (int k = 0; k < NRH; ++k) {
             hat[k] = (unsigned)(mul24(wrap_line<FASTW>(i0 + c.hwr[k] - 1, L, wmagic), L) + wrap_line<FASTW>(j0 + c.hwc[k] - 1, L, wmagic)) * 8u
                      + 4u * (unsigned)c.hwq[k];
             hv[k][0] = ldu2(sh1, hat[k]); hv[k][1] = ldu2(sh1, hat[k] + 2);
         }
+        cb = b; cti = ti; ctj = tj;
+    };
+    auto issue_rest = [&]() {                             // of item (cb, cti, ctj)
+        const Coord c = coords();
+        const int b = cb, i0 = cti * TR, j0 = ctj * TC;
+        const int rmax = min(TR, L - i0), cmax = min(TC, L - j0);
+        const double* __restrict__ gz2g = uniform_ptr(gzl, (size_t)b * 17 * n);
+        const double* __restrict__ gz1g = gz2g + (size_t)8 * n;
+        const double* __restrict__ gog = gz2g + (size_t)16 * n;
+        const double* __restrict__ scs = uniform_ptr(stl, ((size_t)A.B * 18 + b) * n);
+        const bool ovalid = c.orr < rmax && c.occ < cmax;
+        const unsigned oat = ovalid ? (unsigned)(mul24(i0 + c.orr, L) + j0 + c.occ) * 8u + 4u * c.oq : 0u;
+        z2a = ldu2(gz2g, oat); z2b = ldu2(gz2g, oat + 2); z1a = ldu2(gz1g, oat); z1b = ldu2(gz1g, oat + 2);
         {
             const unsigned ic = c.ffrozen ? (unsigned)stash_frozen_idx(wrap_line<FASTW>(i0 + c.fwr - 1, L, wmagic), wrap_line<FASTW>(j0 + c.fwc - 1, L, wmagic), L, mu, off) : 0u;
             fcs = ldu(scs, ic); fsn = ldu(scs + (n >> 1), ic);
@@ -218,7 +210,6 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
             const unsigned ia = avalid ? (unsigned)stash_active_idx(i0 + c.ar, j0 + c.ac, L, mu) * 4u : 0u;
             gva = ldu2(gog, ia); gvc = ldu(gog, ia + 2);
         }
-        cb = b; cti = ti; ctj = tj;
     };
     auto item_coords = [&](int item, int& b, int& ti, int& tj) {        // uniform: scalar divisions, once per item
         b = item / ntiles;
@@ -228,12 +219,15 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     {
         int ib, iti, itj;
         item_coords(first, ib, iti, itj);
-        issue(ib, iti, itj);
+        issue_h1(ib, iti, itj);
+        issue_rest();
     }
 
     // accumulators of the whole walk
-    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};    // this wave's N tile x site half
-    double asum = 0.0;                                                     // bias sums: lanes dy = 0 of the waves nt = 0 (b2) and nt = 3 (b1)
+    double4_t acc[4];                                                      // this wave's K slice of the four N tiles
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double bsum[2] = {0.0, 0.0};                                           // bias sums b2, b1 of the slice: lanes dy = 0
     double acc3[3] = {0.0, 0.0, 0.0};                                      // conv3: thread = (output, site half) in [0]; wave 7: b3 lane partials
 
     STAMP(9);
@@ -278,27 +272,23 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
         {
             int nb, nti, ntj;
             item_coords(first + (it + 1 < nwalk ? it + 1 : it) * ns, nb, nti, ntj);
-            issue(nb, nti, ntj);
+            issue_h1(nb, nti, ntj);
         }
 
-        // ---- phase 1 GEMMs: wave = (N tile nt = wave >> 1: 0..2 conv2, 3 conv1; half of the site rows = wave & 1)
+        // ---- phase 1 GEMMs: wave = K slice (window rows 2 wave, 2 wave + 1; waves 0..3 also the step (row TR, cs = wave)) of all
+        //      four N tiles (0..2 conv2, 3 conv1)
         {
-            const int nt = wave >> 1, kh = wave & 1;
-            constexpr int RH = (TR + 2) / 2;              // rows 0 .. TR of the K walk: [0, RH) and [RH, TR + 1)
-            if (nt < 3) {
-                if (nt == 0) {
-                    if (kh == 0) wgrad_half<TC, PSG, W1C, PSH, 8, 0, RH, true>(sGZ2, sHA, 0, lane, acc0, acc1, asum);
-                    else         wgrad_half<TC, PSG, W1C, PSH, 8, RH, TR + 1, true>(sGZ2, sHA, 0, lane, acc0, acc1, asum);
-                } else {
-                    if (kh == 0) wgrad_half<TC, PSG, W1C, PSH, 8, 0, RH, false>(sGZ2, sHA, nt, lane, acc0, acc1, asum);
-                    else         wgrad_half<TC, PSG, W1C, PSH, 8, RH, TR + 1, false>(sGZ2, sHA, nt, lane, acc0, acc1, asum);
-                }
-            } else {
-                if (kh == 0) wgrad_half<TC, PSG, W1C, PSH, 2, 0, RH, true>(sGZ1, sIn, 0, lane, acc0, acc1, asum);
-                else         wgrad_half<TC, PSG, W1C, PSH, 2, RH, TR + 1, true>(sGZ1, sIn, 0, lane, acc0, acc1, asum);
-            }
+            const WgradLane wl = wgrad_lane<TC, PSG, W1C, PSH>(lane);
+            const int oa0 = 2 * wave * TC, ob0 = 2 * wave * W1C;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int cs = 0; cs < TC / 4; ++cs)
+                    wgrad_step(sGZ2, sGZ1, sHA, sIn, wl, oa0 + r * TC + 4 * cs, ob0 + r * W1C + 4 * cs, acc, bsum);
+            if (wave < 4) wgrad_step(sGZ2, sGZ1, sHA, sIn, wl, TR * TC + 4 * wave, TR * W1C + 4 * wave, acc, bsum);
         }
         STAMP(3);
+        issue_rest();                                                    // the next item's gz, cos / sin, g_out: they land under the phases below
         lds_barrier();
         STAMP(4);
 
@@ -328,24 +318,50 @@ __global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     }
 
     STAMP(10);
-    // ---- the group's partials
+    // ---- the group's partial: the waves' K slices summed through LDS in a fixed order
+    lds_barrier();
     {
-        const int lane = tid0 & 63, nt = wave >> 1, kh = wave & 1;
-        double* gw = gw0 + (size_t)kh * FLOW_GW_STRIDE;
-        const double4_t acc = acc0 + acc1;
-        if (nt < 3) wgrad_store<8>(acc, nt, lane, [&](int co, int ci, int ky, int kx, double v) { gw[CW1 + (co * 8 + ci) * 9 + ky * 3 + kx] = v; });
-        else        wgrad_store<2>(acc, 0, lane, [&](int co, int ci, int ky, int kx, double v) { gw[CW0 + (co * 2 + ci) * 9 + ky * 3 + kx] = v; });
-        // biases b2 (waves nt = 0), b1 (waves nt = 3): the lane partials of A rows (co, dy = 0) over the four K lane groups
-        asum += __shfl_xor(asum, 16); asum += __shfl_xor(asum, 32);
-        if ((nt == 0 || nt == 3) && lane < 8) gw[(nt == 0 ? CB1 : CB0) + lane] = asum;
-        if (tid0 < 432) gw0[(size_t)(tid0 >= 216 ? 1 : 0) * FLOW_GW_STRIDE + CW2 + (tid0 >= 216 ? tid0 - 216 : tid0)] = acc3[0];
+        const int lane = tid0 & 63;
+        double* R = sm + S::RED; double* BS = sm + S::RBS; double* C3 = sm + S::RC3;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R[((wave * 4 + nt) * 4 + q) * 64 + lane] = acc[nt][q];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                                    // A rows (co, dy = 0): lanes co + 16 g
+            double v = bsum[k];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (lane < 8) BS[(wave * 2 + k) * 8 + lane] = v;
+        }
+        if (tid0 < 432) C3[tid0] = acc3[0];
         else if (tid0 >= 448) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const double v = ft_wave_sum(acc3[k]);
-                if (lane == 0) { gw0[CB2 + k] = v; gw0[FLOW_GW_STRIDE + CB2 + k] = 0.0; }
+                if (lane == 0) gw0[CB2 + k] = v;
             }
         }
+        lds_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                    // element e = (nt, q, lane) = D_nt[row g + 4 q][col i]
+            const int e = tid0 + NT * h, nt = e >> 8, q = (e >> 6) & 3, ln = e & 63;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += R[w * 1024 + e];
+            const int g = ln >> 4, i = ln & 15, m = g + 4 * q, co = m & 7, dy = m >> 3;
+            const int ncol = (nt < 3 ? nt * 16 : 0) + i;
+            if (ncol < (nt < 3 ? 48 : 12)) {
+                const int ci = ncol / 6, kx = (ncol % 6) >> 1, ky = 2 * (ncol & 1) + dy;
+                if (ky <= 2) gw0[(nt < 3 ? CW1 + (co * 8 + ci) * 9 : CW0 + (co * 2 + ci) * 9) + ky * 3 + kx] = v;
+            }
+        }
+        if (tid0 < 16) {
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += BS[w * 16 + tid0];
+            gw0[(tid0 < 8 ? CB1 : CB0) + (tid0 & 7)] = v;
+        }
+        if (tid0 < 216) gw0[CW2 + tid0] = C3[tid0] + C3[216 + tid0];
     }
     STAMP(11);
 #undef STAMP

@@ -137,11 +137,11 @@ inline int flow_wgrad_ns(int B, int L, int tpw) {
     const int items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L), n = (items + 8 * tpw - 1) / (8 * tpw);
     return n < 1 ? 1 : n > 64 ? 64 : n;
 }
-// partials of a launch: two per workgroup that has an item (k_flow_wgrad numbers those 0, 1, 2, ...)
+// partials of a launch: one per workgroup that has an item (k_flow_wgrad numbers those 0, 1, 2, ...)
 inline int flow_wgrad_nparts(int B, int L, int tpw) {
     const int items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L), ns = flow_wgrad_ns(B, L, tpw);
     const int k0 = items / (tpw * ns), rem = items - k0 * tpw * ns;
-    return 2 * (k0 * ns + (rem < ns ? rem : ns));
+    return k0 * ns + (rem < ns ? rem : ns);
 }
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }

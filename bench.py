@@ -314,11 +314,8 @@ def main():
             ops.ft_trajectory(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=None if stateless else state,
                               groups=Gsplit)
         else:
-            r = ops.hmc_trajectory(x, v, u, BETA, dt, NSTEP)
-            for k in ('x_new', 'dH', 'acc', 'H0', 'H1'):
-                out[k].copy_(r[k])
-            _, qn, pn = ops.wilson_action_charge(out['x_new'], BETA)
-            out['plaq'].copy_(pn); out['Q'].copy_(qn)
+            ops.hmc_trajectory(x, v, u, BETA, dt, NSTEP, out=out)          # results written in place: no copy launches behind it
+            ops.wilson_action_charge(out['x_new'], BETA, out=out)
         # the chain state moves on and the run statistics accumulate inside the same (captured) sequence
         if not flowed:
             x.copy_(out['x_new'])

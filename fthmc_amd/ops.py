@@ -235,9 +235,21 @@ def plaquettes(x):
     return P
 
 
-def wilson_action_charge(x, beta: float):
+def _out_vec(out, key, B, like):
+    """out[key] when the caller supplies it (a contiguous float64 device vector of B entries, written in place: no copy
+    launches behind the kernel in a captured loop), else a fresh one"""
+    t = None if out is None else out.get(key)
+    if t is None:
+        return torch.empty(B, dtype=like.dtype, device=like.device)
+    if not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != B:
+        raise FthmcError(f'out[{key!r}]: expected a contiguous float64 device vector of {B} entries')
+    return t
+
+
+def wilson_action_charge(x, beta: float, out=None):
+    """-> (S, Q, plaq) per chain; out: optional dict with any of 'S', 'Q', 'plaq' to write into"""
     x = _field(x); B, _, L, _ = x.shape
-    S, Q, plaq = (torch.empty(B, dtype=x.dtype, device=x.device) for _ in range(3))
+    S, Q, plaq = (_out_vec(out, k, B, x) for k in ('S', 'Q', 'plaq'))
     check(_lib.load().fthmc_wilson_action_charge(_p(x), B, L, float(beta), _p(S), _p(Q), _p(plaq), _stream(x)),
           'fthmc_wilson_action_charge')
     return S, Q, plaq
@@ -349,13 +361,17 @@ def leapfrog(x, p, beta: float, dt: float, nstep: int):
     return xo, po
 
 
-def hmc_trajectory(x, v, u, beta: float, dt: float, nstep: int):
-    """-> dict(x_new, dH, acc, H0, H1), per chain."""
+def hmc_trajectory(x, v, u, beta: float, dt: float, nstep: int, out=None):
+    """-> dict(x_new, dH, acc, H0, H1), per chain; out: optional dict with any of these to write into (x_new must not be x)."""
     x = _field(x); v = _field(v, 'v'); u = _dev(u, 'u').reshape(-1); B, _, L, _ = x.shape
     if u.numel() != B:
         raise FthmcError(f'u: expected {B} uniforms, got {u.numel()}')
-    xn = torch.empty_like(x)
-    dH, acc, H0, H1 = (torch.empty(B, dtype=x.dtype, device=x.device) for _ in range(4))
+    xn = None if out is None else out.get('x_new')
+    if xn is None:
+        xn = torch.empty_like(x)
+    elif xn.shape != x.shape or xn.dtype != x.dtype or not xn.is_cuda or not xn.is_contiguous() or xn.data_ptr() == x.data_ptr():
+        raise FthmcError('out[\'x_new\']: expected a contiguous device tensor of the shape of x that is not x')
+    dH, acc, H0, H1 = (_out_vec(out, k, B, x) for k in ('dH', 'acc', 'H0', 'H1'))
     ws, nb = _ws(x, B, L, 0)
     check(_lib.load().fthmc_hmc_trajectory(_p(x), _p(v), _p(u), B, L, float(beta), float(dt), int(nstep),
                                            _p(xn), _p(dH), _p(acc), _p(H0), _p(H1), ws, nb, _stream(x)),

@@ -591,3 +591,31 @@ def test_config5_full_batch_on_one_gpu():
     finally:
         ops.release_workspaces()
         torch.cuda.empty_cache()
+
+
+def test_plain_hmc_outputs_in_place():
+    """ops.hmc_trajectory / ops.wilson_action_charge write into caller-supplied tensors (`out=`: the bench loop's captured sequence
+    carries no copy launches behind them) and return the same numbers as the allocating form; x_new must not alias x."""
+    import math
+    from fthmc_amd import ops
+    from fthmc_amd.ops import FthmcError
+    gen = torch.Generator().manual_seed(5)
+    B, L = 3, 8
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64).cuda()
+    u = torch.rand(B, generator=gen, dtype=torch.float64).cuda()
+    ref = ops.hmc_trajectory(x, v, u, 2.0, 0.1, 10)
+    out = {'x_new': torch.empty_like(x)}
+    for k in ('dH', 'acc', 'H0', 'H1', 'plaq', 'Q'):
+        out[k] = torch.full((B,), float('nan'), dtype=torch.float64, device='cuda')
+    r = ops.hmc_trajectory(x, v, u, 2.0, 0.1, 10, out=out)
+    for k in ('x_new', 'dH', 'acc', 'H0', 'H1'):
+        assert r[k].data_ptr() == out[k].data_ptr() and torch.equal(out[k], ref[k]), k
+    S, Q, plaq = ops.wilson_action_charge(out['x_new'], 2.0)
+    S2, Q2, plaq2 = ops.wilson_action_charge(out['x_new'], 2.0, out=out)
+    assert Q2.data_ptr() == out['Q'].data_ptr() and plaq2.data_ptr() == out['plaq'].data_ptr()
+    assert torch.equal(S, S2) and torch.equal(Q, out['Q']) and torch.equal(plaq, out['plaq'])
+    with pytest.raises(FthmcError):
+        ops.hmc_trajectory(x, v, u, 2.0, 0.1, 10, out={'x_new': x})
+    with pytest.raises(FthmcError):
+        ops.hmc_trajectory(x, v, u, 2.0, 0.1, 10, out={'dH': torch.empty(B + 1, dtype=torch.float64, device='cuda')})

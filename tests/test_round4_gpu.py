@@ -619,3 +619,36 @@ def test_plain_hmc_outputs_in_place():
         ops.hmc_trajectory(x, v, u, 2.0, 0.1, 10, out={'x_new': x})
     with pytest.raises(FthmcError):
         ops.hmc_trajectory(x, v, u, 2.0, 0.1, 10, out={'dH': torch.empty(B + 1, dtype=torch.float64, device='cuda')})
+
+
+@pytest.mark.parametrize('L,nl,B', [(8, 2, 6), (32, 2, 4)])
+def test_reference_shaped_run_carries_state_and_observables(L, nl, B):
+    """FieldTransformation.run(batch=True) (ft_hmc.py:272-346): the trajectory hands (S_eff, plaq, Q) of the accepted field to the
+    next one and its plaq / Q to the history -- no H0 sweep, no extra flow sweep for the metrics -- and the history equals the one of
+    the loop that recomputes both, as the reference does (ft_hmc.py:205, 266-270), on the same momenta and uniforms."""
+    from fthmc_amd import train as T
+    from fthmc_amd.config import TrainConfig, lfConfig
+    from fthmc_amd.ft_hmc import FieldTransformation
+    cfg = TrainConfig(L=L, beta=2.0, n_layers=nl, batch_size=B, print_freq=0)
+    torch.manual_seed(11)
+    model = T.get_model(cfg)
+    x0 = (0.3 * (2 * torch.rand(B, 2, L, L, dtype=torch.float64) - 1)).cuda()
+    n = 4
+    ft = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=8))
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    h = ft.run(x0.clone(), nprint=0, num_trajs=n, batch=True)
+    assert ft._carry is not None and ft._carry[0] is ft.x_last
+    ft2 = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=8))
+    torch.manual_seed(5); torch.cuda.manual_seed(5)
+    x = x0.clone()
+    qold = ft2.lattice_metrics(ft2.flow_forward(x)[0], torch.zeros(B, dtype=torch.float64, device='cuda'))['q']
+    for i in range(n):
+        x, m = ft2._batch_hmc(x.clone(), step=i)                         # a copy: nothing is carried over
+        lm = ft2.lattice_metrics(ft2.flow_forward(x)[0], qold)
+        assert torch.equal(m['acc'], h['acc'][i])
+        assert torch.allclose(m['dh'], h['dh'][i], rtol=0, atol=1e-9)
+        assert torch.allclose(lm['plaq'], h['plaq'][i], rtol=1e-13, atol=0)
+        assert torch.allclose(lm['q'], h['q'][i], rtol=0, atol=1e-11)
+        assert torch.allclose(lm['dq'], h['dq'][i], rtol=0, atol=1e-11)
+        qold = lm['q']
+    assert torch.equal(x, ft.x_last)

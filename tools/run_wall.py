@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Wall time per trajectory of the REFERENCE-SHAPED driver (fthmc.ft_hmc.FieldTransformation.run, batch of independent chains)
+beside bench.py's raw loop, on the GPU box:  python3 tools/run_wall.py [L beta n_layers chains trajectories] ...
+default: BASELINE configs[1] and configs[2]."""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fthmc_amd.config import TrainConfig, lfConfig
+from fthmc_amd.ft_hmc import FieldTransformation
+from fthmc_amd import train as T
+
+a = sys.argv[1:]
+shapes = [tuple(a[i:i + 5]) for i in range(0, len(a), 5)] or [('16', '4.0', '4', '32', '200'), ('64', '6.0', '8', '128', '40')]
+for L, beta, nl, B, n in shapes:
+    L, beta, nl, B, n = int(L), float(beta), int(nl), int(B), int(n)
+    torch.manual_seed(7)
+    cfg = TrainConfig(L=L, beta=beta, n_layers=nl, batch_size=B, print_freq=0)
+    model = T.get_model(cfg)
+    ft = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=10))
+    x = (0.1 * (2 * torch.rand(B, 2, L, L, dtype=torch.float64) - 1)).cuda()
+    ft.run(x, nprint=0, num_trajs=5, batch=True)                      # warm-up
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    h = ft.run(ft.x_last, nprint=0, num_trajs=n, batch=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    acc = float(torch.stack([torch.as_tensor(t, dtype=torch.float64).mean() for t in h['acc']]).mean())
+    print(json.dumps({'L': L, 'beta': beta, 'n_layers': nl, 'chains': B, 'trajectories': n, 'ms_per_trajectory': round(dt / n * 1e3, 4),
+                      'chain_steps_per_s': round(B * 10 * n / dt, 1), 'acceptance': round(acc, 3)}), flush=True)

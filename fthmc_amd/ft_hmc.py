@@ -106,10 +106,15 @@ class FieldTransformation(nn.Module):
         if u is None:
             u = torch.rand([], dtype=torch.float64, device=x.device)
         if x.shape[0] == 1:
-            r = ops.ft_trajectory(x, v, u.reshape(1), self.weights(x.device), len(self.flow), self.config.beta,
-                                  self.dt, self.nstep, self._act, mode=self._mode())
+            w = self.weights(x.device)
+            c = self._carry                                              # see _batch_hmc
+            state = c[3] if c is not None and c[0] is x and c[1] == x._version and c[2] is w else None
+            r = ops.ft_trajectory(x, v, u.reshape(1), w, len(self.flow), self.config.beta,
+                                  self.dt, self.nstep, self._act, mode=self._mode(), state_in=state)
             # the packaged code maps the end point with wrap, the notebook with regularize: same set
             xnew, acc, dh = r['x_new'], r['acc'][0] > 0.5, r['dH'][0]
+            self._carry = (xnew, xnew._version, w, r['state'])
+            metrics.update({'_plaq': r['plaq'], '_q': r['Q']})
         else:
             h0 = self.action(x).sum() + 0.5 * ops.kinetic(v).sum()
             x_, v_ = self.leapfrog(x, v)

@@ -652,3 +652,29 @@ def test_reference_shaped_run_carries_state_and_observables(L, nl, B):
         assert torch.allclose(lm['dq'], h['dq'][i], rtol=0, atol=1e-11)
         qold = lm['q']
     assert torch.equal(x, ft.x_last)
+
+
+def test_reference_shaped_single_chain_run_carries_state():
+    """FieldTransformation.run() on the reference's [1, 2, L, L] field: same carry as the batch loop; the history equals the loop
+    that recomputes H0 and flows the field again for its metrics."""
+    from fthmc_amd import train as T
+    from fthmc_amd.config import TrainConfig, lfConfig
+    from fthmc_amd.ft_hmc import FieldTransformation
+    L, nl, n = 8, 2, 5
+    cfg = TrainConfig(L=L, beta=2.0, n_layers=nl, batch_size=1, print_freq=0)
+    torch.manual_seed(13)
+    model = T.get_model(cfg)
+    x0 = (0.3 * (2 * torch.rand(1, 2, L, L, dtype=torch.float64) - 1)).cuda()
+    ft = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=8))
+    torch.manual_seed(6); torch.cuda.manual_seed(6)
+    h = ft.run(x0.clone(), nprint=0, num_trajs=n)
+    ft2 = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=8))
+    torch.manual_seed(6); torch.cuda.manual_seed(6)
+    x = x0.clone()
+    for i in range(n):
+        x, m = ft2.hmc(x.clone(), step=i)
+        lm = ft2.lattice_metrics(ft2.flow_forward(x)[0], torch.zeros(1, dtype=torch.float64, device='cuda'))
+        assert bool(m['acc']) == bool(h['acc'][i])
+        assert torch.allclose(m['dh'], h['dh'][i], rtol=0, atol=1e-9)
+        assert torch.allclose(lm['plaq'], h['plaq'][i], rtol=1e-13, atol=0) and torch.allclose(lm['q'], h['q'][i], rtol=0, atol=1e-11)
+    assert torch.equal(x, ft.x_last)

@@ -979,7 +979,7 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, const fthmc
     for (int k = 0; k < 16; ++k) cycles_host16[k] = 0.0;
     for (size_t r = 0; r < nrec; ++r)
         for (int k = 1; k < 16; ++k) {
-            const int ref = kind == 3 ? k - 1 : (kind >= 1 && k >= 6) ? 0 : (kind == 0 && k == 7) ? 1 : (kind == 0 && k == 11) ? 2 : k - 1;   // forward 7..12 (-DFT_DIAG builds): inside conv1 / conv2      // backward, slots 6..13: per-wave arrival at the first barrier
+            const int ref = k == 15 ? 14 : kind == 3 ? k - 1 : (kind >= 1 && k >= 6) ? 0 : (kind == 0 && k == 7) ? 1 : (kind == 0 && k == 11) ? 2 : k - 1;   // forward 7..12 (-DFT_DIAG builds): inside conv1 / conv2      // backward, slots 6..13: per-wave arrival at the first barrier
             if (h[r * 16 + k] && h[r * 16 + ref]) cycles_host16[k] += (double)(h[r * 16 + k] - h[r * 16 + ref]) / nused;
         }
     free(h);

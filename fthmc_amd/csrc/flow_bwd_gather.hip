@@ -103,6 +103,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
+    if (dbg && tid == 0) dbg[14] = (long long)__builtin_amdgcn_s_memrealtime();   // 14, 15: the 100 MHz counter (see k_flow_fwd)
 
     // wrapped lattice coordinates of window lines, relative to the tile origin (rows premultiplied by L)
     const unsigned wmagic = EXACT ? (unsigned)(L - 1) : (FASTW ? 0u : wrap_magic(L));
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
         A.gp_out[(size_t)b * n + mul24(i0 + orr, L) + j0 + occ] = gpin + (cls != 3 ? sDir[tid] : 0.0);
     }
     STAMP(5);
+    if (dbg && tid == 0) dbg[15] = (long long)__builtin_amdgcn_s_memrealtime();
 #undef STAMP
 }
 

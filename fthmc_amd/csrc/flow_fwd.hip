@@ -80,6 +80,9 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
+    // slots 14, 15: the constant 100 MHz counter at both ends of the workgroup -- lifetime in cycles / lifetime in ticks = the
+    // shader clock the kernel actually ran at (tools/lifetime.py)
+    if (dbg && tid == 0) dbg[14] = (long long)__builtin_amdgcn_s_memrealtime();
 
     const unsigned fastw = EXACT ? (unsigned)(L - 1) : (FASTW ? 0u : wrap_magic(L));
     // this layer's forward weight block (the conv2 table padded along the pair direction of this mu): the loads are
@@ -544,6 +547,7 @@ __global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
             if (EXACT || (i < L && j < L)) A.pout[(size_t)b * n + mul24(i, L) + j] = ft_stripe(i, j, mu, off) == 0 ? sDL[tid] : xv0;
         }
         STAMP(6);
+        if (dbg && tid == 0) dbg[15] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 

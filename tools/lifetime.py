@@ -19,5 +19,7 @@ for B in [int(a) for a in sys.argv[1:]] or (16, 32, 48, 64, 96, 128, 256):
         if kind == 'flow_bwd' and 'diag' in os.environ.get('FTHMC_LIB', '') and any(cyc[6:10]):
             t2 = sum(cyc[1:3])
             print('      inside conv2T, cycles after the conv3T barrier: wave 0 tile 0 mfma / epilogue, tile 1 mfma / epilogue; wave 4 mfma / epilogue:', ' '.join(f'{c - t2:.0f}' for c in cyc[6:12]))
+        if kind in ('flow_fwd', 'flow_bwd') and cyc[15] > 0:
+            print(f'      {kind} shader clock while this launch runs: {tot / (cyc[15] * 10e-9) / 1e9:.3f} GHz ({tot:.0f} cycles in {cyc[15] * 10:.0f} ns per workgroup)')
         if kind == 'flow_wgrad': print(f'      flow_wgrad workgroup: prologue {cyc[9]:.0f}, the walk {cyc[10]:.0f}, epilogue {cyc[11]:.0f} cycles (stages below: its last item)')
         print(f'B={B:3d} WGs={B*16:5d} {kind}: {ms*1e3:7.2f} us; lifetime {tot:6.0f} cycles/WG; ' + ', '.join(f'{n} {c:.0f}' for n, c in zip(names[kind][1:], cyc[1:]) if n), flush=True)

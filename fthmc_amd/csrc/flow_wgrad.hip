@@ -7,21 +7,20 @@
 // is a GEMM with K = sites.  One 512-thread workgroup owns a 16 x 16 tile (hin with a halo of one site) and runs it on
 // v_mfma_f64_16x16x4_f64: M = 16 = 8 co x (dy = 0, 1) with A[(co, dy)][s] = gz[co][s - dy rows], N = (ci, kx, kyb) with
 // ky = 2 kyb + dy, so D[(co, dy)][(ci, kx, kyb)] = gw[co][ci][2 kyb + dy][kx] (the ky = 3 row is discarded: 75 % useful).
-// conv2 (8 -> 8): 48 columns = 3 N tiles, conv1 (2 -> 8): 12 columns = 1 N tile; each of the four tiles is split over two
-// waves by halves of the site rows, so all eight waves run 32..36 MFMAs with both operands addressed as lane part +
-// compile-time constant (gz planes carry a zero row above and below: no bounds logic in the K loop).  conv3 (8 -> 3,
-// active sites only) runs on the VALU in a second phase that reuses the h1 planes for h2.
+// conv2 (8 -> 8): 48 columns = 3 N tiles, conv1 (2 -> 8): 12 columns = 1 N tile.  The K walk (17 window rows x 4 steps) is
+// split over the eight waves (two rows each, the last row's four steps on waves 0..3) and every wave runs ALL FOUR tiles on its
+// slice: 32..36 MFMAs on 1.5 LDS reads each (the three conv2 tiles share their A operand), both operands addressed as lane
+// part + wave-uniform row offset + compile-time constant (gz planes carry a zero row above and below: no bounds logic in the
+// K loop).  conv3 (8 -> 3, active sites only) runs on the VALU in a second phase that reuses the h1 planes for h2.
 // A workgroup WALKS A.tpw (chain, tile) items of its layer, A.wg_ns apart (the sum over sites simply runs on: accumulators
-// stay in registers) with the next item's operands prefetched into registers while the current one is in the MFMA phase:
-// one tile per workgroup spent 8 k of its 21 k cycles issuing loads and waiting for them (profiles/r04_workgroup_lifetime.txt).
-// At the end it writes TWO complete 955-entry partials (site halves) to A.gw_part; k_reduce_gw sums them in a fixed
-// order.  Replaces the in-kernel weight-gradient stages of round 1 (8 x 16 tiles, most of them on 1..3 waves:
-// 49 k cycles per 128 sites; this kernel: see DESIGN.md section 4).
+// stay in registers); the next item's operands are prefetched into registers in two halves, its h1 window ahead of the
+// current item's MFMA phase, its gz / cos, sin / g_out behind it (all of it plus the 32 accumulator registers does not fit
+// the 128 a wave has at two workgroups per CU, and a spill inside the walk costs more than anything else here: DESIGN.md
+// section 4).  At the end the waves' slices are summed through LDS in a fixed order and the workgroup writes ONE complete
+// 955-entry partial to A.gw_part; k_reduce_gw sums the partials in a fixed order.  Replaces the in-kernel weight-gradient
+// stages of round 1 (8 x 16 tiles, most of them on 1..3 waves: 49 k cycles per 128 sites).
 #include "flow_mfma_common.h"
 
-#ifndef FT_WGRAD_TEST
-#define FT_WGRAD_TEST 0
-#endif
 
 namespace {
 

@@ -113,7 +113,7 @@ summary = {'L': L, 'beta': beta, 'n_layers': NL, 'plaq_exact': PLAQ_EXACT[beta],
                         'loss_dkl_first': round(float(np.mean(loss[:k])), 3), 'loss_dkl_last': round(float(np.mean(loss[-k:])), 3), 'pre_training': pre}}
 print(json.dumps(summary), flush=True)
 summary['runs'] = [run(None, 0, 'plain HMC'), run(w_init, NL, f'ftHMC, flow as moved from L = {args.transfer_from}' if pre else 'ftHMC, flow at its random initialisation', prior_start=bool(pre))]
-for ns in [int(t) for t in args.nstep_trained.split(',')]:
+for ns in ([int(t) for t in args.nstep_trained.split(',') if t] if args.train_steps or pre else []):
     summary['runs'].append(run(w_tr, NL, f'ftHMC, flow after {args.train_steps} reverse-KL steps', ns, prior_start=True))
 if args.out:
     json.dump(summary, open(args.out, 'w'), indent=1)

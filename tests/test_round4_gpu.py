@@ -678,3 +678,38 @@ def test_reference_shaped_single_chain_run_carries_state():
         assert torch.allclose(m['dh'], h['dh'][i], rtol=0, atol=1e-9)
         assert torch.allclose(lm['plaq'], h['plaq'][i], rtol=1e-13, atol=0) and torch.allclose(lm['q'], h['q'][i], rtol=0, atol=1e-11)
     assert torch.equal(x, ft.x_last)
+
+
+def test_headline_size_sampler_reproduces_the_exact_plaquette():
+    """L = 64 (the tiled MFMA kernels, two chain groups), beta = 6: plain HMC and ftHMC with an untrained 2-layer flow from the
+    near-cold start; <cos P> of the (flowed) field against I1/I0 and <exp(-dH)> against 1, errors over independent chains
+    (tools/operating_point.py is the long version: profiles/r04_headline_size_plaquette.json).  Seeds are fixed: deterministic."""
+    import math
+    from fthmc_amd import ops, parallel, train as T
+    from fthmc_amd.config import PLAQ_EXACT, TrainConfig
+    from fthmc_amd.utils.layers import net_weights
+    L, beta, B, nl, therm, ntraj, nstep = 64, 6.0, 128, 2, 250, 250, 20
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(3)
+    model = T.get_model(TrainConfig(L=L, beta=beta, n_layers=nl, batch_size=B, print_freq=0))
+    w = ops.pack_weights([net_weights(l.plaq_coupling.net) for l in model.layers], device=dev)
+    for flowed in (False, True):
+        g0, _ = ops.random_momenta(parallel.chain_seeds(77, 0, B, 0).to(dev), (B, 2, L, L), need_u=False)
+        x = (0.1 * torch.erf(g0 / math.sqrt(2.0))).contiguous()
+        plaq_s = torch.zeros(B, dtype=torch.float64, device=dev); emdh_s = torch.zeros_like(plaq_s); acc_s = torch.zeros_like(plaq_s)
+        for it in range(therm + ntraj):
+            v, u = ops.random_momenta(parallel.chain_seeds(78, 0, B, it).to(dev), (B, 2, L, L))
+            if flowed:
+                r = ops.ft_trajectory(x, v, u, w, nl, beta, 1.0 / nstep, nstep, mode='md', groups=2)
+                plaq = r['plaq']
+            else:
+                r = ops.hmc_trajectory(x, v, u, beta, 1.0 / nstep, nstep)
+                plaq = ops.wilson_action_charge(r['x_new'], beta)[2]
+            x = r['x_new']
+            if it >= therm:
+                plaq_s += plaq; emdh_s += torch.exp(-r['dH']); acc_s += r['acc']
+        p = (plaq_s / ntraj).cpu().numpy(); e = (emdh_s / ntraj).cpu().numpy()
+        perr, eerr = p.std(ddof=1) / math.sqrt(B), e.std(ddof=1) / math.sqrt(B)
+        assert float(acc_s.mean()) / ntraj > 0.6
+        assert perr < 5e-5 and abs(p.mean() - PLAQ_EXACT[beta]) < 4 * perr, (flowed, p.mean(), perr)
+        assert abs(e.mean() - 1.0) < 4 * eerr, (flowed, e.mean(), eerr)

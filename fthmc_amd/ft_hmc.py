@@ -40,11 +40,16 @@ class FieldTransformation(nn.Module):
         self._denom = self.config.beta * self.config.volume
         self._w = None
         self._w_versions = None
+        self._params = None
         self._carry = None            # (field tensor, its version, weights, state [3, B]) of the last batch trajectory's result
 
     # ---- weights: packed once, refreshed when a parameter changed in place -----------
     def weights(self, dev) -> torch.Tensor:
-        vers = tuple(p._version for p in self.flow.parameters())
+        # the parameter list is gathered once (Module.parameters() walks the module tree: it was two thirds of the host time of a
+        # trajectory at L = 16); a flow whose modules are swapped afterwards wants a new FieldTransformation
+        if self._params is None:
+            self._params = list(self.flow.parameters())
+        vers = tuple(p._version for p in self._params)
         if self._w is None or self._w_versions != vers or self._w.device != dev:
             self._w = flow_weights(self.flow, dev)
             self._w_versions = vers

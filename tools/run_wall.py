@@ -10,7 +10,7 @@ from fthmc_amd.ft_hmc import FieldTransformation
 from fthmc_amd import train as T
 
 a = sys.argv[1:]
-shapes = [tuple(a[i:i + 5]) for i in range(0, len(a), 5)] or [('16', '4.0', '4', '32', '200'), ('64', '6.0', '8', '128', '40')]
+shapes = [tuple(a[i:i + 5]) for i in range(0, len(a), 5)] or [('16', '4.0', '4', '32', '400'), ('64', '6.0', '8', '128', '40')]
 for L, beta, nl, B, n in shapes:
     L, beta, nl, B, n = int(L), float(beta), int(nl), int(B), int(n)
     torch.manual_seed(7)
@@ -21,7 +21,8 @@ for L, beta, nl, B, n in shapes:
     ft.run(x, nprint=0, num_trajs=5, batch=True)                      # warm-up
     torch.cuda.synchronize(); t0 = time.perf_counter()
     h = ft.run(ft.x_last, nprint=0, num_trajs=n, batch=True)
+    host = time.perf_counter() - t0                                   # the loop has enqueued everything
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     acc = float(torch.stack([torch.as_tensor(t, dtype=torch.float64).mean() for t in h['acc']]).mean())
-    print(json.dumps({'L': L, 'beta': beta, 'n_layers': nl, 'chains': B, 'trajectories': n, 'ms_per_trajectory': round(dt / n * 1e3, 4),
+    print(json.dumps({'L': L, 'beta': beta, 'n_layers': nl, 'chains': B, 'trajectories': n, 'ms_per_trajectory': round(dt / n * 1e3, 4), 'host_ms_per_trajectory': round(host / n * 1e3, 4),
                       'chain_steps_per_s': round(B * 10 * n / dt, 1), 'acceptance': round(acc, 3)}), flush=True)

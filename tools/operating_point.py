@@ -33,6 +33,7 @@ ap.add_argument('--nstep-trained', default='10,20,40', help='leapfrog steps per 
 ap.add_argument('--seed', type=int, default=1331)
 ap.add_argument('--transfer-from', type=int, default=0, help='train.py:434-455 recipe: train at this lattice size first, then move the nets to --L')
 ap.add_argument('--pre-steps', type=int, default=0, help='training steps at the --transfer-from size')
+ap.add_argument('--anneal', default='', help='beta:steps,beta:steps,... trained in this order at the --transfer-from size before --beta (a curriculum in the coupling)')
 ap.add_argument('--out', default=None)
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
@@ -91,7 +92,16 @@ if args.transfer_from and args.pre_steps:                                # the r
     from fthmc_amd.train import transfer_to_new_lattice
     cfg0 = TrainConfig(L=args.transfer_from, beta=beta, n_layers=NL, batch_size=args.train_batch, n_era=1, n_epoch=args.pre_steps,
                        base_lr=args.lr, print_freq=0)
-    o0 = train(cfg0, model=get_model(cfg0), verbose=False, save=False)
+    m0 = get_model(cfg0)
+    for item in [t for t in args.anneal.split(',') if t]:                # earlier couplings first, same nets
+        b_, n_ = item.split(':')
+        cfga = TrainConfig(L=args.transfer_from, beta=float(b_), n_layers=NL, batch_size=args.train_batch, n_era=1, n_epoch=int(n_),
+                           base_lr=args.lr, print_freq=0)
+        oa = train(cfga, model=m0, verbose=False, save=False)
+        m0 = oa['model']
+        ea = [float(e) for e in oa['history']['ess']]
+        print(json.dumps({'anneal_beta': float(b_), 'steps': int(n_), 'ess_last': round(float(np.mean(ea[-max(1, len(ea) // 20):])), 4)}), flush=True)
+    o0 = train(cfg0, model=m0, verbose=False, save=False)
     e0 = [float(e) for e in o0['history']['ess']]
     k0 = max(1, len(e0) // 20)
     pre = {'L': args.transfer_from, 'steps': args.pre_steps, 'ess_first': round(float(np.mean(e0[:k0])), 4), 'ess_last': round(float(np.mean(e0[-k0:])), 4)}

@@ -34,6 +34,7 @@ import argparse
 import json
 import math
 import os
+import re
 import subprocess
 import sys
 import time
@@ -85,6 +86,9 @@ def parse():
     ap.add_argument('--regions', type=int, default=None,
                     help='timed regions of --steps trajectories each (value = the median region); default: 1, or 5 when '
                          'the first region is shorter than 1 s')
+    ap.add_argument('--min-seconds', type=float, default=6.0,
+                    help='keep timing regions of exactly --steps trajectories until this many seconds of timed GPU work have '
+                         'accumulated (the value is the median region; a monitor that samples the card every few seconds sees it busy)')
     ap.add_argument('--dump', type=str, default=None,
                     help='write every rank\'s per-chain end state (global chain ids, field, last dH / acc / Q) to '
                          'DUMP.<world>.<rank>.npz (sharding tests)')
@@ -189,6 +193,36 @@ def pmc_traffic(kernel):
                  'csrc_sha16': d.get('csrc_sha16'), 'library_sha16': lib_sha16(),
                  # stale: the summary was taken on other kernels than the ones the loaded library was built from
                  'stale': d.get('csrc_sha16') != lib_sha16(), 'library_matches_sources': lib_sha16() == csrc_sha16()})
+    except Exception:
+        return None, None
+
+
+def rocprof_launch(kernel):
+    """Average launch duration (ms) of `kernel` in the newest committed `rocprofv3 --kernel-trace --stats` summary of this
+    command (profiles/rNN_kernel_stats.csv: in situ, both chain groups' streams running) and which summary that was: the
+    figure roofline.frac_rocprof is reproducible from.  The tiled coupling kernels are instantiated per stripe direction:
+    the call-weighted average over the instances of the timed region (forward sweeps: not the REV = true instances)."""
+    import csv
+    prof = os.path.join(ROOT, 'profiles')
+    try:
+        names = sorted(f for f in os.listdir(prof) if re.fullmatch(r'r\d+_kernel_stats\.csv', f))
+        calls = tot = 0
+        with open(os.path.join(prof, names[-1])) as f:
+            for row in csv.DictReader(f):
+                n = row['Name']
+                if kernel + '<' in n and ', true, true, 0' not in n and ', true, true, 1' not in n and ', false, true,' not in n:
+                    calls += int(row['Calls']); tot += int(row['TotalDurationNs'])
+        meta = {}
+        try:
+            with open(os.path.join(prof, names[-1].replace('.csv', '.meta.json'))) as f:
+                meta = json.load(f)
+        except Exception:
+            pass
+        if not calls:
+            return None, None
+        return tot / calls * 1e-6, {'file': 'profiles/' + names[-1], 'launches': calls, 'csrc_sha16': meta.get('csrc_sha16'),
+                                    'command': meta.get('command'), 'library_sha16': lib_sha16(),
+                                    'stale': meta.get('csrc_sha16') != lib_sha16()}
     except Exception:
         return None, None
 
@@ -383,7 +417,9 @@ def main():
         # a region shorter than a second is at the mercy of the clock ramp and of one late host wake-up: time more
         # regions of the same --steps trajectories and report the median one (every rank sees the same MAX-reduced
         # time, so all ranks agree on the count)
-        nreg = args.regions if args.regions else (5 if times[0] < 1.0 else 1)
+        # ... and keep going until --min-seconds of timed GPU work have accumulated, so that the record of a run shows the
+        # card busy whatever --steps was (20 trajectories are 0.12 s)
+        nreg = args.regions if args.regions else max(5 if times[0] < 1.0 else 1, min(400, math.ceil(args.min_seconds / max(times[0], 1e-6))))
         while len(times) < nreg:
             times.append(region())
         # side figure: the same trajectories with H0 recomputed (one more flow sweep per trajectory), one region
@@ -537,11 +573,18 @@ def main():
         traffic, traffic_src = pmc_traffic(names[dom][1])
         traffic_b, _ = pmc_traffic(names['bwd'][1])
         frac = lambda ms, nb: round(CONV_FLOPS_PER_SITE * L * L * nb / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 4)
+        ms_prof, prof_src = rocprof_launch(names[dom][1])
+        ms_prof_b, _ = rocprof_launch(names['bwd'][1])
         roofline = {
             'bound': 'mfma', 'kernel': names[dom][0],
             'achieved': round(achieved, 3), 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / FP64_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
             'avg_launch_ms': round(ms_dom, 4),
+            'avg_launch_note': 'HIP events around back-to-back launches of the kernel alone, on this stream, in this run; '
+                               'rocprof_avg_launch_ms: the same kernel inside the timed sequence (both chain groups\' streams running) from the '
+                               'committed rocprofv3 summary -- frac_rocprof follows from it to the digit',
+            'rocprof_avg_launch_ms': None if ms_prof is None else round(ms_prof, 5),
+            'frac_rocprof': None if ms_prof is None else frac(ms_prof, Bl), 'rocprof_source': prof_src,
             'algorithmic_flops_per_launch': flops_launch,
             'chains_per_launch': Bl,
             'kernel_ms_per_trajectory': {k: round(v_, 3) for k, v_ in share.items()},
@@ -549,7 +592,9 @@ def main():
                                      'fwd_frac': frac(ms_fwd_full, B), 'bwd_frac': frac(ms_bwd_full, B)},
             'fwd_kernel_ms': round(ms_fwd, 4), 'bwd_kernel_ms': round(ms_bwd, 4),
             'bwd_kernel': {'kernel': names['bwd'][0], 'achieved': round(flops_launch / (ms_bwd * 1e-3) / 1e12, 3),
-                           'frac': frac(ms_bwd, Bl), 'traffic': traffic_b},
+                           'frac': frac(ms_bwd, Bl), 'traffic': traffic_b,
+                           'rocprof_avg_launch_ms': None if ms_prof_b is None else round(ms_prof_b, 5),
+                           'frac_rocprof': None if ms_prof_b is None else frac(ms_prof_b, Bl)},
             'whole_step_tflops': round(step_flops * (NSTEP * args.steps) / elapsed / 1e12, 3),
             'whole_step_frac': round(step_flops * (NSTEP * args.steps) / elapsed / 1e12 / FP64_PEAK_TFLOPS, 4),
             'attainable': ATTAINABLE,

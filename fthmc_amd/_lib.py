@@ -73,6 +73,9 @@ SIGNATURES = {
     'fthmc_ft_trajectory': [_D, _D, _D, _D, _A, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_int, _D, _D, _D, _D, _D, _D, _D, _D, _D, _P, c_size_t, _P],
     'fthmc_train_grad': [_D, _D, _A, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
     'fthmc_random_uniform': [_D, c_int, c_int, c_double, c_double, _D, _P],
+    'fthmc_chain_seeds': [ctypes.c_int64, ctypes.c_int64, c_int, ctypes.c_int64, _D, c_int, _D, _P],
+    'fthmc_hint_weights_packed': [c_int],
+    'fthmc_pack_weights': [_D, _A, c_int, _P, c_size_t, _P],
     'fthmc_adam_step': [_D, _D, _D, _D, _D, c_size_t, c_double, c_double, c_double, c_double, c_int, _P],
     'fthmc_train_metrics': [_D, _D, _D, _D, c_int, c_int, c_double, c_double, _D, _P, c_size_t, _P],
     'fthmc_time_kernel': [c_int, _D, _D, _A, c_int, c_int, c_int, c_int, c_int, c_double, c_int, ctypes.POINTER(c_double), _P, c_size_t, _P],

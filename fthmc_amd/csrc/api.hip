@@ -98,9 +98,12 @@ inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
 
 // The caller's canonical weights: the tuned kernels read their own expansion (k_pack_weights -> W.wint), the kernels for
 // other net shapes (flow_generic.hip) read the canonical layout itself.
+static thread_local int g_weights_packed = 0;     // fthmc_hint_weights_packed: consumed by the next call on this thread
 inline int use_weights(Ctx& C, const double* w, int nl, const WS& W, hipStream_t s) {
     C.wcan = w;
-    return C.A.is_default() ? launch_pack_weights(w, nl, W.wint, s) : FTHMC_OK;
+    const bool packed = g_weights_packed != 0;
+    g_weights_packed = 0;
+    return C.A.is_default() && !packed ? launch_pack_weights(w, nl, W.wint, s) : FTHMC_OK;
 }
 inline GenLayerArgs gen_args(const Ctx& C, const WS& w, int l, int B, int L, int act, bool own_region) {
     GenLayerArgs g{};
@@ -356,6 +359,22 @@ int fthmc_stats_accumulate(const double* acc, const double* plaq, const double* 
 int fthmc_random_momenta(const int64_t* seeds, int B, int n_per_chain, double* v, double* u, void* stream) {
     if (!seeds || !v || B <= 0 || n_per_chain <= 0) return FTHMC_ERR_ARG;
     return launch_random_momenta(seeds, B, n_per_chain, v, u, ft_stream(stream));
+}
+
+int fthmc_hint_weights_packed(int packed) { g_weights_packed = packed ? 1 : 0; return FTHMC_OK; }
+
+int fthmc_pack_weights(const double* w, const fthmc_arch_t* arch, int n_layers, void* ws, size_t ws_bytes, void* stream) {
+    if (!w || n_layers <= 0) return FTHMC_ERR_ARG;
+    FT_CTX(arch);
+    g_weights_packed = 0;
+    if (!ws || ws_bytes < up((size_t)n_layers * FLOW_WINT) * sizeof(double)) return FTHMC_ERR_WS;
+    const WS W = ws_layout(C.A, static_cast<double*>(ws), 1, 4, n_layers);      // the expansion is the workspace's first region whatever B, L
+    return use_weights(C, w, n_layers, W, s);
+}
+
+int fthmc_chain_seeds(int64_t seed, int64_t lo, int B, int64_t traj, int64_t* counter, int advance, int64_t* seeds, void* stream) {
+    if (!seeds || B <= 0 || (advance && !counter)) return FTHMC_ERR_ARG;
+    return launch_chain_seeds(seed, lo, B, traj, counter, advance, seeds, ft_stream(stream));
 }
 
 int fthmc_random_uniform(const int64_t* seeds, int B, int n_per_chain, double lo, double hi, double* out, void* stream) {

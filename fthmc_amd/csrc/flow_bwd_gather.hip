@@ -68,7 +68,7 @@ template <int TR, int TC> struct SmemG {
 // EXACT: the tiles divide the lattice and L is a power of two (64, 128, 256): every own site is a lattice site, the lattice-edge
 // tests fold away, a window line wraps by one v_and.
 template <int TR, int TC, bool FASTW, int MU, bool EXACT>
-__global__ __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
+__global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(FlowLayerArgs A) {
     using S = SmemG<TR, TC>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
     constexpr int W1R = S::W1R, W1C = S::W1C, N3 = S::N3, PS1 = S::PS1, PS2 = S::PS2, RS2 = S::RS2;

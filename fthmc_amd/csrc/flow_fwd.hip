@@ -49,7 +49,7 @@ template <int TR, int TC> struct SmemF {
 // is a lattice site -- the lattice-edge halves of the bounds tests of the stash stores, the link update and the active sites
 // fold away -- and a window line wraps by one v_and.
 template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT>
-__global__ __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
+__global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;

@@ -699,7 +699,7 @@ enum { SM_ACTION = 0, SM_FORCE = 1, SM_LEAPFROG = 2, SM_TRAJ = 3, SM_TRAIN = 4 }
 //                dL/dlogJ = -1 / B, writing each layer's pre-activation gradients for k_flow_wgrad
 // The sweep loop has ONE call site of the layer bodies (the kernel is register- and code-size-bound otherwise).
 template <int L, bool TRAIN>
-__global__ __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
+__global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
     using G = GS<L>;
     constexpr int N = G::N;
     __shared__ __attribute__((aligned(16))) double sm[G::SIZE];

@@ -90,9 +90,9 @@ __device__ __forceinline__ void conv3_acc(const double* __restrict__ pg, const d
 }
 
 template <int TR, int TC, bool FASTW>
-__global__ __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
+__global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     using S = SmemW<TR, TC>;
-    constexpr int PSG = S::PSG, PSH = S::PSH, W1C = S::W1C, NH = S::NH, N3 = S::N3, NA = S::NA;
+    constexpr int PSG = S::PSG, PSH = S::PSH, W1C = S::W1C, NH = S::NH, NA = S::NA;
     __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
     double* sGZ2 = sm + S::GZ2; double* sHA = sm + S::HA; double* sGZ1 = sm + S::GZ1; double* sIn = sm + S::IN;
     double* sGO = sm + S::GO;

@@ -47,6 +47,7 @@ int launch_adam(double* p, const double* g, double* m, double* v, double* hp, si
 // ---- rng.hip
 int launch_random_momenta(const int64_t* seeds, int B, int n, double* v, double* u, hipStream_t s);
 int launch_random_uniform(const int64_t* seeds, int B, int n, double lo, double hi, double* out, hipStream_t s);
+int launch_chain_seeds(int64_t seed, int64_t lo, int B, int64_t traj, int64_t* counter, int advance, int64_t* seeds, hipStream_t s);
 
 // ---- flow.hip
 constexpr int FLOW_TILE = 16;                 // VALU variant (flow.hip): 16 x 16 sites per tile

@@ -61,9 +61,30 @@ __global__ void k_random_uniform(const int64_t* __restrict__ seeds, int n, doubl
     }
 }
 
+// seeds[b] = SplitMix64 mix of (seed, global chain id, trajectory) & (2^63 - 1): the arithmetic of parallel.chain_seeds.
+// One workgroup: every thread reads the counter before thread 0 moves it on.
+__global__ void k_chain_seeds(uint64_t seed, uint64_t lo, int B, uint64_t traj, int64_t* __restrict__ counter, int advance,
+                              int64_t* __restrict__ seeds) {
+    const uint64_t t = traj + (counter ? (uint64_t)*counter : 0ull);
+    __syncthreads();
+    const uint64_t base = (seed * 2ull + 1ull) * 0x2545F4914F6CDD1Dull + t * 0xBF58476D1CE4E5B9ull;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        uint64_t z = (lo + (uint64_t)b) * 0x9E3779B97F4A7C15ull + base;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        seeds[b] = (int64_t)(z & 0x7FFFFFFFFFFFFFFFull);
+    }
+    if (advance && threadIdx.x == 0) *counter = (int64_t)(t - traj + 1ull);
+}
+
 }  // namespace
 
 namespace fthmc {
+int launch_chain_seeds(int64_t seed, int64_t lo, int B, int64_t traj, int64_t* counter, int advance, int64_t* seeds, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_seeds, dim3(1), dim3(256), 0, s, (uint64_t)seed, (uint64_t)lo, B, (uint64_t)traj, counter, advance, seeds);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
 int launch_random_uniform(const int64_t* seeds, int B, int n, double lo, double hi, double* out, hipStream_t s) {
     int gx = ((n + 1) / 2 + 255) / 256; if (gx > 32) gx = 32; if (gx < 1) gx = 1;
     hipLaunchKernelGGL(k_random_uniform, dim3(gx, B), dim3(256), 0, s, seeds, n, lo, hi, out);

@@ -11,6 +11,7 @@
 // Built by csrc/Makefile with g++ (host code only; links libfthmc_hip.so next to it and PyTorch's libraries).
 // Reference call sites each operator replaces: fthmc_amd/torch_ops.py docstring.
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -22,6 +23,10 @@ namespace {
 
 using at::Tensor;
 using IntList = c10::optional<at::IntArrayRef>;
+
+// every operator runs with its first tensor's device current: the workspace and the outputs are allocated there and the launch
+// goes to THAT device's current stream, whatever device the calling thread had selected (several GPUs in one process)
+#define FT_DEVICE_GUARD(t) const c10::hip::OptionalHIPGuardMasqueradingAsCUDA device_guard_((t).device())
 
 void* cur_stream(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
@@ -84,6 +89,7 @@ Tensor perchain(const Tensor& t, int64_t B, const char* name) {
 
 // ---------------------------------------------------------------- Wilson
 std::tuple<Tensor, Tensor, Tensor> wilson_action_charge(const Tensor& x_, double beta) {
+    FT_DEVICE_GUARD(x_);
     Tensor x = field(x_, "x");
     const int B = (int)x.size(0), L = (int)x.size(2);
     Tensor S = at::empty({B}, x.options()), Q = at::empty({B}, x.options()), plaq = at::empty({B}, x.options());
@@ -91,12 +97,14 @@ std::tuple<Tensor, Tensor, Tensor> wilson_action_charge(const Tensor& x_, double
     return {S, Q, plaq};
 }
 Tensor wilson_force(const Tensor& x_, double beta) {
+    FT_DEVICE_GUARD(x_);
     Tensor x = field(x_, "x");
     Tensor F = at::empty_like(x);
     ok(fthmc_wilson_force(cp(x), (int)x.size(0), (int)x.size(2), beta, mp(F), cur_stream(x)), "fthmc_wilson_force");
     return F;
 }
 std::tuple<Tensor, Tensor, Tensor> hmc_trajectory(const Tensor& x_, const Tensor& v_, const Tensor& u_, double beta, double dt, int64_t nstep) {
+    FT_DEVICE_GUARD(x_);
     Tensor x = field(x_, "x"), v = field(v_, "v");
     const int B = (int)x.size(0), L = (int)x.size(2);
     Tensor u = perchain(u_, B, "u");
@@ -111,6 +119,7 @@ std::tuple<Tensor, Tensor, Tensor> hmc_trajectory(const Tensor& x_, const Tensor
 // ---------------------------------------------------------------- one coupling layer
 std::tuple<Tensor, Tensor> flow_layer_fwd(const Tensor& x_, const Tensor& w_, int64_t mu, int64_t off, int64_t n_mix, int64_t act,
                                           IntList hidden, int64_t kernel_size) {
+    FT_DEVICE_GUARD(x_);
     Tensor x = field(x_, "x");
     Arch A(n_mix, hidden, kernel_size);
     Tensor w = weights(w_, A.params(), "w");
@@ -123,6 +132,7 @@ std::tuple<Tensor, Tensor> flow_layer_fwd(const Tensor& x_, const Tensor& w_, in
 }
 std::tuple<Tensor, Tensor> layer_bwd(const Tensor& x_, const Tensor& gy_, const Tensor& glogJ_, const Tensor& w_, int64_t mu, int64_t off,
                                      int64_t n_mix, int64_t act, IntList hidden, int64_t kernel_size, bool need_gw) {
+    FT_DEVICE_GUARD(x_);
     Tensor x = field(x_, "x"), gy = field(gy_, "gy");
     Arch A(n_mix, hidden, kernel_size);
     Tensor w = weights(w_, A.params(), "w");
@@ -149,6 +159,7 @@ std::tuple<Tensor, Tensor> flow_layer_bwd(const Tensor& x, const Tensor& gy, con
 }
 std::tuple<Tensor, Tensor> flow_layer_rev(const Tensor& y_, const Tensor& w_, int64_t mu, int64_t off, int64_t n_mix, int64_t act, double tol,
                                           IntList hidden, int64_t kernel_size) {
+    FT_DEVICE_GUARD(y_);
     Tensor y = field(y_, "y");
     Arch A(n_mix, hidden, kernel_size);
     Tensor w = weights(w_, A.params(), "w");
@@ -163,6 +174,7 @@ std::tuple<Tensor, Tensor> flow_layer_rev(const Tensor& y_, const Tensor& w_, in
 // ---------------------------------------------------------------- whole flow
 std::tuple<Tensor, Tensor, Tensor> ft_action_force(const Tensor& x_, const Tensor& w_all, int64_t n_layers, double beta, int64_t act,
                                                    int64_t n_mix, IntList hidden, int64_t kernel_size) {
+    FT_DEVICE_GUARD(x_);
     Tensor x = field(x_, "x");
     Arch A(n_mix, hidden, kernel_size);
     Tensor w = weights(w_all, n_layers * A.params(), "w_all");
@@ -177,6 +189,7 @@ std::tuple<Tensor, Tensor, Tensor> ft_action_force(const Tensor& x_, const Tenso
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> fthmc_trajectory(const Tensor& x_, const Tensor& v_, const Tensor& u_, const Tensor& w_all,
                                                                     int64_t n_layers, double beta, double dt, int64_t nstep, int64_t mode,
                                                                     int64_t act, int64_t n_mix, IntList hidden, int64_t kernel_size) {
+    FT_DEVICE_GUARD(x_);
     TORCH_CHECK(mode == FTHMC_MODE_MD || mode == FTHMC_MODE_LITERAL, "mode: expected 0 (md) or 1 (literal), got ", mode);
     Tensor x = field(x_, "x"), v = field(v_, "v");
     Arch A(n_mix, hidden, kernel_size);
@@ -193,6 +206,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> fthmc_trajectory(const Tensor
 }
 std::tuple<Tensor, Tensor, Tensor, Tensor> train_grad(const Tensor& xi_, const Tensor& w_all, int64_t n_layers, double beta, int64_t act,
                                                       int64_t n_mix, IntList hidden, int64_t kernel_size) {
+    FT_DEVICE_GUARD(xi_);
     Tensor xi = field(xi_, "xi");
     Arch A(n_mix, hidden, kernel_size);
     Tensor w = weights(w_all, n_layers * A.params(), "w_all");

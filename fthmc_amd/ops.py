@@ -67,6 +67,10 @@ def _ws(t: torch.Tensor, B: int, L: int, nl: int, train: bool = False, arch=None
         _WS[key] = buf
     if torch.cuda.is_current_stream_capturing():
         _WS_CAPTURED.add(key)
+    # whoever takes the workspace may expand other weights into it: the record of what it holds is dropped here and put back
+    # by _packed_hint for the entry points that run under a caller-stated weight version
+    global _LAST_PACKED
+    _LAST_PACKED = (key, _WS_PACKED.pop(key, None))
     return buf.data_ptr(), buf.numel() * 8
 
 
@@ -76,6 +80,94 @@ def release_workspaces():
     _WS.clear()
     _WS_CAPTURED.clear()
     _WS_RETIRED.clear()
+    _WS_PACKED.clear()
+
+
+# Which weights' kernel-layout expansion the workspace of a (device, stream) holds: (buffer id, w.data_ptr(), n_layers, wkey).
+# `wkey` is the CALLER's statement of the weights' content version (FieldTransformation: parameter versions + the flat
+# buffer's generation, utils/layers.py weights_generation); calls that pass none expand their weights every time.
+_WS_PACKED: dict = {}
+_LAST_PACKED = (None, None)      # (workspace key, the record _ws() just dropped)
+
+
+def _packed_hint(t: torch.Tensor, w, n_layers: int, wkey):
+    """Before an entry point that runs the net on this stream's workspace: skip its weight expansion (C ABI
+    fthmc_hint_weights_packed) when that workspace already holds the expansion of these weights at this version.  Never
+    during graph capture: a captured sequence either carries its own expansion or its owner re-establishes the workspace
+    before replaying (`pack_workspace`)."""
+    if w is None or not n_layers:
+        return
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
+    buf = _WS.get(key)
+    prev = _LAST_PACKED[1] if _LAST_PACKED[0] == key else None
+    rec = None if (wkey is None or buf is None) else (buf.data_ptr(), w.data_ptr(), int(n_layers), wkey)
+    if _ASSUME_PACKED[0] and arch_of(w) == DEFAULT_ARCH:
+        _lib.load().fthmc_hint_weights_packed(1)
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return                         # the captured call expands its weights itself; no record survives it (dropped in _ws)
+    if rec is not None and prev == rec and arch_of(w) == DEFAULT_ARCH:
+        _lib.load().fthmc_hint_weights_packed(1)
+    if rec is not None:
+        _WS_PACKED[key] = rec
+
+
+_ASSUME_PACKED = [False]
+
+
+class assume_packed:
+    """Context: every entry point called inside tells the library that its workspace already holds the expansion of its weights
+    (fthmc_hint_weights_packed) -- also during graph capture, so that the captured sequence carries no expansion launch.  The
+    owner of such a sequence re-establishes the workspaces (`pack_trajectory_workspaces`) before it replays."""
+
+    def __enter__(self):
+        self.prev = _ASSUME_PACKED[0]
+        _ASSUME_PACKED[0] = True
+
+    def __exit__(self, *exc):
+        _ASSUME_PACKED[0] = self.prev
+
+
+def _group_edges(groups, B: int):
+    if isinstance(groups, (list, tuple)):
+        if sum(groups) != B or min(groups) < 1:
+            raise FthmcError(f'groups: sizes {tuple(groups)} do not add up to {B} chains')
+        return [sum(groups[:k]) for k in range(len(groups) + 1)]
+    G = max(1, min(int(groups), B))
+    return [k * B // G for k in range(G + 1)]
+
+
+def pack_trajectory_workspaces(x: torch.Tensor, w, n_layers: int, groups=1, arch=None):
+    """Expand `w` into the workspace of every stream an `ft_trajectory(x, ..., groups=groups)` call from the current stream
+    runs on (the current stream and the side streams of the chain groups) -> a token (the workspaces' addresses): a captured
+    sequence stays valid while the token does."""
+    x = _field(x); B, _, L, _ = x.shape
+    edges = _group_edges(groups, B)
+    G = len(edges) - 1
+    main = torch.cuda.current_stream(x.device)
+    sides = _side_streams(x.device, G - 1) if G > 1 else []
+    for st in sides:
+        st.wait_stream(main)
+    token = []
+    for gi in list(range(1, G)) + [0]:
+        st = main if gi == 0 else sides[gi - 1]
+        with torch.cuda.stream(st):
+            pack_workspace(x, w, n_layers, edges[gi + 1] - edges[gi], L, arch=arch)
+            token.append(_WS[(x.device.index, st.cuda_stream)].data_ptr())
+    for st in sides:
+        main.wait_stream(st)
+    return tuple(token)
+
+
+def pack_workspace(t: torch.Tensor, w, n_layers: int, B: int, L: int, wkey=None, arch=None):
+    """Expand `w` into the workspace of the current stream (grown to serve [B, 2, L, L] calls with n_layers layers) and
+    record it under `wkey`: what the owner of a captured sequence WITHOUT its own expansion calls before replaying it."""
+    w, ap, a = _wall(w, n_layers, arch)
+    ws, nb = _ws(t, B, L, n_layers, arch=a)
+    check(_lib.load().fthmc_pack_weights(_p(w), ap, n_layers, ws, nb, _stream(t)), 'fthmc_pack_weights')
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
+    if wkey is not None and not torch.cuda.is_current_stream_capturing():
+        _WS_PACKED[key] = (_WS[key].data_ptr(), w.data_ptr(), int(n_layers), wkey)
 
 
 # ---------------------------------------------------------------- s/t net shape
@@ -299,6 +391,22 @@ def random_momenta(seeds, shape, need_u=True, out_v=None, out_u=None):
     return v, u
 
 
+def chain_seeds(seed: int, lo: int, B: int, traj: int = 0, counter: Optional[torch.Tensor] = None, advance: bool = False,
+                out: Optional[torch.Tensor] = None, device=None):
+    """Per-chain int64 seeds of trajectory / step `traj (+ counter[0])` for the global chain ids lo .. lo + B - 1, formed on
+    the device (C ABI fthmc_chain_seeds): the same numbers as parallel.chain_seeds.  `counter`: a device int64 scalar added
+    to `traj`; advance=True adds 1 to it behind the read, so that a captured launch draws fresh seeds at every replay."""
+    if out is None:
+        out = torch.empty(B, dtype=torch.int64, device=device if device is not None else counter.device)
+    if not out.is_cuda or out.dtype != torch.int64 or not out.is_contiguous() or out.numel() != B:
+        raise FthmcError(f'chain_seeds: out must be a contiguous int64 device tensor of {B} entries')
+    if counter is not None and (not counter.is_cuda or counter.dtype != torch.int64 or counter.numel() != 1):
+        raise FthmcError('chain_seeds: counter must be one int64 on the HIP device')
+    check(_lib.load().fthmc_chain_seeds(int(seed), int(lo), int(B), int(traj), _p(counter), int(bool(advance)), _p(out),
+                                        _stream(out)), 'fthmc_chain_seeds')
+    return out
+
+
 def random_uniform(seeds, shape, lo: float, hi: float, out=None):
     """U[lo, hi) of `shape` = (B, ...) from per-chain int64 seeds: the prior draw of a training step on the device."""
     if not seeds.is_cuda or seeds.dtype != torch.int64:
@@ -503,52 +611,57 @@ def _wall(w, n_layers, arch=None):
     return w, _arch(a), a
 
 
-def flow_forward(x, w, n_layers: int, act='silu', arch=None):
+def flow_forward(x, w, n_layers: int, act='silu', arch=None, wkey=None):
     x = _field(x); B, _, L, _ = x.shape
     w, ap, a = _wall(w, n_layers, arch)
     y = torch.empty_like(x); ld = torch.empty(B, dtype=x.dtype, device=x.device)
     ws, nb = _ws(x, B, L, n_layers, arch=a)
+    _packed_hint(x, w, n_layers, wkey)
     check(_lib.load().fthmc_flow_forward(_p(x), _p(w), ap, n_layers, B, L, act_code(act), _p(y), _p(ld), ws, nb,
                                          _stream(x)), 'fthmc_flow_forward')
     return y, ld
 
 
-def flow_reverse(y, w, n_layers: int, act='silu', tol: float = 1e-12, arch=None):
+def flow_reverse(y, w, n_layers: int, act='silu', tol: float = 1e-12, arch=None, wkey=None):
     y = _field(y, 'y'); B, _, L, _ = y.shape
     w, ap, a = _wall(w, n_layers, arch)
     x = torch.empty_like(y); ld = torch.empty(B, dtype=y.dtype, device=y.device)
     ws, nb = _ws(y, B, L, n_layers, arch=a)
+    _packed_hint(y, w, n_layers, wkey)
     check(_lib.load().fthmc_flow_reverse(_p(y), _p(w), ap, n_layers, B, L, act_code(act), float(tol), _p(x), _p(ld),
                                          ws, nb, _stream(y)), 'fthmc_flow_reverse')
     return x, ld
 
 
-def ft_action(x, w, n_layers: int, beta: float, act='silu', arch=None):
+def ft_action(x, w, n_layers: int, beta: float, act='silu', arch=None, wkey=None):
     """-> (S_eff, logdet, plaq, Q) each [B]."""
     x = _field(x); B, _, L, _ = x.shape
     w, ap, a = _wall(w, n_layers, arch)
     S, ld, plaq, Q = (torch.empty(B, dtype=x.dtype, device=x.device) for _ in range(4))
     ws, nb = _ws(x, B, L, n_layers, arch=a)
+    _packed_hint(x, w, n_layers, wkey)
     check(_lib.load().fthmc_ft_action(_p(x), _p(w), ap, n_layers, B, L, act_code(act), float(beta), _p(S), _p(ld),
                                       _p(plaq), _p(Q), ws, nb, _stream(x)), 'fthmc_ft_action')
     return S, ld, plaq, Q
 
 
-def ft_force(x, w, n_layers: int, beta: float, act='silu', arch=None):
+def ft_force(x, w, n_layers: int, beta: float, act='silu', arch=None, wkey=None):
     x = _field(x); B, _, L, _ = x.shape
     w, ap, a = _wall(w, n_layers, arch)
     F = torch.empty_like(x)
     ws, nb = _ws(x, B, L, n_layers, arch=a)
+    _packed_hint(x, w, n_layers, wkey)
     check(_lib.load().fthmc_ft_force(_p(x), _p(w), ap, n_layers, B, L, act_code(act), float(beta), _p(F), ws, nb,
                                      _stream(x)), 'fthmc_ft_force')
     return F
 
 
-def ft_leapfrog(x, v, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', arch=None):
+def ft_leapfrog(x, v, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', arch=None, wkey=None):
     x = _field(x); v = _field(v, 'v'); B, _, L, _ = x.shape
     w, ap, a = _wall(w, n_layers, arch)
     xo, vo = torch.empty_like(x), torch.empty_like(v)
     ws, nb = _ws(x, B, L, n_layers, arch=a)
+    _packed_hint(x, w, n_layers, wkey)
     check(_lib.load().fthmc_ft_leapfrog(_p(x), _p(v), _p(w), ap, n_layers, B, L, act_code(act), float(beta), float(dt),
                                         int(nstep), _p(xo), _p(vo), ws, nb, _stream(x)), 'fthmc_ft_leapfrog')
     return xo, vo
@@ -574,7 +687,7 @@ def _side_streams(device, n: int):
 
 
 def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', mode='md',
-                  out: Optional[dict] = None, state_in: Optional[torch.Tensor] = None, groups: int = 1, arch=None):
+                  out: Optional[dict] = None, state_in: Optional[torch.Tensor] = None, groups: int = 1, arch=None, wkey=None):
     """One ftHMC trajectory per chain -> dict(x_new, dH, acc, H0, H1, plaq, Q, state).
 
     `out` may carry preallocated output tensors (same keys) so that a caller can replay the call
@@ -595,14 +708,8 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
             out[k] = torch.empty(B, dtype=x.dtype, device=x.device)
     if 'state' not in out:
         out['state'] = torch.empty(3, B, dtype=x.dtype, device=x.device)
-    if isinstance(groups, (list, tuple)):                               # explicit group sizes (chains per group)
-        if sum(groups) != B or min(groups) < 1:
-            raise FthmcError(f'groups: sizes {tuple(groups)} do not add up to {B} chains')
-        G = len(groups)
-        edges = [sum(groups[:k]) for k in range(G + 1)]
-    else:
-        G = max(1, min(int(groups), B))
-        edges = [k * B // G for k in range(G + 1)]
+    edges = _group_edges(groups, B)                                     # an int, or explicit group sizes (chains per group)
+    G = len(edges) - 1
     if G > 1:
         arch_ = a
         if state_in is not None:
@@ -621,7 +728,7 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
             with torch.cuda.stream(st):
                 og = {k: t[a:b_] for k, t in out.items() if k != 'state'}
                 sg = state_in[:, a:b_].contiguous() if state_in is not None else None
-                ft_trajectory(x[a:b_], v[a:b_], u[a:b_], w, n_layers, beta, dt, nstep, act, mode, og, sg, arch=arch_)
+                ft_trajectory(x[a:b_], v[a:b_], u[a:b_], w, n_layers, beta, dt, nstep, act, mode, og, sg, arch=arch_, wkey=wkey)
                 out['state'][:, a:b_].copy_(og['state'])
                 parts.append(og)                                        # keep the group's temporaries alive until the join
         for st in sides:
@@ -633,6 +740,7 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
             raise FthmcError(f'state_in: expected [3, {B}]')
     m = {'md': MODE_MD, 'literal': MODE_LITERAL, 'reference_literal': MODE_LITERAL}[mode]
     ws, nb = _ws(x, B, L, n_layers, arch=a)
+    _packed_hint(x, w, n_layers, wkey)
     check(_lib.load().fthmc_ft_trajectory(_p(x), _p(v), _p(u), _p(w), ap, n_layers, B, L, act_code(act), float(beta),
                                           float(dt), int(nstep), m, _p(out['x_new']), _p(out['dH']), _p(out['acc']),
                                           _p(out['H0']), _p(out['H1']), _p(out['plaq']), _p(out['Q']),

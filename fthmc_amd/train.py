@@ -21,7 +21,7 @@ from . import ops, parallel
 from .config import DTYPE, FlowModel, Param, TrainConfig, device
 from .utils import qed_helpers as qed
 from .utils.distributions import MultivariateUniform, calc_dkl, calc_ess
-from .utils.layers import (attach_grads, flatten_flow, flow_activation, flow_grad_buffer, flow_weights, get_nets,
+from .utils.layers import (attach_grads, bump_weights_generation, flatten_flow, flow_activation, flow_grad_buffer, flow_weights, get_nets,
                            make_net_from_layers, make_u1_equiv_layers, net_weights, set_weights)
 from .utils.samplers import apply_flow_to_prior
 
@@ -211,9 +211,12 @@ class GraphTrainer:
     device-to-device copy per step) and come to the host when somebody looks (`metrics()`, `history()`).
 
     Needs an optimizer whose step is capturable (`FlatAdam` = `make_optimizer`, or a torch one built with capturable=True).  With a process
-    group (more than one rank, or FTHMC_FORCE_PG=1) the same device sequence runs eagerly, with the C2 collectives
-    (gradient all-reduce, global loss mean and ESS) in it.  A ReduceLROnPlateau scheduler needs the loss on the host after
-    every step and so brings one synchronisation per step back."""
+    group (more than one rank, or FTHMC_FORCE_PG=1) the C2 collectives (gradient all-reduce, global loss mean, MAX + SUM of
+    the ESS) are part of the captured sequence -- RCCL collectives are graph-capturable -- so the 8-GPU step is the same
+    replayed graph as the 1-GPU one; the ranks agree (one eager MIN all-reduce) on whether every capture succeeded and all
+    fall back to the eager sequence otherwise (FTHMC_GRAPH_COLLECTIVES=0 forces that).  The per-chain seeds of a step are
+    formed on the device from (seed, global chain id, a device step counter): a step costs the host no copy.  A
+    ReduceLROnPlateau scheduler needs the loss on the host after every step and so brings one synchronisation per step back."""
 
     def __init__(self, model: FlowModel, config: TrainConfig, optimizer: optim.Optimizer, batch_size: int,
                  dkl_factor: float = 1., scheduler: Any = None, seed: int = 1234, use_graph: bool = True, chunk: int = 256):
@@ -225,6 +228,7 @@ class GraphTrainer:
         self.rank, self.world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) if parallel.have_group() else (0, 1)
         self.lo = self.rank * self.B                                   # global chain ids of this rank's batch
         self.seeds = torch.empty(self.B, dtype=torch.int64, device=self.dev)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.dev)      # steps taken, on the device: keys the step's draws
         self.xi = torch.empty(self.B, 2, L, L, dtype=DTYPE, device=self.dev)
         self.row = torch.empty(2 + 5 * self.B, dtype=DTYPE, device=self.dev)
         self.chunk = max(1, int(chunk))
@@ -237,15 +241,41 @@ class GraphTrainer:
         # the steps run on the trainer's own stream (a capture needs one): it starts behind whatever initialised the model and
         # the optimizer on the caller's stream; metrics() / history() / synchronize() are where the caller waits for it
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
-        self.use_graph = bool(use_graph) and not parallel.have_group()
+        self.use_graph = bool(use_graph) and (not parallel.have_group() or os.environ.get('FTHMC_GRAPH_COLLECTIVES', '1') not in ('', '0'))
         if self.use_graph and not (getattr(optimizer, 'graph_safe', False) or all(g.get('capturable', False) for g in optimizer.param_groups)):
             raise ValueError('GraphTrainer captures optimizer.step(): pass a FlatAdam (train.make_optimizer) or a torch '
                              'optimizer built with capturable=True, or use_graph=False')
 
     def _enqueue(self):
+        # seeds of step `counter` for this rank's global chain ids (= parallel.chain_seeds(seed, lo, lo + B, step)); counter += 1
+        ops.chain_seeds(self.seed, self.lo, self.B, counter=self.counter, advance=True, out=self.seeds)
         ops.random_uniform(self.seeds, self.xi.shape, -PI, PI, out=self.xi)        # MultivariateUniform(-pi, pi).sample_n
         _fused_step_device(self.model, self.action, self.B, self.dkl_factor, self.xi, row=self.row)
         self.optimizer.step()
+
+    def _capture(self):
+        """capture one step; under a process group every rank learns whether every rank's capture succeeded"""
+        ok = 1.0
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
+                self._enqueue()
+        except Exception as e:                                             # noqa: BLE001 -- whatever the capture objects to
+            if not parallel.have_group():
+                raise
+            ok, self.capture_error = 0.0, repr(e)
+        if parallel.have_group():
+            flag = torch.tensor([ok], dtype=torch.float64, device=self.dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            ok = float(flag)
+        if ok > 0.5:
+            self.graph = g
+        else:
+            self.use_graph = False                                          # every rank: the eager sequence with its collectives
+
+    @property
+    def captured(self) -> bool:
+        return self.graph is not None
 
     def _flush(self):
         k = self.nstep % self.chunk or (self.chunk if self.nstep else 0)
@@ -255,16 +285,14 @@ class GraphTrainer:
     def step(self):
         """enqueue one training step; returns nothing and waits for nothing (unless a scheduler is attached)"""
         with torch.cuda.stream(self.stream):
-            self.seeds.copy_(parallel.chain_seeds(self.seed, self.lo, self.lo + self.B, self.nstep).to(self.dev, non_blocking=True))
             if self.use_graph and self.graph is None:
-                # first step: once eagerly (allocator, workspaces, optimizer state), then capture the SAME sequence; the
-                # eager step counts as step 0 and the capture run is not replayed into the statistics (capture does not execute)
+                # first step: once eagerly (allocator, workspaces, optimizer state, RCCL's communicator), then capture the SAME
+                # sequence; the eager step counts as step 0 and the capture run is not replayed into the statistics (capture
+                # does not execute)
                 self._enqueue()
                 attach_grads(self.model.layers)
                 self.stream.synchronize()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode='thread_local'):
-                    self._enqueue()
+                self._capture()
             elif self.use_graph:
                 if hasattr(self.optimizer, 'sync_lr'):
                     self.optimizer.sync_lr()                   # a scheduler's new rate -> the device scalar the replay reads
@@ -274,6 +302,7 @@ class GraphTrainer:
             else:
                 self._enqueue()
                 attach_grads(self.model.layers)
+            bump_weights_generation(flatten_flow(self.model.layers))     # a replay writes the weights behind every version counter
             self.hist_dev[self.nstep % self.chunk].copy_(self.row)
             self.nstep += 1
             if self.nstep % self.chunk == 0:
@@ -349,6 +378,7 @@ class FlatAdam(optim.Adam):
     def count_step(self, n: int = 1):
         """a step the host did not launch itself (graph replay): keep the host mirror of the step count in line"""
         self._nstep += n
+        bump_weights_generation(self._flat)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -363,6 +393,7 @@ class FlatAdam(optim.Adam):
                       weight_decay=g['weight_decay'], decoupled=self._decoupled)
         if not torch.cuda.is_current_stream_capturing():
             self._nstep += 1
+            bump_weights_generation(self._flat)          # the kernel wrote through raw pointers: no tensor version moved
 
     def state_dict(self):
         for st in self.state.values():

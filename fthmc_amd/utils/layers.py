@@ -92,40 +92,38 @@ def random_gauge_transform(x):
 
 
 # ---------------------------------------------------------------- stripe masks (host logic)
+# Index form, as the kernels state them (ft_stripe, csrc/common.h): line k of the axis across the stripes (columns for mu = 0, rows for
+# mu = 1) belongs to stripe class ((k - off) mod n) mod 4 -- 0 active, 1 and 2 frozen (for the plaquette masks with off + 1),
+# 3 passive.
+def _stripe_class(n: int, off: int) -> np.ndarray:
+    return ((np.arange(n) - off) % n) % 4
+
+
+def _stripes(shape, mu: int, off: int, classes) -> np.ndarray:
+    """[L0, L1] uint8: 1 on the lines across axis 1 - mu whose stripe class is in `classes`"""
+    assert len(shape) == 2 and mu in (0, 1)
+    across = 1 - mu                                   # mu = 0: the class is a function of the column index, mu = 1: of the row
+    line = np.isin(_stripe_class(shape[across], off), classes).astype(np.uint8)
+    return np.ascontiguousarray(np.broadcast_to(line[None, :] if across == 1 else line[:, None], shape))
+
+
 def make_2d_link_active_stripes(shape, mu, off):
-    """layers.py:213-237: channel `mu`, every 4th line across the other axis, rolled by `off`."""
+    """layers.py:213-237: the links of direction `mu` on every 4th line across the other axis, first one `off`: float32 [2, L, L]."""
     assert len(shape) == 3 and shape[0] == 2, 'need a (2, L, L) shape'
     assert mu in (0, 1)
-    mask = np.zeros(shape).astype(np.uint8)
-    if mu == 0:
-        mask[mu, :, 0::4] = 1
-    else:
-        mask[mu, 0::4] = 1
-    return np.roll(mask, off, axis=(1 - mu) + 1).astype(np.float32)
+    mask = np.zeros(shape, dtype=np.float32)
+    mask[mu] = _stripes(shape[1:], mu, off, (0,))
+    return mask
 
 
 def make_single_stripes(shape, mu, off):
-    """layers.py:240-259."""
-    assert len(shape) == 2 and mu in (0, 1)
-    mask = np.zeros(shape).astype(np.uint8)
-    if mu == 0:
-        mask[:, 0::4] = 1
-    else:
-        mask[0::4] = 1
-    return np.roll(mask, off, axis=1 - mu)
+    """layers.py:240-259: every 4th line, first one `off`."""
+    return _stripes(shape, mu, off, (0,))
 
 
 def make_double_stripes(shape, mu, off):
-    """layers.py:261-284."""
-    assert len(shape) == 2 and mu in (0, 1)
-    mask = np.zeros(shape).astype(np.uint8)
-    if mu == 0:
-        mask[:, 0::4] = 1
-        mask[:, 1::4] = 1
-    else:
-        mask[0::4] = 1
-        mask[1::4] = 1
-    return np.roll(mask, off, axis=1 - mu)
+    """layers.py:261-284: two adjacent lines of every four, first pair at `off`."""
+    return _stripes(shape, mu, off, (0, 1))
 
 
 def make_plaq_masks(mask_shape, mask_mu, mask_off):
@@ -338,6 +336,17 @@ def _flat_of(rows):
                 return None
             o += p.numel()
     return flat if o == flat.numel() else None
+
+
+def weights_generation(flat: torch.Tensor) -> int:
+    """How often the flat weight buffer was written behind PyTorch's back (kernels that take raw pointers -- FlatAdam's step,
+    its graph replays -- bump no tensor version): part of the key under which FieldTransformation keeps anything derived from
+    the weights (the carried S_eff, the packed-weights record)."""
+    return getattr(flat, '_fthmc_gen', 0)
+
+
+def bump_weights_generation(flat: torch.Tensor) -> None:
+    flat._fthmc_gen = getattr(flat, '_fthmc_gen', 0) + 1
 
 
 def flatten_flow(flow: nn.ModuleList) -> torch.Tensor:

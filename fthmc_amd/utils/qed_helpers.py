@@ -231,37 +231,95 @@ def ft_hmc(param, flow, field: torch.Tensor, v: Optional[torch.Tensor] = None, u
     return float(dH), float(exp_mdH), acc, newfield.reshape(field.shape)
 
 
-def ft_run(param, flow, field: Optional[torch.Tensor] = None, logfile: Optional[str] = None, verbose: bool = False):
+def ft_run(param, flow, field: Optional[torch.Tensor] = None, logfile: Optional[str] = None, verbose: bool = False,
+           use_graph: Optional[bool] = None):
     """ipynb/ft_hmc.py:437-487: `param.nrun` x `param.ntraj` physical-field ftHMC trajectories of one
     configuration [2, L, L].  Returns (field, history) with per-trajectory dH, exp_mdH, acc, plaq, topo
     (the notebook returns the field and keeps the histories in module globals); the status lines it prints
-    go to `logfile` when given."""
+    go to `logfile` when given.
+
+    On the device the trajectory sequence (inverse flow, momenta and the uniform from torch's generator, the fused trajectory,
+    forward flow, observables) is captured once in a hipGraph and replayed (`use_graph`, default on; FTHMC_RUN_GRAPH=0 turns it
+    off): the notebook's loop synchronises five times per trajectory, this one not at all; the histories and the log are
+    written when the loop has run.  Same draws, identical numbers."""
+    import os
     if field is None:
         field = param.initializer()[0]
     history = {k: [] for k in ('dH', 'exp_mdH', 'acc', 'plaq', 'topo')}
     out = open(logfile, 'w') if logfile else None
+    if use_graph is None:
+        use_graph = os.environ.get('FTHMC_RUN_GRAPH', '1') not in ('', '0')
 
     def put(s):
         if out is not None:
             out.write(s)
         if verbose:
             print(s, end='', flush=True)
+
+    def line(k, dH, exp_mdH, acc, plaq, topo):
+        return (f'Traj: {k:4}  {"ACCEPT" if acc else "REJECT"}  dH: {dH:< 12.8}  '
+                f'exp(-dH): {exp_mdH:< 12.8}  plaq: {plaq:< 12.8}  topo: {topo:< 3.3}\n')
     try:
         S, Q, plaq = ops.wilson_action_charge(_batched(field), param.beta)
         put(f'Initial configuration:  plaq: {float(plaq[0])}  topo: {float(Q[0])} {tuple(field.shape)}\n')
-        for n in range(param.nrun):
-            for i in range(param.ntraj):
-                dH, exp_mdH, acc, field_run = ft_hmc(param, flow, field.reshape((1,) + tuple(field.shape[-3:])))
-                field = field_run[0]
-                S, Q, plaq = ops.wilson_action_charge(field_run, param.beta)
-                for k, val in zip(history, (dH, exp_mdH, float(bool(acc)), float(plaq[0]), float(Q[0]))):
-                    history[k].append(val)
-                put(f'Traj: {n * param.ntraj + i + 1:4}  {"ACCEPT" if bool(acc) else "REJECT"}  dH: {dH:< 12.8}  '
-                    f'exp(-dH): {exp_mdH:< 12.8}  plaq: {float(plaq[0]):< 12.8}  topo: {float(Q[0]):< 3.3}\n')
+        ntot = param.nrun * param.ntraj
+        if use_graph and field.is_cuda and ntot > 0:
+            field, rows = _ft_run_captured(param, flow, field, ntot)
+            for k, (dH, acc, plaq_, topo, exp_mdH) in enumerate(rows.tolist()):
+                for key, val in zip(history, (dH, exp_mdH, float(acc > 0.5), plaq_, topo)):
+                    history[key].append(val)
+                put(line(k + 1, dH, exp_mdH, acc > 0.5, plaq_, topo))
+        else:
+            for n in range(param.nrun):
+                for i in range(param.ntraj):
+                    dH, exp_mdH, acc, field_run = ft_hmc(param, flow, field.reshape((1,) + tuple(field.shape[-3:])))
+                    field = field_run[0]
+                    S, Q, plaq = ops.wilson_action_charge(field_run, param.beta)
+                    for k, val in zip(history, (dH, exp_mdH, float(bool(acc)), float(plaq[0]), float(Q[0]))):
+                        history[k].append(val)
+                    put(line(n * param.ntraj + i + 1, dH, exp_mdH, bool(acc), float(plaq[0]), float(Q[0])))
     finally:
         if out is not None:
             out.close()
     return field, history
+
+
+def _ft_run_captured(param, flow, field: torch.Tensor, ntot: int, tol: float = 1e-12):
+    """the loop of ft_run as one captured sequence per trajectory -> (final field [2, L, L], rows [ntot, 5] on the host:
+    dH, acc, plaq, Q, exp(-dH))"""
+    from ..graph_loop import GraphLoop
+    dev = field.device
+    fs = field.detach().reshape((1,) + tuple(field.shape[-3:])).clone()
+    L = fs.shape[-1]
+    w, nl, act = flow_weights(flow, dev), len(flow), flow_activation(flow)
+    v = torch.empty_like(fs)
+    u = torch.empty(1, dtype=torch.float64, device=dev)
+    row = torch.empty(5, dtype=torch.float64, device=dev)
+    res = {'x_new': torch.empty_like(fs), 'dH': row[0:1], 'acc': row[1:2], 'plaq': torch.empty(1, dtype=torch.float64, device=dev),
+           'Q': torch.empty(1, dtype=torch.float64, device=dev), 'H0': torch.empty(1, dtype=torch.float64, device=dev),
+           'H1': torch.empty(1, dtype=torch.float64, device=dev)}
+    obs = {'S': torch.empty(1, dtype=torch.float64, device=dev), 'Q': row[3:4], 'plaq': row[2:3]}
+
+    def enqueue():
+        x = ops.flow_reverse(fs, w, nl, act, tol=tol)[0]                 # x = F^-1(field)
+        v.normal_()                                                      # randn_like(x), then rand([]): ipynb/ft_hmc.py:423-424
+        u.uniform_()
+        ops.ft_trajectory(x, v, u, w, nl, param.beta, param.dt, param.nstep, act, mode='md', out=res)
+        fs.copy_(ops.flow_forward(res['x_new'], w, nl, act)[0])          # newfield = F(newx)
+        ops.wilson_action_charge(fs, param.beta, out=obs)
+        torch.exp(torch.neg(row[0:1]), out=row[4:5])
+    loop = GraphLoop(enqueue, row, use_graph=True, capture_ctx=ops.assume_packed)
+    with torch.cuda.stream(loop.stream):
+        ops.pack_workspace(fs, w, nl, 1, L)
+    for k in range(ntot):
+        was = loop.captured
+        loop.step()
+        if loop.captured and not was:
+            with torch.cuda.stream(loop.stream):
+                ops.pack_workspace(fs, w, nl, 1, L)                      # what the replays assume (the eager first step may have grown the workspace)
+    rows = loop.rows()
+    loop.join()
+    return fs[0].clone(), rows
 
 
 def flow_resize(flow: nn.ModuleList, lat_new):

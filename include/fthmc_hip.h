@@ -82,6 +82,18 @@ int fthmc_arch_params(const fthmc_arch_t* arch);   /* doubles per layer; 955 for
  * LDS, and fthmc_ft_trajectory / _ft_leapfrog / _ft_force / _ft_action / _flow_forward are ONE launch each instead of
  * one launch per layer.  0 switches it off (the tiled kernels then serve every L): A/B runs and parity tests. */
 int fthmc_set_small_path(int on);
+
+/* Promise for the NEXT entry point called on this thread (consumed by it, whatever it is): the workspace passed to that
+ * call already holds the kernel-layout expansion of exactly the weights passed to it -- same contents, same n_layers --
+ * left there by an earlier call on the same stream.  The call then skips the expansion launch (7 us; the reference packs
+ * nothing: its convs read nn.Conv2d parameters, fthmc/utils/layers.py:138-167).  Thread-local: no state is shared between
+ * threads or streams.  Without the promise every call expands the weights it is given. */
+int fthmc_hint_weights_packed(int packed);
+
+/* Expand the canonical weights (n_layers x params, the layout of every `w` argument below) into the workspace and do nothing
+ * else: what every entry point that runs the net does first.  With fthmc_hint_weights_packed a caller that replays a captured
+ * sequence many times under constant weights expands them once per weight version instead of once per call. */
+int fthmc_pack_weights(const double* w, const fthmc_arch_t* arch, int n_layers, void* ws, size_t ws_bytes, void* stream);
 int fthmc_get_small_path(void);
 
 /* Bytes of scratch the flow / trajectory entry points need for (B, L, n_layers). */
@@ -244,6 +256,14 @@ int fthmc_train_grad(const double* xi, const double* w, const fthmc_arch_t* arch
  * seed (MultivariateUniform.sample_n, fthmc/utils/distributions.py:65-76, called at fthmc/train.py:191 through
  * apply_flow_to_prior, fthmc/utils/samplers.py:40-56).  A chain's draw depends on its seed only, not on the sharding. */
 int fthmc_random_uniform(const int64_t* seeds, int B, int n_per_chain, double lo, double hi, double* out, void* stream);
+
+/* Per-chain seeds of one trajectory / training step, formed on the device: seeds[b] = the 63-bit SplitMix64 mix of
+ * (seed, global chain id lo + b, t) -- the same numbers as the host helper of the multi-GPU layer (fthmc_amd/parallel.py
+ * chain_seeds; SURVEY 7 "RNG": a chain's stream is keyed by its global id, never by the rank).  t = traj + *counter when
+ * `counter` (a device int64) is given, else traj; with advance != 0 the kernel then adds 1 to *counter, so that a
+ * captured launch draws fresh seeds at every replay without a host-to-device copy.  Replaces the host side of
+ * torch.randn_like / prior.sample_n in the loops of fthmc/ft_hmc.py:204 and fthmc/train.py:191. */
+int fthmc_chain_seeds(int64_t seed, int64_t lo, int B, int64_t traj, int64_t* counter, int advance, int64_t* seeds, void* stream);
 
 /* Metrics of one training step from its pieces (train_step, fthmc/train.py:206-228; calc_dkl / calc_ess,
  * fthmc/utils/distributions.py:23-37; batch_charges, fthmc/utils/qed_helpers.py:108-116), ONE rank's batch:

@@ -463,9 +463,9 @@ out = None
 for k in range(3):
     xi = ops.random_uniform(parallel.chain_seeds(5, 0, 32, k).cuda(), (32, 2, 16, 16), -math.pi, math.pi)
     out = T.train_step(model, tc, act, opt, 32, xi=xi, fused=True)
-# and the loop object in its eager (collective) mode
+# and the loop object: with a group its captured step carries the C2 collectives
 tr = T.GraphTrainer(model, tc, T.make_optimizer(model, tc), 32, seed=5)
-for _ in range(2):
+for _ in range(4):
     tr.step()
 m = tr.metrics()
 w = LY.flow_weights(model.layers).cpu().numpy()
@@ -479,7 +479,8 @@ if parallel.have_group():
 
 def test_single_rank_nccl_group_train_step():
     """train_step(fused=True) and GraphTrainer under a one-rank `nccl` group: the C2 branches (gradient all-reduce, global
-    loss mean, MAX + SUM all-reduces of the ESS logsumexp) run over RCCL and leave the same weights, bit for bit, as no group."""
+    loss mean, MAX + SUM all-reduces of the ESS logsumexp) run over RCCL -- in GraphTrainer as part of the CAPTURED step, replayed
+    -- and leave the same weights, bit for bit, as no group."""
     res = {}
     for tag, extra in (('plain', {}), ('forced', {'FTHMC_FORCE_PG': '1'})):
         env = dict(os.environ, FTHMC_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2', **extra)
@@ -488,7 +489,7 @@ def test_single_rank_nccl_group_train_step():
         assert p.returncode == 0, p.stderr[-3000:]
         res[tag] = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
     assert res['plain']['group'] is False and res['plain']['captured'] is True
-    assert res['forced']['group'] is True and res['forced']['backend'] == 'nccl' and res['forced']['captured'] is False
+    assert res['forced']['group'] is True and res['forced']['backend'] == 'nccl' and res['forced']['captured'] is True
     assert res['plain']['w'] == res['forced']['w']
     # with a group the loss mean and the ESS go through torch sums + all-reduces instead of the metrics kernel: rounding only
     for k in ('loss', 'loss2', 'ess'):

@@ -1,0 +1,230 @@
+"""GPU tests added in round 5: the reference-shaped drivers as captured loops (FieldTransformation.run, qed_helpers.ft_run)
+against their eager loops, the carried state keyed by the weights' content, per-chain seeds formed on the device, the
+packed-weights promise of the C ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+ops = None
+R = None
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _mods():
+    global ops, R
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from fthmc_amd import ops as _ops
+    from oracle import ref_cpu as _R
+    ops, R = _ops, _R
+    ops.set_variant(1)
+
+
+def H(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def _model(L, nl, B, beta=2.0, seed=11):
+    from fthmc_amd import train as T
+    from fthmc_amd.config import TrainConfig
+    cfg = TrainConfig(L=L, beta=beta, n_layers=nl, batch_size=B, print_freq=0)
+    torch.manual_seed(seed)
+    return cfg, T.get_model(cfg)
+
+
+# ---------------------------------------------------------------- seeds on the device
+@pytest.mark.parametrize('seed,lo,B,traj', [(1331, 0, 128, 0), (7, 96, 32, 41), (2 ** 40 + 3, 1000, 5, 2 ** 33)])
+def test_chain_seeds_on_the_device_equal_the_host_helper(seed, lo, B, traj):
+    """fthmc_chain_seeds = parallel.chain_seeds (SplitMix64 of (seed, global chain id, trajectory)), also through a device
+    counter that a captured launch advances."""
+    from fthmc_amd import parallel
+    want = parallel.chain_seeds(seed, lo, lo + B, traj)
+    got = ops.chain_seeds(seed, lo, B, traj=traj, device='cuda')
+    assert torch.equal(got.cpu(), want)
+    counter = torch.tensor([traj], dtype=torch.int64, device='cuda')
+    out = torch.empty(B, dtype=torch.int64, device='cuda')
+    for k in range(3):
+        ops.chain_seeds(seed, lo, B, counter=counter, advance=True, out=out)
+        assert torch.equal(out.cpu(), parallel.chain_seeds(seed, lo, lo + B, traj + k)), k
+    assert int(counter) == traj + 3
+
+
+# ---------------------------------------------------------------- the captured run loop
+@pytest.mark.parametrize('L,nl,B', [(8, 2, 4), (16, 4, 8), (32, 2, 16)])
+def test_captured_run_equals_the_eager_loop(L, nl, B):
+    """FieldTransformation.run(batch=True): the captured loop (one graph launch per trajectory, momenta and uniforms from
+    torch's generator inside the graph, state carried in place, history read back lazily) returns the history and the
+    final field of the eager loop, bit for bit (fthmc/ft_hmc.py:272-346)."""
+    from fthmc_amd.config import lfConfig
+    from fthmc_amd.ft_hmc import FieldTransformation, LazyHistory
+    cfg, model = _model(L, nl, B)
+    x0 = (0.3 * (2 * torch.rand(B, 2, L, L, dtype=torch.float64) - 1)).cuda()
+    n = 6
+    out = {}
+    for mode in ('graph', 'eager'):
+        ft = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=6))
+        torch.manual_seed(5); torch.cuda.manual_seed(5)
+        h = ft.run(x0.clone(), nprint=0, num_trajs=n, batch=True, use_graph=(mode == 'graph'))
+        assert isinstance(h, LazyHistory) == (mode == 'graph')
+        assert (ft._loop is not None and ft._loop['loop'].captured) == (mode == 'graph')
+        # a second run from the field the first one returned: the carried state is taken over (no H0 sweep) in both modes
+        h2 = ft.run(ft.x_last, nprint=0, num_trajs=3, batch=True, use_graph=(mode == 'graph'))
+        out[mode] = (h, h2, ft.x_last.clone())
+    for a, b in zip(out['graph'][:2], out['eager'][:2]):
+        assert set(a.keys()) == set(b.keys()) == {'traj', 'dt', 'acc', 'dh', 'exp_mdh', 'plaq', 'q', 'dq'}
+        for k in ('acc', 'dh', 'exp_mdh', 'plaq', 'q', 'dq'):
+            assert len(a[k]) == len(b[k])
+            for i, (ta, tb) in enumerate(zip(a[k], b[k])):
+                assert torch.equal(ta, tb), (k, i)
+        assert a['traj'] == b['traj']
+    assert torch.equal(out['graph'][2], out['eager'][2])
+
+
+def test_captured_single_chain_run_equals_the_eager_loop():
+    """the reference's own shape: one [1, 2, L, L] system, one accept (ft_hmc.py:190-224)"""
+    from fthmc_amd.config import lfConfig
+    from fthmc_amd.ft_hmc import FieldTransformation
+    L, nl, n = 8, 2, 7
+    cfg, model = _model(L, nl, 1, seed=13)
+    x0 = (0.3 * (2 * torch.rand(1, 2, L, L, dtype=torch.float64) - 1)).cuda()
+    out = {}
+    for mode in ('graph', 'eager'):
+        ft = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=8))
+        torch.manual_seed(6); torch.cuda.manual_seed(6)
+        out[mode] = (ft.run(x0.clone(), nprint=0, num_trajs=n, use_graph=(mode == 'graph')), ft.x_last.clone())
+    a, b = out['graph'][0], out['eager'][0]
+    for k in ('dh', 'plaq', 'q', 'dq'):
+        for ta, tb in zip(a[k], b[k]):
+            assert torch.equal(ta, tb), k
+    assert [bool(t) for t in a['acc']] == [bool(t) for t in b['acc']]
+    assert torch.equal(out['graph'][1], out['eager'][1])
+
+
+def test_literal_reference_modes_stay_on_the_eager_loop():
+    """energy_mode='reference_literal' (calc_energy's batch-wide kinetic term) has no fused trajectory: run() keeps
+    the step-by-step loop and returns a plain dict"""
+    from fthmc_amd.config import lfConfig
+    from fthmc_amd.ft_hmc import FieldTransformation, LazyHistory
+    cfg, model = _model(8, 2, 3)
+    ft = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=0.5, nstep=4), energy_mode='reference_literal')
+    x0 = (0.3 * (2 * torch.rand(3, 2, 8, 8, dtype=torch.float64) - 1)).cuda()
+    h = ft.run(x0, nprint=0, num_trajs=2, batch=True)
+    assert not isinstance(h, LazyHistory) and len(h['acc']) == 2 and '_plaq' not in h and '_q' not in h
+
+
+# ---------------------------------------------------------------- carry keyed by the weights' content
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_carried_state_is_dropped_when_the_weights_change(use_graph):
+    """run, a FlatAdam step (the kernel writes the flat buffer through raw pointers: no tensor version moves and
+    flow_weights() hands out the same object), run(ft.x_last): the second run must take H0 from the NEW weights -- equal to the
+    loop that recomputes everything -- and the same after load_state_dict and after a change of beta."""
+    from fthmc_amd import train as T
+    from fthmc_amd.config import lfConfig
+    from fthmc_amd.ft_hmc import FieldTransformation
+    from fthmc_amd.utils import layers as LY
+    L, nl, B = 8, 2, 6
+    cfg, model = _model(L, nl, B)
+    opt = T.make_optimizer(model, cfg)                                   # FlatAdam: flattens the flow
+    assert isinstance(opt, T.FlatAdam)
+    ft = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=6))
+    x0 = (0.3 * (2 * torch.rand(B, 2, L, L, dtype=torch.float64) - 1)).cuda()
+    torch.manual_seed(3); torch.cuda.manual_seed(3)
+    ft.run(x0.clone(), nprint=0, num_trajs=3, batch=True, use_graph=use_graph)
+    saved = {k: v.clone() for k, v in model.layers.state_dict().items()}
+
+    def change_by_optimizer():
+        w_before = LY.flow_weights(model.layers)
+        LY.flow_grad_buffer(model.layers).normal_()
+        opt.param_groups[0]['lr'] = 0.05
+        opt.step()
+        assert LY.flow_weights(model.layers) is w_before                 # the same object: identity says nothing
+
+    def change_by_load():
+        model.layers.load_state_dict(saved)
+
+    def change_beta():
+        cfg.beta = 2.7
+        ft._denom = cfg.beta * cfg.volume
+
+    for change in (change_by_optimizer, change_by_load, change_beta):
+        x = ft.x_last
+        change()
+        torch.manual_seed(4); torch.cuda.manual_seed(4)
+        h = ft.run(x, nprint=0, num_trajs=2, batch=True, use_graph=use_graph)
+        # the stateless loop under the new weights on the same draws
+        ft2 = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=6))
+        torch.manual_seed(4); torch.cuda.manual_seed(4)
+        xx = x.clone()
+        for i in range(2):
+            xx, m = ft2._batch_hmc(xx.clone(), step=i)
+            assert torch.equal(m['acc'], h['acc'][i]), change.__name__
+            assert torch.equal(m['dh'], h['dh'][i]), change.__name__
+        assert torch.equal(xx, ft.x_last), change.__name__
+
+
+def test_weights_cache_follows_a_replaced_net():
+    """FieldTransformation.weights() keeps the parameter list of the flow it saw; a conv net swapped inside the same
+    ModuleList (transfer-style reuse) must be picked up"""
+    from fthmc_amd.config import lfConfig
+    from fthmc_amd.ft_hmc import FieldTransformation
+    cfg, model = _model(8, 2, 2)
+    _, other = _model(8, 2, 2, seed=99)
+    ft = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=4))
+    x = (0.3 * (2 * torch.rand(2, 2, 8, 8, dtype=torch.float64) - 1)).cuda()
+    s0 = ft.action(x).clone()
+    model.layers[1].plaq_coupling.net = other.layers[1].plaq_coupling.net
+    s1 = ft.action(x)
+    ft_fresh = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=4))
+    assert torch.equal(s1, ft_fresh.action(x)) and not torch.equal(s0, s1)
+
+
+# ---------------------------------------------------------------- the packed-weights promise
+def test_packed_weights_promise_skips_only_the_expansion():
+    """ops with a caller-stated weight version (`wkey`) expand the weights once per version into the stream's workspace
+    (C ABI fthmc_hint_weights_packed); any other call on that workspace, another version or other weights expand again.
+    Results are the ones of calls without the promise."""
+    gen = torch.Generator().manual_seed(3)
+    L, nl, B, beta = 16, 4, 5, 3.0
+    wa = ops.pack_weights(R.default_flow(nl, gen), device='cuda')
+    wb = ops.pack_weights(R.default_flow(nl, gen), device='cuda')
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    ref_a = ops.ft_action(x, wa, nl, beta)[0].clone()
+    ref_b = ops.ft_action(x, wb, nl, beta)[0].clone()
+    Fa = ops.ft_force(x, wa, nl, beta).clone()
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)      # expands, records
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)      # promise taken: no expansion
+    assert torch.equal(ops.ft_force(x, wa, nl, beta, wkey='v1'), Fa)
+    assert torch.equal(ops.ft_action(x, wb, nl, beta, wkey='v1')[0], ref_b)      # other weights under the same key: expands
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)
+    ops.flow_layer_fwd(x, wb[:955].contiguous(), 0, 0)                           # a call without a key overwrites the expansion ...
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)      # ... and the record: expanded again
+    wa.mul_(1.01)                                                                # new content, new key
+    ref_a2 = ops.ft_action(x, wa, nl, beta)[0].clone()
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v2')[0], ref_a2) and not torch.equal(ref_a2, ref_a)
+
+
+# ---------------------------------------------------------------- physical-field driver
+def test_captured_ft_run_equals_the_eager_loop(tmp_path):
+    """qed_helpers.ft_run (ipynb/ft_hmc.py:437-487: inverse flow, trajectory, forward flow, observables per trajectory of ONE
+    configuration) as a captured loop against its eager loop: same histories, same final field, same log lines."""
+    from fthmc_amd.config import Param
+    from fthmc_amd.utils import qed_helpers as qed
+    L, nl = 8, 2
+    _, model = _model(L, nl, 1, seed=21)
+    param = Param(beta=2.0, L=L, tau=1.0, nstep=6, ntraj=5, nrun=2)
+    f0 = (0.4 * (2 * torch.rand(2, L, L, dtype=torch.float64) - 1)).cuda()
+    res = {}
+    for mode in ('graph', 'eager'):
+        torch.manual_seed(8); torch.cuda.manual_seed(8)
+        log = tmp_path / f'{mode}.log'
+        field, hist = qed.ft_run(param, model.layers, f0.clone(), logfile=str(log), use_graph=(mode == 'graph'))
+        res[mode] = (field.clone(), {k: list(v) for k, v in hist.items()}, log.read_text())
+    assert torch.equal(res['graph'][0], res['eager'][0])
+    for k in ('dH', 'exp_mdH', 'acc', 'plaq', 'topo'):
+        assert res['graph'][1][k] == res['eager'][1][k], k
+    assert res['graph'][2] == res['eager'][2]

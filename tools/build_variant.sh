@@ -2,7 +2,7 @@
 # A second build of the library with extra compiler flags, for A/B runs in one call on one device (tools/abn.sh):
 #   bash tools/build_variant.sh NAME "-DFLAG=1 ..."   ->  experiments/lib_NAME.so   (objects under /tmp/fthmc_NAME)
 ROOT=$(cd "$(dirname "$0")/.." && pwd); NAME=$1; EXTRA=$2; D=/tmp/fthmc_$NAME; mkdir -p $D
-LDSFLAGS="-Xclang -target-feature -Xclang -load-store-opt -mllvm -amdgpu-load-store-vectorizer=0"
+LDSFLAGS="-mllvm -amdgpu-load-store-vectorizer=0"
 SHA=$(python3 "$ROOT/tools/csrc_sha.py")
 cd "$ROOT/fthmc_amd/csrc" || exit 1
 for f in wilson flow flow_fwd flow_bwd_gather flow_wgrad flow_small flow_generic rng api; do

@@ -16,7 +16,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
     i=$((i+1))
     echo "[pmc] pass $i: $grp" | tee -a "$OUT/progress.log"
-    rocprofv3 --pmc $grp --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pass$i.log" 2>&1 || echo "[pmc] pass $i failed" | tee -a "$OUT/progress.log"
+    rocprofv3 --pmc $grp --output-format csv -d "$OUT/pass$i" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --regions 5 --no-cpu-baseline > "$OUT/pass$i.log" 2>&1 || echo "[pmc] pass $i failed" | tee -a "$OUT/progress.log"
 done
 cd "$ROOT"
 python3 tools/pmc_summary.py "$OUT" "$OUT/pmc_summary.json"

@@ -12,9 +12,11 @@ for c in 3 1 2 5; do
   echo "[refresh] bench config $c done"
 done
 FTHMC_SMALL_PATH=0 python3 bench.py --config 2 --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/bench_config2_tiled.json" 2> "$OUT/bench_config2_tiled.log"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/stats.log" 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --regions 5 --no-cpu-baseline > "$OUT/stats.log" 2>&1)
 cp $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -- python3 "$ROOT/bench.py" --config 2 --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/stats2.log" 2>&1)
+# which kernels the summary was taken on (bench.py: roofline.rocprof_source)
+python3 -c "import json,sys; sys.path.insert(0,'tools'); from csrc_sha import csrc_sha16; json.dump({'csrc_sha16': csrc_sha16('.'), 'commit': '$COMMIT', 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --regions 5 --no-cpu-baseline'}, open('$OUT/kernel_stats.meta.json','w'))"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats2" -- python3 "$ROOT/bench.py" --config 2 --steps 20 --warmup 2 --regions 5 --no-cpu-baseline > "$OUT/stats2.log" 2>&1)
 cp $(find "$OUT/stats2" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats_config2.csv"
 echo "[refresh] kernel stats done"
 bash tools/collect_pmc.sh "$OUT/pmc" > "$OUT/pmc.log" 2>&1

@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/.." || exit 1
 mode=$1; shift
 if [ "$mode" = build ]; then
-  FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Xclang -target-feature -Xclang -load-store-opt -mllvm -amdgpu-load-store-vectorizer=0"
+  FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -mllvm -amdgpu-load-store-vectorizer=0"
   for k in "$@"; do
     /opt/rocm/bin/hipcc $FL -DFT_KNOB=$k -c fthmc_amd/csrc/flow_small.hip -o /tmp/flow_small_k$k.o 2>/dev/null || exit 1
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o experiments/small_k$k.so $(ls fthmc_amd/csrc/*.o | grep -v flow_small.o) /tmp/flow_small_k$k.o || exit 1

@@ -419,8 +419,8 @@ def main():
         # time, so all ranks agree on the count)
         # ... and keep going until --min-seconds of timed GPU work have accumulated, so that the record of a run shows the
         # card busy whatever --steps was (20 trajectories are 0.12 s)
-        nreg = args.regions if args.regions else max(5 if times[0] < 1.0 else 1, min(400, math.ceil(args.min_seconds / max(times[0], 1e-6))))
-        while len(times) < nreg:
+        nmin = args.regions if args.regions else (5 if times[0] < 1.0 else 1)
+        while len(times) < nmin or (not args.regions and sum(times) < args.min_seconds and len(times) < 400):
             times.append(region())
         # side figure: the same trajectories with H0 recomputed (one more flow sweep per trajectory), one region
         elapsed_sl = region(stateless=True) if flowed else None
@@ -480,7 +480,8 @@ def main():
                 torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
             m_ = tr.metrics()
             del tr, model
-            return float(tw) / steps_w * 1e3, bool(np.isfinite(m_['loss_dkl'])), ('hipGraph replay' if not grouped else 'eager + collectives')
+            mode_ = ('hipGraph replay' + (' (C2 collectives captured)' if grouped else '')) if tr.captured else 'eager + collectives'
+            return float(tw) / steps_w * 1e3, bool(np.isfinite(m_['loss_dkl'])), mode_
         import numpy as np
         wall_ms, wall_ok, wall_mode = train_wall(L, B, N_LAYERS, BETA, nt)
         small_ms, small_ok, _ = train_wall(16, 512, 8, 4.0, 100)

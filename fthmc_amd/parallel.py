@@ -135,6 +135,24 @@ def global_logsumexp(logw: torch.Tensor) -> torch.Tensor:
     return m + torch.log(torch.exp(logw - m).sum())
 
 
+def global_ess(logw: torch.Tensor, n_global: int) -> torch.Tensor:
+    """calc_ess (fthmc/utils/distributions.py:27-37) over the chains of all ranks with ONE collective: every rank contributes
+    (m, sum exp(logw - m), sum exp(2 (logw - m))) with its own maximum m, an all-gather of the three doubles lets every rank
+    rescale them to the common maximum: ESS = (sum w)^2 / (n sum w^2).  (global_logsumexp twice = four all-reduces.)"""
+    m = logw.max()
+    z = logw - m
+    loc = torch.stack([m, torch.exp(z).sum(), torch.exp(2 * z).sum()])
+    if have_group():
+        parts = [torch.empty_like(loc) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, loc)
+        allv = torch.stack(parts)
+    else:
+        allv = loc[None]
+    f = torch.exp(allv[:, 0] - allv[:, 0].max())
+    s1, s2 = (allv[:, 1] * f).sum(), (allv[:, 2] * f * f).sum()
+    return s1 * s1 / s2 / n_global
+
+
 def global_mean(t: torch.Tensor, n_global: int) -> torch.Tensor:
     s = t.sum()
     if have_group():

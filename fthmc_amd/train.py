@@ -21,7 +21,7 @@ from . import ops, parallel
 from .config import DTYPE, FlowModel, Param, TrainConfig, device
 from .utils import qed_helpers as qed
 from .utils.distributions import MultivariateUniform, calc_dkl, calc_ess
-from .utils.layers import (attach_grads, bump_weights_generation, flatten_flow, flow_activation, flow_grad_buffer, flow_weights, get_nets,
+from .utils.layers import (attach_grads, bump_weights_generation, flatten_flow, flow_activation, flow_grad_buffer, flow_grad_ext, flow_weights, get_nets,
                            make_net_from_layers, make_u1_equiv_layers, net_weights, set_weights)
 from .utils.samplers import apply_flow_to_prior
 
@@ -130,13 +130,18 @@ def _fused_step_device(model: FlowModel, action, batch_size: int, dkl_factor: fl
     scale = dkl_factor / world                   # kernel seeds 1 / B_local; the loss is the global mean
     if scale != 1.0:
         gflat.mul_(scale)
-    parallel.allreduce_grads(gflat)
     row = ops.train_metrics(xi, r['x'], r['logq'], r['logp'], action.beta, dkl_factor, out=row)
-    if parallel.have_group():                    # C2: loss mean and ESS over the chains of all ranks
+    if parallel.have_group():
+        # C2 in two collectives: ONE SUM all-reduce of [gradients, sum_b (logq - logp)] and ONE all-gather of three doubles
+        # for the ESS (parallel.global_ess) -- the messages are tiny, so the step pays per collective, not per byte
         n_global = B * world
-        logw = r['logp'] - r['logq']
-        row[0] = dkl_factor * parallel.global_mean(r['logq'] - r['logp'], n_global)
-        row[1] = torch.exp(2 * parallel.global_logsumexp(logw) - parallel.global_logsumexp(2 * logw)) / n_global
+        gext = flow_grad_ext(layers)
+        d = r['logq'] - r['logp']
+        n = gflat.numel()
+        torch.sum(d, dim=0, keepdim=True, out=gext[n:n + 1])
+        parallel.allreduce_grads(gext)
+        row[0] = dkl_factor * gext[n] / n_global
+        row[1] = parallel.global_ess(-d, n_global)
     return row, r['x']
 
 
@@ -257,12 +262,20 @@ class GraphTrainer:
         """capture one step; under a process group every rank learns whether every rank's capture succeeded"""
         ok = 1.0
         g = torch.cuda.CUDAGraph()
+        if parallel.have_group():
+            # The captured collectives pull RCCL's internal stream into the capture, and the HIP runtime refuses an event
+            # query (hipErrorCapturedEvent) on ANY event of a stream that is capturing -- also one recorded there eagerly
+            # before: the process group's watchdog thread polls exactly such events for collectives issued earlier (a barrier,
+            # an asynchronous C1 all-reduce) and would take the process down.  So: every earlier collective done, and the
+            # watchdog given a few of its 100 ms rounds to retire them, before the capture starts.
+            torch.cuda.synchronize(self.dev)
+            time.sleep(0.5)
         try:
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
                 self._enqueue()
         except Exception as e:                                             # noqa: BLE001 -- whatever the capture objects to
-            if not parallel.have_group():
-                raise
+            if not parallel.have_group() or torch.cuda.is_current_stream_capturing():
+                raise                                                      # no group to agree with / the capture cannot be left: not recoverable here
             ok, self.capture_error = 0.0, repr(e)
         if parallel.have_group():
             flag = torch.tensor([ok], dtype=torch.float64, device=self.dev)

@@ -377,11 +377,15 @@ def flatten_flow(flow: nn.ModuleList) -> torch.Tensor:
 
 
 def flow_grad_buffer(flow: nn.ModuleList) -> torch.Tensor:
-    """Flat gradient buffer shaped like flatten_flow(flow); `attach_grads` makes every conv parameter's .grad a view of it."""
+    """Flat gradient buffer shaped like flatten_flow(flow); `attach_grads` makes every conv parameter's .grad a view of it.
+    It is the head of a slightly longer allocation (`flow_grad_ext`): the training step's scalar sums ride behind the
+    gradients in the same all-reduce."""
     flat = flatten_flow(flow)
     g = getattr(flow, '_fthmc_gflat', None)
     if g is None or g.numel() != flat.numel() or g.device != flat.device:
-        g = torch.zeros_like(flat)
+        ext = torch.zeros(flat.numel() + GRAD_EXT, dtype=flat.dtype, device=flat.device)
+        g = ext[:flat.numel()]
+        flow._fthmc_gext = ext
         flow._fthmc_gflat = g
         o, views = 0, []
         for row in _flow_rows(flow):
@@ -389,6 +393,16 @@ def flow_grad_buffer(flow: nn.ModuleList) -> torch.Tensor:
                 views.append(g[o:o + p.numel()].view(p.shape)); o += p.numel()
         flow._fthmc_gviews = views
     return g
+
+
+GRAD_EXT = 8      # doubles behind the gradients in flow_grad_ext (slot 0: sum over this rank's chains of logq - logp)
+
+
+def flow_grad_ext(flow: nn.ModuleList) -> torch.Tensor:
+    """[n_params + GRAD_EXT]: the flat gradient buffer and, behind it, the scalars of a training step that are summed over the
+    ranks with it (C2: ONE SUM all-reduce per step)."""
+    flow_grad_buffer(flow)
+    return flow._fthmc_gext
 
 
 def attach_grads(flow: nn.ModuleList):

@@ -153,9 +153,10 @@ for traj in range(2):
 m = stats.means()
 lw = torch.arange(lo, hi, dtype=torch.float64) * 0.3
 lse = float(P.global_logsumexp(lw)); mean = float(P.global_mean(lw, B))
+ess = float(P.global_ess(1000.0 * torch.sin(torch.arange(lo, hi, dtype=torch.float64)), B))     # one all-gather (C2 of a training step)
 g = torch.full((3,), float(rank + 1)); P.allreduce_grads(g)
 if rank == 0:
-    print("RESULT", m["n"], m["acc"], m["plaq"], m["q"], m["dh"], lse, mean, float(g[0]))
+    print("RESULT", m["n"], m["acc"], m["plaq"], m["q"], m["dh"], lse, mean, float(g[0]), ess)
 if world > 1: dist.destroy_process_group()
 '''
 
@@ -182,6 +183,10 @@ def test_two_rank_gloo_equals_single_process():
     assert one[0] == two[0] == 8.0                                   # 4 chains x 2 trajectories
     np.testing.assert_allclose(two[:7], one[:7], rtol=1e-12, atol=1e-12)
     assert one[7] == 1.0 and two[7] == 3.0                           # SUM all-reduce of "gradients"
+    # calc_ess (distributions.py:27-37) of the whole batch: exp(2 lse(logw) - lse(2 logw)) / B
+    lw = 1000.0 * torch.sin(torch.arange(4, dtype=torch.float64))
+    want = float(torch.exp(2 * torch.logsumexp(lw, 0) - torch.logsumexp(2 * lw, 0)) / 4)
+    np.testing.assert_allclose([one[8], two[8]], [want, want], rtol=1e-12)
 
 
 def test_eight_rank_gloo_equals_single_process():
@@ -192,6 +197,7 @@ def test_eight_rank_gloo_equals_single_process():
     assert one[0] == eight[0] == 32.0                                # 16 chains x 2 trajectories
     np.testing.assert_allclose(eight[:7], one[:7], rtol=1e-12, atol=1e-12)
     assert eight[7] == 36.0                                          # SUM over ranks of rank + 1
+    np.testing.assert_allclose(eight[8], one[8], rtol=1e-12)         # the ESS from one all-gather of three doubles per rank
 
 
 def test_reference_import_path_is_an_alias_of_this_package():

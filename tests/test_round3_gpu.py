@@ -135,12 +135,13 @@ def test_bench_times_several_regions_when_one_is_short(tmp_path):
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', '1', '--steps', '5', '--warmup', '2',
-                        '--thermalize', '2', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+                        '--thermalize', '2', '--no-cpu-baseline', '--min-seconds', '0.02'], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
     reg = line['regions']
-    assert reg['n'] == 5 and len(reg['seconds']) == 5 and line['steps'] == 5
-    med = sorted(reg['seconds'])[2]
+    # at least five regions when one is short, and as many as it takes to time --min-seconds of GPU work (default 6 s)
+    assert reg['n'] >= 5 and len(reg['seconds']) == reg['n'] and line['steps'] == 5 and sum(reg['seconds']) >= 0.02
+    med = sorted(reg['seconds'])[reg['n'] // 2]
     assert abs(line['ms_per_step'] - med / 5 * 1e3) < 1e-2 * line['ms_per_step']
     assert abs(line['value'] - line['config']['chains_total'] * 10 * 5 / med) < 1e-2 * line['value']
 

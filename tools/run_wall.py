@@ -19,10 +19,16 @@ for L, beta, nl, B, n in shapes:
     ft = FieldTransformation(flow=model.layers, config=cfg, lfconfig=lfConfig(tau=1.0, nstep=10))
     x = (0.1 * (2 * torch.rand(B, 2, L, L, dtype=torch.float64) - 1)).cuda()
     ft.run(x, nprint=0, num_trajs=5, batch=True)                      # warm-up
+    # what a trajectory costs the HOST: a short run on an idle device (nothing throttles the enqueue; in the long run below
+    # the launch queue fills and the host waits for the device inside the launch calls)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ft.run(ft.x_last, nprint=0, num_trajs=12, batch=True)
+    host_idle = (time.perf_counter() - t0) / 12
     torch.cuda.synchronize(); t0 = time.perf_counter()
     h = ft.run(ft.x_last, nprint=0, num_trajs=n, batch=True)
     host = time.perf_counter() - t0                                   # the loop has enqueued everything
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     acc = float(torch.stack([torch.as_tensor(t, dtype=torch.float64).mean() for t in h['acc']]).mean())
-    print(json.dumps({'L': L, 'beta': beta, 'n_layers': nl, 'chains': B, 'trajectories': n, 'ms_per_trajectory': round(dt / n * 1e3, 4), 'host_ms_per_trajectory': round(host / n * 1e3, 4),
+    print(json.dumps({'L': L, 'beta': beta, 'n_layers': nl, 'chains': B, 'trajectories': n, 'ms_per_trajectory': round(dt / n * 1e3, 4), 'host_ms_per_trajectory': round(host_idle * 1e3, 4),
+                      'host_ms_per_trajectory_queue_full': round(host / n * 1e3, 4), 'captured': bool(ft._loop is not None and ft._loop['loop'].captured),
                       'chain_steps_per_s': round(B * 10 * n / dt, 1), 'acceptance': round(acc, 3)}), flush=True)

@@ -479,8 +479,9 @@ def main():
             if grouped:
                 torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
             m_ = tr.metrics()
+            captured_ = tr.captured
             del tr, model
-            mode_ = ('hipGraph replay' + (' (C2 collectives captured)' if grouped else '')) if tr.captured else 'eager + collectives'
+            mode_ = ('hipGraph replay' + (' (C2 collectives captured)' if grouped else '')) if captured_ else 'eager + collectives'
             return float(tw) / steps_w * 1e3, bool(np.isfinite(m_['loss_dkl'])), mode_
         import numpy as np
         wall_ms, wall_ok, wall_mode = train_wall(L, B, N_LAYERS, BETA, nt)
@@ -716,7 +717,7 @@ def main():
 
 
 # Attainable bound of the coupling-layer forward kernel at 16 x 16 tiles, from the work it cannot avoid with this
-# algorithm (DESIGN.md section 4): per workgroup 264 v_mfma_f64_16x16x4 (64 cycles each on one SIMD), 5216 sigmoids
+# algorithm (DESIGN.md section 4.1): per workgroup 264 v_mfma_f64_16x16x4 (64 cycles each on one SIMD), 5216 sigmoids
 # + 484 sincos + 64 tan-mixture transforms on the fp64 VALU, conv3 at the 64 active sites; fp64 MFMA and fp64 VALU
 # share one DP pipe per SIMD (profiles/r01_microbench_fp64.txt).  Filled in by tools/attainable.py.
 ATTAINABLE = None

@@ -12,7 +12,7 @@ A caller of nftqcd/fthmc keeps its imports (fthmc/main.py:73-104, fthmc/train.py
 Every `fthmc.X` resolves to the module object `fthmc_amd.X` (one module, two names: patching an attribute
 through either name is seen through both).  Nothing is re-implemented here and nothing of the reference is copied.
 The reference's orchestration modules that are out of scope (main, utils.io, utils.logger, utils.plot_helpers,
-utils.parse_configs) do not exist under either name and raise ModuleNotFoundError.
+utils.parse_configs; DESIGN.md, Scope) do not exist under either name and raise ModuleNotFoundError.
 """
 import importlib
 import importlib.abc

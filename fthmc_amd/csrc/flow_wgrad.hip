@@ -15,7 +15,7 @@
 // A workgroup WALKS A.tpw (chain, tile) items of its layer, A.wg_ns apart (the sum over sites simply runs on: accumulators
 // stay in registers); the next item's operands are prefetched into registers in two halves, its h1 window ahead of the
 // current item's MFMA phase, its gz / cos, sin / g_out behind it (all of it plus the 32 accumulator registers does not fit
-// the 128 a wave has at two workgroups per CU, and a spill inside the walk costs more than anything else here: DESIGN.md
+// the 128 a wave has at two workgroups per CU, and a spill inside the walk costs more than anything else here: docs/history.md
 // section 4).  At the end the waves' slices are summed through LDS in a fixed order and the workgroup writes ONE complete
 // 955-entry partial to A.gw_part; k_reduce_gw sums the partials in a fixed order.  Replaces the in-kernel weight-gradient
 // stages of round 1 (8 x 16 tiles, most of them on 1..3 waves: 49 k cycles per 128 sites).

@@ -21,6 +21,8 @@ namespace {
 using namespace fthmc;
 using namespace fthmc_flow;
 
+constexpr unsigned FWD_HAS_POUT = 1u << 16, FWD_HAS_DBG = 1u << 17, FWD_HAS_PIN = 1u << 18;     // flags in the forward kernel's hoa word
+
 // LDS plan: three workgroups share a CU (3 x 51.7 KB), so planes whose lifetimes do not overlap share memory:
 //   region A: h1 (conv1 -> conv2's MFMA reads), then h2 (conv2's epilogue, after a barrier -> conv3)
 //   region B: the net input (stage 0 -> conv1), then the conv3 partials / delta and the transform scratch
@@ -48,8 +50,17 @@ template <int TR, int TC> struct SmemF {
 // EXACT: the tiles divide the lattice and L is a power of two (L = 64, 128, 256: BASELINE configs 3, 4, 5), so every tile site
 // is a lattice site -- the lattice-edge halves of the bounds tests of the stash stores, the link update and the active sites
 // fold away -- and a window line wraps by one v_and.
+// Hot arguments: the explicit scalars ahead of the argument block arrive in SGPRs WITH the wave (kernarg preload: csrc/Makefile
+// -amdgpu-kernarg-preload-count=16; 15 dwords here), so the first loads of a workgroup do not wait for a scalar load of a cold
+// argument segment; the block itself (A0) serves what is needed later or rarely.  hoa = off | act << 8 | flags << 16
+// (13 dwords: the preload takes 14).
 template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT>
-__global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLayerArgs A) {
+__global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const double* hx, const double* hw, double* hy, double* hstash, double* hlogj,
+                                                                          int hB, int hL, unsigned hoa, FlowLayerArgs A0) {
+    FlowLayerArgs A = A0;
+    A.x = hx; A.wint = hw; A.y = hy; A.stash = hstash; A.logj_part = hlogj; A.B = hB; A.L = hL;
+    A.off = (int)(hoa & 0xffu); A.act = (int)((hoa >> 8) & 0xffu);
+    const bool has_pout = (hoa & FWD_HAS_POUT) != 0, has_dbg = (hoa & FWD_HAS_DBG) != 0, has_pin = (hoa & FWD_HAS_PIN) != 0;
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
@@ -75,14 +86,18 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLay
     const double* __restrict__ x1 = x0 + n;
     // plaquette-level map (NCPPlaqCouplingLayer.forward / .reverse, layers.py:348-396): the plaquette field
     // is the input (A.pin) and the output (A.pout) instead of being derived from / folded back into links
-    const double* __restrict__ pin = A.pin ? uniform_ptr(A.pin, (size_t)b * n) : nullptr;
+    const double* __restrict__ pin = has_pin ? uniform_ptr(A0.pin, (size_t)b * n) : nullptr;
     const double* __restrict__ w = A.wint;
-    long long* dbg = A.dbg ? A.dbg + ((size_t)b * ntiles + tile) * 16 : nullptr;
-#define STAMP(k) do { if (dbg && tid == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
+    // the stamp record is addressed inside the flag's branch: the pointer is not waited for in a production launch
+#define DBG_REC (A0.dbg + ((size_t)b * ntiles + tile) * 16)
+#define STAMP(k) do { if (has_dbg && tid == 0) DBG_REC[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(0);
     // slots 14, 15: the constant 100 MHz counter at both ends of the workgroup -- lifetime in cycles / lifetime in ticks = the
     // shader clock the kernel actually ran at (tools/lifetime.py)
-    if (dbg && tid == 0) dbg[14] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (has_dbg && tid == 0) DBG_REC[14] = (long long)__builtin_amdgcn_s_memrealtime();
+#ifdef FT_DIAG
+    long long* dbg = has_dbg ? DBG_REC : nullptr;
+#endif
 
     const unsigned fastw = EXACT ? (unsigned)(L - 1) : (FASTW ? 0u : wrap_magic(L));
     // this layer's forward weight block (the conv2 table padded along the pair direction of this mu): the loads are
@@ -97,7 +112,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLay
     }
     // the tile's own links for the final link update: issued now, consumed in the last stage
     double xv0 = 0.0, xv1 = 0.0;
-    if ((A.y || A.pout) && tid < N3) {
+    if ((A.y || has_pout) && tid < N3) {
         const int r = fdiv<TC>(tid), c = tid - r * TC;
         if (EXACT || (i0 + r < L && j0 + c < L)) {
             const unsigned at = (unsigned)(mul24(i0 + r, L) + j0 + c);
@@ -337,7 +352,12 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLay
         mfma_stage<KConv2Row, 16 * NW, RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
             [&](int) { return 2 * pl * RS1 + min(wl, R2C - 1); },
             [&](int g, int, bool, double (&z)[4], int) { conv2_epi(g, pok, 2 * pl, wl, 1, 0, z); },
-            dbg ? dbg + 11 : nullptr, bias2);
+#ifdef FT_DIAG
+            dbg ? dbg + 11 : nullptr,
+#else
+            nullptr,
+#endif
+            bias2);
     } else {
         // B[k = (tap = ky * 4 + kx4, ci)][n = (co, dd)] = W1[co][ci][ky][kx4 - dd]; pairs = columns (2 pc, 2 pc + 1)
         mfma_stage<KConv2Col, 16 * NW, RS1, PS1, false, false, FT_NCH ? FT_NCH : 1>(sH1, sW + LF_P2, wave, lane,
@@ -438,7 +458,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLay
                 xsol = xs;
                 lj = -(log(fp));                                     // log J of the inverse = -log mean_k 1/D_k at the root
             }
-            if (avalid) sDL[ar * TC + ac] = A.pout ? xsol : dl;
+            if (avalid) sDL[ar * TC + ac] = has_pout ? xsol : dl;
             if (A.logj_part) {
                 const double tot = ft_wave_sum(avalid ? lj : 0.0);
                 if (lane == 0) A.logj_part[(size_t)b * ntiles + tile] = tot;
@@ -459,7 +479,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLay
                 stu(y0, at, v0); stu(y0, (unsigned)n + at, v1);
             }
         }
-        if (A.pout && tid < N3) {                                    // plaquette-level inverse: x1 at the active sites, fx elsewhere
+        if (has_pout && tid < N3) {                                    // plaquette-level inverse: x1 at the active sites, fx elsewhere
             const int r = fdiv<TC>(tid), c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
             if (EXACT || (i < L && j < L)) A.pout[(size_t)b * n + mul24(i, L) + j] = ft_stripe(i, j, mu, off) == 0 ? sDL[tid] : xv0;
@@ -519,7 +539,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLay
             for (int k = 0; k < NMIX; ++k) { ysum += sT2[(k * TQ) * NAS + (lane & (NAS - 1))]; si += sT2[(k * TQ + 1) * NAS + (lane & (NAS - 1))]; }
             const double tval = sP[(ar + 3) * R0C + ac + 3 + 3 * (mu == 0 ? 1 : R0C)];
             const double newP = ft_wrap(ysum / NMIX + tval);
-            if (avalid) sDL[ar * TC + ac] = A.pout ? newP : newP - Pa;
+            if (avalid) sDL[ar * TC + ac] = has_pout ? newP : newP - Pa;
             if (A.logj_part) {                                       // force sweeps do not ask for log J
                 const double lj = avalid ? log(si) - log((double)NMIX) : 0.0;
                 const double tot = ft_wave_sum(lj);
@@ -541,13 +561,13 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(FlowLay
                 stu(y0, at, v0); stu(y0, (unsigned)n + at, v1);
             }
         }
-        if (A.pout && tid < N3) {                                    // plaquette-level map: P' at the active sites, P elsewhere
+        if (has_pout && tid < N3) {                                    // plaquette-level map: P' at the active sites, P elsewhere
             const int r = fdiv<TC>(tid), c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
             if (EXACT || (i < L && j < L)) A.pout[(size_t)b * n + mul24(i, L) + j] = ft_stripe(i, j, mu, off) == 0 ? sDL[tid] : xv0;
         }
         STAMP(6);
-        if (dbg && tid == 0) dbg[15] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (has_dbg && tid == 0) DBG_REC[15] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -556,18 +576,20 @@ int g_variant = 1;
 }  // namespace
 
 namespace {
+#define FWD_LAUNCH(...) hipLaunchKernelGGL((k_flow_fwd<__VA_ARGS__>), grid, dim3(NT), 0, s, a.x, a.wint, a.y, a.stash, a.logj_part, a.B, a.L, hoa, a)
 template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hipStream_t s) {
     constexpr int TR = fthmc::MF_FWD_TR, TC = fthmc::MF_FWD_TC;
+    const unsigned hoa = (unsigned)a.off | (unsigned)a.act << 8 | (a.pout ? FWD_HAS_POUT : 0u) | (a.dbg ? FWD_HAS_DBG : 0u) | (a.pin ? FWD_HAS_PIN : 0u);
     const bool fast = wrap_fast_ok(a.L, TR, TC);
     const bool exact = fast && a.L % TR == 0 && a.L % TC == 0 && (a.L & (a.L - 1)) == 0;
     if (a.mu == 0) {
-        if (exact) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 0, true>), grid, dim3(NT), 0, s, a);
-        else if (fast) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 0, false>), grid, dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((k_flow_fwd<TR, TC, false, REV, 0, false>), grid, dim3(NT), 0, s, a);
+        if (exact) FWD_LAUNCH(TR, TC, true, REV, 0, true);
+        else if (fast) FWD_LAUNCH(TR, TC, true, REV, 0, false);
+        else FWD_LAUNCH(TR, TC, false, REV, 0, false);
     } else {
-        if (exact) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 1, true>), grid, dim3(NT), 0, s, a);
-        else if (fast) hipLaunchKernelGGL((k_flow_fwd<TR, TC, true, REV, 1, false>), grid, dim3(NT), 0, s, a);
-        else hipLaunchKernelGGL((k_flow_fwd<TR, TC, false, REV, 1, false>), grid, dim3(NT), 0, s, a);
+        if (exact) FWD_LAUNCH(TR, TC, true, REV, 1, true);
+        else if (fast) FWD_LAUNCH(TR, TC, true, REV, 1, false);
+        else FWD_LAUNCH(TR, TC, false, REV, 1, false);
     }
 }
 }  // namespace

@@ -251,7 +251,9 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
         if (T < NU) { pu[it] = T; pv[it] = i; pok[it] = true; }
         else { pu[it] = 2 * (i >> 1) + (T - NU); pv[it] = 16 + (i & 1); pok[it] = T < NTILE1 && pu[it] < NU; if (!pok[it]) { pu[it] = 0; pv[it] = 0; } }
         const int ra = mu == 0 ? pv[it] : 2 * pu[it], ca = mu == 0 ? 2 * pu[it] : pv[it];
-        const int ga = WI(ra - 1) + WJ(ca - 1), gb = mu == 0 ? WI(ra - 1) + WJ(ca) : WI(ra) + WJ(ca - 1);
+        // mu = 0: the act'(z1) plane is stored transposed (FT_D1_T, flow_mfma_common.h): site index j L + i
+        const int ga = (FT_D1_T && mu == 0) ? mul24(WJ(ca - 1), L) + wi(ra - 1) : WI(ra - 1) + WJ(ca - 1);
+        const int gb = mu == 0 ? (FT_D1_T ? mul24(WJ(ca), L) + wi(ra - 1) : WI(ra - 1) + WJ(ca)) : WI(ra) + WJ(ca - 1);
         if (!FT_RECOMP_D1) {
             const unsigned og = 2u * (unsigned)(lane >> 4);                  // channels 2 g, 2 g + 1: one 16-byte load per site
             const double2_t va = ldu2(st1, (unsigned)ga * 8u + og), vb = ldu2(st1, (unsigned)gb * 8u + og);

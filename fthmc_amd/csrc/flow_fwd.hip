@@ -250,12 +250,14 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
             if (FT_RECOMP_D1 ? (A.stash && A.stash_h) : (A.stash != nullptr)) {   // act'(z1) (and h1) of the tile's own sites
                 const int r0 = r - 2, c0 = c - 2, r1 = mu == 0 ? r0 : r0 + 1, c1 = mu == 0 ? c0 + 1 : c0;
                 const int at = mul24(i0 + r0, L) + j0 + c0, dat = mu == 0 ? 1 : L;
+                // act'(z1) of a mu = 0 layer: transposed site index (FT_D1_T): the lanes of a tile run down a column
+                const int atd = (FT_D1_T && mu == 0) ? mul24(j0 + c0, L) + i0 + r0 : at, datd = (FT_D1_T && mu == 0) ? L : dat;
                 if ((unsigned)r0 < (unsigned)rmax && (unsigned)c0 < (unsigned)cmax) {
-                    if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)at + stg, double2_t{d[0], d[1]});
+                    if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)atd + stg, double2_t{d[0], d[1]});
                     if (A.stash_h) stu2(st_h1, 8u * (unsigned)at + stg, double2_t{h[0], h[1]});
                 }
                 if ((unsigned)r1 < (unsigned)rmax && (unsigned)c1 < (unsigned)cmax) {
-                    if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)(at + dat) + stg, double2_t{d[2], d[3]});
+                    if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)(atd + datd) + stg, double2_t{d[2], d[3]});
                     if (A.stash_h) stu2(st_h1, 8u * (unsigned)(at + dat) + stg, double2_t{h[2], h[3]});
                 }
             }
@@ -286,7 +288,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
             const int rr = r - 2, cc = c - 2;
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
                 const int at = mul24(i0 + rr, L) + j0 + cc;
-                if (!FT_RECOMP_D1) stu(st_d1, 8u * (unsigned)at + (unsigned)co, d);
+                if (!FT_RECOMP_D1) stu(st_d1, 8u * (unsigned)((FT_D1_T && mu == 0) ? mul24(j0 + cc, L) + i0 + rr : at) + (unsigned)co, d);
                 if (A.stash_h) stu(st_h1, 8u * (unsigned)at + (unsigned)co, h);
             }
         }

@@ -36,6 +36,15 @@
 #define FT_RECOMP_D1 0
 #endif
 
+// 1 (default): the act'(z1) plane of a mu = 0 layer is stored TRANSPOSED ([j][i][8]: site index j L + i).  Both kernels walk that
+// plane down the stripe lines -- conv1 and conv2^T pair their output sites ACROSS the lines, so the 16 lanes of a tile are 16
+// positions ALONG a line: 16 consecutive rows for mu = 0 --, and row-major storage made every one of those 16-byte accesses its own
+// 64-byte piece of a line 4 KB from the next (16 half lines per wave instruction where mu = 1 touches 8 whole ones): the mu = 0
+// instances were 4 % (forward) and 10 % (backward) slower than the mu = 1 ones, all of it in load / store issue.
+#ifndef FT_D1_T
+#define FT_D1_T 1
+#endif
+
 namespace fthmc_flow {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -131,7 +140,8 @@ template <int TR, int TC> struct Geom {
 
 // Per-layer activation stash written by the forward kernel and read back by the gather-form backward
 // (n = L * L; per chain b):
-//   d1  [n][8]     act'(z1), channel-minor        d2  [n][8]   act'(z2)  (dead lines unwritten)
+//   d1  [n][8]     act'(z1), channel-minor (mu = 0 layers: site index TRANSPOSED, j L + i: FT_D1_T)
+//   d2  [n][8]     act'(z2), channel-minor (dead lines unwritten)
 //                  (64 B per site: a window row of 20 sites is 10 cache lines for all channels, not 8 x 2..3,
 //                   and the channel pair (2 g, 2 g + 1) of a lane is one 16-byte access)
 //   tc  [K][n/4][4] adjoint coefficients of the tan-mixture transform at the ACTIVE sites, compact, component-major:

@@ -246,7 +246,11 @@ class GraphTrainer:
         # the steps run on the trainer's own stream (a capture needs one): it starts behind whatever initialised the model and
         # the optimizer on the caller's stream; metrics() / history() / synchronize() are where the caller waits for it
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
-        self.use_graph = bool(use_graph) and (not parallel.have_group() or os.environ.get('FTHMC_GRAPH_COLLECTIVES', '1') not in ('', '0'))
+        # with a process group the step is captured only over RCCL ("nccl": its collectives are stream-ordered device work; gloo
+        # moves the tensors through the host and cannot be captured) and unless FTHMC_GRAPH_COLLECTIVES=0 asks for the eager sequence
+        group_ok = (not parallel.have_group() or
+                    (torch.distributed.get_backend() == 'nccl' and os.environ.get('FTHMC_GRAPH_COLLECTIVES', '1') not in ('', '0')))
+        self.use_graph = bool(use_graph) and group_ok
         if self.use_graph and not (getattr(optimizer, 'graph_safe', False) or all(g.get('capturable', False) for g in optimizer.param_groups)):
             raise ValueError('GraphTrainer captures optimizer.step(): pass a FlatAdam (train.make_optimizer) or a torch '
                              'optimizer built with capturable=True, or use_graph=False')

@@ -304,9 +304,18 @@ model.layers.load_state_dict({f"{li}.plaq_coupling.{n}": flow[li][pi].to(dev) fo
 opt = torch.optim.SGD(model.layers.parameters(), lr=0.0)
 met = T.train_step(model, tc, qed.BatchAction(beta), opt, hi - lo, xi=xi_all[lo:hi].to(dev), fused=True)
 grads = torch.cat([p_.grad.reshape(-1) for p_ in model.layers.parameters()])
+# the training LOOP object: every rank draws the prior of its own global chain ids on the device and steps the same weights
+model2 = T.get_model(tc)
+model2.layers.load_state_dict({f"{li}.plaq_coupling.{n}": flow[li][pi].to(dev) for li in range(nl) for pi, n in enumerate(names)})
+tc2 = TrainConfig(L=L, beta=beta, n_layers=nl, batch_size=hi - lo, base_lr=1e-3)
+tr = T.GraphTrainer(model2, tc2, T.make_optimizer(model2, tc2), hi - lo, seed=9)
+for _ in range(3):
+    tr.step()
+mt = tr.metrics()
 np.savez(os.environ["FT_OUT"] + f".{world}.{rank}.npz", lo=lo, hi=hi, x=x.cpu().numpy(), dH=torch.stack(dHs).cpu().numpy(),
          means=np.array([m[k] for k in sorted(m)]), grads=grads.cpu().numpy(), loss=met["loss_dkl"], ess=met["ess"],
-         logq=met["logq"], logp=met["logp"])
+         logq=met["logq"], logp=met["logp"], w_loop=Lyr.flow_weights(model2.layers).cpu().numpy(), loop_captured=tr.captured,
+         loop_loss=mt["loss_dkl"], loop_ess=mt["ess"])
 if world > 1:
     torch.distributed.destroy_process_group()
 '''
@@ -345,6 +354,13 @@ def test_two_process_sharding_equals_one_process(tmp_path):
         scale = np.abs(one['grads']).max()
         np.testing.assert_allclose(t['grads'], one['grads'], rtol=1e-10, atol=1e-12 * scale)
     assert np.abs(one['grads']).max() > 0
+    # GraphTrainer: captured without a group; over gloo (host-side collectives cannot be captured) the eager sequence -- the same
+    # weights, loss and ESS on both ranks as the one process on the full batch (the draws are keyed by the global chain id)
+    assert bool(one['loop_captured']) and not any(bool(t['loop_captured']) for t in two)
+    for t in two:
+        np.testing.assert_allclose(t['w_loop'], one['w_loop'], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(t['loop_loss'], one['loop_loss'], rtol=1e-10)
+        np.testing.assert_allclose(t['loop_ess'], one['loop_ess'], rtol=1e-9)
 
 
 def test_bench_self_launches_its_ranks(tmp_path):

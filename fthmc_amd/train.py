@@ -159,10 +159,12 @@ def train_step(model: FlowModel, config: TrainConfig, action: ActionFn, optimize
                  the Wilson `BatchAction(config.beta)`, which is what train.py:291 passes); the gradient lands in the
                  flat buffer the parameters' .grad are views of, the metrics come back in ONE device-to-host copy;
     fused=False: the layers run one by one through autograd (any `action` callable).
+    `scaler` (a torch GradScaler, train.py:206-209, 321-324): the reference's scale / step / update sequence on the autograd
+    route; on the fp64 path it changes nothing but the order of two multiplications (there is no fp16 to protect).
     A whole training loop without any per-step host synchronisation: `GraphTrainer` (what `train` uses)."""
     t0 = time.time()
     if scaler is not None:
-        raise NotImplementedError('GradScaler (fp16 autocast) does not apply to the fp64 HIP path')
+        fused = False        # train.py:206-209: scaler.scale(loss).backward() needs the loss as an autograd tensor: the layer-wise route
     if pre_model is not None:
         pre_xi = pre_model.prior.sample_n(batch_size)
         x_pre = qed.ft_flow(pre_model.layers, pre_xi)
@@ -187,7 +189,10 @@ def train_step(model: FlowModel, config: TrainConfig, action: ActionFn, optimize
     x, xi, logq = apply_flow_to_prior(model.prior, layers, xi=xi, batch_size=batch_size)
     logp = (-1.) * action(x)
     loss_local = dkl_factor * (logq - logp).sum() / n_global
-    loss_local.backward()
+    if scaler is not None:
+        scaler.scale(loss_local).backward()      # the scaled gradients are summed over the ranks below, unscaled inside scaler.step
+    else:
+        loss_local.backward()
     if parallel.have_group():
         for p in layers.parameters():
             parallel.allreduce_grads(p.grad)
@@ -198,7 +203,11 @@ def train_step(model: FlowModel, config: TrainConfig, action: ActionFn, optimize
     q = qed.batch_charges(x.detach())
     plaq = logp.detach() / (config.beta * config.volume)
     dq = torch.sqrt((q - qi) ** 2)
-    optimizer.step()
+    if scaler is not None:
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        optimizer.step()
     if scheduler is not None:
         scheduler.step(loss_dkl)
     # one stacked copy instead of seven synchronising ones
@@ -444,16 +453,18 @@ def make_optimizer(model: FlowModel, config: TrainConfig, capturable: bool = Tru
 
 def train(config: TrainConfig, model: Optional[FlowModel] = None, pre_model: FlowModel = None,
           figsize=None, dpi: int = 120, scheduler_config=None, dkl_factor: float = 1., save: bool = False,
-          verbose: bool = True, use_graph: bool = True, seed: int = 1234):
+          verbose: bool = True, use_graph: bool = True, seed: int = 1234, use_scaler: bool = False):
     """train.py:236-431 without plots / tensorboard: n_era x n_epoch steps, one checkpoint per era
     (save=True).  Returns dict(model, optimizer, history, ckpt_files).
 
     The steps run through `GraphTrainer` (one captured hipGraph per step, metrics kept on the device until the end or
-    the next `print_freq` line); `pre_model` (a prior passed through another flow and back) keeps the step-by-step
-    `train_step` route."""
+    the next `print_freq` line); `pre_model` (a prior passed through another flow and back) and `use_scaler` (train.py:250,
+    321-324: a torch GradScaler around the step) keep the step-by-step `train_step` route."""
     if model is None:
         model = get_model(config)
-    optimizer = make_optimizer(model, config, capturable=(pre_model is None))
+    stepwise = pre_model is not None or use_scaler
+    optimizer = make_optimizer(model, config, capturable=not stepwise)
+    scaler = torch.amp.GradScaler('cuda') if (use_scaler and torch.cuda.is_available()) else None
     scheduler = None
     if scheduler_config is not None:
         sc = {k: v for k, v in vars(scheduler_config).items() if k != 'verbose'}
@@ -462,7 +473,7 @@ def train(config: TrainConfig, model: Optional[FlowModel] = None, pre_model: Flo
     history, ckpts = {}, []
     step = 0
     t0 = time.time()
-    trainer = None if pre_model is not None else GraphTrainer(model, config, optimizer, config.batch_size, dkl_factor=dkl_factor,
+    trainer = None if stepwise else GraphTrainer(model, config, optimizer, config.batch_size, dkl_factor=dkl_factor,
                                                               scheduler=scheduler, seed=seed, use_graph=use_graph)
     for era in range(config.n_era):
         for epoch in range(config.n_epoch):
@@ -471,7 +482,7 @@ def train(config: TrainConfig, model: Optional[FlowModel] = None, pre_model: Flo
                 trainer.step()
                 metrics = trainer.metrics() if show else None
             else:
-                metrics = train_step(model, config, action, optimizer, config.batch_size, scheduler=scheduler,
+                metrics = train_step(model, config, action, optimizer, config.batch_size, scheduler=scheduler, scaler=scaler,
                                      pre_model=pre_model, dkl_factor=dkl_factor)
                 for k, v in metrics.items():
                     history.setdefault(k, []).append(v)

@@ -228,3 +228,33 @@ def test_captured_ft_run_equals_the_eager_loop(tmp_path):
     for k in ('dH', 'exp_mdH', 'acc', 'plaq', 'topo'):
         assert res['graph'][1][k] == res['eager'][1][k], k
     assert res['graph'][2] == res['eager'][2]
+
+
+# ---------------------------------------------------------------- the reference's GradScaler option
+def test_train_step_with_a_grad_scaler_equals_the_plain_step():
+    """train_step(scaler=GradScaler()) (train.py:206-209, 321-324): scale(loss).backward(), scaler.step, scaler.update on the
+    autograd route leave the weights of the plain step (fp64: the scale is a power of two, scaling and unscaling are exact) and
+    the same metrics; train(use_scaler=True) runs."""
+    from fthmc_amd import train as T
+    from fthmc_amd.config import TrainConfig
+    from fthmc_amd.utils import layers as LY
+    from fthmc_amd.utils import qed_helpers as qed
+    tc = TrainConfig(L=8, beta=2.0, n_layers=2, batch_size=6, base_lr=1e-3, print_freq=0, n_era=1, n_epoch=3)
+    torch.manual_seed(4)
+    m0 = T.get_model(tc)
+    init = {k: v.clone() for k, v in m0.layers.state_dict().items()}
+    xi = m0.prior.sample_n(6)
+    act = qed.BatchAction(tc.beta)
+    res = {}
+    for tag in ('plain', 'scaler'):
+        model = T.get_model(tc); model.layers.load_state_dict(init)
+        opt = torch.optim.Adam(model.layers.parameters(), lr=tc.base_lr)
+        sc = torch.amp.GradScaler('cuda') if tag == 'scaler' else None
+        met = [T.train_step(model, tc, act, opt, 6, xi=xi, scaler=sc, fused=False) for _ in range(3)]
+        res[tag] = (LY.flow_weights(model.layers).clone(), met)
+    assert torch.equal(res['plain'][0], res['scaler'][0])
+    for a, b in zip(res['plain'][1], res['scaler'][1]):
+        for k in T.METRIC_KEYS:
+            np.testing.assert_array_equal(a[k], b[k])
+    out = T.train(tc, use_scaler=True, verbose=False)
+    assert len(out['history']['loss_dkl']) == 3 and np.isfinite(out['history']['loss_dkl'][-1])

@@ -323,6 +323,7 @@ def main():
         S0, q0, p0 = ops.wilson_action_charge(x, BETA)
     qold = q0.clone()
     seeds = torch.empty(B, dtype=torch.int64, device=dev)
+    traj_dev = torch.zeros(1, dtype=torch.int64, device=dev)          # trajectories done, on the device: keys every trajectory's draws
     v = torch.empty_like(x)
     u = torch.empty(B, dtype=torch.float64, device=dev)
     stream = torch.cuda.Stream(device=dev)
@@ -341,6 +342,9 @@ def main():
         """momentum refresh + one trajectory of every chain of this GPU, forked from the current stream.
         stateless: H0 is recomputed by a flow sweep at the start of the trajectory, as the reference does (ft_hmc.py:205),
         instead of being carried over from the previous trajectory's H1 (bit-identical numbers either way)."""
+        # the trajectory's per-chain seeds from (SEED, global chain id, trajectory counter) on the device; the counter moves on inside
+        # the launch, so a replay costs the host no copy (= parallel.chain_seeds(SEED, lo, hi, trajectory))
+        ops.chain_seeds(SEED, lo, B, counter=traj_dev, advance=True, out=seeds)
         ops.random_momenta(seeds, x.shape, out_v=v, out_u=u)
         if flowed:
             # in place: the accepted field replaces x, its (S_eff, plaq, Q) replace the carried state (the C ABI allows
@@ -359,8 +363,7 @@ def main():
     if not args.no_graph:
         # the launches of a trajectory (~200 with the flow) are captured once and replayed (launch-bound otherwise)
         with torch.cuda.stream(stream):
-            seeds.copy_(parallel.chain_seeds(SEED, lo, hi, 0).to(dev))
-            enqueue()                       # warm allocator / workspaces before capture
+            enqueue()                       # warm allocator / workspaces before capture (trajectory 0's draws)
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
             # thread_local: the process group's watchdog thread may poll its events while this thread captures
@@ -375,7 +378,6 @@ def main():
     pending = [None]
 
     def step(stateless=False):
-        seeds.copy_(parallel.chain_seeds(SEED, lo, hi, traj[0]), non_blocking=True)      # ONE host-to-device copy (no staging tensor)
         if graph is not None:
             (graph_sl if stateless else graph).replay()
         else:

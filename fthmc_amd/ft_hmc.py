@@ -53,6 +53,8 @@ class LazyHistory(dict):
     def items(self): self._fill(); return super().items()
     def setdefault(self, k, d=None): self._fill(); return super().setdefault(k, d)
     def __repr__(self): self._fill(); return super().__repr__()
+    def __eq__(self, other): self._fill(); return super().__eq__(other)
+    def __reduce__(self): self._fill(); return (dict, (dict(super().items()),))     # pickles / copies as the plain dict it stands for
 
 
 class FieldTransformation(nn.Module):
@@ -303,7 +305,7 @@ class FieldTransformation(nn.Module):
                 q0_ = lp['state'][2].clone() if batch else qed.batch_charges(xd)
                 lp['x'].copy_(xd)
                 # the captured sequence carries no weight expansion: the workspaces of its streams get it here, once per run
-                return q0_, ops.pack_trajectory_workspaces(lp['x'], w, nl, groups=G)
+                return q0_, ops.pack_trajectory_workspaces(lp['x'], w, nl, groups=G, side_streams=lp['sides'])
         q0, token = prepare(self._loop)
         if self._loop['loop'].captured and self._loop['token'] != token:
             # a workspace moved since the capture (grown by another caller of these streams): capture again
@@ -321,7 +323,7 @@ class FieldTransformation(nn.Module):
             if loop.captured and not was_captured:
                 # the eager first step may have grown a workspace: the capture that followed saw the final ones
                 with torch.cuda.stream(loop.stream):
-                    lp['token'] = ops.pack_trajectory_workspaces(xs, w, nl, groups=G)
+                    lp['token'] = ops.pack_trajectory_workspaces(xs, w, nl, groups=G, side_streams=lp['sides'])
             if nprint and i % nprint == 0:
                 r = torch.from_numpy(loop.last()).view(4, B)
                 self._print_line(i, r[0], r[1], r[2], r[3])
@@ -368,13 +370,18 @@ class FieldTransformation(nn.Module):
         out = {'x_new': xs, 'acc': row[0], 'dH': row[1], 'plaq': row[2], 'Q': row[3], 'state': state,
                'H0': torch.empty(B, dtype=torch.float64, device=dev), 'H1': torch.empty(B, dtype=torch.float64, device=dev)}
 
+        # the loop's own streams for the chain groups beyond the first: the replays rely on what the workspaces of its streams
+        # hold (the weight expansion), so nobody else may run on them
+        sides = [torch.cuda.Stream(device=dev) for _ in range(max(G, 1) - 1)]
+
         def enqueue():
             v.normal_()                                                   # = torch.randn_like(x), then torch.rand(B): ft_hmc.py:204, 243
             u.uniform_()
             # in place: the accepted field replaces x, its (S_eff, plaq, Q) the carried state (both read before they are written)
-            ops.ft_trajectory(xs, v, u, w, nl, beta, self.dt, self.nstep, act, mode=mode, out=out, state_in=state, groups=G)
+            ops.ft_trajectory(xs, v, u, w, nl, beta, self.dt, self.nstep, act, mode=mode, out=out, state_in=state, groups=G,
+                              side_streams=sides)
         loop = GraphLoop(enqueue, row, use_graph=True, capture_ctx=ops.assume_packed)
-        return {'sig': sig, 'loop': loop, 'x': xs, 'state': state, 'row': row, 'token': None, 'pending': None}
+        return {'sig': sig, 'loop': loop, 'x': xs, 'state': state, 'row': row, 'token': None, 'pending': None, 'sides': sides}
 
 
 def run_ftHMC(flow: torch.nn.Module, config: TrainConfig, tau: float, nstep: int, num_trajs: int = 1024,

@@ -137,7 +137,7 @@ def _group_edges(groups, B: int):
     return [k * B // G for k in range(G + 1)]
 
 
-def pack_trajectory_workspaces(x: torch.Tensor, w, n_layers: int, groups=1, arch=None):
+def pack_trajectory_workspaces(x: torch.Tensor, w, n_layers: int, groups=1, arch=None, side_streams=None):
     """Expand `w` into the workspace of every stream an `ft_trajectory(x, ..., groups=groups)` call from the current stream
     runs on (the current stream and the side streams of the chain groups) -> a token (the workspaces' addresses): a captured
     sequence stays valid while the token does."""
@@ -145,7 +145,7 @@ def pack_trajectory_workspaces(x: torch.Tensor, w, n_layers: int, groups=1, arch
     edges = _group_edges(groups, B)
     G = len(edges) - 1
     main = torch.cuda.current_stream(x.device)
-    sides = _side_streams(x.device, G - 1) if G > 1 else []
+    sides = (list(side_streams)[:G - 1] if side_streams is not None else _side_streams(x.device, G - 1)) if G > 1 else []
     for st in sides:
         st.wait_stream(main)
     token = []
@@ -687,7 +687,8 @@ def _side_streams(device, n: int):
 
 
 def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int, act='silu', mode='md',
-                  out: Optional[dict] = None, state_in: Optional[torch.Tensor] = None, groups: int = 1, arch=None, wkey=None):
+                  out: Optional[dict] = None, state_in: Optional[torch.Tensor] = None, groups: int = 1, arch=None, wkey=None,
+                  side_streams=None):
     """One ftHMC trajectory per chain -> dict(x_new, dH, acc, H0, H1, plaq, Q, state).
 
     `out` may carry preallocated output tensors (same keys) so that a caller can replay the call
@@ -718,7 +719,9 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
                 raise FthmcError(f'state_in: expected [3, {B}]')
             state_in = state_in.reshape(3, B)
         main = torch.cuda.current_stream(x.device)
-        sides = _side_streams(x.device, G - 1)
+        sides = list(side_streams)[:G - 1] if side_streams is not None else _side_streams(x.device, G - 1)
+        if len(sides) != G - 1:
+            raise FthmcError(f'side_streams: {G - 1} streams needed for {G} chain groups')
         parts = []
         for st in sides:                                                # fork before anything of this call is on `main`
             st.wait_stream(main)
@@ -728,7 +731,7 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
             with torch.cuda.stream(st):
                 og = {k: t[a:b_] for k, t in out.items() if k != 'state'}
                 sg = state_in[:, a:b_].contiguous() if state_in is not None else None
-                ft_trajectory(x[a:b_], v[a:b_], u[a:b_], w, n_layers, beta, dt, nstep, act, mode, og, sg, arch=arch_, wkey=wkey)
+                ft_trajectory(x[a:b_], v[a:b_], u[a:b_], w, n_layers, beta, dt, nstep, act, mode, og, sg, arch=arch_, wkey=wkey)   # one group: no side streams
                 out['state'][:, a:b_].copy_(og['state'])
                 parts.append(og)                                        # keep the group's temporaries alive until the join
         for st in sides:

@@ -258,3 +258,42 @@ def test_train_step_with_a_grad_scaler_equals_the_plain_step():
             np.testing.assert_array_equal(a[k], b[k])
     out = T.train(tc, use_scaler=True, verbose=False)
     assert len(out['history']['loss_dkl']) == 3 and np.isfinite(out['history']['loss_dkl'][-1])
+
+
+def test_two_captured_loops_with_different_flows_do_not_disturb_each_other():
+    """Two FieldTransformations over different flows, their captured runs interleaved (and an eager batch call in between on
+    the shared stream pool): every run equals the eager loop of its own flow -- the replays carry no weight expansion, so each
+    loop owns the streams (and with them the workspaces) it replays into, and re-establishes them at every run."""
+    import pickle
+    from fthmc_amd.config import lfConfig
+    from fthmc_amd.ft_hmc import FieldTransformation
+    L, nl, B = 32, 2, 16                                                  # two chain groups: the side-stream path
+    cfg, ma = _model(L, nl, B, seed=31)
+    _, mb = _model(L, nl, B, seed=32)
+    x0 = (0.3 * (2 * torch.rand(B, 2, L, L, dtype=torch.float64) - 1)).cuda()
+    lf = lfConfig(tau=1.0, nstep=5)
+    want = {}
+    for tag, m in (('a', ma), ('b', mb)):
+        ft = FieldTransformation(flow=m.layers, config=cfg, lfconfig=lf)
+        torch.manual_seed(7); torch.cuda.manual_seed(7)
+        h1 = ft.run(x0.clone(), nprint=0, num_trajs=3, batch=True, use_graph=False)
+        h2 = ft.run(ft.x_last, nprint=0, num_trajs=3, batch=True, use_graph=False)
+        want[tag] = (torch.stack(h1['dh'] + h2['dh']), ft.x_last.clone())
+    fa = FieldTransformation(flow=ma.layers, config=cfg, lfconfig=lf)
+    fb = FieldTransformation(flow=mb.layers, config=cfg, lfconfig=lf)
+    torch.manual_seed(7); torch.cuda.manual_seed(7)
+    ga = torch.cuda.get_rng_state()
+    ha1 = fa.run(x0.clone(), nprint=0, num_trajs=3, batch=True)
+    sa = torch.cuda.get_rng_state()
+    torch.cuda.set_rng_state(ga)
+    hb1 = fb.run(x0.clone(), nprint=0, num_trajs=3, batch=True)
+    sb = torch.cuda.get_rng_state()
+    fb._batch_hmc(x0.clone())                                             # an eager two-group call on the shared side-stream pool
+    torch.cuda.set_rng_state(sa)
+    ha2 = fa.run(fa.x_last, nprint=0, num_trajs=3, batch=True)
+    torch.cuda.set_rng_state(sb)
+    hb2 = fb.run(fb.x_last, nprint=0, num_trajs=3, batch=True)
+    assert torch.equal(torch.stack(ha1['dh'] + ha2['dh']), want['a'][0]) and torch.equal(fa.x_last, want['a'][1])
+    assert torch.equal(torch.stack(hb1['dh'] + hb2['dh']), want['b'][0]) and torch.equal(fb.x_last, want['b'][1])
+    plain = pickle.loads(pickle.dumps(ha1))                               # a LazyHistory travels as the dict it stands for
+    assert type(plain) is dict and torch.equal(torch.stack(plain['dh']), torch.stack(ha1['dh']))

@@ -448,7 +448,8 @@ def _device_code_objects(path, tmp):
 def test_hot_kernels_are_what_the_build_intends(tmp_path):
     """Static check of the shipped library's gfx950 code (no GPU needed): the three coupling-layer kernels run on
     v_mfma_f64_16x16x4_f64, feed it with ds_read_b64 (the Makefile switches the ds_read2_b64 pairing off: half the LDS
-    bandwidth) and use no scratch memory (no register spills)."""
+    bandwidth) and use no scratch memory (no register spills); the forward and the backward are built for kernel-argument
+    preload (round 5: their first loads do not wait for a scalar fetch of the argument segment)."""
     import re
     import subprocess
     from fthmc_amd import _lib
@@ -463,11 +464,17 @@ def test_hot_kernels_are_what_the_build_intends(tmp_path):
             for key in ('k_flow_fwd', 'k_flow_bwd_gather', 'k_flow_wgrad'):
                 if key in name:
                     m = re.search(r'\.name:\s+' + re.escape(name) + r'\s.*?\.private_segment_fixed_size:\s+(\d+)', notes, flags=re.S)
+                    # a kernel built for kernel-argument preload starts with the fall-back prologue for firmware without it: scalar
+                    # loads of the preloaded arguments, one wait, a branch over the padding to the real entry 256 bytes in
+                    head = body.split('\n')[:8]
+                    preload = any('s_branch' in l for l in head) and sum('s_load_dword' in l for l in head) >= 2
                     seen.setdefault(key, []).append((body.count('v_mfma_f64_16x16x4'), body.count('ds_read2_b64'),
-                                                     body.count('ds_read_b64'), int(m.group(1)) if m else -1))
+                                                     body.count('ds_read_b64'), int(m.group(1)) if m else -1, preload))
     assert set(seen) == {'k_flow_fwd', 'k_flow_bwd_gather', 'k_flow_wgrad'}, seen.keys()
     for key, variants in seen.items():
-        for mfma, read2, read1, scratch in variants:
+        for mfma, read2, read1, scratch, preload in variants:
+            # the two coupling kernels take their hot arguments as explicit scalars delivered with the wave (csrc/Makefile PRELOAD)
+            assert preload == (key in ('k_flow_fwd', 'k_flow_bwd_gather')), f'{key}: kernel-argument preload prologue {preload}'
             assert mfma > 0 and read1 > 0, (key, mfma, read1)
             # the one paired read the ISel itself forms is conv2's bias pair (the accumulator's start value, once per tile);
             # with the pairing passes on there are dozens, in the MFMA operand streams

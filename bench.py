@@ -366,13 +366,16 @@ def main():
             enqueue()                       # warm allocator / workspaces before capture (trajectory 0's draws)
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
+            # The weights do not change while sampling: the captured sequence carries no weight expansion (ops.assume_packed: the
+            # C ABI's fthmc_hint_weights_packed ahead of every call), the workspaces of its streams get it ONCE below.
             # thread_local: the process group's watchdog thread may poll its events while this thread captures
-            with torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
+            with ops.assume_packed(), torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
                 enqueue()
             if flowed:                      # the stateless variant of the same trajectory, for the side figure below
                 graph_sl = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_sl, stream=stream, capture_error_mode='thread_local'):
+                with ops.assume_packed(), torch.cuda.graph(graph_sl, stream=stream, capture_error_mode='thread_local'):
                     enqueue(stateless=True)
+                ops.pack_trajectory_workspaces(x, w, N_LAYERS, groups=Gsplit)
 
     traj = [0]
     pending = [None]

@@ -297,3 +297,35 @@ def test_two_captured_loops_with_different_flows_do_not_disturb_each_other():
     assert torch.equal(torch.stack(hb1['dh'] + hb2['dh']), want['b'][0]) and torch.equal(fb.x_last, want['b'][1])
     plain = pickle.loads(pickle.dumps(ha1))                               # a LazyHistory travels as the dict it stands for
     assert type(plain) is dict and torch.equal(torch.stack(plain['dh']), torch.stack(ha1['dh']))
+
+
+# ---------------------------------------------------------------- more of the headline size against the oracle
+def test_headline_size_two_chain_groups_against_the_oracle():
+    """BASELINE configs[2] at its own lattice size and depth (L = 64, beta = 6, 8 layers), 24 chains = two chain groups on two
+    streams: S_eff, log det J, plaquette, Q, the force and ONE WHOLE 10-step trajectory (H0, H1, dH, accepts, end field) against
+    the oracle on all 24 chains (the round-4 suite compared 3 chains at this size; bench.py compares 128 in every run)."""
+    B, L, nl, beta, dt, nstep = 24, 64, 8, 6.0, 0.1, 10
+    gen = torch.Generator().manual_seed(4242)
+    flow = R.default_flow(nl, gen)
+    w = ops.pack_weights(flow, device='cuda')
+    x = 0.35 * (torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1)        # near-cold, as the bench's chains
+    v = torch.randn(B, 2, L, L, generator=gen, dtype=torch.float64)
+    u = torch.rand(B, generator=gen, dtype=torch.float64)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    y, ld = R.flow_forward(x, flow)
+    Sg, ldg, pg, qg = ops.ft_action(x.cuda(), w, nl, beta)
+    np.testing.assert_allclose(H(ldg), H(ld), rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(H(Sg), H(R.ft_action(x, flow, beta)), rtol=1e-12)
+    np.testing.assert_allclose(H(pg), H(R.plaq_mean(y, beta)), rtol=1e-12)
+    np.testing.assert_allclose(H(qg), H(R.charge(y)), atol=1e-8)
+    F = R.ft_force(x, flow, beta)
+    np.testing.assert_allclose(H(ops.ft_force(x.cuda(), w, nl, beta)), H(F), rtol=1e-8, atol=1e-9 * float(F.abs().max()))
+    dH, _, acc, newx, h0, h1 = R.ft_hmc(x, v, u, flow, beta, dt, nstep, mode='md')
+    r = ops.ft_trajectory(x.cuda(), v.cuda(), u.cuda(), w, nl, beta, dt, nstep, mode='md', groups=2)
+    np.testing.assert_allclose(H(r['H0']), H(h0), rtol=1e-12)
+    np.testing.assert_allclose(H(r['H1']), H(h1), rtol=1e-9)                     # ten MD steps amplify rounding
+    np.testing.assert_allclose(H(r['dH']), H(dH), rtol=0, atol=1e-6 * float(h1.abs().max()))
+    border = (u - torch.exp(-dH)).abs() < 1e-9
+    assert bool((((r['acc'].cpu() > 0.5) == acc) | border).all())
+    d = (r['x_new'].cpu() - newx + math.pi) % (2 * math.pi) - math.pi
+    assert float(d.abs().max()) < 1e-6

@@ -54,7 +54,9 @@ template <int TR, int TC> struct SmemF {
 // -amdgpu-kernarg-preload-count=16; 15 dwords here), so the first loads of a workgroup do not wait for a scalar load of a cold
 // argument segment; the block itself (A0) serves what is needed later or rarely.  hoa = off | act << 8 | flags << 16
 // (13 dwords: the preload takes 14).
-template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT>
+// SILU: the activation (A.act: silu / relu / leaky_relu, layers.py:124-135) is the reference's default and known at compile time:
+// the other two activations' code and the tests on `act` around every sigmoid-of-four leave the kernel (trajectory -0.9 %).
+template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT, bool SILU>
 __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const double* hx, const double* hw, double* hy, double* hstash, double* hlogj,
                                                                           int hB, int hL, unsigned hoa, FlowLayerArgs A0) {
     FlowLayerArgs A = A0;
@@ -75,7 +77,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int mu = MU;
-    const int L = A.L, off = A.off, act = A.act;
+    const int L = A.L, off = A.off, act = SILU ? (int)FTHMC_ACT_SILU : A.act;
     const int n = L * L;
     const int nti_ = (A.L + TR - 1) / TR, ntj_ = (A.L + TC - 1) / TC;
     BlockTile bt;
@@ -578,7 +580,8 @@ int g_variant = 1;
 }  // namespace
 
 namespace {
-#define FWD_LAUNCH(...) hipLaunchKernelGGL((k_flow_fwd<__VA_ARGS__>), grid, dim3(NT), 0, s, a.x, a.wint, a.y, a.stash, a.logj_part, a.B, a.L, hoa, a)
+#define FWD_LAUNCH_(...) hipLaunchKernelGGL((k_flow_fwd<__VA_ARGS__>), grid, dim3(NT), 0, s, a.x, a.wint, a.y, a.stash, a.logj_part, a.B, a.L, hoa, a)
+#define FWD_LAUNCH(...) do { if (a.act == FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, true); else FWD_LAUNCH_(__VA_ARGS__, false); } while (0)
 template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hipStream_t s) {
     constexpr int TR = fthmc::MF_FWD_TR, TC = fthmc::MF_FWD_TC;
     const unsigned hoa = (unsigned)a.off | (unsigned)a.act << 8 | (a.pout ? FWD_HAS_POUT : 0u) | (a.dbg ? FWD_HAS_DBG : 0u) | (a.pin ? FWD_HAS_PIN : 0u);

@@ -68,7 +68,10 @@ template <int TR, int TC> struct SmemG {
 // one of the two conv2^T code paths).
 // EXACT: the tiles divide the lattice and L is a power of two (64, 128, 256): every own site is a lattice site, the lattice-edge
 // tests fold away, a window line wraps by one v_and.
-template <int TR, int TC, bool FASTW, int MU, bool EXACT>
+// FS: the launch is a layer of a FORCE sweep (all 160 backward launches of a trajectory): upstream gradient = the plaquette-gradient
+// field, dL/dlogJ a constant, no pre-activation gradients written -- the tests on those (uniform) conditions and the code behind
+// the other outcomes leave the kernel.  false: whatever the argument block says (standalone VJPs, training).
+template <int TR, int TC, bool FASTW, int MU, bool EXACT, bool FS>
 // Hot arguments as explicit scalars ahead of the argument block (kernarg preload, as k_flow_fwd): 13 dwords.
 // hoa = off | act << 8 | flags << 16.
 __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const double* hw, double* hstash, const double* hup_gp, double* hgp_out, double hglogj_const,
@@ -76,8 +79,9 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     FlowLayerArgs A = A0;
     A.wint = hw; A.stash = hstash; A.up_gp = hup_gp; A.gp_out = hgp_out; A.glogj_const = hglogj_const; A.B = hB; A.L = hL;
     A.off = (int)(hoa & 0xffu); A.act = (int)((hoa >> 8) & 0xffu);
-    const bool has_uplink = (hoa & BWD_HAS_UPLINK) != 0, has_glogj = (hoa & BWD_HAS_GLOGJ) != 0, has_gz = (hoa & BWD_HAS_GZ) != 0,
-               has_dbg = (hoa & BWD_HAS_DBG) != 0;
+    const bool has_uplink = !FS && (hoa & BWD_HAS_UPLINK) != 0, has_glogj = !FS && (hoa & BWD_HAS_GLOGJ) != 0,
+               has_gz = !FS && (hoa & BWD_HAS_GZ) != 0, has_dbg = (hoa & BWD_HAS_DBG) != 0;
+    const bool has_upgp = FS || A.up_gp != nullptr;
     using S = SmemG<TR, TC>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
     constexpr int W1R = S::W1R, W1C = S::W1C, N3 = S::N3, PS1 = S::PS1, PS2 = S::PS2, RS2 = S::RS2;
@@ -199,9 +203,9 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     const bool ovalid = tid < N3 && (EXACT || (orr < rmax && occ < cmax));
     double gpin;
     {
-        const double* gsrc = A.up_gp ? uniform_ptr(A.up_gp, (size_t)b * n) : scs;   // no pass-through without up_gp
+        const double* gsrc = has_upgp ? uniform_ptr(A.up_gp, (size_t)b * n) : scs;   // no pass-through without up_gp
         gpin = ldu(gsrc, ovalid ? (unsigned)(mul24(i0 + orr, L) + j0 + occ) : 0u);
-        if (!ovalid || !A.up_gp) gpin = 0.0;
+        if (!ovalid || !has_upgp) gpin = 0.0;
     }
     // (4) act'(z2) and act'(z1) go straight into the registers of the thread that multiplies by them
     //     (conv3^T task layout / conv2^T epilogue layout), never through LDS: they are issued here with
@@ -520,7 +524,9 @@ int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s) {
     const bool exact = fast && a.L % MG_TR == 0 && a.L % MG_TC == 0 && (a.L & (a.L - 1)) == 0;
     const unsigned hoa = (unsigned)a.off | (unsigned)a.act << 8 | (a.up_link ? BWD_HAS_UPLINK : 0u) | (a.glogj ? BWD_HAS_GLOGJ : 0u) |
                          (a.gz ? BWD_HAS_GZ : 0u) | (a.dbg ? BWD_HAS_DBG : 0u);
-#define BWD_LAUNCH(...) hipLaunchKernelGGL((k_flow_bwd_gather<__VA_ARGS__>), grid, dim3(NT), 0, s, a.wint, a.stash, a.up_gp, a.gp_out, a.glogj_const, a.B, a.L, hoa, a)
+    const bool force_sweep = a.up_gp && !a.up_link && !a.glogj && !a.gz;       // what the FS instances serve
+#define BWD_LAUNCH_(...) hipLaunchKernelGGL((k_flow_bwd_gather<__VA_ARGS__>), grid, dim3(NT), 0, s, a.wint, a.stash, a.up_gp, a.gp_out, a.glogj_const, a.B, a.L, hoa, a)
+#define BWD_LAUNCH(...) do { if (force_sweep) BWD_LAUNCH_(__VA_ARGS__, true); else BWD_LAUNCH_(__VA_ARGS__, false); } while (0)
     if (a.mu == 0) {
         if (exact) BWD_LAUNCH(MG_TR, MG_TC, true, 0, true);
         else if (fast) BWD_LAUNCH(MG_TR, MG_TC, true, 0, false);

@@ -56,13 +56,19 @@ template <int TR, int TC> struct SmemF {
 // (13 dwords: the preload takes 14).
 // SILU: the activation (A.act: silu / relu / leaky_relu, layers.py:124-135) is the reference's default and known at compile time:
 // the other two activations' code and the tests on `act` around every sigmoid-of-four leave the kernel (trajectory -0.9 %).
-template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT, bool SILU>
+// SWEEP = 1: the launch is a layer of a FORCE sweep (the forward's hot case: 160 of the 176 launches of a trajectory) -- link
+// field in and out, activation stash without h1 / h2, no log J, no plaquette-level map -- so every test on those (uniform)
+// conditions and the code behind the other outcome leave the kernel.  0: whatever the argument block says.
+template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT, bool SILU, int SWEEP>
 __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const double* hx, const double* hw, double* hy, double* hstash, double* hlogj,
                                                                           int hB, int hL, unsigned hoa, FlowLayerArgs A0) {
     FlowLayerArgs A = A0;
     A.x = hx; A.wint = hw; A.y = hy; A.stash = hstash; A.logj_part = hlogj; A.B = hB; A.L = hL;
     A.off = (int)(hoa & 0xffu); A.act = (int)((hoa >> 8) & 0xffu);
-    const bool has_pout = (hoa & FWD_HAS_POUT) != 0, has_dbg = (hoa & FWD_HAS_DBG) != 0, has_pin = (hoa & FWD_HAS_PIN) != 0;
+    constexpr bool FS = SWEEP == 1;
+    const bool has_pout = !FS && (hoa & FWD_HAS_POUT) != 0, has_dbg = (hoa & FWD_HAS_DBG) != 0, has_pin = !FS && (hoa & FWD_HAS_PIN) != 0;
+    const bool has_stash = FS || A.stash != nullptr, has_y = FS || A.y != nullptr, want_logj = !FS && A.logj_part != nullptr;
+    const bool stash_h = !FS && has_stash && A0.stash_h != 0;
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
@@ -114,7 +120,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
     }
     // the tile's own links for the final link update: issued now, consumed in the last stage
     double xv0 = 0.0, xv1 = 0.0;
-    if ((A.y || has_pout) && tid < N3) {
+    if ((has_y || has_pout) && tid < N3) {
         const int r = fdiv<TC>(tid), c = tid - r * TC;
         if (EXACT || (i0 + r < L && j0 + c < L)) {
             const unsigned at = (unsigned)(mul24(i0 + r, L) + j0 + c);
@@ -171,7 +177,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
             } else {
                 sIn[at] = cs;
                 sIn[PS0 + at] = sn;
-                if (A.stash && (unsigned)(r - 3) < (unsigned)(EXACT ? TR : min(TR, L - i0)) &&
+                if (has_stash && (unsigned)(r - 3) < (unsigned)(EXACT ? TR : min(TR, L - i0)) &&
                     (unsigned)(c - 3) < (unsigned)(EXACT ? TC : min(TC, L - j0))) {         // the net input of the tile's own frozen sites
                     double* cs_ = uniform_ptr(A.stash, ((size_t)A.B * 18 + b) * n);
                     const unsigned fi = (unsigned)stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
@@ -194,13 +200,13 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
     // stash of this lane's output channels 2 g, 2 g + 1, g = lane >> 4 (fixed for the kernel): act' channel-minor
     // (one 16-byte store per site), and so is h (training)
     const int rmax = EXACT ? TR : min(TR, L - i0), cmax = EXACT ? TC : min(TC, L - j0);    // tile sites inside the lattice
-    const Stash sv = A.stash ? stash_view(A.stash, A.B, b, n) : Stash{};
+    const Stash sv = has_stash ? stash_view(A.stash, A.B, b, n) : Stash{};
     typedef double double2_t __attribute__((ext_vector_type(2)));
     // uniform plane bases (SGPRs) + this lane's channel pair as part of the 32-bit element index
-    double* const st_d1 = sv.d1 ? uniform_ptr(sv.d1, 0) : nullptr;
-    double* const st_d2 = sv.d1 ? uniform_ptr(sv.d2, 0) : nullptr;
-    double* const st_h1 = sv.d1 ? uniform_ptr(sv.h1, 0) : nullptr;
-    double* const st_h2 = sv.d1 ? uniform_ptr(sv.h2, 0) : nullptr;
+    double* const st_d1 = has_stash ? uniform_ptr(sv.d1, 0) : nullptr;
+    double* const st_d2 = has_stash ? uniform_ptr(sv.d2, 0) : nullptr;
+    double* const st_h1 = has_stash ? uniform_ptr(sv.h1, 0) : nullptr;
+    double* const st_h2 = has_stash ? uniform_ptr(sv.h2, 0) : nullptr;
     const unsigned stg = 2u * (unsigned)(lane >> 4);
 
     // ---- conv1 (2 -> 8) + act on the tile+2 window ---------------------------
@@ -249,18 +255,18 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
             const int ds = mu == 0 ? 1 : RS1;
             double* ph = sH1 + 2 * g * PS1 + r * RS1 + c;
             ph[0] = h[0]; ph[PS1] = h[1]; ph[ds] = h[2]; ph[PS1 + ds] = h[3];
-            if (FT_RECOMP_D1 ? (A.stash && A.stash_h) : (A.stash != nullptr)) {   // act'(z1) (and h1) of the tile's own sites
+            if (FT_RECOMP_D1 ? stash_h : has_stash) {   // act'(z1) (and h1) of the tile's own sites
                 const int r0 = r - 2, c0 = c - 2, r1 = mu == 0 ? r0 : r0 + 1, c1 = mu == 0 ? c0 + 1 : c0;
                 const int at = mul24(i0 + r0, L) + j0 + c0, dat = mu == 0 ? 1 : L;
                 // act'(z1) of a mu = 0 layer: transposed site index (FT_D1_T): the lanes of a tile run down a column
                 const int atd = (FT_D1_T && mu == 0) ? mul24(j0 + c0, L) + i0 + r0 : at, datd = (FT_D1_T && mu == 0) ? L : dat;
                 if ((unsigned)r0 < (unsigned)rmax && (unsigned)c0 < (unsigned)cmax) {
                     if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)atd + stg, double2_t{d[0], d[1]});
-                    if (A.stash_h) stu2(st_h1, 8u * (unsigned)at + stg, double2_t{h[0], h[1]});
+                    if (stash_h) stu2(st_h1, 8u * (unsigned)at + stg, double2_t{h[0], h[1]});
                 }
                 if ((unsigned)r1 < (unsigned)rmax && (unsigned)c1 < (unsigned)cmax) {
                     if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)(atd + datd) + stg, double2_t{d[2], d[3]});
-                    if (A.stash_h) stu2(st_h1, 8u * (unsigned)(at + dat) + stg, double2_t{h[2], h[3]});
+                    if (stash_h) stu2(st_h1, 8u * (unsigned)(at + dat) + stg, double2_t{h[2], h[3]});
                 }
             }
         };
@@ -286,12 +292,12 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
         double h, d;
         act_eval(z, act, h, d);
         sH1[co * PS1 + r * RS1 + c] = h;
-        if (A.stash) {
+        if (has_stash) {
             const int rr = r - 2, cc = c - 2;
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
                 const int at = mul24(i0 + rr, L) + j0 + cc;
                 if (!FT_RECOMP_D1) stu(st_d1, 8u * (unsigned)((FT_D1_T && mu == 0) ? mul24(j0 + cc, L) + i0 + rr : at) + (unsigned)co, d);
-                if (A.stash_h) stu(st_h1, 8u * (unsigned)at + (unsigned)co, h);
+                if (stash_h) stu(st_h1, 8u * (unsigned)at + (unsigned)co, h);
             }
         }
     }
@@ -321,14 +327,14 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
             double* ph = sH2 + 2 * g * PS2 + r * R2C + c;
             ph[0] = h[0]; ph[PS2] = h[1]; ph[so] = h[2]; ph[PS2 + so] = h[3];
         }
-        if (A.stash && ok) {                                // act'(z2) (and h2) of the tile's own sites
+        if (has_stash && ok) {                                // act'(z2) (and h2) of the tile's own sites
             const int at = mul24(i0 + r - 1, L) + j0 + c - 1;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 if ((unsigned)(r - 1 + q * dr) < (unsigned)rmax && (unsigned)(c - 1 + q * dc) < (unsigned)cmax) {
                     const int aq = at + q * (dr * L + dc);
                     stu2(st_d2, 8u * (unsigned)aq + stg, double2_t{d[2 * q], d[2 * q + 1]});
-                    if (A.stash_h) stu2(st_h2, 8u * (unsigned)aq + stg, double2_t{h[2 * q], h[2 * q + 1]});
+                    if (stash_h) stu2(st_h2, 8u * (unsigned)aq + stg, double2_t{h[2 * q], h[2 * q + 1]});
                 }
         }
     };
@@ -463,13 +469,13 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
                 lj = -(log(fp));                                     // log J of the inverse = -log mean_k 1/D_k at the root
             }
             if (avalid) sDL[ar * TC + ac] = has_pout ? xsol : dl;
-            if (A.logj_part) {
+            if (want_logj) {
                 const double tot = ft_wave_sum(avalid ? lj : 0.0);
                 if (lane == 0) A.logj_part[(size_t)b * ntiles + tile] = tot;
             }
         }
         lds_barrier();
-        if (A.y && tid < N3) {
+        if (has_y && tid < N3) {
             const int r = fdiv<TC>(tid), c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
             if (EXACT || (i < L && j < L)) {
@@ -510,7 +516,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
         sT2[(wave * TQ + 1) * NAS + lane] = invD;
         // tan(P/2) = sn / cs: |cs| can be tiny (P near +-pi) -- a true division keeps the correctly rounded quotient there
         sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
-        if (A.stash && avalid) {
+        if (has_stash && avalid) {
             // coefficients of the transform's adjoint (struct Stash): the backward kernel then needs no
             // plaquettes, sincos or exp at the active sites of its tile+3 window
             const double sinP = 2.0 * sincs, invD2 = invD * invD;
@@ -544,14 +550,14 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
             const double tval = sP[(ar + 3) * R0C + ac + 3 + 3 * (mu == 0 ? 1 : R0C)];
             const double newP = ft_wrap(ysum / NMIX + tval);
             if (avalid) sDL[ar * TC + ac] = has_pout ? newP : newP - Pa;
-            if (A.logj_part) {                                       // force sweeps do not ask for log J
+            if (want_logj) {                                       // force sweeps do not ask for log J
                 const double lj = avalid ? log(si) - log((double)NMIX) : 0.0;
                 const double tot = ft_wave_sum(lj);
                 if (lane == 0) A.logj_part[(size_t)b * ntiles + tile] = tot;
             }
         }
         lds_barrier();
-        if (A.y && tid < N3) {
+        if (has_y && tid < N3) {
             const int r = fdiv<TC>(tid), c = tid - r * TC;
             const int i = i0 + r, j = j0 + c;
             if (EXACT || (i < L && j < L)) {
@@ -581,10 +587,13 @@ int g_variant = 1;
 
 namespace {
 #define FWD_LAUNCH_(...) hipLaunchKernelGGL((k_flow_fwd<__VA_ARGS__>), grid, dim3(NT), 0, s, a.x, a.wint, a.y, a.stash, a.logj_part, a.B, a.L, hoa, a)
-#define FWD_LAUNCH(...) do { if (a.act == FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, true); else FWD_LAUNCH_(__VA_ARGS__, false); } while (0)
+#define FWD_LAUNCH(...) do { if (a.act != FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, false, 0); else if (force_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 1); \
+                             else FWD_LAUNCH_(__VA_ARGS__, true, 0); } while (0)
 template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hipStream_t s) {
     constexpr int TR = fthmc::MF_FWD_TR, TC = fthmc::MF_FWD_TC;
     const unsigned hoa = (unsigned)a.off | (unsigned)a.act << 8 | (a.pout ? FWD_HAS_POUT : 0u) | (a.dbg ? FWD_HAS_DBG : 0u) | (a.pin ? FWD_HAS_PIN : 0u);
+    // the SWEEP = 1 instances serve exactly this combination (a layer of a force sweep)
+    const bool force_sweep = !REV && a.y && a.stash && !a.stash_h && !a.logj_part && !a.pin && !a.pout;
     const bool fast = wrap_fast_ok(a.L, TR, TC);
     const bool exact = fast && a.L % TR == 0 && a.L % TC == 0 && (a.L & (a.L - 1)) == 0;
     if (a.mu == 0) {

@@ -885,6 +885,7 @@ int fthmc_time_kernel(int kind, const double* x, const double* w, const fthmc_ar
 #endif
         if (C.mfma) {            // the hot path: forward stashes, backward reads the stash
             a.stash = W.stash;
+            a.logj_part = nullptr;       // ... and asks for no log J: exactly what a layer of a force sweep launches (the SWEEP / FS instances)
             FT_TRY(launch_flow_fwd_mfma(a, s));
         }
     } else {
@@ -980,9 +981,10 @@ int fthmc_profile_stages(int kind, const double* x, const double* w, const fthmc
     FT_TRY(use_weights(C, w, 1, W, s));
     FT_TRY(launch_wilson_gp(x, B, L, beta, W.gp, s));
     FlowLayerArgs a{};
-    a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = W.lj_part;
+    a.x = x; a.wint = W.wint; a.y = W.X; a.logj_part = train ? W.lj_part : nullptr;      // kind 0, 1: the launch of a force sweep
     a.up_gp = W.gp; a.glogj_const = -1.0; a.gp_part = W.gp_part; a.gp_out = W.gp2; a.dbg = dbg;
     a.B = B; a.L = L; a.mu = mu; a.off = off; a.act = act;
+    if (kind == 0) a.stash = W.stash;             // the forward as a force sweep launches it: with the activation stash, without log J
     if (kind >= 1) {                              // stash backward needs the forward's stash first
         a.stash = W.stash; a.stash_h = train ? 1 : 0; a.gw_part = W.gw_part; a.gz = train ? W.gz : nullptr; a.dbg = nullptr;
         FT_TRY(launch_flow_fwd_mfma(a, s));

@@ -68,10 +68,11 @@ template <int TR, int TC> struct SmemG {
 // one of the two conv2^T code paths).
 // EXACT: the tiles divide the lattice and L is a power of two (64, 128, 256): every own site is a lattice site, the lattice-edge
 // tests fold away, a window line wraps by one v_and.
-// FS: the launch is a layer of a FORCE sweep (all 160 backward launches of a trajectory): upstream gradient = the plaquette-gradient
+// SWEEP >= 1 (FS): the launch is a layer of a FORCE sweep (all 160 backward launches of a trajectory): upstream gradient = the plaquette-gradient
 // field, dL/dlogJ a constant, no pre-activation gradients written -- the tests on those (uniform) conditions and the code behind
-// the other outcomes leave the kernel.  false: whatever the argument block says (standalone VJPs, training).
-template <int TR, int TC, bool FASTW, int MU, bool EXACT, bool FS>
+// the other outcomes leave the kernel; SWEEP = 1 also drops the cycle stamps of the diagnostic launches (those run SWEEP = 2).
+// 0: whatever the argument block says (standalone VJPs, training).
+template <int TR, int TC, bool FASTW, int MU, bool EXACT, int SWEEP>
 // Hot arguments as explicit scalars ahead of the argument block (kernarg preload, as k_flow_fwd): 13 dwords.
 // hoa = off | act << 8 | flags << 16.
 __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const double* hw, double* hstash, const double* hup_gp, double* hgp_out, double hglogj_const,
@@ -79,8 +80,9 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     FlowLayerArgs A = A0;
     A.wint = hw; A.stash = hstash; A.up_gp = hup_gp; A.gp_out = hgp_out; A.glogj_const = hglogj_const; A.B = hB; A.L = hL;
     A.off = (int)(hoa & 0xffu); A.act = (int)((hoa >> 8) & 0xffu);
+    constexpr bool FS = SWEEP >= 1;
     const bool has_uplink = !FS && (hoa & BWD_HAS_UPLINK) != 0, has_glogj = !FS && (hoa & BWD_HAS_GLOGJ) != 0,
-               has_gz = !FS && (hoa & BWD_HAS_GZ) != 0, has_dbg = (hoa & BWD_HAS_DBG) != 0;
+               has_gz = !FS && (hoa & BWD_HAS_GZ) != 0, has_dbg = SWEEP != 1 && (hoa & BWD_HAS_DBG) != 0;
     const bool has_upgp = FS || A.up_gp != nullptr;
     using S = SmemG<TR, TC>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
@@ -526,7 +528,8 @@ int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s) {
                          (a.gz ? BWD_HAS_GZ : 0u) | (a.dbg ? BWD_HAS_DBG : 0u);
     const bool force_sweep = a.up_gp && !a.up_link && !a.glogj && !a.gz;       // what the FS instances serve
 #define BWD_LAUNCH_(...) hipLaunchKernelGGL((k_flow_bwd_gather<__VA_ARGS__>), grid, dim3(NT), 0, s, a.wint, a.stash, a.up_gp, a.gp_out, a.glogj_const, a.B, a.L, hoa, a)
-#define BWD_LAUNCH(...) do { if (force_sweep) BWD_LAUNCH_(__VA_ARGS__, true); else BWD_LAUNCH_(__VA_ARGS__, false); } while (0)
+#define BWD_LAUNCH(...) do { if (force_sweep && !a.dbg) BWD_LAUNCH_(__VA_ARGS__, 1); else if (force_sweep) BWD_LAUNCH_(__VA_ARGS__, 2); \
+                             else BWD_LAUNCH_(__VA_ARGS__, 0); } while (0)
     if (a.mu == 0) {
         if (exact) BWD_LAUNCH(MG_TR, MG_TC, true, 0, true);
         else if (fast) BWD_LAUNCH(MG_TR, MG_TC, true, 0, false);

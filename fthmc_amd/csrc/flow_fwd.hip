@@ -58,17 +58,21 @@ template <int TR, int TC> struct SmemF {
 // the other two activations' code and the tests on `act` around every sigmoid-of-four leave the kernel (trajectory -0.9 %).
 // SWEEP = 1: the launch is a layer of a FORCE sweep (the forward's hot case: 160 of the 176 launches of a trajectory) -- link
 // field in and out, activation stash without h1 / h2, no log J, no plaquette-level map -- so every test on those (uniform)
-// conditions and the code behind the other outcome leave the kernel.  0: whatever the argument block says.
+// conditions and the code behind the other outcome leave the kernel, and so do the cycle stamps of the diagnostic launches
+// (tools/lifetime.py, fthmc_profile_stages: those run SWEEP = 2, the same specialization WITH the stamps).  SWEEP = 3: a layer
+// of an ACTION sweep (the H1 sweep of a trajectory, ft_action: link field in and out, log J, no stash).  0: whatever the
+// argument block says.
 template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT, bool SILU, int SWEEP>
 __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const double* hx, const double* hw, double* hy, double* hstash, double* hlogj,
                                                                           int hB, int hL, unsigned hoa, FlowLayerArgs A0) {
     FlowLayerArgs A = A0;
     A.x = hx; A.wint = hw; A.y = hy; A.stash = hstash; A.logj_part = hlogj; A.B = hB; A.L = hL;
     A.off = (int)(hoa & 0xffu); A.act = (int)((hoa >> 8) & 0xffu);
-    constexpr bool FS = SWEEP == 1;
-    const bool has_pout = !FS && (hoa & FWD_HAS_POUT) != 0, has_dbg = (hoa & FWD_HAS_DBG) != 0, has_pin = !FS && (hoa & FWD_HAS_PIN) != 0;
-    const bool has_stash = FS || A.stash != nullptr, has_y = FS || A.y != nullptr, want_logj = !FS && A.logj_part != nullptr;
-    const bool stash_h = !FS && has_stash && A0.stash_h != 0;
+    constexpr bool FS = SWEEP == 1 || SWEEP == 2, ES = SWEEP == 3, SW = FS || ES;
+    const bool has_pout = !SW && (hoa & FWD_HAS_POUT) != 0, has_pin = !SW && (hoa & FWD_HAS_PIN) != 0;
+    const bool has_dbg = (SWEEP == 0 || SWEEP == 2) && (hoa & FWD_HAS_DBG) != 0;
+    const bool has_stash = FS || (!ES && A.stash != nullptr), has_y = SW || A.y != nullptr, want_logj = ES || (!FS && A.logj_part != nullptr);
+    const bool stash_h = !SW && has_stash && A0.stash_h != 0;
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
@@ -587,13 +591,16 @@ int g_variant = 1;
 
 namespace {
 #define FWD_LAUNCH_(...) hipLaunchKernelGGL((k_flow_fwd<__VA_ARGS__>), grid, dim3(NT), 0, s, a.x, a.wint, a.y, a.stash, a.logj_part, a.B, a.L, hoa, a)
-#define FWD_LAUNCH(...) do { if (a.act != FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, false, 0); else if (force_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 1); \
+#define FWD_LAUNCH(...) do { if (a.act != FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, false, 0); \
+                             else if (force_sweep && !a.dbg) FWD_LAUNCH_(__VA_ARGS__, true, 1); \
+                             else if (force_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 2); else if (action_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 3); \
                              else FWD_LAUNCH_(__VA_ARGS__, true, 0); } while (0)
 template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hipStream_t s) {
     constexpr int TR = fthmc::MF_FWD_TR, TC = fthmc::MF_FWD_TC;
     const unsigned hoa = (unsigned)a.off | (unsigned)a.act << 8 | (a.pout ? FWD_HAS_POUT : 0u) | (a.dbg ? FWD_HAS_DBG : 0u) | (a.pin ? FWD_HAS_PIN : 0u);
     // the SWEEP = 1 instances serve exactly this combination (a layer of a force sweep)
     const bool force_sweep = !REV && a.y && a.stash && !a.stash_h && !a.logj_part && !a.pin && !a.pout;
+    const bool action_sweep = !REV && a.y && !a.stash && a.logj_part && !a.pin && !a.pout && !a.dbg;
     const bool fast = wrap_fast_ok(a.L, TR, TC);
     const bool exact = fast && a.L % TR == 0 && a.L % TC == 0 && (a.L & (a.L - 1)) == 0;
     if (a.mu == 0) {

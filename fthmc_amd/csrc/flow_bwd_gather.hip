@@ -80,9 +80,9 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     FlowLayerArgs A = A0;
     A.wint = hw; A.stash = hstash; A.up_gp = hup_gp; A.gp_out = hgp_out; A.glogj_const = hglogj_const; A.B = hB; A.L = hL;
     A.off = (int)(hoa & 0xffu); A.act = (int)((hoa >> 8) & 0xffu);
-    constexpr bool FS = SWEEP >= 1;
+    constexpr bool FS = SWEEP >= 1, TS = SWEEP == 3;        // TS: a layer of a TRAINING sweep = a force sweep that also writes A.gz
     const bool has_uplink = !FS && (hoa & BWD_HAS_UPLINK) != 0, has_glogj = !FS && (hoa & BWD_HAS_GLOGJ) != 0,
-               has_gz = !FS && (hoa & BWD_HAS_GZ) != 0, has_dbg = SWEEP != 1 && (hoa & BWD_HAS_DBG) != 0;
+               has_gz = TS || (!FS && (hoa & BWD_HAS_GZ) != 0), has_dbg = (SWEEP == 0 || SWEEP == 2) && (hoa & BWD_HAS_DBG) != 0;
     const bool has_upgp = FS || A.up_gp != nullptr;
     using S = SmemG<TR, TC>;
     constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
@@ -526,18 +526,20 @@ int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s) {
     const bool exact = fast && a.L % MG_TR == 0 && a.L % MG_TC == 0 && (a.L & (a.L - 1)) == 0;
     const unsigned hoa = (unsigned)a.off | (unsigned)a.act << 8 | (a.up_link ? BWD_HAS_UPLINK : 0u) | (a.glogj ? BWD_HAS_GLOGJ : 0u) |
                          (a.gz ? BWD_HAS_GZ : 0u) | (a.dbg ? BWD_HAS_DBG : 0u);
-    const bool force_sweep = a.up_gp && !a.up_link && !a.glogj && !a.gz;       // what the FS instances serve
+    const bool force_sweep = a.up_gp && !a.up_link && !a.glogj && !a.gz, train_sweep = a.up_gp && !a.up_link && !a.glogj && a.gz && !a.dbg;       // what the FS instances serve
 #define BWD_LAUNCH_(...) hipLaunchKernelGGL((k_flow_bwd_gather<__VA_ARGS__>), grid, dim3(NT), 0, s, a.wint, a.stash, a.up_gp, a.gp_out, a.glogj_const, a.B, a.L, hoa, a)
 #define BWD_LAUNCH(...) do { if (force_sweep && !a.dbg) BWD_LAUNCH_(__VA_ARGS__, 1); else if (force_sweep) BWD_LAUNCH_(__VA_ARGS__, 2); \
+                             else if (train_sweep) BWD_LAUNCH_(__VA_ARGS__, 3); \
                              else BWD_LAUNCH_(__VA_ARGS__, 0); } while (0)
+    // the sweep specializations exist for the tiled-exactly shapes (L = 64, 128, 256); everything else runs the generic instance
     if (a.mu == 0) {
         if (exact) BWD_LAUNCH(MG_TR, MG_TC, true, 0, true);
-        else if (fast) BWD_LAUNCH(MG_TR, MG_TC, true, 0, false);
-        else BWD_LAUNCH(MG_TR, MG_TC, false, 0, false);
+        else if (fast) BWD_LAUNCH_(MG_TR, MG_TC, true, 0, false, 0);
+        else BWD_LAUNCH_(MG_TR, MG_TC, false, 0, false, 0);
     } else {
         if (exact) BWD_LAUNCH(MG_TR, MG_TC, true, 1, true);
-        else if (fast) BWD_LAUNCH(MG_TR, MG_TC, true, 1, false);
-        else BWD_LAUNCH(MG_TR, MG_TC, false, 1, false);
+        else if (fast) BWD_LAUNCH_(MG_TR, MG_TC, true, 1, false, 0);
+        else BWD_LAUNCH_(MG_TR, MG_TC, false, 1, false, 0);
     }
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }

@@ -60,19 +60,20 @@ template <int TR, int TC> struct SmemF {
 // field in and out, activation stash without h1 / h2, no log J, no plaquette-level map -- so every test on those (uniform)
 // conditions and the code behind the other outcome leave the kernel, and so do the cycle stamps of the diagnostic launches
 // (tools/lifetime.py, fthmc_profile_stages: those run SWEEP = 2, the same specialization WITH the stamps).  SWEEP = 3: a layer
-// of an ACTION sweep (the H1 sweep of a trajectory, ft_action: link field in and out, log J, no stash).  0: whatever the
-// argument block says.
+// of an ACTION sweep (the H1 sweep of a trajectory, ft_action: link field in and out, log J, no stash).  SWEEP = 4: a layer of a
+// TRAINING sweep (fthmc_train_grad: stash with h1 / h2, log J).  0: whatever the argument block says.
 template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT, bool SILU, int SWEEP>
 __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const double* hx, const double* hw, double* hy, double* hstash, double* hlogj,
                                                                           int hB, int hL, unsigned hoa, FlowLayerArgs A0) {
     FlowLayerArgs A = A0;
     A.x = hx; A.wint = hw; A.y = hy; A.stash = hstash; A.logj_part = hlogj; A.B = hB; A.L = hL;
     A.off = (int)(hoa & 0xffu); A.act = (int)((hoa >> 8) & 0xffu);
-    constexpr bool FS = SWEEP == 1 || SWEEP == 2, ES = SWEEP == 3, SW = FS || ES;
+    constexpr bool FS = SWEEP == 1 || SWEEP == 2, ES = SWEEP == 3, TS = SWEEP == 4, SW = FS || ES || TS;
     const bool has_pout = !SW && (hoa & FWD_HAS_POUT) != 0, has_pin = !SW && (hoa & FWD_HAS_PIN) != 0;
     const bool has_dbg = (SWEEP == 0 || SWEEP == 2) && (hoa & FWD_HAS_DBG) != 0;
-    const bool has_stash = FS || (!ES && A.stash != nullptr), has_y = SW || A.y != nullptr, want_logj = ES || (!FS && A.logj_part != nullptr);
-    const bool stash_h = !SW && has_stash && A0.stash_h != 0;
+    const bool has_stash = FS || TS || (!ES && A.stash != nullptr), has_y = SW || A.y != nullptr;
+    const bool want_logj = ES || TS || (!FS && A.logj_part != nullptr);
+    const bool stash_h = TS || (!SW && has_stash && A0.stash_h != 0);
     using S = SmemF<TR, TC>;
     using G = Geom<TR, TC>;
     constexpr int R0C = G::R0C, R1R = G::R1R, R1C = G::R1C, R2R = G::R2R, R2C = G::R2C;
@@ -591,9 +592,13 @@ int g_variant = 1;
 
 namespace {
 #define FWD_LAUNCH_(...) hipLaunchKernelGGL((k_flow_fwd<__VA_ARGS__>), grid, dim3(NT), 0, s, a.x, a.wint, a.y, a.stash, a.logj_part, a.B, a.L, hoa, a)
-#define FWD_LAUNCH(...) do { if (a.act != FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, false, 0); \
+// the silu / other-activation instances of a shape, generic in everything else
+#define FWD_LAUNCH(...) do { if (a.act != FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, false, 0); else FWD_LAUNCH_(__VA_ARGS__, true, 0); } while (0)
+// ... and with the sweep specializations (SWEEP template parameter): the forward map on the tiled-exactly shapes, silu
+#define FWD_LAUNCH_SWEEPS(...) do { if (a.act != FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, false, 0); \
                              else if (force_sweep && !a.dbg) FWD_LAUNCH_(__VA_ARGS__, true, 1); \
                              else if (force_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 2); else if (action_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 3); \
+                             else if (train_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 4); \
                              else FWD_LAUNCH_(__VA_ARGS__, true, 0); } while (0)
 template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hipStream_t s) {
     constexpr int TR = fthmc::MF_FWD_TR, TC = fthmc::MF_FWD_TC;
@@ -601,17 +606,19 @@ template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hi
     // the SWEEP = 1 instances serve exactly this combination (a layer of a force sweep)
     const bool force_sweep = !REV && a.y && a.stash && !a.stash_h && !a.logj_part && !a.pin && !a.pout;
     const bool action_sweep = !REV && a.y && !a.stash && a.logj_part && !a.pin && !a.pout && !a.dbg;
+    const bool train_sweep = !REV && a.y && a.stash && a.stash_h && a.logj_part && !a.pin && !a.pout && !a.dbg;
     const bool fast = wrap_fast_ok(a.L, TR, TC);
     const bool exact = fast && a.L % TR == 0 && a.L % TC == 0 && (a.L & (a.L - 1)) == 0;
     if (a.mu == 0) {
-        if (exact) FWD_LAUNCH(TR, TC, true, REV, 0, true);
+        if (exact) { if constexpr (REV) FWD_LAUNCH(TR, TC, true, REV, 0, true); else FWD_LAUNCH_SWEEPS(TR, TC, true, REV, 0, true); }
         else if (fast) FWD_LAUNCH(TR, TC, true, REV, 0, false);
         else FWD_LAUNCH(TR, TC, false, REV, 0, false);
     } else {
-        if (exact) FWD_LAUNCH(TR, TC, true, REV, 1, true);
+        if (exact) { if constexpr (REV) FWD_LAUNCH(TR, TC, true, REV, 1, true); else FWD_LAUNCH_SWEEPS(TR, TC, true, REV, 1, true); }
         else if (fast) FWD_LAUNCH(TR, TC, true, REV, 1, false);
         else FWD_LAUNCH(TR, TC, false, REV, 1, false);
     }
+    (void)force_sweep; (void)action_sweep; (void)train_sweep;
 }
 }  // namespace
 

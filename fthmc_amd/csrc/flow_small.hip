@@ -698,17 +698,20 @@ enum { SM_ACTION = 0, SM_FORCE = 1, SM_LEAPFROG = 2, SM_TRAJ = 3, SM_TRAIN = 4 }
 //                the Wilson action of the flowed field -> x, logq, logp; the seed (beta / B) sin P, every layer backward with
 //                dL/dlogJ = -1 / B, writing each layer's pre-activation gradients for k_flow_wgrad
 // The sweep loop has ONE call site of the layer bodies (the kernel is register- and code-size-bound otherwise).
-template <int L, bool TRAIN>
+// TRAJ: the launch is a whole trajectory (fthmc_ft_trajectory: the hot entry point of the small lattices): the other entry
+// points' branches leave that instance.  DBG: the stage stamps of tools/small_profile.py (A.dbg) exist in their own instance
+// of the generic kernel only: compiled out, config 2 runs 4 % faster (0.497 -> 0.477 ms per trajectory).
+template <int L, bool TRAIN, bool TRAJ, bool DBG>
 __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
     using G = GS<L>;
     constexpr int N = G::N;
     __shared__ __attribute__((aligned(16))) double sm[G::SIZE];
     const int b = blockIdx.x;
-    const Hot hot{Aarg.wint, Aarg.stash, Aarg.dbg, Aarg.B, Aarg.nl, Aarg.act, TRAIN ? Aarg.gz : nullptr};
+    const Hot hot{Aarg.wint, Aarg.stash, DBG ? Aarg.dbg : nullptr, Aarg.B, Aarg.nl, Aarg.act, TRAIN ? Aarg.gz : nullptr};
     Chain<L, TRAIN> C(sm, hot, b);
     const int tid = C.tid;
     double* red = sm + G::RED;
-    const int mode = TRAIN ? (int)SM_TRAIN : Aarg.mode, nl = hot.nl;
+    const int mode = TRAIN ? (int)SM_TRAIN : (TRAJ ? (int)SM_TRAJ : Aarg.mode), nl = hot.nl;
     const double beta = Aarg.beta, dt = Aarg.dt;
     const bool have_state = Aarg.state_in != nullptr;
     {
@@ -859,17 +862,35 @@ int launch_ft_small(const SmallArgs& a, int L, hipStream_t s) {
     if (a.mode == SM_TRAIN) {
         if (!a.gz) return FTHMC_ERR_ARG;
         switch (L) {
-            case 8: hipLaunchKernelGGL((k_ft_small<8, true>), grid, block, 0, s, a); break;
-            case 12: hipLaunchKernelGGL((k_ft_small<12, true>), grid, block, 0, s, a); break;
-            case 16: hipLaunchKernelGGL((k_ft_small<16, true>), grid, block, 0, s, a); break;
+            case 8: hipLaunchKernelGGL((k_ft_small<8, true, false, false>), grid, block, 0, s, a); break;
+            case 12: hipLaunchKernelGGL((k_ft_small<12, true, false, false>), grid, block, 0, s, a); break;
+            case 16: hipLaunchKernelGGL((k_ft_small<16, true, false, false>), grid, block, 0, s, a); break;
+            default: return FTHMC_ERR_UNSUPPORTED;
+        }
+        FT_LAUNCH_CHECK(); return FTHMC_OK;
+    }
+    if (a.dbg) {                                            // diagnostic launches: the generic kernel with its stage stamps
+        switch (L) {
+            case 8: hipLaunchKernelGGL((k_ft_small<8, false, false, true>), grid, block, 0, s, a); break;
+            case 12: hipLaunchKernelGGL((k_ft_small<12, false, false, true>), grid, block, 0, s, a); break;
+            case 16: hipLaunchKernelGGL((k_ft_small<16, false, false, true>), grid, block, 0, s, a); break;
+            default: return FTHMC_ERR_UNSUPPORTED;
+        }
+        FT_LAUNCH_CHECK(); return FTHMC_OK;
+    }
+    if (a.mode == SM_TRAJ) {
+        switch (L) {
+            case 8: hipLaunchKernelGGL((k_ft_small<8, false, true, false>), grid, block, 0, s, a); break;
+            case 12: hipLaunchKernelGGL((k_ft_small<12, false, true, false>), grid, block, 0, s, a); break;
+            case 16: hipLaunchKernelGGL((k_ft_small<16, false, true, false>), grid, block, 0, s, a); break;
             default: return FTHMC_ERR_UNSUPPORTED;
         }
         FT_LAUNCH_CHECK(); return FTHMC_OK;
     }
     switch (L) {
-        case 8: hipLaunchKernelGGL((k_ft_small<8, false>), grid, block, 0, s, a); break;
-        case 12: hipLaunchKernelGGL((k_ft_small<12, false>), grid, block, 0, s, a); break;
-        case 16: hipLaunchKernelGGL((k_ft_small<16, false>), grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_ft_small<8, false, false, false>), grid, block, 0, s, a); break;
+        case 12: hipLaunchKernelGGL((k_ft_small<12, false, false, false>), grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_ft_small<16, false, false, false>), grid, block, 0, s, a); break;
         default: return FTHMC_ERR_UNSUPPORTED;
     }
     FT_LAUNCH_CHECK(); return FTHMC_OK;

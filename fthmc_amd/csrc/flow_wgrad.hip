@@ -89,7 +89,8 @@ __device__ __forceinline__ void conv3_acc(const double* __restrict__ pg, const d
     }
 }
 
-template <int TR, int TC, bool FASTW>
+// DBG: the cycle stamps of the diagnostic launches (fthmc_profile_stages kind 3) exist in their own instance only
+template <int TR, int TC, bool FASTW, bool DBG>
 __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A) {
     using S = SmemW<TR, TC>;
     constexpr int PSG = S::PSG, PSH = S::PSH, W1C = S::W1C, NH = S::NH, NA = S::NA;
@@ -122,7 +123,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_wgrad(FlowLayerArgs A
     const double* __restrict__ gzl = uniform_ptr((const double*)A.gz, (size_t)lz * A.gz_lstride);
     const double* __restrict__ stl = uniform_ptr((const double*)A.stash, (size_t)lz * A.stash_lstride);
     double* gw0 = A.gw_part + (size_t)lz * A.gwp_lstride + (size_t)grp * FLOW_GW_STRIDE;         // the group's partial
-    long long* dbg = A.dbg ? A.dbg + (size_t)grp * 16 : nullptr;
+    long long* dbg = (DBG && A.dbg) ? A.dbg + (size_t)grp * 16 : nullptr;
 #define STAMP(k) do { if (dbg && tid0 == 0) dbg[k] = (long long)__builtin_readcyclecounter(); } while (0)
     STAMP(8);                                                              // 8 -> 9 prologue, 9 -> 10 the walk, 10 -> 11 epilogue
 
@@ -377,8 +378,10 @@ int launch_flow_wgrad(const FlowLayerArgs& a, hipStream_t s) {
     const int items = a.B * FlowGeom{MG_TR, MG_TC}.ntiles(a.L);
     const int KR = (items + b.tpw * b.wg_ns - 1) / (b.tpw * b.wg_ns), R = (KR + 7) / 8;
     const dim3 grid(8 * R * b.wg_ns, a.nlb > 0 ? a.nlb : 1, 1);
-    if (wrap_fast_ok(a.L, MG_TR, MG_TC)) hipLaunchKernelGGL((k_flow_wgrad<MG_TR, MG_TC, true>), grid, dim3(NT), 0, s, b);
-    else hipLaunchKernelGGL((k_flow_wgrad<MG_TR, MG_TC, false>), grid, dim3(NT), 0, s, b);
+    if (wrap_fast_ok(a.L, MG_TR, MG_TC)) {
+        if (b.dbg) hipLaunchKernelGGL((k_flow_wgrad<MG_TR, MG_TC, true, true>), grid, dim3(NT), 0, s, b);
+        else hipLaunchKernelGGL((k_flow_wgrad<MG_TR, MG_TC, true, false>), grid, dim3(NT), 0, s, b);
+    } else hipLaunchKernelGGL((k_flow_wgrad<MG_TR, MG_TC, false, false>), grid, dim3(NT), 0, s, b);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 

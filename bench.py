@@ -209,9 +209,17 @@ def rocprof_launch(kernel):
         calls = tot = 0
         with open(os.path.join(prof, names[-1])) as f:
             for row in csv.DictReader(f):
-                n = row['Name']
-                if kernel + '<' in n and ', true, true, 0' not in n and ', true, true, 1' not in n and ', false, true,' not in n:
-                    calls += int(row['Calls']); tot += int(row['TotalDurationNs'])
+                m = re.search(re.escape(kernel) + r'<([^>]*)>', row['Name'])
+                if not m:
+                    continue
+                targs = [t.strip() for t in m.group(1).split(',')]
+                # k_flow_fwd<TR, TC, FASTW, REV, MU, EXACT, SILU, SWEEP> / k_flow_bwd_gather<TR, TC, FASTW, MU, EXACT, SWEEP>: the
+                # force-sweep instances (SWEEP = 1: what the HIP-event figure of this run times), never the inverse map (REV)
+                if kernel == 'k_flow_fwd' and (targs[3] != 'false' or (len(targs) >= 8 and targs[7] != '1')):
+                    continue
+                if kernel == 'k_flow_bwd_gather' and len(targs) >= 6 and targs[5] != '1':
+                    continue
+                calls += int(row['Calls']); tot += int(row['TotalDurationNs'])
         meta = {}
         try:
             with open(os.path.join(prof, names[-1].replace('.csv', '.meta.json'))) as f:

@@ -451,8 +451,13 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     double w0s[18];
     {
         cdptr wq = (cdptr)(size_t)(w + (mu == 0 ? WBWD1 : WBWD) + LB_W0 + wave * 18);
+        // wide scalar loads written out (8 + 8 + 2 doubles): the merging pass is off for this kernel (FT_LDS_B64)
+        typedef double double8c_t __attribute__((ext_vector_type(8)));
+        typedef const double8c_t __attribute__((address_space(4))) * cd8ptr;
+        const double8c_t va = *(cd8ptr)(wq), vb = *(cd8ptr)(wq + 8);
 #pragma unroll
-        for (int k = 0; k < 18; ++k) w0s[k] = wq[k];
+        for (int k = 0; k < 8; ++k) { w0s[k] = va[k]; w0s[8 + k] = vb[k]; }
+        w0s[16] = wq[16]; w0s[17] = wq[17];
     }
     lds_barrier();
     STAMP(3);

@@ -387,10 +387,17 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
     double w3[27];
     {
         cdptr w3p = (cdptr)(size_t)(w + (mu == 0 ? WFWD0 : WFWD1) + LF_W2 + wave * 9);
+        // wide scalar loads written out (8 + 1 doubles per output channel: s_load_dwordx16 + s_load_dwordx2): the pass that would
+        // merge 27 s_load_dwordx2 is off for this kernel (FT_LDS_B64), and 27 scalar-memory instructions per wave are not free
+        typedef double double8c_t __attribute__((ext_vector_type(8)));
+        typedef const double8c_t __attribute__((address_space(4))) * cd8ptr;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k) {
+            const double8c_t v8 = *(cd8ptr)(w3p + k * 72);
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) w3[k * 9 + tp] = w3p[k * 72 + tp];
+            for (int tp = 0; tp < 8; ++tp) w3[k * 9 + tp] = v8[tp];
+            w3[k * 9 + 8] = w3p[k * 72 + 8];
+        }
     }
     lds_barrier();
     STAMP(3);

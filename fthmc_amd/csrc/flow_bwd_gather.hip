@@ -107,9 +107,10 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     const double* __restrict__ w = A.wint;
     const Stash sv = stash_view(A.stash, A.B, b, n);
     // stash planes of this chain (struct Stash), as kernel-argument base + uniform offset
-    const double* __restrict__ st1 = uniform_ptr(A.stash, (size_t)b * 8 * n);
-    const double* __restrict__ stc = uniform_ptr(A.stash, ((size_t)A.B * 16 + (size_t)b * 2) * n);
-    const double* __restrict__ scs = uniform_ptr(A.stash, ((size_t)A.B * 18 + b) * n);
+    const unsigned bn = (unsigned)b * (unsigned)n, Bn = (unsigned)A.B * (unsigned)n;       // 32-bit plane offsets: uniform_at()
+    const double* __restrict__ st1 = uniform_at(A.stash, 8u * bn);
+    const double* __restrict__ stc = uniform_at(A.stash, 16u * Bn + 2u * bn);
+    const double* __restrict__ scs = uniform_at(A.stash, 18u * Bn + bn);
     (void)sv;
     // training outputs of this chain (kernels.h: FlowLayerArgs::gz)
     double* const gz2o = has_gz ? A0.gz + (size_t)b * 17 * n : nullptr;
@@ -160,10 +161,10 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
             tcv[q] = t2.x; tcv[q + 1] = t2.y;
         }
         // upstream gradient: a link field (first layer of a standalone call) or the plaquette-gradient field
-        const double* gsrc = uniform_ptr(A.up_gp, (size_t)b * n);
+        const double* gsrc = uniform_at(A.up_gp, bn);
         if (has_uplink) {                      // a real branch (the empty asm keeps it one): the rarely used pointer is fetched from the
             asm volatile("" ::: "memory");     // argument block only here, and nobody waits for that fetch in a force sweep
-            gsrc = uniform_ptr(A0.up_link, (size_t)b * 2 * n + (size_t)mu * n);
+            gsrc = uniform_at(A0.up_link, 2u * bn + (unsigned)(mu * n));
         }
         const int iL = mul24(i, L);
         ag[0] = ldu(gsrc, (unsigned)(iL + j));
@@ -205,7 +206,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     const bool ovalid = tid < N3 && (EXACT || (orr < rmax && occ < cmax));
     double gpin;
     {
-        const double* gsrc = has_upgp ? uniform_ptr(A.up_gp, (size_t)b * n) : scs;   // no pass-through without up_gp
+        const double* gsrc = has_upgp ? uniform_at(A.up_gp, bn) : scs;   // no pass-through without up_gp
         gpin = ldu(gsrc, ovalid ? (unsigned)(mul24(i0 + orr, L) + j0 + occ) : 0u);
         if (!ovalid || !has_upgp) gpin = 0.0;
     }
@@ -230,7 +231,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
         const int goA = c3live ? WI(c3r - 2) + WJ(c3c - 2) : 0;
         const int goB = !c3live ? 0 : mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
         // channel-minor stash (struct Stash): the task's four channels of a site are 32 contiguous bytes
-        const double* pl = uniform_ptr(A.stash, ((size_t)A.B + b) * 8 * n + (size_t)(c3half * 4));
+        const double* pl = uniform_at(A.stash, 8u * (Bn + bn) + (unsigned)(c3half * 4));
 #pragma unroll
         for (int k = 0; k < 4; k += 2) {
             const double2_t va = ldu2(pl + k, (unsigned)goA * 8u), vb = ldu2(pl + k, (unsigned)goB * 8u);
@@ -514,7 +515,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     // ---- gP_out = gP_in + this layer's contribution at the own sites ---------------------------
     if (ovalid) {
         const int cls = ((mu == 0 ? j0 + occ : i0 + orr) - off) & 3;  // 0 active, 1|2 frozen, 3 passive
-        A.gp_out[(size_t)b * n + mul24(i0 + orr, L) + j0 + occ] = gpin + (cls != 3 ? sDir[tid] : 0.0);
+        uniform_at(A.gp_out, bn)[mul24(i0 + orr, L) + j0 + occ] = gpin + (cls != 3 ? sDir[tid] : 0.0);
     }
     STAMP(5);
     if (has_dbg && tid == 0) dbg[15] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -526,6 +527,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
 namespace fthmc {
 
 int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s) {
+    if (!flow_stash_fits32(a.B, a.L, false)) return FTHMC_ERR_UNSUPPORTED;                  // 32-bit plane offsets (uniform_at)
     const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
     const bool fast = wrap_fast_ok(a.L, MG_TR, MG_TC);
     const bool exact = fast && a.L % MG_TR == 0 && a.L % MG_TC == 0 && (a.L & (a.L - 1)) == 0;

@@ -95,11 +95,12 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
     if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
     const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
-    const double* __restrict__ x0 = uniform_ptr(A.x, (size_t)b * 2 * n);
+    const unsigned bn = (unsigned)b * (unsigned)n;                    // 32-bit plane offsets: uniform_at()
+    const double* __restrict__ x0 = uniform_at(A.x, 2u * bn);
     const double* __restrict__ x1 = x0 + n;
     // plaquette-level map (NCPPlaqCouplingLayer.forward / .reverse, layers.py:348-396): the plaquette field
     // is the input (A.pin) and the output (A.pout) instead of being derived from / folded back into links
-    const double* __restrict__ pin = has_pin ? uniform_ptr(A0.pin, (size_t)b * n) : nullptr;
+    const double* __restrict__ pin = has_pin ? uniform_at(A0.pin, bn) : nullptr;
     const double* __restrict__ w = A.wint;
     // the stamp record is addressed inside the flag's branch: the pointer is not waited for in a production launch
 #define DBG_REC (A0.dbg + ((size_t)b * ntiles + tile) * 16)
@@ -184,7 +185,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
                 sIn[PS0 + at] = sn;
                 if (has_stash && (unsigned)(r - 3) < (unsigned)(EXACT ? TR : min(TR, L - i0)) &&
                     (unsigned)(c - 3) < (unsigned)(EXACT ? TC : min(TC, L - j0))) {         // the net input of the tile's own frozen sites
-                    double* cs_ = uniform_ptr(A.stash, ((size_t)A.B * 18 + b) * n);
+                    double* cs_ = uniform_at(A.stash, 18u * (unsigned)A.B * (unsigned)n + bn);
                     const unsigned fi = (unsigned)stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
                     stu(cs_, fi, cs); stu(cs_, fi + (unsigned)(n >> 1), sn);
                 }
@@ -496,7 +497,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
                     const double d = sDL[tid];
                     if (mu == 0) v0 = ft_wrap(d + v0); else v1 = ft_wrap(-d + v1);
                 }
-                double* y0 = uniform_ptr(A.y, (size_t)b * 2 * n);
+                double* y0 = uniform_at(A.y, 2u * bn);
                 const unsigned at = (unsigned)(mul24(i, L) + j);
                 stu(y0, at, v0); stu(y0, (unsigned)n + at, v1);
             }
@@ -578,7 +579,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
                     const double d = sDL[tid];
                     if (mu == 0) v0 = ft_wrap(d + v0); else v1 = ft_wrap(-d + v1);
                 }
-                double* y0 = uniform_ptr(A.y, (size_t)b * 2 * n);
+                double* y0 = uniform_at(A.y, 2u * bn);
                 const unsigned at = (unsigned)(mul24(i, L) + j);
                 stu(y0, at, v0); stu(y0, (unsigned)n + at, v1);
             }
@@ -635,12 +636,14 @@ void set_flow_variant(int v) { g_variant = v; }
 int get_flow_variant() { return g_variant; }
 
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
+    if (!flow_stash_fits32(a.B, a.L, a.stash_h != 0)) return FTHMC_ERR_UNSUPPORTED;                  // 32-bit plane offsets (uniform_at)
     // 16 x 16 tiles, three workgroups per CU (SmemF)
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
     launch_fwd<false>(a, grid, s);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_rev_mfma(const FlowLayerArgs& a, hipStream_t s) {
+    if (!flow_stash_fits32(a.B, a.L, a.stash_h != 0)) return FTHMC_ERR_UNSUPPORTED;                  // 32-bit plane offsets (uniform_at)
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
     launch_fwd<true>(a, grid, s);
     FT_LAUNCH_CHECK(); return FTHMC_OK;

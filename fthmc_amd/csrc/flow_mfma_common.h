@@ -79,6 +79,11 @@ __device__ __forceinline__ size_t uniform_u64(size_t v) {
     return ((size_t)hi << 32) | lo;
 }
 template <class T> __device__ __forceinline__ T* uniform_ptr(T* base, size_t off) { return base + uniform_u64(off); }
+// the same with a 32-bit element offset (the launchers refuse shapes whose stash exceeds 2^32 doubles): offsets of a chain's
+// planes are then 32-bit scalar products, where size_t arithmetic costs a 64-bit multiply (s_mul_i32 + s_mul_hi + adds) per base
+template <class T> __device__ __forceinline__ T* uniform_at(T* base, unsigned off) {
+    return base + (size_t)(unsigned)__builtin_amdgcn_readfirstlane(off);
+}
 // element `idx` (32-bit, idx * 8 < 2^32) of a uniform base: the byte offset is formed in 32 bits so that the
 // load can be base-in-SGPRs + one VGPR offset
 __device__ __forceinline__ double ldu(const double* base, unsigned idx) {
@@ -153,13 +158,14 @@ template <int TR, int TC> struct Geom {
 // = 16 + 2 + 1 = 19 doubles per site and layer (35 with h1, h2): kernels.h flow_stash_doubles().
 struct Stash { double *d1, *d2, *tc, *cs, *h1, *h2; };
 __device__ __forceinline__ Stash stash_view(double* base, int B, int b, int n) {
+    const unsigned bn = (unsigned)b * (unsigned)n, Bn = (unsigned)B * (unsigned)n;     // 35 B n < 2^32: checked by the launchers
     Stash v;
-    v.d1 = base + (size_t)b * 8 * n;
-    v.d2 = base + ((size_t)B + b) * 8 * n;
-    v.tc = base + ((size_t)B * 16 + (size_t)b * 2) * n;
-    v.cs = base + ((size_t)B * 18 + b) * n;
-    v.h1 = base + ((size_t)B * 19 + (size_t)b * 8) * n;
-    v.h2 = base + ((size_t)B * 27 + (size_t)b * 8) * n;
+    v.d1 = base + (size_t)(8u * bn);
+    v.d2 = base + (size_t)(8u * (Bn + bn));
+    v.tc = base + (size_t)(16u * Bn + 2u * bn);
+    v.cs = base + (size_t)(18u * Bn + bn);
+    v.h1 = base + (size_t)(19u * Bn + 8u * bn);
+    v.h2 = base + (size_t)(27u * Bn + 8u * bn);
     return v;
 }
 // compact index of an active site (i, j): every 4th column (mu = 0) or row (mu = 1)

@@ -859,6 +859,7 @@ bool ft_small_shape(int L, int nl) { return nl >= 1 && (L == 8 || L == 12 || L =
 
 int launch_ft_small(const SmallArgs& a, int L, hipStream_t s) {
     const dim3 grid(a.B), block(NT);
+    if (!flow_stash_fits32(a.B, L, true)) return FTHMC_ERR_UNSUPPORTED;                  // stash_view: 32-bit plane offsets
     if (a.mode == SM_TRAIN) {
         if (!a.gz) return FTHMC_ERR_ARG;
         switch (L) {

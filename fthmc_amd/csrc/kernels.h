@@ -146,6 +146,9 @@ inline int flow_wgrad_nparts(int B, int L, int tpw) {
 }
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }
+// the tuned kernels form a chain's plane offsets inside one layer's stash in 32 bits (flow_mfma_common.h: uniform_at, stash_view)
+// -- one layer's stash below 32 GiB; beyond that the launchers return FTHMC_ERR_UNSUPPORTED
+inline bool flow_stash_fits32(int B, int L, bool train) { return flow_stash_doubles(B, L, train) < ((size_t)1 << 32); }
 // ---- flow_generic.hip: any s/t net shape (hidden sizes, kernel size, mixture components); plain kernels, HBM-resident planes
 constexpr int FLOW_ARCH_MAXH = 8;
 // Shape of the s/t conv net: 2 -> hid[0] -> ... -> hid[nh - 1] -> nmix + 1 channels, k x k kernels.  A VALUE that travels with

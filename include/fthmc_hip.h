@@ -68,6 +68,8 @@ int fthmc_get_variant(void);
  * same results, one launch per operation, activations through HBM).  Weights: n_layers * fthmc_arch_params(arch) doubles,
  * per layer [w0 b0 w1 b1 ...] in PyTorch order; the workspace sizes follow the shape.  Limits: n_hidden <= 8, hidden sizes
  * <= 256, kernel_size <= 15 (and kernel_size / 2 <= L), n_mix <= 64; FTHMC_ERR_UNSUPPORTED otherwise.
+ * The tuned kernels address one layer's activation stash with 32-bit element offsets: B * 19 * L * L (training: * 35)
+ * must stay below 2^32 doubles (32 GiB per layer; FTHMC_ERR_UNSUPPORTED beyond -- shard the chains instead).
  * The shape is read during the call only: the library keeps no net shape between calls, two threads may run two different
  * flows on two streams at the same time. */
 typedef struct fthmc_arch_t {

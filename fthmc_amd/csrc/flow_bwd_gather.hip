@@ -228,8 +228,13 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
         // both sites of a task sit on the same line class; on a dead line (no active site within reach, conv3^T writes an
         // exact 0 there) the stash holds nothing: those lanes all read element 0 (one cache line) instead of a window row
         const bool c3live = ((mu == 0 ? c3c + 2 - c0 : c3r + 2 - r0) & 3) <= 2;
+#if FT_D2_C
+        const int goA = c3live ? stash_live_idx<EXACT>(wi(c3r - 2), WJ(c3c - 2), L, mu, off) : 0;
+        const int goB = !c3live ? 0 : mu == 0 ? stash_live_idx<EXACT>(wi(c3r + W2R / 2 - 2), WJ(c3c - 2), L, mu, off) : stash_live_idx<EXACT>(wi(c3r - 2), WJ(c3c + W2C / 2 - 2), L, mu, off);
+#else
         const int goA = c3live ? WI(c3r - 2) + WJ(c3c - 2) : 0;
         const int goB = !c3live ? 0 : mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
+#endif
         // channel-minor stash (struct Stash): the task's four channels of a site are 32 contiguous bytes
         const double* pl = uniform_at(A.stash, 8u * (Bn + bn) + (unsigned)(c3half * 4));
 #pragma unroll

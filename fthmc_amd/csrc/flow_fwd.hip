@@ -335,11 +335,14 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
         }
         if (has_stash && ok) {                                // act'(z2) (and h2) of the tile's own sites
             const int at = mul24(i0 + r - 1, L) + j0 + c - 1;
+            // act'(z2): live lines only (FT_D2_C, stash_live_idx); the pair's second site is one line-step along the stripe lines
+            const int a2 = FT_D2_C ? stash_live_idx<EXACT>(i0 + r - 1, j0 + c - 1, L, mu, off) : at;
+            const int da2 = FT_D2_C ? (mu == 0 ? dr * 3 * (L >> 2) + dc : dr * L + dc) : dr * L + dc;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
                 if ((unsigned)(r - 1 + q * dr) < (unsigned)rmax && (unsigned)(c - 1 + q * dc) < (unsigned)cmax) {
                     const int aq = at + q * (dr * L + dc);
-                    stu2(st_d2, 8u * (unsigned)aq + stg, double2_t{d[2 * q], d[2 * q + 1]});
+                    stu2(st_d2, 8u * (unsigned)(a2 + q * da2) + stg, double2_t{d[2 * q], d[2 * q + 1]});
                     if (stash_h) stu2(st_h2, 8u * (unsigned)aq + stg, double2_t{h[2 * q], h[2 * q + 1]});
                 }
         }

@@ -41,6 +41,9 @@
 // positions ALONG a line: 16 consecutive rows for mu = 0 --, and row-major storage made every one of those 16-byte accesses its own
 // 64-byte piece of a line 4 KB from the next (16 half lines per wave instruction where mu = 1 touches 8 whole ones): the mu = 0
 // instances were 4 % (forward) and 10 % (backward) slower than the mu = 1 ones, all of it in load / store issue.
+#ifndef FT_D2_C
+#define FT_D2_C 1
+#endif
 #ifndef FT_D1_T
 #define FT_D1_T 1
 #endif
@@ -171,6 +174,15 @@ __device__ __forceinline__ Stash stash_view(double* base, int B, int b, int n) {
 // compact index of an active site (i, j): every 4th column (mu = 0) or row (mu = 1)
 __device__ __forceinline__ int stash_active_idx(int i, int j, int L, int mu) {
     return mu == 0 ? mul24(i, L >> 2) + (j >> 2) : mul24(i >> 2, L) + j;
+}
+// act'(z2) plane: index of site (i, j) when only the live stripe lines are stored (FT_D2_C): conv3 reads h2 within one site of an
+// active line, so the lines x = off + 2 (mod 4) are never written nor used; live lines in order, 3 of every 4
+template <bool POW2> __device__ __forceinline__ int stash_live_idx(int i, int j, int L, int mu, int off) {
+    int u = (mu == 0 ? j : i) - off - 3;                  // (x - off - 3) mod L: class 0, 1, 2 live (off - 1, off, off + 1), 3 dead
+    if (POW2) u &= L - 1;
+    else { u += u < 0 ? L : 0; u += u < 0 ? L : 0; }      // twice: x - off - 3 >= -6 and L may be 4
+    const int cx = 3 * (u >> 2) + (u & 3);
+    return mu == 0 ? mul24(i, 3 * (L >> 2)) + cx : mul24(cx, L) + j;
 }
 // compact index of a frozen site (stripe classes 1, 2 of its line): two of every 4 columns / rows
 __device__ __forceinline__ int stash_frozen_idx(int i, int j, int L, int mu, int off) {

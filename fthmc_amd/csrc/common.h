@@ -78,6 +78,54 @@ __device__ __forceinline__ void ft_sincos(double x, double* sn, double* cs) {
     *cs = ((q + 1) & 2) ? -c_ : c_;
 }
 
+// atan for the tan-mixture transform.  |x| > 1 folds to 1 / |x| (v_rcp_f64 + one third-order step; |x| clamped to 1e300 first, so
+// that an infinite tangent gives pi/2 and not 0 * inf), then atan(a) = a + a s p(s), s = a^2, with the 20-coefficient near-minimax
+// p of tools/minimax_atan.py (7.7e-17 relative, exact arithmetic) and its constants as SGPR operands.  ~40 DP operations, no
+// branch; ocml's atan is ~80: an IEEE division for the fold and its 19 coefficients built in VGPR pairs (38 v_mov_b32).  A NaN
+// argument comes back as NaN.  tools/atan_check.hip compares it with ocml's over the range.
+__device__ __forceinline__ double ft_atan(double x) {
+    double am;
+    asm("v_min_f64 %0, |%1|, %2" : "=v"(am) : "v"(x), "s"(1e300));       // min(|x|, 1e300) (a NaN becomes 1e300: unused below then)
+    double y = __builtin_amdgcn_rcp(am);
+    const double u = fma(-am, y, 1.0);
+    y = fma(fma(u, u, u), y, y);
+    const double ax = fabs(x);
+    const bool big = ax > 1.0;
+    const double a = big ? y : ax;                                       // NaN: not big, a = NaN
+    const double z = a * a;
+    double p = 1.806195461861215e-05;
+    p = ft_fma_vvs(p, z, -0.00019996189377901382);
+    p = ft_fma_vvs(p, z, 0.0010496035084968515);
+    p = ft_fma_vvs(p, z, -0.0034958859739163094);
+    p = ft_fma_vvs(p, z, 0.008368931178450162);
+    p = ft_fma_vvs(p, z, -0.015535152475414177);
+    p = ft_fma_vvs(p, z, 0.023696731580048622);
+    p = ft_fma_vvs(p, z, -0.031277189066996385);
+    p = ft_fma_vvs(p, z, 0.03749486812535247);
+    p = ft_fma_vvs(p, z, -0.04260356632601652);
+    p = ft_fma_vvs(p, z, 0.04737749579527779);
+    p = ft_fma_vvs(p, z, -0.052579733342841106);
+    p = ft_fma_vvs(p, z, 0.05881506877793656);
+    p = ft_fma_vvs(p, z, -0.06666564699289104);
+    p = ft_fma_vvs(p, z, 0.07692298971033217);
+    p = ft_fma_vvs(p, z, -0.09090908590891934);
+    p = ft_fma_vvs(p, z, 0.11111111093490827);
+    p = ft_fma_vvs(p, z, -0.14285714285384132);
+    p = ft_fma_vvs(p, z, 0.1999999999999753);
+    p = ft_fma_vvs(p, z, -0.3333333333333333);
+    double r = fma(a * z, p, a);
+    const double rb = (1.5707963267948966 - r) + 6.123233995736766e-17;  // pi/2 - r, pi/2 in two pieces
+    r = big ? rb : r;
+    return copysign(r, x);
+}
+// torch.remainder(x + pi, 2 pi) - pi for -pi <= x <= pi (2 atan of anything): the one case that moves is x = pi -> -pi; the same
+// additions as ft_wrap's short path, bit for bit
+__device__ __forceinline__ double ft_wrap_pm_pi(double x) {
+    double r = x + FT_PI;
+    r = r >= FT_TWO_PI ? r - FT_TWO_PI : r;
+    return r - FT_PI;
+}
+
 __device__ __forceinline__ int ft_modL(int v, int L) {   // v >= -L
     int r = (v + L) % L;
     return r;

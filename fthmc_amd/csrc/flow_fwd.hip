@@ -468,7 +468,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
                     fp = 0.0;
 #pragma unroll
                     for (int k = 0; k < NMIX; ++k) {
-                        f += ft_wrap(2 * atan(eo[2 * k] * th));
+                        f += ft_wrap_pm_pi(2 * ft_atan(eo[2 * k] * th));
                         fp += 1.0 / (eo[2 * k + 1] * cs * cs + eo[2 * k] * sn * sn);
                     }
                     f /= NMIX; fp /= NMIX;
@@ -531,7 +531,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
         const double invD = ft_rcp(ems * cs2 + es * sn2);
         sT2[(wave * TQ + 1) * NAS + lane] = invD;
         // tan(P/2) = sn / cs: |cs| can be tiny (P near +-pi) -- a true division keeps the correctly rounded quotient there
-        sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
+        sT2[(wave * TQ + 0) * NAS + lane] = ft_wrap_pm_pi(2 * ft_atan(es * (sn / cs)));
         if (has_stash && avalid) {
             // coefficients of the transform's adjoint (struct Stash): the backward kernel then needs no
             // plaquettes, sincos or exp at the active sites of its tile+3 window

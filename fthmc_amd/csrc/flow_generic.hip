@@ -93,7 +93,7 @@ __device__ __forceinline__ MixOut mix_forward(const double* __restrict__ Zb, int
     double ysum = 0.0, si = 0.0;
     for (int k = 0; k < K; ++k) {
         const double es = ft_exp(Zb[(size_t)k * n + s]), ems = ft_rcp(es);
-        ysum += ft_wrap(2 * atan(es * tn));
+        ysum += ft_wrap_pm_pi(2 * ft_atan(es * tn));
         si += ft_rcp(ems * cs2 + es * sn2);
     }
     return MixOut{ft_wrap(ysum / K + Zb[(size_t)K * n + s]), si};
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_gen_transform(const double* __restrict_
                 fp = 0.0;
                 for (int k = 0; k < K; ++k) {
                     const double es = ft_exp(Zb[(size_t)k * n + s]), ems = ft_rcp(es);
-                    f += ft_wrap(2 * atan(es * tn));
+                    f += ft_wrap_pm_pi(2 * ft_atan(es * tn));
                     fp += 1.0 / (ems * cs * cs + es * sn * sn);
                 }
                 f /= K; fp /= K;

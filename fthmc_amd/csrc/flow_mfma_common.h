@@ -41,11 +41,16 @@
 // positions ALONG a line: 16 consecutive rows for mu = 0 --, and row-major storage made every one of those 16-byte accesses its own
 // 64-byte piece of a line 4 KB from the next (16 half lines per wave instruction where mu = 1 touches 8 whole ones): the mu = 0
 // instances were 4 % (forward) and 10 % (backward) slower than the mu = 1 ones, all of it in load / store issue.
-#ifndef FT_D2_C
-#define FT_D2_C 1
-#endif
 #ifndef FT_D1_T
 #define FT_D1_T 1
+#endif
+// 1 (default): the act'(z2) plane holds the live stripe lines only, in order (stash_live_idx).  conv3 reads h2 within one site of
+// an active line, so every fourth line (x = off + 2 mod 4) is dead: never written, never used.  Row-major storage left the dead
+// COLUMNS of a mu = 0 layer inside the cache lines the backward fetches (record = 64 B, line = 128 B: a window row cost 10 lines
+// for 15 live records; per-kernel counters: 32 % more L2 read requests and 11 % more HBM reads than the mu = 1 instance, whose
+// dead ROWS are skipped whole).  Compact, the backward's mu = 0 / mu = 1 gap went from 8.5 % to 4 %.
+#ifndef FT_D2_C
+#define FT_D2_C 1
 #endif
 
 namespace fthmc_flow {
@@ -149,7 +154,9 @@ template <int TR, int TC> struct Geom {
 // Per-layer activation stash written by the forward kernel and read back by the gather-form backward
 // (n = L * L; per chain b):
 //   d1  [n][8]     act'(z1), channel-minor (mu = 0 layers: site index TRANSPOSED, j L + i: FT_D1_T)
-//   d2  [n][8]     act'(z2), channel-minor (dead lines unwritten)
+//   d2  [3n/4][8]  act'(z2), channel-minor, the LIVE stripe lines only, compact (FT_D2_C, stash_live_idx; the tiled kernels --
+//                  k_ft_small keeps [n][8] with its dead lines unwritten; the plane is n records either way): a window row of a
+//                  mu = 0 layer is 15 consecutive records, not 20 of which every fourth is fetched with its cache line and dropped
 //                  (64 B per site: a window row of 20 sites is 10 cache lines for all channels, not 8 x 2..3,
 //                   and the channel pair (2 g, 2 g + 1) of a lane is one 16-byte access)
 //   tc  [K][n/4][4] adjoint coefficients of the tan-mixture transform at the ACTIVE sites, compact, component-major:

@@ -376,7 +376,7 @@ template <int L, bool TRAIN> struct Chain {
             const double cs2 = cs * cs, sn2 = sn * sn, sincs = sn * cs;
             const double invD = ft_rcp(ems * cs2 + es * sn2);
             sT2[(wave * 2 + 1) * NAS + lane] = invD;
-            sT2[(wave * 2 + 0) * NAS + lane] = ft_wrap(2 * atan(es * (sn / cs)));
+            sT2[(wave * 2 + 0) * NAS + lane] = ft_wrap_pm_pi(2 * ft_atan(es * (sn / cs)));
             if (STASH) {
                 const double sinP = 2.0 * sincs, invD2 = invD * invD;
                 double* tc = sv.tc + (size_t)wave * N + 4 * (size_t)lane;

@@ -195,7 +195,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
         }
         fwin = fr1 * W1C + fc1;
         const unsigned ic = ftask ? (unsigned)stash_frozen_idx(wi(fr1 - 1), WJ(fc1 - 1), L, mu, off) : 0u;
-        fcs = ldu(scs, ic); fsn = ldu(scs + (n >> 1), ic);
+        fcs = ldu_j(scs, ic); fsn = ldu_j(scs + (n >> 1), ic);
         if (!ftask) { fcs = 1.0; fsn = 0.0; }
     }
     // the conv1 tables of the forward block (P1, BC: flow_common.h), one entry per thread
@@ -207,7 +207,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     double gpin;
     {
         const double* gsrc = has_upgp ? uniform_at(A.up_gp, bn) : scs;   // no pass-through without up_gp
-        gpin = ldu(gsrc, ovalid ? (unsigned)(mul24(i0 + orr, L) + j0 + occ) : 0u);
+        gpin = ldu_j(gsrc, ovalid ? (unsigned)(mul24(i0 + orr, L) + j0 + occ) : 0u);
         if (!ovalid || !has_upgp) gpin = 0.0;
     }
     // (4) act'(z2) and act'(z1) go straight into the registers of the thread that multiplies by them
@@ -229,17 +229,21 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
         // exact 0 there) the stash holds nothing: those lanes all read element 0 (one cache line) instead of a window row
         const bool c3live = ((mu == 0 ? c3c + 2 - c0 : c3r + 2 - r0) & 3) <= 2;
 #if FT_D2_C
-        const int goA = c3live ? stash_live_idx<EXACT>(wi(c3r - 2), WJ(c3c - 2), L, mu, off) : 0;
-        const int goB = !c3live ? 0 : mu == 0 ? stash_live_idx<EXACT>(wi(c3r + W2R / 2 - 2), WJ(c3c - 2), L, mu, off) : stash_live_idx<EXACT>(wi(c3r - 2), WJ(c3c + W2C / 2 - 2), L, mu, off);
+        // live lines only (stash_live_idx): the two sites share their stripe line, i.e. its compact index
+        const int lx = stash_live_line<EXACT>(mu == 0 ? WJ(c3c - 2) : wi(c3r - 2), L, off);
+        const int goA = !c3live ? 0 : mu == 0 ? mul24(wi(c3r - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ(c3c - 2);
+        const int goB = !c3live ? 0 : mu == 0 ? mul24(wi(c3r + W2R / 2 - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ(c3c + W2C / 2 - 2);
 #else
         const int goA = c3live ? WI(c3r - 2) + WJ(c3c - 2) : 0;
         const int goB = !c3live ? 0 : mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
 #endif
         // channel-minor stash (struct Stash): the task's four channels of a site are 32 contiguous bytes
         const double* pl = uniform_at(A.stash, 8u * (Bn + bn) + (unsigned)(c3half * 4));
+        const unsigned oA = ft_off32((unsigned)goA * 8u), oB = ft_off32((unsigned)goB * 8u);       // byte offsets of the two records
+        auto ldu2o = [](const double* base, unsigned o) { return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + o); };
 #pragma unroll
         for (int k = 0; k < 4; k += 2) {
-            const double2_t va = ldu2(pl + k, (unsigned)goA * 8u), vb = ldu2(pl + k, (unsigned)goB * 8u);
+            const double2_t va = ldu2o(pl + k, oA), vb = ldu2o(pl + k, oB);
             d2v[0][k] = va.x; d2v[0][k + 1] = va.y; d2v[1][k] = vb.x; d2v[1][k + 1] = vb.y;
         }
     }

@@ -97,6 +97,17 @@ template <class T> __device__ __forceinline__ T* uniform_at(T* base, unsigned of
 __device__ __forceinline__ double ldu(const double* base, unsigned idx) {
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + idx * 8u);
 }
+// the same for an index that comes out of a branch (idle lanes read element 0): hipcc otherwise carries the ZERO-EXTENDED offset
+// through the join and forms a 64-bit VGPR address per load (v_mov 0 + v_lshl_add_u64); the empty asm pins the 32-bit byte offset
+// behind the join, the load keeps its base-in-SGPRs form
+__device__ __forceinline__ unsigned ft_off32(unsigned idx) {
+    unsigned o = idx * 8u;
+    asm("" : "+v"(o));
+    return o;
+}
+__device__ __forceinline__ double ldu_j(const double* base, unsigned idx) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + ft_off32(idx));
+}
 // stores through a uniform base + a 32-bit element index: the address is base-in-SGPRs + one VGPR offset (one shift per
 // store); through a per-lane 64-bit pointer every stash store cost a sign extension, a 64-bit shift and a 64-bit add
 typedef double double2u_t __attribute__((ext_vector_type(2)));
@@ -180,15 +191,19 @@ __device__ __forceinline__ Stash stash_view(double* base, int B, int b, int n) {
 }
 // compact index of an active site (i, j): every 4th column (mu = 0) or row (mu = 1)
 __device__ __forceinline__ int stash_active_idx(int i, int j, int L, int mu) {
-    return mu == 0 ? mul24(i, L >> 2) + (j >> 2) : mul24(i >> 2, L) + j;
+    // unsigned 24-bit multiply-adds (coordinates are lattice sites): the signed form came out as v_bfe_i32 + the quarter-rate v_mad_u64_u32
+    return (int)(mu == 0 ? __umul24((unsigned)i, (unsigned)(L >> 2)) + (unsigned)(j >> 2) : __umul24((unsigned)(i >> 2), (unsigned)L) + (unsigned)j);
 }
 // act'(z2) plane: index of site (i, j) when only the live stripe lines are stored (FT_D2_C): conv3 reads h2 within one site of an
 // active line, so the lines x = off + 2 (mod 4) are never written nor used; live lines in order, 3 of every 4
-template <bool POW2> __device__ __forceinline__ int stash_live_idx(int i, int j, int L, int mu, int off) {
-    int u = (mu == 0 ? j : i) - off - 3;                  // (x - off - 3) mod L: class 0, 1, 2 live (off - 1, off, off + 1), 3 dead
+template <bool POW2> __device__ __forceinline__ int stash_live_line(int x, int L, int off) {     // compact index of stripe line x
+    int u = x - off - 3;                                  // (x - off - 3) mod L: class 0, 1, 2 live (off - 1, off, off + 1), 3 dead
     if (POW2) u &= L - 1;
     else { u += u < 0 ? L : 0; u += u < 0 ? L : 0; }      // twice: x - off - 3 >= -6 and L may be 4
-    const int cx = 3 * (u >> 2) + (u & 3);
+    return mul24(u >> 2, 3) + (u & 3);                    // 24-bit multiply-add (a plain one becomes the quarter-rate v_mad_u64_u32)
+}
+template <bool POW2> __device__ __forceinline__ int stash_live_idx(int i, int j, int L, int mu, int off) {
+    const int cx = stash_live_line<POW2>(mu == 0 ? j : i, L, off);
     return mu == 0 ? mul24(i, 3 * (L >> 2)) + cx : mul24(cx, L) + j;
 }
 // compact index of a frozen site (stripe classes 1, 2 of its line): two of every 4 columns / rows

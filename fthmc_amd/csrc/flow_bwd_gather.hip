@@ -95,14 +95,19 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(wave >= 0 && wave < NW);                          // lets the tile maps below fold their wave-uniform cases (T = wave + NW it)
     constexpr int mu = MU;
     const int L = A.L, off = A.off;
+    // what the launchers guarantee, said to the compiler (ranges decide between 24-bit and 64-bit index arithmetic)
+    __builtin_assume(off >= 0 && off < 4 && L >= 4 && L <= 8192 && (L & 3) == 0);
+    if (EXACT) __builtin_assume(L >= 16 && (L & (L - 1)) == 0);
     const int n = L * L;
     const int nti_ = (L + TR - 1) / TR, ntj_ = (L + TC - 1) / TC;
     BlockTile bt;
     if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
     const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
+    __builtin_assume(i0 >= 0 && i0 < L && j0 >= 0 && j0 < L && b >= 0 && b < (1 << 20));
     const int rmax = EXACT ? TR : min(TR, L - i0), cmax = EXACT ? TC : min(TC, L - j0);    // own sites inside the lattice
     const double* __restrict__ w = A.wint;
     const Stash sv = stash_view(A.stash, A.B, b, n);
@@ -536,6 +541,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
 namespace fthmc {
 
 int launch_flow_bwd_gather(const FlowLayerArgs& a, hipStream_t s) {
+    if (!flow_shape_ok(a.B, a.L, a.off)) return FTHMC_ERR_ARG;
     if (!flow_stash_fits32(a.B, a.L, false)) return FTHMC_ERR_UNSUPPORTED;                  // 32-bit plane offsets (uniform_at)
     const dim3 grid = xcd_grid(a.B, (a.L + MG_TR - 1) / MG_TR, (a.L + MG_TC - 1) / MG_TC);
     const bool fast = wrap_fast_ok(a.L, MG_TR, MG_TC);

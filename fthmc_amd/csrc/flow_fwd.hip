@@ -87,14 +87,19 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(wave >= 0 && wave < NW);
     constexpr int mu = MU;
     const int L = A.L, off = A.off, act = SILU ? (int)FTHMC_ACT_SILU : A.act;
+    // what the launchers guarantee, said to the compiler (ranges decide between 24-bit and 64-bit index arithmetic)
+    __builtin_assume(off >= 0 && off < 4 && L >= 4 && L <= 8192 && (L & 3) == 0);
+    if (EXACT) __builtin_assume(L >= 16 && (L & (L - 1)) == 0);
     const int n = L * L;
     const int nti_ = (A.L + TR - 1) / TR, ntj_ = (A.L + TC - 1) / TC;
     BlockTile bt;
     if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
     const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
+    __builtin_assume(i0 >= 0 && i0 < L && j0 >= 0 && j0 < L && b >= 0 && b < (1 << 20));
     const unsigned bn = (unsigned)b * (unsigned)n;                    // 32-bit plane offsets: uniform_at()
     const double* __restrict__ x0 = uniform_at(A.x, 2u * bn);
     const double* __restrict__ x1 = x0 + n;
@@ -639,6 +644,7 @@ void set_flow_variant(int v) { g_variant = v; }
 int get_flow_variant() { return g_variant; }
 
 int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
+    if (!flow_shape_ok(a.B, a.L, a.off)) return FTHMC_ERR_ARG;
     if (!flow_stash_fits32(a.B, a.L, a.stash_h != 0)) return FTHMC_ERR_UNSUPPORTED;                  // 32-bit plane offsets (uniform_at)
     // 16 x 16 tiles, three workgroups per CU (SmemF)
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
@@ -646,6 +652,7 @@ int launch_flow_fwd_mfma(const FlowLayerArgs& a, hipStream_t s) {
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_rev_mfma(const FlowLayerArgs& a, hipStream_t s) {
+    if (!flow_shape_ok(a.B, a.L, a.off)) return FTHMC_ERR_ARG;
     if (!flow_stash_fits32(a.B, a.L, a.stash_h != 0)) return FTHMC_ERR_UNSUPPORTED;                  // 32-bit plane offsets (uniform_at)
     const dim3 grid = xcd_grid(a.B, (a.L + MF_FWD_TR - 1) / MF_FWD_TR, (a.L + MF_FWD_TC - 1) / MF_FWD_TC);
     launch_fwd<true>(a, grid, s);

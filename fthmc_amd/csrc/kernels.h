@@ -149,6 +149,8 @@ inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (siz
 // the tuned kernels form a chain's plane offsets inside one layer's stash in 32 bits (flow_mfma_common.h: uniform_at, stash_view)
 // -- one layer's stash below 32 GiB; beyond that the launchers return FTHMC_ERR_UNSUPPORTED
 inline bool flow_stash_fits32(int B, int L, bool train) { return flow_stash_doubles(B, L, train) < ((size_t)1 << 32); }
+// ranges the tuned kernels state as assumptions (__builtin_assume in k_flow_fwd / k_flow_bwd_gather): checked by their launchers
+inline bool flow_shape_ok(int B, int L, int off) { return B > 0 && B <= (1 << 20) && L >= 4 && L <= 8192 && (L & 3) == 0 && off >= 0 && off < 4; }
 // ---- flow_generic.hip: any s/t net shape (hidden sizes, kernel size, mixture components); plain kernels, HBM-resident planes
 constexpr int FLOW_ARCH_MAXH = 8;
 // Shape of the s/t conv net: 2 -> hid[0] -> ... -> hid[nh - 1] -> nmix + 1 channels, k x k kernels.  A VALUE that travels with

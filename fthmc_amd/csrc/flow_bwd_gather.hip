@@ -93,6 +93,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     double* sIn = sm + S::IN;   double* sDir = sm + S::DIR;  double* sW = sm + S::SW;
 
     const int tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < NT);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(wave >= 0 && wave < NW);                          // lets the tile maps below fold their wave-uniform cases (T = wave + NW it)
@@ -107,7 +108,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
     const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
-    __builtin_assume(i0 >= 0 && i0 < L && j0 >= 0 && j0 < L && b >= 0 && b < (1 << 20));
+    __builtin_assume(i0 >= 0 && i0 < L && j0 >= 0 && j0 < L && b >= 0 && b < (1 << 20) && A.B > 0 && A.B <= (1 << 20));
     const int rmax = EXACT ? TR : min(TR, L - i0), cmax = EXACT ? TC : min(TC, L - j0);    // own sites inside the lattice
     const double* __restrict__ w = A.wint;
     const Stash sv = stash_view(A.stash, A.B, b, n);

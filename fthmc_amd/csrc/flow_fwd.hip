@@ -85,6 +85,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
     double* sP1 = sm + S::P1;
 
     const int tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < NT);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __builtin_assume(wave >= 0 && wave < NW);
@@ -99,7 +100,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
     if (!block_tile(A.B, nti_, ntj_, bt)) return;               // padding blocks when B % 8 != 0 (whole block exits)
     const int b = bt.b, tile = bt.tile, ntiles = nti_ * ntj_;
     const int i0 = bt.ti * TR, j0 = bt.tj * TC;
-    __builtin_assume(i0 >= 0 && i0 < L && j0 >= 0 && j0 < L && b >= 0 && b < (1 << 20));
+    __builtin_assume(i0 >= 0 && i0 < L && j0 >= 0 && j0 < L && b >= 0 && b < (1 << 20) && A.B > 0 && A.B <= (1 << 20));
     const unsigned bn = (unsigned)b * (unsigned)n;                    // 32-bit plane offsets: uniform_at()
     const double* __restrict__ x0 = uniform_at(A.x, 2u * bn);
     const double* __restrict__ x1 = x0 + n;

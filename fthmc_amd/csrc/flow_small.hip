@@ -138,6 +138,7 @@ template <int L, bool TRAIN> struct Chain {
     long long last;                                              // profiling runs (A.dbg): time of the previous stamp
     __device__ Chain(double* sm_, const Hot& A_, int b_) : sm(sm_), A(A_), b(b_) {
         tid = threadIdx.x; lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        __builtin_assume(tid >= 0 && tid < NT && wave >= 0 && wave < NW);       // the tile maps fold their wave-uniform cases
         wcur = 0;
         last = A.dbg ? (long long)__builtin_readcyclecounter() : 0;
     }

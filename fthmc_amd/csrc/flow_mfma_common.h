@@ -94,8 +94,9 @@ template <class T> __device__ __forceinline__ T* uniform_at(T* base, unsigned of
 }
 // element `idx` (32-bit, idx * 8 < 2^32) of a uniform base: the byte offset is formed in 32 bits so that the
 // load can be base-in-SGPRs + one VGPR offset
+#define FT_G __attribute__((address_space(1)))                    // global memory, said in the pointer type (see flow_small.hip: gld / gst)
 __device__ __forceinline__ double ldu(const double* base, unsigned idx) {
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + idx * 8u);
+    return *(const FT_G double*)((const FT_G char*)base + idx * 8u);
 }
 // the same for an index that comes out of a branch (idle lanes read element 0): hipcc otherwise carries the ZERO-EXTENDED offset
 // through the join and forms a 64-bit VGPR address per load (v_mov 0 + v_lshl_add_u64); the empty asm pins the 32-bit byte offset
@@ -106,16 +107,16 @@ __device__ __forceinline__ unsigned ft_off32(unsigned idx) {
     return o;
 }
 __device__ __forceinline__ double ldu_j(const double* base, unsigned idx) {
-    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + ft_off32(idx));
+    return *(const FT_G double*)((const FT_G char*)base + ft_off32(idx));
 }
 // stores through a uniform base + a 32-bit element index: the address is base-in-SGPRs + one VGPR offset (one shift per
 // store); through a per-lane 64-bit pointer every stash store cost a sign extension, a 64-bit shift and a 64-bit add
 typedef double double2u_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void stu(double* base, unsigned idx, double v) {
-    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + idx * 8u) = v;
+    *(FT_G double*)((FT_G char*)base + idx * 8u) = v;
 }
 __device__ __forceinline__ void stu2(double* base, unsigned idx, double2u_t v) {
-    *reinterpret_cast<double2u_t*>(reinterpret_cast<char*>(base) + idx * 8u) = v;
+    *(FT_G double2u_t*)((FT_G char*)base + idx * 8u) = v;
 }
 // Wrapped lattice coordinate (v mod L) of window line v, -L <= v.  FAST (L exceeds the window by a
 // margin, chosen at launch): the line wraps at most once, two selects.  Otherwise (small test lattices)

@@ -100,9 +100,16 @@ __device__ __forceinline__ void wrap3(int v, int (&o)[3]) {
     o[0] = (v == 0 ? L - 1 : v - 1) + 1; o[1] = v + 1; o[2] = (v == L - 1 ? 0 : v + 1) + 1;
 }
 
+// Global-memory accesses of this kernel go through pointers typed as such.  Its pointers pass through empty asm statements that
+// pin them in SGPRs (stash(), gz(), block_of(), the kernarg-segment reads of cold()) and come out GENERIC: every stash / field
+// access was a FLAT instruction with a 64-bit VGPR address, and FLAT instructions count on lgkmcnt as well as vmcnt -- every LDS
+// wait of a pass then also waited for its stash stores to reach memory.
+__device__ __forceinline__ double gld(const double* p) { return *(const FT_G double*)p; }
+__device__ __forceinline__ void gst(double* p, double v) { *(FT_G double*)p = v; }
+__device__ __forceinline__ void gst2(double* p, double2_t v) { *(FT_G double2_t*)p = v; }
 __device__ __forceinline__ double2_t ldg2(const double* p) {
     if (FT_KNOB & 16) return double2_t{0.5, 0.25};
-    return *reinterpret_cast<const double2_t*>(p);
+    return *(const FT_G double2_t*)p;
 }
 
 // What a pass over one layer needs from the kernel arguments, and nothing else: the full argument block stays in the
@@ -115,8 +122,9 @@ struct Hot {
     int B, nl, act;
     double* gz;              // training sweep: the pre-activation gradients of every layer (null otherwise)
 };
-__device__ __forceinline__ const SmallArgs& cold() {
-    const SmallArgs* p = (const SmallArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // the one explicit kernel argument, offset 0
+typedef const __attribute__((address_space(4))) SmallArgs ColdArgs;        // the kernarg segment is constant memory: scalar loads
+__device__ __forceinline__ ColdArgs& cold() {
+    ColdArgs* p = (ColdArgs*)__builtin_amdgcn_kernarg_segment_ptr();                     // the one explicit kernel argument, offset 0
     asm volatile("" : "+s"(p));
     return *p;
 }
@@ -156,14 +164,14 @@ template <int L, bool TRAIN> struct Chain {
     __device__ __forceinline__ double* stash(int l) const {
         double* p = A.stash; int B_ = A.B;
         asm volatile("" : "+s"(p), "+s"(B_));
-        return p + (size_t)l * ((size_t)B_ * (TRAIN ? 35 : 19) * L * L);   // kernels.h flow_stash_doubles (training: + h1, h2)
+        return (p) + (size_t)l * ((size_t)B_ * (TRAIN ? 35 : 19) * L * L);   // kernels.h flow_stash_doubles (training: + h1, h2)
     }
     // training sweep: this chain's slice of layer l's pre-activation gradients (kernels.h FlowLayerArgs::gz): gz2 [n][8],
     // gz1 [n][8] channel-minor, g_out [n/4][4]
     __device__ __forceinline__ double* gz(int l) const {
         double* p = A.gz; int B_ = A.B, c = b;
         asm volatile("" : "+s"(p), "+s"(B_), "+s"(c));
-        return p + ((size_t)l * B_ + c) * (size_t)(17 * L * L);
+        return (p) + ((size_t)l * B_ + c) * (size_t)(17 * L * L);
     }
     __device__ __forceinline__ double* sW() const { return sm + G::SW + wcur * LF_LDS; }
 
@@ -172,7 +180,7 @@ template <int L, bool TRAIN> struct Chain {
     static __device__ __forceinline__ const double* block_of(const double* wint, bool bwd, int l) {
         asm volatile("" : "+s"(wint));
         const int mu = l & 1;
-        return wint + (size_t)l * FLOW_WINT + (bwd ? (mu == 0 ? WBWD1 : WBWD) : (mu == 0 ? WFWD0 : WFWD1));
+        return (wint) + (size_t)l * FLOW_WINT + (bwd ? (mu == 0 ? WBWD1 : WBWD) : (mu == 0 ? WFWD0 : WFWD1));
     }
     __device__ __forceinline__ void weights_issue(bool bwd, int l) {
         int tid = this->tid;
@@ -248,7 +256,7 @@ template <int L, bool TRAIN> struct Chain {
             }
             if (STASH && frozen) {
                 double* cs_ = sv.cs + stash_frozen_idx(i, j, L, mu, off);
-                cs_[0] = cs; cs_[N >> 1] = sn;
+                gst(cs_, cs); gst(cs_ + (N >> 1), sn);
             }
         }
         lds_barrier();
@@ -287,11 +295,11 @@ template <int L, bool TRAIN> struct Chain {
                 put2<L, RS, PSZ>(sH1 + 2 * g * PSZ, pr + dr, pc + dc, h[2], h[3]);
                 if (STASH) {
                     const int at = pr * L + pc;
-                    *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)at) = double2_t{d[0], d[1]};
-                    *reinterpret_cast<double2_t*>(st_d1 + 8 * (size_t)(at + dr * L + dc)) = double2_t{d[2], d[3]};
+                    gst2(st_d1 + 8 * (size_t)at, double2_t{d[0], d[1]});
+                    gst2(st_d1 + 8 * (size_t)(at + dr * L + dc), double2_t{d[2], d[3]});
                     if (HST) {
-                        *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)at) = double2_t{h[0], h[1]};
-                        *reinterpret_cast<double2_t*>(st_h1 + 8 * (size_t)(at + dr * L + dc)) = double2_t{h[2], h[3]};
+                        gst2(st_h1 + 8 * (size_t)at, double2_t{h[0], h[1]});
+                        gst2(st_h1 + 8 * (size_t)(at + dr * L + dc), double2_t{h[2], h[3]});
                     }
                 }
             }
@@ -309,11 +317,11 @@ template <int L, bool TRAIN> struct Chain {
             put2i<RS, PSZ>(sH2 + 2 * g * PSZ, r + dr, c + dc, h[2], h[3]);
             if (STASH) {
                 const int at = r * L + c;
-                *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)at) = double2_t{d[0], d[1]};
-                *reinterpret_cast<double2_t*>(st_d2 + 8 * (size_t)(at + dr * L + dc)) = double2_t{d[2], d[3]};
+                gst2(st_d2 + 8 * (size_t)at, double2_t{d[0], d[1]});
+                gst2(st_d2 + 8 * (size_t)(at + dr * L + dc), double2_t{d[2], d[3]});
                 if (HST) {
-                    *reinterpret_cast<double2_t*>(st_h2 + 8 * (size_t)at) = double2_t{h[0], h[1]};
-                    *reinterpret_cast<double2_t*>(st_h2 + 8 * (size_t)(at + dr * L + dc)) = double2_t{h[2], h[3]};
+                    gst2(st_h2 + 8 * (size_t)at, double2_t{h[0], h[1]});
+                    gst2(st_h2 + 8 * (size_t)(at + dr * L + dc), double2_t{h[2], h[3]});
                 }
             }
         };
@@ -381,8 +389,8 @@ template <int L, bool TRAIN> struct Chain {
             if (STASH) {
                 const double sinP = 2.0 * sincs, invD2 = invD * invD;
                 double* tc = sv.tc + (size_t)wave * N + 4 * (size_t)lane;
-                *reinterpret_cast<double2_t*>(tc) = double2_t{sinP * invD / NMIX, (ems * cs2 - es * sn2) * invD2};
-                *reinterpret_cast<double2_t*>(tc + 2) = double2_t{invD / NMIX, sinP * 0.5 * (es - ems) * invD2};
+                gst2(tc, double2_t{sinP * invD / NMIX, (ems * cs2 - es * sn2) * invD2});
+                gst2(tc + 2, double2_t{invD / NMIX, sinP * 0.5 * (es - ems) * invD2});
             }
         }
         if (wave == NMIX && alane) {
@@ -436,7 +444,7 @@ template <int L, bool TRAIN> struct Chain {
         int fr, fc;
         frozen_site(tid < NF ? tid : 0, mu, off, fr, fc);                  // cos / sin of frozen site tid
         const int ic = stash_frozen_idx(fr, fc, L, mu, off);
-        if (FT_KNOB & 16) { q.fcs = 0.6; q.fsn = 0.8; } else { q.fcs = sv.cs[ic]; q.fsn = sv.cs[(N >> 1) + ic]; }
+        if (FT_KNOB & 16) { q.fcs = 0.6; q.fsn = 0.8; } else { q.fcs = gld(sv.cs + ic); q.fsn = gld(sv.cs + (N >> 1) + ic); }
     }
     __device__ __forceinline__ void issue_d2(int tid, int l, BwdPre& q) const {
         constexpr int N = G::N;
@@ -512,8 +520,8 @@ template <int L, bool TRAIN> struct Chain {
             if (gzo) {                                                     // g_out record of active site tid: dL/ds_0, dL/ds_1, dL/dt, 0
                 static_assert(NMIX == 2, "g_out record");
                 double* po = gzo + 16 * (size_t)N + 4 * (size_t)tid;
-                *reinterpret_cast<double2_t*>(po) = double2_t{gdelta * pre.tcv[0] + cbr * pre.tcv[1], gdelta * pre.tcv[4] + cbr * pre.tcv[5]};
-                *reinterpret_cast<double2_t*>(po + 2) = double2_t{gdelta, 0.0};
+                gst2(po, double2_t{gdelta * pre.tcv[0] + cbr * pre.tcv[1], gdelta * pre.tcv[4] + cbr * pre.tcv[5]});
+                gst2(po + 2, double2_t{gdelta, 0.0});
             }
         }
         if (refill) issue_tc(tid, nl_, pre);
@@ -550,7 +558,7 @@ template <int L, bool TRAIN> struct Chain {
             put2<L, RS, PSZ>(sGZ2 + (c3half * 4 + 2) * PSZ, r, c, acc[2], acc[3]);
             if (gzo) {
                 double* po = gzo + 8 * (size_t)c3s + 4 * c3half;
-                *reinterpret_cast<double2_t*>(po) = double2_t{acc[0], acc[1]}; *reinterpret_cast<double2_t*>(po + 2) = double2_t{acc[2], acc[3]};
+                gst2(po, double2_t{acc[0], acc[1]}); gst2(po + 2, double2_t{acc[2], acc[3]});
             }
         }
         if (refill) issue_d2(tid, nl_, pre);
@@ -566,8 +574,8 @@ template <int L, bool TRAIN> struct Chain {
                 put2i<RS, PSZ>(sD1 + 2 * g * PSZ, pr_ + (mu == 0 ? 0 : 1), pc_ + (mu == 0 ? 1 : 0), v2, v3);
                 if (gzo) {
                     const int s0 = pr_ * L + pc_, s1 = s0 + (mu == 0 ? 1 : L);
-                    *reinterpret_cast<double2_t*>(gzo + 8 * (size_t)N + 8 * (size_t)s0 + 2 * g) = double2_t{v0, v1};
-                    *reinterpret_cast<double2_t*>(gzo + 8 * (size_t)N + 8 * (size_t)s1 + 2 * g) = double2_t{v2, v3};
+                    gst2(gzo + 8 * (size_t)N + 8 * (size_t)s0 + 2 * g, double2_t{v0, v1});
+                    gst2(gzo + 8 * (size_t)N + 8 * (size_t)s1 + 2 * g, double2_t{v2, v3});
                 }
             };
             // the pair's four-line window holds exactly one line on which gz2 is zero (class 2: no active site within reach):
@@ -708,7 +716,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
     constexpr int N = G::N;
     __shared__ __attribute__((aligned(16))) double sm[G::SIZE];
     const int b = blockIdx.x;
-    const Hot hot{Aarg.wint, Aarg.stash, DBG ? Aarg.dbg : nullptr, Aarg.B, Aarg.nl, Aarg.act, TRAIN ? Aarg.gz : nullptr};
+    const Hot hot{(Aarg.wint), (Aarg.stash), DBG ? (Aarg.dbg) : nullptr, Aarg.B, Aarg.nl, Aarg.act, TRAIN ? (Aarg.gz) : nullptr};
     Chain<L, TRAIN> C(sm, hot, b);
     const int tid = C.tid;
     double* red = sm + G::RED;
@@ -763,7 +771,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
                 // the loss pieces of this chain (train.py:191-206): x = F(xi), logq = -2 L^2 log(2 pi) - log det J, logp = -S_W(x)
                 double S, Q;
                 C.action_charge(beta, S, Q);
-                const SmallArgs& At = cold();
+                ColdArgs& At = cold();
                 if (tid == 0) {
                     if (At.logq) At.logq[b] = -(double)(2 * N) * log(FT_TWO_PI) - ld;
                     if (At.logp) At.logp[b] = -S;
@@ -800,7 +808,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_ft_small(SmallArgs Aarg) {
         }
     }
 
-    const SmallArgs& A = cold();                                           // outputs: read from the kernarg segment here
+    ColdArgs& A = cold();                                           // outputs: read from the kernarg segment here
     if (mode == SM_ACTION) {
         if (tid == 0) {
             if (A.S_eff) A.S_eff[b] = stt[0];

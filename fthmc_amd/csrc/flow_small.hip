@@ -343,10 +343,17 @@ template <int L, bool TRAIN> struct Chain {
         double w3[27];
         {
             cdptr w3p = (cdptr)(size_t)(block_of(A.wint, false, l) + LF_W2 + wave * 9);
+            // wide scalar loads written out (s_load_dwordx16 + s_load_dwordx2 per output channel, as in flow_fwd.hip: the pass that
+            // would merge 27 s_load_dwordx2 is off for this kernel)
+            typedef double double8c_t __attribute__((ext_vector_type(8)));
+            typedef const double8c_t __attribute__((address_space(4))) * cd8ptr;
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < 3; ++k) {
+                const double8c_t v8 = *(cd8ptr)(w3p + k * 72);
 #pragma unroll
-                for (int tp = 0; tp < 9; ++tp) w3[k * 9 + tp] = w3p[k * 72 + tp];
+                for (int tp = 0; tp < 8; ++tp) w3[k * 9 + tp] = v8[tp];
+                w3[k * 9 + 8] = w3p[k * 72 + 8];
+            }
         }
         lds_barrier();
         stamp(2);
@@ -608,8 +615,12 @@ template <int L, bool TRAIN> struct Chain {
         double w0s[18];
         {
             cdptr wq = (cdptr)(size_t)(block_of(A.wint, true, l) + LB_W0 + wave * 18);
+            typedef double double8c_t __attribute__((ext_vector_type(8)));                   // wide scalar loads (8 + 8 + 2), as above
+            typedef const double8c_t __attribute__((address_space(4))) * cd8ptr;
+            const double8c_t va = *(cd8ptr)(wq), vb = *(cd8ptr)(wq + 8);
 #pragma unroll
-            for (int k = 0; k < 18; ++k) w0s[k] = wq[k];
+            for (int k = 0; k < 8; ++k) { w0s[k] = va[k]; w0s[8 + k] = vb[k]; }
+            w0s[16] = wq[16]; w0s[17] = wq[17];
         }
         if (refill) issue_d1(lane, nl_, pre);
         lds_barrier();

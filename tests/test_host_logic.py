@@ -471,6 +471,24 @@ def test_hot_kernels_are_what_the_build_intends(tmp_path):
                     seen.setdefault(key, []).append((body.count('v_mfma_f64_16x16x4'), body.count('ds_read2_b64'),
                                                      body.count('ds_read_b64'), int(m.group(1)) if m else -1, preload))
     assert set(seen) == {'k_flow_fwd', 'k_flow_bwd_gather', 'k_flow_wgrad'}, seen.keys()
+    # round 5: no FLAT memory instruction in the coupling kernels, and at most the two kernel-entry ones in the small-lattice
+    # kernel (its pointers pass through SGPR-pinning asm statements and used to come out generic: 91 flat loads / stores that
+    # count on lgkmcnt as well, so that every LDS wait also waited for the stash stores in flight); its spilled SGPRs stay below
+    # what MachineLICM's hoisted fp64 constants used to cost (171 with the pass, 71 without: csrc/Makefile NOLICM)
+    n_small = 0
+    for dev in _device_code_objects(_lib.LIB_PATH, str(tmp_path)):
+        dis = subprocess.run([f'{llvm}/llvm-objdump', '-d', dev], check=True, capture_output=True, text=True).stdout
+        notes = subprocess.run([f'{llvm}/llvm-readelf', '--notes', dev], check=True, capture_output=True, text=True).stdout
+        for name, body in re.findall(r'<(_Z\w+)>:\n(.*?)(?=\n\n|\Z)', dis, flags=re.S):
+            flat = len(re.findall(r'\bflat_(?:load|store)_', body))
+            if 'k_flow_fwd' in name or 'k_flow_bwd_gather' in name or 'k_flow_wgrad' in name:
+                assert flat == 0, f'{name}: {flat} FLAT memory instructions'
+            if 'k_ft_small' in name:
+                n_small += 1
+                assert flat <= 4, f'{name}: {flat} FLAT memory instructions (global pointers lost their address space?)'
+                m = re.search(r'\.name:\s+' + re.escape(name) + r'\s.*?\.sgpr_spill_count:\s+(\d+)', notes, flags=re.S)
+                assert m and int(m.group(1)) <= 120, f'{name}: {m and m.group(1)} spilled SGPRs (NOLICM of csrc/Makefile not applied?)'
+    assert n_small >= 12, n_small
     for key, variants in seen.items():
         for mfma, read2, read1, scratch, preload in variants:
             # the two coupling kernels take their hot arguments as explicit scalars delivered with the wave (csrc/Makefile PRELOAD)

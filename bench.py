@@ -308,6 +308,7 @@ def main():
     gen = torch.Generator(device='cpu').manual_seed(SEED)
     flow = make_flow(gen, N_LAYERS)
     w = ops.pack_weights(flow, device=dev) if flowed else None
+    WKEY = ('bench', time.time_ns()) if flowed else None     # the weights' content version: fixed for the run
     # Untimed preparation: a hot start U(-pi, pi) at large beta rejects every trajectory, so the chains start
     # near-cold (|x| < 0.1) and are brought to the Wilson ensemble at this beta by plain HMC on the HIP path.
     # The flow is untrained (random init, as the workload prescribes), so the timed ftHMC trajectories accept
@@ -358,7 +359,7 @@ def main():
             # in place: the accepted field replaces x, its (S_eff, plaq, Q) replace the carried state (the C ABI allows
             # x_new == x and state_out == state_in: both are read before they are written)
             ops.ft_trajectory(x, v, u, w, N_LAYERS, BETA, dt, NSTEP, mode='md', out=out, state_in=None if stateless else state,
-                              groups=Gsplit)
+                              groups=Gsplit, wkey=WKEY)
         else:
             ops.hmc_trajectory(x, v, u, BETA, dt, NSTEP, out=out)          # results written in place: no copy launches behind it
             ops.wilson_action_charge(out['x_new'], BETA, out=out)
@@ -374,16 +375,15 @@ def main():
             enqueue()                       # warm allocator / workspaces before capture (trajectory 0's draws)
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
-            # The weights do not change while sampling: the captured sequence carries no weight expansion (ops.assume_packed: the
-            # C ABI's fthmc_hint_weights_packed ahead of every call), the workspaces of its streams get it ONCE below.
+            # The weights do not change while sampling: every trajectory call states their content version (wkey -> the C ABI's
+            # `_v` entry points), the library expands them once and finds its stamps on the device from then on.
             # thread_local: the process group's watchdog thread may poll its events while this thread captures
-            with ops.assume_packed(), torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
+            with torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
                 enqueue()
             if flowed:                      # the stateless variant of the same trajectory, for the side figure below
                 graph_sl = torch.cuda.CUDAGraph()
-                with ops.assume_packed(), torch.cuda.graph(graph_sl, stream=stream, capture_error_mode='thread_local'):
+                with torch.cuda.graph(graph_sl, stream=stream, capture_error_mode='thread_local'):
                     enqueue(stateless=True)
-                ops.pack_trajectory_workspaces(x, w, N_LAYERS, groups=Gsplit)
 
     traj = [0]
     pending = [None]

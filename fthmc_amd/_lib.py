@@ -12,7 +12,7 @@ import os
 # resolve this library's DT_NEEDED libamdhip64.so.7 to that same runtime instance, so torch's
 # streams / allocations and our launches live in ONE HIP runtime (two would not share streams).
 import torch  # noqa: F401  (keep before the CDLL below)
-from ctypes import c_char_p, c_double, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_int, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # FTHMC_LIB: another build of the same library (A/B kernel measurements in one run on one device)
@@ -74,8 +74,8 @@ SIGNATURES = {
     'fthmc_train_grad': [_D, _D, _A, c_int, c_int, c_int, c_int, c_double, _D, _D, _D, _D, _P, c_size_t, _P],
     'fthmc_random_uniform': [_D, c_int, c_int, c_double, c_double, _D, _P],
     'fthmc_chain_seeds': [ctypes.c_int64, ctypes.c_int64, c_int, ctypes.c_int64, _D, c_int, _D, _P],
-    'fthmc_hint_weights_packed': [c_int],
-    'fthmc_pack_weights': [_D, _A, c_int, _P, c_size_t, _P],
+    'fthmc_ws_head_bytes': [],
+    'fthmc_pack_weights': [_D, _A, c_int, c_uint64, _P, c_size_t, _P],
     'fthmc_adam_step': [_D, _D, _D, _D, _D, c_size_t, c_double, c_double, c_double, c_double, c_int, _P],
     'fthmc_train_metrics': [_D, _D, _D, _D, c_int, c_int, c_double, c_double, _D, _P, c_size_t, _P],
     'fthmc_time_kernel': [c_int, _D, _D, _A, c_int, c_int, c_int, c_int, c_int, c_double, c_int, ctypes.POINTER(c_double), _P, c_size_t, _P],
@@ -83,7 +83,10 @@ SIGNATURES = {
     'fthmc_small_profile': [_D, _D, _D, _D, _A, c_int, c_int, c_int, c_int, c_double, c_double, c_int, ctypes.POINTER(c_double), _P, c_size_t, _P],
     'fthmc_profile_stages': [c_int, _D, _D, _A, c_int, c_int, c_int, c_int, c_int, c_double, ctypes.POINTER(c_double), _P, c_size_t, _P],
 }
-_RESTYPE = {'fthmc_layer_stash_bytes': c_size_t, 'fthmc_version': c_char_p, 'fthmc_last_error': c_char_p, 'fthmc_train_ws_bytes': c_size_t, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
+# the `_v` twins of the whole-flow entry points: the same arguments + the caller's weight version (include/fthmc_hip.h)
+for _n in ('fthmc_flow_forward', 'fthmc_flow_reverse', 'fthmc_ft_action', 'fthmc_ft_force', 'fthmc_ft_leapfrog', 'fthmc_ft_trajectory'):
+    SIGNATURES[_n + '_v'] = SIGNATURES[_n] + [c_uint64]
+_RESTYPE = {'fthmc_ws_head_bytes': c_size_t, 'fthmc_layer_stash_bytes': c_size_t, 'fthmc_version': c_char_p, 'fthmc_last_error': c_char_p, 'fthmc_train_ws_bytes': c_size_t, 'fthmc_strerror': c_char_p, 'fthmc_ws_bytes': c_size_t}
 
 _lib = None
 
@@ -106,6 +109,9 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
         fn = getattr(lib, name)                 # AttributeError if a symbol is missing
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, c_int)
+    if b'DRYRUN' in lib.fthmc_version() and os.environ.get('FTHMC_ALLOW_DRYRUN') != '1':
+        # csrc/Makefile `san`: the host-side sanitizer build launches nothing -- it must never stand in for the product
+        raise FthmcError(f'{path} is the host-side sanitizer build (launches are no-ops): not a library to compute with')
     _lib = lib
     return lib
 

@@ -61,7 +61,9 @@ WS ws_layout(const FlowArch& A, double* base, int B, int L, int nl, bool train =
     size_t o = 0;
     auto take = [&](size_t n) { double* p = base ? base + o : nullptr; o += up(n); return p; };
     w.n2 = n2;
-    w.wint = take((size_t)(nl > 0 ? nl : 1) * FLOW_WINT);
+    // the weight expansions: a FIXED head of FLOW_WHEAD_LAYERS layer regions in every layout (kernels.h: no call of any shape puts
+    // another region there, so the stamps of k_pack_weights vouch for what sits behind them), longer for deeper flows
+    w.wint = take((size_t)(nl > FLOW_WHEAD_LAYERS ? nl : FLOW_WHEAD_LAYERS) * FLOW_WINT);
     w.X = take((size_t)nl * n2);
     w.gp = take(n1);
     w.gp2 = take(nl > 0 ? n1 : 0);                       // second plaquette-gradient field (gather-form backward)
@@ -98,12 +100,18 @@ inline bool bad_shape(int B, int L) { return B <= 0 || L < 4 || (L % 4) != 0; }
 
 // The caller's canonical weights: the tuned kernels read their own expansion (k_pack_weights -> W.wint), the kernels for
 // other net shapes (flow_generic.hip) read the canonical layout itself.
-static thread_local int g_weights_packed = 0;     // fthmc_hint_weights_packed: consumed by the next call on this thread
-inline int use_weights(Ctx& C, const double* w, int nl, const WS& W, hipStream_t s) {
+// wver: the caller's statement of the weights' content version (the `_v` entry points; 0 = none: expand).  The library keeps
+// nothing between calls: the launch compares the token of (version, address of w) with the stamps the last expansion left in
+// the workspace and expands the layers whose stamps differ -- a stale or wrong version costs an expansion, never a result.
+inline unsigned long long weights_token(const double* w, uint64_t wver) {
+    if (wver == 0) return 0ull;
+    unsigned long long z = (unsigned long long)wver ^ ((unsigned long long)(uintptr_t)w * 0xD6E8FEB86659FD93ull);
+    z ^= z >> 32; z *= 0xD6E8FEB86659FD93ull; z ^= z >> 32;            // a 64-bit mix: versions 1, 2, 3 ... do not look alike
+    return z | 2ull;                                                     // never 0
+}
+inline int use_weights(Ctx& C, const double* w, int nl, const WS& W, hipStream_t s, uint64_t wver = 0) {
     C.wcan = w;
-    const bool packed = g_weights_packed != 0;
-    g_weights_packed = 0;
-    return C.A.is_default() && !packed ? launch_pack_weights(w, nl, W.wint, s) : FTHMC_OK;
+    return C.A.is_default() ? launch_pack_weights(w, nl, W.wint, s, weights_token(w, wver)) : FTHMC_OK;
 }
 inline GenLayerArgs gen_args(const Ctx& C, const WS& w, int l, int B, int L, int act, bool own_region) {
     GenLayerArgs g{};
@@ -267,7 +275,12 @@ extern "C" {
 #define FTHMC_SRC_SHA "unknown"
 #endif
 // "... src <fingerprint>": the kernel sources this library was built from (tools/csrc_sha.py, csrc/Makefile)
-const char* fthmc_version(void) { return "fthmc_hip 0.4 (gfx950) src " FTHMC_SRC_SHA; }
+#ifdef FT_DRYRUN      // the sanitizer build (make san): launches are no-ops -- the name says so, fthmc_amd/_lib.py refuses to load it as the product
+#define FTHMC_BUILD_KIND " DRYRUN (host-side sanitizer build: launches nothing)"
+#else
+#define FTHMC_BUILD_KIND ""
+#endif
+const char* fthmc_version(void) { return "fthmc_hip 0.5 (gfx950) src " FTHMC_SRC_SHA FTHMC_BUILD_KIND; }
 
 int fthmc_set_variant(int v) {
     if (v != 0 && v != 1) return FTHMC_ERR_ARG;
@@ -361,15 +374,15 @@ int fthmc_random_momenta(const int64_t* seeds, int B, int n_per_chain, double* v
     return launch_random_momenta(seeds, B, n_per_chain, v, u, ft_stream(stream));
 }
 
-int fthmc_hint_weights_packed(int packed) { g_weights_packed = packed ? 1 : 0; return FTHMC_OK; }
+size_t fthmc_ws_head_bytes(void) { return up((size_t)FLOW_WHEAD_LAYERS * FLOW_WINT) * sizeof(double); }
 
-int fthmc_pack_weights(const double* w, const fthmc_arch_t* arch, int n_layers, void* ws, size_t ws_bytes, void* stream) {
+int fthmc_pack_weights(const double* w, const fthmc_arch_t* arch, int n_layers, uint64_t weights_version, void* ws, size_t ws_bytes,
+                       void* stream) {
     if (!w || n_layers <= 0) return FTHMC_ERR_ARG;
     FT_CTX(arch);
-    g_weights_packed = 0;
-    if (!ws || ws_bytes < up((size_t)n_layers * FLOW_WINT) * sizeof(double)) return FTHMC_ERR_WS;
+    if (!ws || ws_bytes < up((size_t)(n_layers > FLOW_WHEAD_LAYERS ? n_layers : FLOW_WHEAD_LAYERS) * FLOW_WINT) * sizeof(double)) return FTHMC_ERR_WS;
     const WS W = ws_layout(C.A, static_cast<double*>(ws), 1, 4, n_layers);      // the expansion is the workspace's first region whatever B, L
-    return use_weights(C, w, n_layers, W, s);
+    return use_weights(C, w, n_layers, W, s, weights_version);
 }
 
 int fthmc_chain_seeds(int64_t seed, int64_t lo, int B, int64_t traj, int64_t* counter, int advance, int64_t* seeds, void* stream) {
@@ -641,13 +654,13 @@ int fthmc_flow_layer_bwd_stash(const double* stash, const double* w, const fthmc
     return layer_bwd_impl(nullptr, stash, w, arch, gy, glogJ, B, L, mu, off, act, gx, gw, ws, ws_bytes, stream);
 }
 
-int fthmc_flow_forward(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
-                       double* y, double* logdet, void* ws, size_t ws_bytes, void* stream) {
+int fthmc_flow_forward_v(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
+                       double* y, double* logdet, void* ws, size_t ws_bytes, void* stream, uint64_t weights_version) {
     if (!x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(C, w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s, weights_version));
     double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
     if (n_layers == 0 && hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     if (C.small(L, n_layers)) {
@@ -661,13 +674,18 @@ int fthmc_flow_forward(const double* x, const double* w, const fthmc_arch_t* arc
     return FTHMC_OK;
 }
 
-int fthmc_flow_reverse(const double* y, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double tol,
-                       double* x, double* logdet, void* ws, size_t ws_bytes, void* stream) {
+int fthmc_flow_forward(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
+                       double* y, double* logdet, void* ws, size_t ws_bytes, void* stream) {
+    return fthmc_flow_forward_v(x, w, arch, n_layers, B, L, act, y, logdet, ws, ws_bytes, stream, 0);
+}
+
+int fthmc_flow_reverse_v(const double* y, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double tol,
+                       double* x, double* logdet, void* ws, size_t ws_bytes, void* stream, uint64_t weights_version) {
     if (!y || !x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(C, w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s, weights_version));
     double* ld = logdet ? logdet : W.scal + (size_t)SC_LOGDET * B;
     if (hipMemsetAsync(ld, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     // The last layer maps y -> x, the others run in place on x.  In place is safe: a layer only rewrites its ACTIVE links,
@@ -699,14 +717,19 @@ int fthmc_flow_reverse(const double* y, const double* w, const fthmc_arch_t* arc
     return FTHMC_OK;
 }
 
-int fthmc_ft_action(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,
+int fthmc_flow_reverse(const double* y, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double tol,
+                       double* x, double* logdet, void* ws, size_t ws_bytes, void* stream) {
+    return fthmc_flow_reverse_v(y, w, arch, n_layers, B, L, act, tol, x, logdet, ws, ws_bytes, stream, 0);
+}
+
+int fthmc_ft_action_v(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,
                     double* S_eff, double* logdet, double* plaq, double* Q, void* ws, size_t ws_bytes,
-                    void* stream) {
+                    void* stream, uint64_t weights_version) {
     if (!x || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(C, w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s, weights_version));
     if (n_layers == 0 && logdet && hipMemsetAsync(logdet, 0, (size_t)B * sizeof(double), s) != hipSuccess) return FTHMC_ERR_LAUNCH;
     if (C.small(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 0);
@@ -716,13 +739,19 @@ int fthmc_ft_action(const double* x, const double* w, const fthmc_arch_t* arch, 
     return eval_action(C, x, W, n_layers, B, L, act, beta, S_eff, logdet, plaq, Q, s);
 }
 
-int fthmc_ft_force(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,
-                   double* F, void* ws, size_t ws_bytes, void* stream) {
+int fthmc_ft_action(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,
+                    double* S_eff, double* logdet, double* plaq, double* Q, void* ws, size_t ws_bytes,
+                    void* stream) {
+    return fthmc_ft_action_v(x, w, arch, n_layers, B, L, act, beta, S_eff, logdet, plaq, Q, ws, ws_bytes, stream, 0);
+}
+
+int fthmc_ft_force_v(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,
+                   double* F, void* ws, size_t ws_bytes, void* stream, uint64_t weights_version) {
     if (!x || !F || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0) return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(C, w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s, weights_version));
     if (C.small(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 1);
         a.F = F;
@@ -732,15 +761,20 @@ int fthmc_ft_force(const double* x, const double* w, const fthmc_arch_t* arch, i
     return launch_kick_from_gp(W.gp, nullptr, nullptr, F, B, L, 0.0, 0.0, s);
 }
 
-int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L,
+int fthmc_ft_force(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,
+                   double* F, void* ws, size_t ws_bytes, void* stream) {
+    return fthmc_ft_force_v(x, w, arch, n_layers, B, L, act, beta, F, ws, ws_bytes, stream, 0);
+}
+
+int fthmc_ft_leapfrog_v(const double* x, const double* v, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L,
                       int act, double beta, double dt, int nstep, double* x_out, double* v_out,
-                      void* ws, size_t ws_bytes, void* stream) {
+                      void* ws, size_t ws_bytes, void* stream, uint64_t weights_version) {
     if (!x || !v || !x_out || !v_out || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0 || nstep < 1)
         return FTHMC_ERR_ARG;
     if (act < 0 || act > 2) return FTHMC_ERR_UNSUPPORTED;
     FT_CTX(arch);
     FT_WS(n_layers);
-    FT_TRY(use_weights(C, w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s, weights_version));
     if (C.small(L, n_layers)) {
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 2);
         a.v = v; a.dt = dt; a.nstep = nstep; a.x_out = x_out; a.v_out = v_out;
@@ -753,11 +787,17 @@ int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, const f
     return FTHMC_OK;
 }
 
-int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch, int n_layers,
+int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L,
+                      int act, double beta, double dt, int nstep, double* x_out, double* v_out,
+                      void* ws, size_t ws_bytes, void* stream) {
+    return fthmc_ft_leapfrog_v(x, v, w, arch, n_layers, B, L, act, beta, dt, nstep, x_out, v_out, ws, ws_bytes, stream, 0);
+}
+
+int fthmc_ft_trajectory_v(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch, int n_layers,
                         int B, int L, int act, double beta, double dt, int nstep, int mode, double* x_new,
                         double* dH, double* acc, double* H0, double* H1, double* plaq, double* Q,
                         const double* state_in, double* state_out,
-                        void* ws, size_t ws_bytes, void* stream) {
+                        void* ws, size_t ws_bytes, void* stream, uint64_t weights_version) {
     if (!x || !v || !u || !x_new || (n_layers > 0 && !w) || bad_shape(B, L) || n_layers < 0 || nstep < 1)
         return FTHMC_ERR_ARG;
     if (act < 0 || act > 2 || (mode != FTHMC_MODE_MD && mode != FTHMC_MODE_LITERAL)) return FTHMC_ERR_UNSUPPORTED;
@@ -770,7 +810,7 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
     double* old = W.scal + (size_t)SC_OLD0 * B;      // slots SC_OLD0.. : 3 consecutive
     double* neu = W.scal + (size_t)SC_NEW0 * B;
     double* sel = state_out ? state_out : W.scal + (size_t)SC_S * B;
-    FT_TRY(use_weights(C, w, n_layers, W, s));
+    FT_TRY(use_weights(C, w, n_layers, W, s, weights_version));
     if (mode == FTHMC_MODE_MD && C.small(L, n_layers)) {          // the whole trajectory in one launch
         SmallArgs a = small_args(x, W, n_layers, B, act, beta, 3);
         a.v = v; a.u = u; a.dt = dt; a.nstep = nstep; a.x_out = x_new; a.state_in = state_in; a.state_out = state_out;
@@ -818,6 +858,14 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
     if (Q && hipMemcpyAsync(Q, sel + 2 * B, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
         return FTHMC_ERR_LAUNCH;
     return FTHMC_OK;
+}
+
+int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch, int n_layers,
+                        int B, int L, int act, double beta, double dt, int nstep, int mode, double* x_new,
+                        double* dH, double* acc, double* H0, double* H1, double* plaq, double* Q,
+                        const double* state_in, double* state_out,
+                        void* ws, size_t ws_bytes, void* stream) {
+    return fthmc_ft_trajectory_v(x, v, u, w, arch, n_layers, B, L, act, beta, dt, nstep, mode, x_new, dH, acc, H0, H1, plaq, Q, state_in, state_out, ws, ws_bytes, stream, 0);
 }
 
 int fthmc_train_grad(const double* xi, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act, double beta,

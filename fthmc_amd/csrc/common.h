@@ -15,6 +15,18 @@ namespace fthmc { void note_hip_error(hipError_t e, const char* file, int line);
     do { hipError_t e_ = hipGetLastError();                                            \
          if (e_ != hipSuccess) { fthmc::note_hip_error(e_, __FILE__, __LINE__); return FTHMC_ERR_LAUNCH; } } while (0)
 
+// -DFT_DRYRUN (the sanitizer build, `make san`): the HOST side only -- every launch, copy and memset is a no-op that succeeds,
+// so that tests/test_sanitizer.py can take every entry point through ALL of its host sequencing (argument checks, workspace
+// carving, launch geometry) under AddressSanitizer + UBSan on a box without a GPU.  Never part of the product library.
+#ifdef FT_DRYRUN
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(...) do { } while (0)
+#define hipMemcpyAsync(...) hipSuccess
+#define hipMemsetAsync(...) hipSuccess
+#undef FT_LAUNCH_CHECK
+#define FT_LAUNCH_CHECK() do { } while (0)
+#endif
+
 // torch.remainder(x + pi, 2 pi) - pi   (fmod is exact; sign fix as ATen does)
 // Within three periods of the principal range the remainder is one exact subtraction (Sterbenz) or
 // the same rounded addition ATen performs, so the short path is bit-identical to fmod's.

@@ -19,11 +19,23 @@ namespace {
 using namespace fthmc;
 using namespace fthmc_flow;
 
-__global__ void k_pack_weights(const double* __restrict__ w, int n_layers, double* __restrict__ o) {
-    const int l = blockIdx.x;                                    // gridDim.y workgroups per layer
+// token != 0: the call states a weight version.  A workgroup whose stamp (kernels.h: FLOW_WSTAMPS) already carries this call's
+// token for its layer leaves at once -- the slice behind the stamp is the expansion of exactly these weights --, any other
+// workgroup expands its slice and stamps it.  token = 0: expand, and clear the stamp.
+__global__ void k_pack_weights(const double* __restrict__ w, int n_layers, double* __restrict__ o, unsigned long long token) {
+    const int l = blockIdx.x;                                    // gridDim.y = FLOW_WSTAMPS workgroups per layer
     const double* c = w + (size_t)l * FTHMC_W_PER_LAYER;
     double* d = o + (size_t)l * FLOW_WINT;
-    for (int t = blockIdx.y * blockDim.x + threadIdx.x; t < FLOW_WINT; t += gridDim.y * blockDim.x) {
+    unsigned long long* stamp = reinterpret_cast<unsigned long long*>(d + FLOW_WSTAMP0) + blockIdx.y;
+    const bool guarded = l < FLOW_WHEAD_LAYERS;                  // layers beyond the workspace head: always expanded, never stamped
+    unsigned long long mine = 0ull;
+    if (token != 0ull && guarded) {
+        mine = (token + 0x9E3779B97F4A7C15ull * (unsigned long long)(l + 1)) | 1ull;
+        const unsigned long long seen = *stamp;
+        __syncthreads();                                         // every thread has read the stamp before thread 0 may rewrite it
+        if (seen == mine) return;
+    }
+    for (int t = blockIdx.y * blockDim.x + threadIdx.x; t < FLOW_WSTAMP0; t += gridDim.y * blockDim.x) {
         double v = 0.0;
         if (t < B1) { int co = t % 8, tap = (t / 8) % 9, ci = t / 72; v = c[CW0 + (co * 2 + ci) * 9 + tap]; }
         else if (t < W2F) v = c[CB0 + t - B1];
@@ -71,6 +83,11 @@ __global__ void k_pack_weights(const double* __restrict__ w, int n_layers, doubl
             }
         }
         d[t] = v;
+    }
+    if (guarded) {
+        __threadfence();
+        __syncthreads();                                         // the slice is written before its stamp says so
+        if (threadIdx.x == 0) *stamp = mine;
     }
 }
 
@@ -613,9 +630,10 @@ inline dim3 flow_grid(int B, int L) { int t = (L + FT - 1) / FT; return dim3(t, 
 
 namespace fthmc {
 
-int launch_pack_weights(const double* w, int n_layers, double* wint, hipStream_t s) {
+int launch_pack_weights(const double* w, int n_layers, double* wint, hipStream_t s, unsigned long long token) {
     if (n_layers <= 0) return FTHMC_OK;
-    hipLaunchKernelGGL(k_pack_weights, dim3(n_layers, 8), dim3(256), 0, s, w, n_layers, wint);
+    static_assert(WBWD1 + LB_SIZE <= FLOW_WSTAMP0, "the stamps sit behind the last weight block");
+    hipLaunchKernelGGL(k_pack_weights, dim3(n_layers, FLOW_WSTAMPS), dim3(256), 0, s, w, n_layers, wint, token);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_flow_fwd(const FlowLayerArgs& a, hipStream_t s) {

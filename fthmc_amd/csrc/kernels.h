@@ -54,6 +54,14 @@ constexpr int FLOW_TILE = 16;                 // VALU variant (flow.hip): 16 x 1
 constexpr int FLOW_R0 = FLOW_TILE + 6;        // plaquette / net-input window edge
 constexpr int FLOW_N0 = FLOW_R0 * FLOW_R0;    // window size of one gP partial
 constexpr int FLOW_WINT = 8768;               // doubles per layer, kernel-side weight layout
+// The expansion of layer l is guarded by STAMPS inside the layer's own region (its last FLOW_WSTAMPS doubles, one per
+// workgroup of k_pack_weights): a workgroup that finds its stamp equal to the token of the call (caller's weight version,
+// address of the canonical weights, layer) leaves at once, otherwise it expands its slice and writes the token.  The
+// first FLOW_WHEAD_LAYERS layer regions are a FIXED head of every workspace layout (ws_layout): no other region of any call,
+// whatever its shape, overlaps them, so a stamp vouches for the data it sits behind; layers beyond the head are expanded
+// by every call.
+constexpr int FLOW_WSTAMPS = 8, FLOW_WSTAMP0 = FLOW_WINT - FLOW_WSTAMPS;
+constexpr int FLOW_WHEAD_LAYERS = 64;
 constexpr int FLOW_GW_STRIDE = 960;           // doubles per (chain, tile) weight-gradient partial
 
 // tile geometry of a variant: partial buffers are indexed [chain][tile][window]
@@ -76,7 +84,8 @@ inline size_t flow_ntiles_max(int L) {
 inline size_t flow_gp_part_max(int L) { return (size_t)flow_geom(false).ntiles(L) * flow_geom(false).n0(); }
 
 // canonical (955/layer, PyTorch order) -> kernel layout (FLOW_WINT/layer)
-int launch_pack_weights(const double* w, int n_layers, double* wint, hipStream_t s);
+// token = 0: expand unconditionally (and clear the stamps); else see FLOW_WSTAMPS above
+int launch_pack_weights(const double* w, int n_layers, double* wint, hipStream_t s, unsigned long long token = 0ull);
 
 struct FlowLayerArgs {
     const double* x;         // [B][2][L][L] layer input

@@ -76,6 +76,7 @@ class FieldTransformation(nn.Module):
         self._carry = None
         self._last_obs = None         # (plaq, Q) of the flowed accepted field of the last trajectory (run() reads them)
         self._loop = None             # the captured run loop (GraphLoop) and what it was captured for
+        self._loop_streams = None     # its stream and the chain groups' side streams: made once, reused by every re-capture
         self.use_graph = os.environ.get('FTHMC_RUN_GRAPH', '1') not in ('', '0')
 
     # ---- weights: packed once, refreshed when a parameter changed in place -----------
@@ -283,13 +284,15 @@ class FieldTransformation(nn.Module):
         xd = x.detach()
         nl, act, mode, beta = len(self.flow), self._act, self._mode(), self.config.beta
         G = ops.default_groups(B, L) if batch else 1
+        # the weights' content version is part of what a capture is FOR: its launches carry it to the library, which checks
+        # it on the device against the stamps in the workspaces (include/fthmc_hip.h "Weight versions")
         sig = (tuple(x.shape), dev, w.data_ptr(), nl, act, mode, beta, self.dt, self.nstep, G, batch,
-               ops.get_variant(), ops.get_small_path())
+               ops.get_variant(), ops.get_small_path(), ops.weights_version(wkey))
         if self._loop is not None and self._loop.get('pending') is not None:
             self._loop['pending']()                                       # an unread history of the previous run: read it before its ring is reused
             self._loop['pending'] = None
         if self._loop is None or self._loop['sig'] != sig:
-            self._loop = self._make_loop(xd, w, nl, act, mode, beta, G, batch, sig)
+            self._loop = self._make_loop(xd, w, nl, act, mode, beta, G, batch, sig, wkey)
 
         def prepare(lp):
             """start field, start state and the weight expansion on the loop's stream -> (q0, workspace token)"""
@@ -304,12 +307,13 @@ class FieldTransformation(nn.Module):
                 # the start of the q history: Q of the flowed start field for a batch (ft_hmc.py:311-313), of the field itself otherwise
                 q0_ = lp['state'][2].clone() if batch else qed.batch_charges(xd)
                 lp['x'].copy_(xd)
-                # the captured sequence carries no weight expansion: the workspaces of its streams get it here, once per run
-                return q0_, ops.pack_trajectory_workspaces(lp['x'], w, nl, groups=G, side_streams=lp['sides'])
+                # the workspaces of the loop's streams at their final size, holding the expansion of these weights: the
+                # replays' own expansion launches find the stamps and leave at once
+                return q0_, ops.trajectory_workspaces(lp['x'], w, nl, groups=G, side_streams=lp['sides'], wkey=wkey)
         q0, token = prepare(self._loop)
         if self._loop['loop'].captured and self._loop['token'] != token:
             # a workspace moved since the capture (grown by another caller of these streams): capture again
-            self._loop = self._make_loop(xd, w, nl, act, mode, beta, G, batch, sig)
+            self._loop = self._make_loop(xd, w, nl, act, mode, beta, G, batch, sig, wkey)
             q0, token = prepare(self._loop)
         lp = self._loop
         loop, xs, state = lp['loop'], lp['x'], lp['state']
@@ -323,7 +327,7 @@ class FieldTransformation(nn.Module):
             if loop.captured and not was_captured:
                 # the eager first step may have grown a workspace: the capture that followed saw the final ones
                 with torch.cuda.stream(loop.stream):
-                    lp['token'] = ops.pack_trajectory_workspaces(xs, w, nl, groups=G, side_streams=lp['sides'])
+                    lp['token'] = ops.trajectory_workspaces(xs, w, nl, groups=G, side_streams=lp['sides'], wkey=wkey)
             if nprint and i % nprint == 0:
                 r = torch.from_numpy(loop.last()).view(4, B)
                 self._print_line(i, r[0], r[1], r[2], r[3])
@@ -360,7 +364,7 @@ class FieldTransformation(nn.Module):
             return h
         return LazyHistory(fill)
 
-    def _make_loop(self, x, w, nl, act, mode, beta, G, batch, sig):
+    def _make_loop(self, x, w, nl, act, mode, beta, G, batch, sig, wkey):
         dev, B = x.device, x.shape[0]
         xs = torch.empty_like(x)
         v = torch.empty_like(x)
@@ -370,17 +374,23 @@ class FieldTransformation(nn.Module):
         out = {'x_new': xs, 'acc': row[0], 'dH': row[1], 'plaq': row[2], 'Q': row[3], 'state': state,
                'H0': torch.empty(B, dtype=torch.float64, device=dev), 'H1': torch.empty(B, dtype=torch.float64, device=dev)}
 
-        # the loop's own streams for the chain groups beyond the first: the replays rely on what the workspaces of its streams
-        # hold (the weight expansion), so nobody else may run on them
-        sides = [torch.cuda.Stream(device=dev) for _ in range(max(G, 1) - 1)]
+        # the loop's own streams (its own and one per chain group beyond the first), made once per FieldTransformation and
+        # reused by every re-capture (a beta scan re-captures per beta: a new stream each time would leave a workspace of
+        # 0.3-0.4 GB behind per stream until torch's stream pool wraps)
+        if self._loop_streams is None or self._loop_streams[0] != dev:
+            self._loop_streams = (dev, torch.cuda.Stream(device=dev), [])
+        _, lstream, pool = self._loop_streams
+        while len(pool) < max(G, 1) - 1:
+            pool.append(torch.cuda.Stream(device=dev))
+        sides = pool[:max(G, 1) - 1]
 
         def enqueue():
             v.normal_()                                                   # = torch.randn_like(x), then torch.rand(B): ft_hmc.py:204, 243
             u.uniform_()
             # in place: the accepted field replaces x, its (S_eff, plaq, Q) the carried state (both read before they are written)
             ops.ft_trajectory(xs, v, u, w, nl, beta, self.dt, self.nstep, act, mode=mode, out=out, state_in=state, groups=G,
-                              side_streams=sides)
-        loop = GraphLoop(enqueue, row, use_graph=True, capture_ctx=ops.assume_packed)
+                              side_streams=sides, wkey=wkey)
+        loop = GraphLoop(enqueue, row, use_graph=True, stream=lstream)
         return {'sig': sig, 'loop': loop, 'x': xs, 'state': state, 'row': row, 'token': None, 'pending': None, 'sides': sides}
 
 

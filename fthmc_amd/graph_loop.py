@@ -21,11 +21,11 @@ class GraphLoop:
 
     The first `step()` runs the sequence eagerly (allocator, workspaces), then captures it -- the capture does not execute,
     so n calls of `step()` are exactly n iterations, with the same random draws as n eager ones (torch's generator takes
-    part in the capture).  `before_replay` is called once before the first replay of the graph (e.g. to re-establish what
-    the captured sequence assumes about its workspaces)."""
+    part in the capture).  `stream`: the stream the loop runs on (default: a new one); an owner that re-captures often hands
+    in the same one every time."""
 
     def __init__(self, enqueue: Callable[[], None], row: torch.Tensor, chunk: int = 256, use_graph: bool = True,
-                 capture_ctx: Optional[Callable] = None):
+                 stream: Optional[torch.cuda.Stream] = None):
         self.enqueue, self.row = enqueue, row
         self.dev = row.device
         self.chunk = max(1, int(chunk))
@@ -34,8 +34,7 @@ class GraphLoop:
         self.n = 0
         self.graph = None
         self.use_graph = bool(use_graph)
-        self.capture_ctx = capture_ctx
-        self.stream = torch.cuda.Stream(device=self.dev)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
 
     @property
@@ -48,15 +47,8 @@ class GraphLoop:
                 self.enqueue()
                 self.stream.synchronize()
                 g = torch.cuda.CUDAGraph()
-                ctx = self.capture_ctx() if self.capture_ctx is not None else None
-                if ctx is not None:
-                    ctx.__enter__()
-                try:
-                    with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
-                        self.enqueue()
-                finally:
-                    if ctx is not None:
-                        ctx.__exit__(None, None, None)
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
+                    self.enqueue()
                 self.graph = g
             elif self.use_graph:
                 self.graph.replay()

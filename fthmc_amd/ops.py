@@ -64,13 +64,12 @@ def _ws(t: torch.Tensor, B: int, L: int, nl: int, train: bool = False, arch=None
         # (a buffer no capture ever saw is simply dropped: the allocator orders its reuse behind this stream's work)
         _WS_CAPTURED.discard(key)
         buf = torch.empty((need + 7) // 8, dtype=torch.float64, device=t.device)
+        # the head holds the weight expansions and their stamps (include/fthmc_hip.h, "Weight versions"): fresh memory may
+        # carry the stamps of an earlier life of the same address
+        buf[:min(buf.numel(), int(_lib.load().fthmc_ws_head_bytes()) // 8)].zero_()
         _WS[key] = buf
     if torch.cuda.is_current_stream_capturing():
         _WS_CAPTURED.add(key)
-    # whoever takes the workspace may expand other weights into it: the record of what it holds is dropped here and put back
-    # by _packed_hint for the entry points that run under a caller-stated weight version
-    global _LAST_PACKED
-    _LAST_PACKED = (key, _WS_PACKED.pop(key, None))
     return buf.data_ptr(), buf.numel() * 8
 
 
@@ -80,52 +79,26 @@ def release_workspaces():
     _WS.clear()
     _WS_CAPTURED.clear()
     _WS_RETIRED.clear()
-    _WS_PACKED.clear()
 
 
-# Which weights' kernel-layout expansion the workspace of a (device, stream) holds: (buffer id, w.data_ptr(), n_layers, wkey).
-# `wkey` is the CALLER's statement of the weights' content version (FieldTransformation: parameter versions + the flat
-# buffer's generation, utils/layers.py weights_generation); calls that pass none expand their weights every time.
-_WS_PACKED: dict = {}
-_LAST_PACKED = (None, None)      # (workspace key, the record _ws() just dropped)
+def drop_stream_workspaces(streams):
+    """Forget the workspaces of streams nobody will run on again (a captured loop that was replaced: its graph is gone with it)."""
+    for st in streams:
+        for key in [k for k in _WS if k[1] == st.cuda_stream]:
+            _WS.pop(key, None)
+            _WS_CAPTURED.discard(key)
 
 
-def _packed_hint(t: torch.Tensor, w, n_layers: int, wkey):
-    """Before an entry point that runs the net on this stream's workspace: skip its weight expansion (C ABI
-    fthmc_hint_weights_packed) when that workspace already holds the expansion of these weights at this version.  Never
-    during graph capture: a captured sequence either carries its own expansion or its owner re-establishes the workspace
-    before replaying (`pack_workspace`)."""
-    if w is None or not n_layers:
-        return
-    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
-    buf = _WS.get(key)
-    prev = _LAST_PACKED[1] if _LAST_PACKED[0] == key else None
-    rec = None if (wkey is None or buf is None) else (buf.data_ptr(), w.data_ptr(), int(n_layers), wkey)
-    if _ASSUME_PACKED[0] and arch_of(w) == DEFAULT_ARCH:
-        _lib.load().fthmc_hint_weights_packed(1)
-        return
-    if torch.cuda.is_current_stream_capturing():
-        return                         # the captured call expands its weights itself; no record survives it (dropped in _ws)
-    if rec is not None and prev == rec and arch_of(w) == DEFAULT_ARCH:
-        _lib.load().fthmc_hint_weights_packed(1)
-    if rec is not None:
-        _WS_PACKED[key] = rec
-
-
-_ASSUME_PACKED = [False]
-
-
-class assume_packed:
-    """Context: every entry point called inside tells the library that its workspace already holds the expansion of its weights
-    (fthmc_hint_weights_packed) -- also during graph capture, so that the captured sequence carries no expansion launch.  The
-    owner of such a sequence re-establishes the workspaces (`pack_trajectory_workspaces`) before it replays."""
-
-    def __enter__(self):
-        self.prev = _ASSUME_PACKED[0]
-        _ASSUME_PACKED[0] = True
-
-    def __exit__(self, *exc):
-        _ASSUME_PACKED[0] = self.prev
+def weights_version(wkey) -> int:
+    """The caller's statement of the weights' CONTENT version (`wkey`: any hashable -- FieldTransformation: parameter
+    versions + the flat buffer's generation, utils/layers.py weights_generation) as the 64-bit number of the C ABI's `_v`
+    entry points; None -> 0 = no statement: the call expands its weights.  The library compares it ON THE DEVICE with the
+    stamps the last expansion left in the workspace (include/fthmc_hip.h, "Weight versions"): nothing is recorded here."""
+    if wkey is None:
+        return 0
+    if isinstance(wkey, int) and 0 < wkey < (1 << 64):
+        return wkey
+    return (hash(('fthmc-weights', wkey)) & 0xFFFFFFFFFFFFFFFF) or 1
 
 
 def _group_edges(groups, B: int):
@@ -137,10 +110,10 @@ def _group_edges(groups, B: int):
     return [k * B // G for k in range(G + 1)]
 
 
-def pack_trajectory_workspaces(x: torch.Tensor, w, n_layers: int, groups=1, arch=None, side_streams=None):
-    """Expand `w` into the workspace of every stream an `ft_trajectory(x, ..., groups=groups)` call from the current stream
-    runs on (the current stream and the side streams of the chain groups) -> a token (the workspaces' addresses): a captured
-    sequence stays valid while the token does."""
+def trajectory_workspaces(x: torch.Tensor, w, n_layers: int, groups=1, arch=None, side_streams=None, wkey=None):
+    """Make sure the workspace of every stream an `ft_trajectory(x, ..., groups=groups)` call from the current stream runs on
+    (the current stream and the side streams of the chain groups) exists at its final size, holding the expansion of `w`
+    -> a token (the workspaces' addresses): a captured sequence stays valid while the token does."""
     x = _field(x); B, _, L, _ = x.shape
     edges = _group_edges(groups, B)
     G = len(edges) - 1
@@ -152,7 +125,7 @@ def pack_trajectory_workspaces(x: torch.Tensor, w, n_layers: int, groups=1, arch
     for gi in list(range(1, G)) + [0]:
         st = main if gi == 0 else sides[gi - 1]
         with torch.cuda.stream(st):
-            pack_workspace(x, w, n_layers, edges[gi + 1] - edges[gi], L, arch=arch)
+            pack_workspace(x, w, n_layers, edges[gi + 1] - edges[gi], L, wkey=wkey, arch=arch)
             token.append(_WS[(x.device.index, st.cuda_stream)].data_ptr())
     for st in sides:
         main.wait_stream(st)
@@ -160,14 +133,11 @@ def pack_trajectory_workspaces(x: torch.Tensor, w, n_layers: int, groups=1, arch
 
 
 def pack_workspace(t: torch.Tensor, w, n_layers: int, B: int, L: int, wkey=None, arch=None):
-    """Expand `w` into the workspace of the current stream (grown to serve [B, 2, L, L] calls with n_layers layers) and
-    record it under `wkey`: what the owner of a captured sequence WITHOUT its own expansion calls before replaying it."""
+    """Expand `w` into the workspace of the current stream (grown to serve [B, 2, L, L] calls with n_layers layers) under the
+    version `wkey` states (C ABI fthmc_pack_weights): later calls on this stream with the same `wkey` find the stamps."""
     w, ap, a = _wall(w, n_layers, arch)
     ws, nb = _ws(t, B, L, n_layers, arch=a)
-    check(_lib.load().fthmc_pack_weights(_p(w), ap, n_layers, ws, nb, _stream(t)), 'fthmc_pack_weights')
-    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
-    if wkey is not None and not torch.cuda.is_current_stream_capturing():
-        _WS_PACKED[key] = (_WS[key].data_ptr(), w.data_ptr(), int(n_layers), wkey)
+    check(_lib.load().fthmc_pack_weights(_p(w), ap, n_layers, weights_version(wkey), ws, nb, _stream(t)), 'fthmc_pack_weights')
 
 
 # ---------------------------------------------------------------- s/t net shape
@@ -616,9 +586,8 @@ def flow_forward(x, w, n_layers: int, act='silu', arch=None, wkey=None):
     w, ap, a = _wall(w, n_layers, arch)
     y = torch.empty_like(x); ld = torch.empty(B, dtype=x.dtype, device=x.device)
     ws, nb = _ws(x, B, L, n_layers, arch=a)
-    _packed_hint(x, w, n_layers, wkey)
-    check(_lib.load().fthmc_flow_forward(_p(x), _p(w), ap, n_layers, B, L, act_code(act), _p(y), _p(ld), ws, nb,
-                                         _stream(x)), 'fthmc_flow_forward')
+    check(_lib.load().fthmc_flow_forward_v(_p(x), _p(w), ap, n_layers, B, L, act_code(act), _p(y), _p(ld), ws, nb,
+                                         _stream(x), weights_version(wkey)), 'fthmc_flow_forward')
     return y, ld
 
 
@@ -627,9 +596,8 @@ def flow_reverse(y, w, n_layers: int, act='silu', tol: float = 1e-12, arch=None,
     w, ap, a = _wall(w, n_layers, arch)
     x = torch.empty_like(y); ld = torch.empty(B, dtype=y.dtype, device=y.device)
     ws, nb = _ws(y, B, L, n_layers, arch=a)
-    _packed_hint(y, w, n_layers, wkey)
-    check(_lib.load().fthmc_flow_reverse(_p(y), _p(w), ap, n_layers, B, L, act_code(act), float(tol), _p(x), _p(ld),
-                                         ws, nb, _stream(y)), 'fthmc_flow_reverse')
+    check(_lib.load().fthmc_flow_reverse_v(_p(y), _p(w), ap, n_layers, B, L, act_code(act), float(tol), _p(x), _p(ld),
+                                         ws, nb, _stream(y), weights_version(wkey)), 'fthmc_flow_reverse')
     return x, ld
 
 
@@ -639,9 +607,8 @@ def ft_action(x, w, n_layers: int, beta: float, act='silu', arch=None, wkey=None
     w, ap, a = _wall(w, n_layers, arch)
     S, ld, plaq, Q = (torch.empty(B, dtype=x.dtype, device=x.device) for _ in range(4))
     ws, nb = _ws(x, B, L, n_layers, arch=a)
-    _packed_hint(x, w, n_layers, wkey)
-    check(_lib.load().fthmc_ft_action(_p(x), _p(w), ap, n_layers, B, L, act_code(act), float(beta), _p(S), _p(ld),
-                                      _p(plaq), _p(Q), ws, nb, _stream(x)), 'fthmc_ft_action')
+    check(_lib.load().fthmc_ft_action_v(_p(x), _p(w), ap, n_layers, B, L, act_code(act), float(beta), _p(S), _p(ld),
+                                      _p(plaq), _p(Q), ws, nb, _stream(x), weights_version(wkey)), 'fthmc_ft_action')
     return S, ld, plaq, Q
 
 
@@ -650,9 +617,8 @@ def ft_force(x, w, n_layers: int, beta: float, act='silu', arch=None, wkey=None)
     w, ap, a = _wall(w, n_layers, arch)
     F = torch.empty_like(x)
     ws, nb = _ws(x, B, L, n_layers, arch=a)
-    _packed_hint(x, w, n_layers, wkey)
-    check(_lib.load().fthmc_ft_force(_p(x), _p(w), ap, n_layers, B, L, act_code(act), float(beta), _p(F), ws, nb,
-                                     _stream(x)), 'fthmc_ft_force')
+    check(_lib.load().fthmc_ft_force_v(_p(x), _p(w), ap, n_layers, B, L, act_code(act), float(beta), _p(F), ws, nb,
+                                     _stream(x), weights_version(wkey)), 'fthmc_ft_force')
     return F
 
 
@@ -661,9 +627,8 @@ def ft_leapfrog(x, v, w, n_layers: int, beta: float, dt: float, nstep: int, act=
     w, ap, a = _wall(w, n_layers, arch)
     xo, vo = torch.empty_like(x), torch.empty_like(v)
     ws, nb = _ws(x, B, L, n_layers, arch=a)
-    _packed_hint(x, w, n_layers, wkey)
-    check(_lib.load().fthmc_ft_leapfrog(_p(x), _p(v), _p(w), ap, n_layers, B, L, act_code(act), float(beta), float(dt),
-                                        int(nstep), _p(xo), _p(vo), ws, nb, _stream(x)), 'fthmc_ft_leapfrog')
+    check(_lib.load().fthmc_ft_leapfrog_v(_p(x), _p(v), _p(w), ap, n_layers, B, L, act_code(act), float(beta), float(dt),
+                                        int(nstep), _p(xo), _p(vo), ws, nb, _stream(x), weights_version(wkey)), 'fthmc_ft_leapfrog')
     return xo, vo
 
 
@@ -743,12 +708,11 @@ def ft_trajectory(x, v, u, w, n_layers: int, beta: float, dt: float, nstep: int,
             raise FthmcError(f'state_in: expected [3, {B}]')
     m = {'md': MODE_MD, 'literal': MODE_LITERAL, 'reference_literal': MODE_LITERAL}[mode]
     ws, nb = _ws(x, B, L, n_layers, arch=a)
-    _packed_hint(x, w, n_layers, wkey)
-    check(_lib.load().fthmc_ft_trajectory(_p(x), _p(v), _p(u), _p(w), ap, n_layers, B, L, act_code(act), float(beta),
+    check(_lib.load().fthmc_ft_trajectory_v(_p(x), _p(v), _p(u), _p(w), ap, n_layers, B, L, act_code(act), float(beta),
                                           float(dt), int(nstep), m, _p(out['x_new']), _p(out['dH']), _p(out['acc']),
                                           _p(out['H0']), _p(out['H1']), _p(out['plaq']), _p(out['Q']),
                                           _p(state_in), _p(out['state']), ws, nb,
-                                          _stream(x)), 'fthmc_ft_trajectory')
+                                          _stream(x), weights_version(wkey)), 'fthmc_ft_trajectory')
     return out
 
 

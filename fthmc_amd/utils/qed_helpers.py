@@ -3,6 +3,7 @@ charge, plain force / leapfrog / HMC, flow drivers, ft_action, ft_force, and the
 physical-field ftHMC wrapper (ipynb/ft_hmc.py:420-513: ft_hmc, ft_run, flow_resize)."""
 from __future__ import annotations
 
+import time
 from dataclasses import dataclass
 from math import pi as PI
 from typing import Optional
@@ -11,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .layers import flow_activation, flow_weights
+from .layers import flow_activation, flow_weights, weights_generation
 
 TWO_PI = 2 * PI
 
@@ -292,6 +293,9 @@ def _ft_run_captured(param, flow, field: torch.Tensor, ntot: int, tol: float = 1
     fs = field.detach().reshape((1,) + tuple(field.shape[-3:])).clone()
     L = fs.shape[-1]
     w, nl, act = flow_weights(flow, dev), len(flow), flow_activation(flow)
+    # the weights do not change inside this loop: every launch states one content version, the library expands them once
+    # (the first call) and checks the stamp on the device afterwards (include/fthmc_hip.h "Weight versions")
+    wkey = ('ft_run', id(flow), w.data_ptr(), w._version, weights_generation(w), time.monotonic_ns())
     v = torch.empty_like(fs)
     u = torch.empty(1, dtype=torch.float64, device=dev)
     row = torch.empty(5, dtype=torch.float64, device=dev)
@@ -301,22 +305,16 @@ def _ft_run_captured(param, flow, field: torch.Tensor, ntot: int, tol: float = 1
     obs = {'S': torch.empty(1, dtype=torch.float64, device=dev), 'Q': row[3:4], 'plaq': row[2:3]}
 
     def enqueue():
-        x = ops.flow_reverse(fs, w, nl, act, tol=tol)[0]                 # x = F^-1(field)
+        x = ops.flow_reverse(fs, w, nl, act, tol=tol, wkey=wkey)[0]      # x = F^-1(field)
         v.normal_()                                                      # randn_like(x), then rand([]): ipynb/ft_hmc.py:423-424
         u.uniform_()
-        ops.ft_trajectory(x, v, u, w, nl, param.beta, param.dt, param.nstep, act, mode='md', out=res)
-        fs.copy_(ops.flow_forward(res['x_new'], w, nl, act)[0])          # newfield = F(newx)
+        ops.ft_trajectory(x, v, u, w, nl, param.beta, param.dt, param.nstep, act, mode='md', out=res, wkey=wkey)
+        fs.copy_(ops.flow_forward(res['x_new'], w, nl, act, wkey=wkey)[0])   # newfield = F(newx)
         ops.wilson_action_charge(fs, param.beta, out=obs)
         torch.exp(torch.neg(row[0:1]), out=row[4:5])
-    loop = GraphLoop(enqueue, row, use_graph=True, capture_ctx=ops.assume_packed)
-    with torch.cuda.stream(loop.stream):
-        ops.pack_workspace(fs, w, nl, 1, L)
+    loop = GraphLoop(enqueue, row, use_graph=True)
     for k in range(ntot):
-        was = loop.captured
         loop.step()
-        if loop.captured and not was:
-            with torch.cuda.stream(loop.stream):
-                ops.pack_workspace(fs, w, nl, 1, L)                      # what the replays assume (the eager first step may have grown the workspace)
     rows = loop.rows()
     loop.join()
     return fs[0].clone(), rows

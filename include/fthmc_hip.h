@@ -85,17 +85,25 @@ int fthmc_arch_params(const fthmc_arch_t* arch);   /* doubles per layer; 955 for
  * one launch per layer.  0 switches it off (the tiled kernels then serve every L): A/B runs and parity tests. */
 int fthmc_set_small_path(int on);
 
-/* Promise for the NEXT entry point called on this thread (consumed by it, whatever it is): the workspace passed to that
- * call already holds the kernel-layout expansion of exactly the weights passed to it -- same contents, same n_layers --
- * left there by an earlier call on the same stream.  The call then skips the expansion launch (7 us; the reference packs
- * nothing: its convs read nn.Conv2d parameters, fthmc/utils/layers.py:138-167).  Thread-local: no state is shared between
- * threads or streams.  Without the promise every call expands the weights it is given. */
-int fthmc_hint_weights_packed(int packed);
+/* Weight versions (the `_v` entry points below and fthmc_pack_weights).  The tuned kernels read a kernel-layout EXPANSION of
+ * the canonical weights (70 KB per layer) that every entry point which runs the net writes into the head of its workspace
+ * first (one launch, ~7 us; the reference packs nothing: its convs read nn.Conv2d parameters, fthmc/utils/layers.py:138-167).
+ * A caller whose weights stay put between calls -- a sampler replaying a captured trajectory -- states their CONTENT VERSION
+ * (any 64-bit number it changes whenever the weights' contents change; 0 = no statement): the launch then compares, on the
+ * device, a token of (version, address of w, layer) with the stamp the last expansion left next to each layer's expansion
+ * and expands only the layers whose stamp differs.  The library keeps no state between calls and trusts nothing: a wrong,
+ * stale or reused version, another tensor, a call without a version in between (it clears the stamps it overwrites) all end
+ * in an expansion, i.e. in the same numbers.  The one promise left with the caller is the meaning of the number: equal
+ * version + equal address = equal contents.
+ * The expansions of the first 64 layers are the HEAD of every workspace layout (fthmc_ws_head_bytes() bytes; no call of
+ * any shape keeps anything else there); deeper layers are expanded by every call.  A workspace must be zero in its head
+ * before its first use with a version (fresh memory may hold the stamps of an earlier life of the same address). */
+size_t fthmc_ws_head_bytes(void);
 
-/* Expand the canonical weights (n_layers x params, the layout of every `w` argument below) into the workspace and do nothing
- * else: what every entry point that runs the net does first.  With fthmc_hint_weights_packed a caller that replays a captured
- * sequence many times under constant weights expands them once per weight version instead of once per call. */
-int fthmc_pack_weights(const double* w, const fthmc_arch_t* arch, int n_layers, void* ws, size_t ws_bytes, void* stream);
+/* Expand the canonical weights (n_layers x params, the layout of every `w` argument below) into the workspace under
+ * `weights_version` (0: unconditionally) and do nothing else: what every entry point that runs the net does first. */
+int fthmc_pack_weights(const double* w, const fthmc_arch_t* arch, int n_layers, uint64_t weights_version,
+                       void* ws, size_t ws_bytes, void* stream);
 int fthmc_get_small_path(void);
 
 /* Bytes of scratch the flow / trajectory entry points need for (B, L, n_layers). */
@@ -205,29 +213,44 @@ int fthmc_plaq_coupling_bwd(const double* P, const double* w, const fthmc_arch_t
                             void* ws, size_t ws_bytes, void* stream);
 
 /* ---- whole flow ---------------------------------------------------------- */
+/* Each entry point of this section has a `_v` twin with a trailing `weights_version` (see "Weight versions" above);
+ * the plain form is the twin with version 0. */
 /* y = F(x), logdet[B] = sum_l logJ_l.  fthmc/ft_hmc.py:143-150 (flow_forward),
  * fthmc/utils/qed_helpers.py:191-198 (ft_flow).  y, logdet may be NULL. */
 int fthmc_flow_forward(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                        double* y, double* logdet, void* ws, size_t ws_bytes, void* stream);
+int fthmc_flow_forward_v(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
+                       double* y, double* logdet, void* ws, size_t ws_bytes, void* stream, uint64_t weights_version);
 /* x = F^-1(y), logdet[B].  fthmc/ft_hmc.py:152-160, qed_helpers.py:201-209.  x may alias y: the last layer maps
  * y -> x and the remaining layers run in place on x (see fthmc_flow_layer_rev). */
 int fthmc_flow_reverse(const double* y, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                        double tol, double* x, double* logdet,
                        void* ws, size_t ws_bytes, void* stream);
+int fthmc_flow_reverse_v(const double* y, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
+                       double tol, double* x, double* logdet,
+                       void* ws, size_t ws_bytes, void* stream, uint64_t weights_version);
 /* S_eff[b] = S_W(F(x)) - logdet.  fthmc/utils/qed_helpers.py:212-223 (ft_action),
  * fthmc/ft_hmc.py:135-141.  Optional outputs (NULL to skip): logdet[B],
  * plaq[B], Q[B] of the physical field F(x). */
 int fthmc_ft_action(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                     double beta, double* S_eff, double* logdet, double* plaq, double* Q,
                     void* ws, size_t ws_bytes, void* stream);
+int fthmc_ft_action_v(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
+                    double beta, double* S_eff, double* logdet, double* plaq, double* Q,
+                    void* ws, size_t ws_bytes, void* stream, uint64_t weights_version);
 /* F = d(sum_b S_eff)/dx.  fthmc/utils/qed_helpers.py:226-242 (ft_force),
  * fthmc/ft_hmc.py:162-171. */
 int fthmc_ft_force(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
                    double beta, double* F, void* ws, size_t ws_bytes, void* stream);
+int fthmc_ft_force_v(const double* x, const double* w, const fthmc_arch_t* arch, int n_layers, int B, int L, int act,
+                   double beta, double* F, void* ws, size_t ws_bytes, void* stream, uint64_t weights_version);
 /* x_, v_ = leapfrog with ft_force.  ipynb/ft_hmc.py:394-418. */
 int fthmc_ft_leapfrog(const double* x, const double* v, const double* w, const fthmc_arch_t* arch, int n_layers,
                       int B, int L, int act, double beta, double dt, int nstep,
                       double* x_out, double* v_out, void* ws, size_t ws_bytes, void* stream);
+int fthmc_ft_leapfrog_v(const double* x, const double* v, const double* w, const fthmc_arch_t* arch, int n_layers,
+                      int B, int L, int act, double beta, double dt, int nstep,
+                      double* x_out, double* v_out, void* ws, size_t ws_bytes, void* stream, uint64_t weights_version);
 /* One ftHMC trajectory per chain in the latent field x with supplied v, u[B].
  * mode FTHMC_MODE_MD: ipynb/ft_hmc.py:420-435 without the flow-inverse wrapper;
  * FTHMC_MODE_LITERAL: fthmc/ft_hmc.py:190-224 as packaged.
@@ -242,6 +265,12 @@ int fthmc_ft_trajectory(const double* x, const double* v, const double* u, const
                         double* H0, double* H1, double* plaq, double* Q,
                         const double* state_in, double* state_out,
                         void* ws, size_t ws_bytes, void* stream);
+int fthmc_ft_trajectory_v(const double* x, const double* v, const double* u, const double* w, const fthmc_arch_t* arch,
+                        int n_layers, int B, int L, int act, double beta, double dt, int nstep,
+                        int mode, double* x_new, double* dH, double* acc,
+                        double* H0, double* H1, double* plaq, double* Q,
+                        const double* state_in, double* state_out,
+                        void* ws, size_t ws_bytes, void* stream, uint64_t weights_version);
 
 /* ---- training ------------------------------------------------------------ */
 /* Reverse-KL loss pieces and weight gradients for a fixed prior draw xi

@@ -1,6 +1,6 @@
 """GPU tests added in round 5: the reference-shaped drivers as captured loops (FieldTransformation.run, qed_helpers.ft_run)
 against their eager loops, the carried state keyed by the weights' content, per-chain seeds formed on the device, the
-packed-weights promise of the C ABI."""
+weight versions of the C ABI (round 6: checked on the device)."""
 import math
 
 import numpy as np
@@ -183,11 +183,13 @@ def test_weights_cache_follows_a_replaced_net():
     assert torch.equal(s1, ft_fresh.action(x)) and not torch.equal(s0, s1)
 
 
-# ---------------------------------------------------------------- the packed-weights promise
-def test_packed_weights_promise_skips_only_the_expansion():
-    """ops with a caller-stated weight version (`wkey`) expand the weights once per version into the stream's workspace
-    (C ABI fthmc_hint_weights_packed); any other call on that workspace, another version or other weights expand again.
-    Results are the ones of calls without the promise."""
+# ---------------------------------------------------------------- weight versions (C ABI `_v` entry points)
+def test_weight_versions_are_checked_on_the_device():
+    """ops with a caller-stated weight version (`wkey` -> the `_v` entry points of the C ABI) expand the weights once per version
+    into the stream's workspace; the library compares the version with the stamps its last expansion left there ON THE DEVICE:
+    a wrong or stale version, other weights under the same version, a call without a version in between all end in an
+    expansion and in the numbers of calls that state nothing.  That an equal version really skips the expansion is shown by
+    wiping the expansion behind its stamps."""
     gen = torch.Generator().manual_seed(3)
     L, nl, B, beta = 16, 4, 5, 3.0
     wa = ops.pack_weights(R.default_flow(nl, gen), device='cuda')
@@ -196,16 +198,44 @@ def test_packed_weights_promise_skips_only_the_expansion():
     ref_a = ops.ft_action(x, wa, nl, beta)[0].clone()
     ref_b = ops.ft_action(x, wb, nl, beta)[0].clone()
     Fa = ops.ft_force(x, wa, nl, beta).clone()
-    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)      # expands, records
-    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)      # promise taken: no expansion
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)      # expands, stamps
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)      # stamps found
     assert torch.equal(ops.ft_force(x, wa, nl, beta, wkey='v1'), Fa)
-    assert torch.equal(ops.ft_action(x, wb, nl, beta, wkey='v1')[0], ref_b)      # other weights under the same key: expands
-    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)
-    ops.flow_layer_fwd(x, wb[:955].contiguous(), 0, 0)                           # a call without a key overwrites the expansion ...
-    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)      # ... and the record: expanded again
-    wa.mul_(1.01)                                                                # new content, new key
+    # the expansion of layer 1 wiped behind its stamps (8768 doubles per layer, the last 8 are the stamps: csrc/kernels.h)
+    ws = ops._WS[(x.device.index, torch.cuda.current_stream().cuda_stream)]
+    from fthmc_amd import _lib
+    assert int(_lib.load().fthmc_ws_head_bytes()) == 64 * 8768 * 8
+    ws[8768:2 * 8768 - 8].zero_()
+    assert not torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v1')[0], ref_a)  # same version: nothing was expanded (the proof)
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='other')[0], ref_a)   # a WRONG version: expanded, same numbers
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='other')[0], ref_a)
+    assert torch.equal(ops.ft_action(x, wb, nl, beta, wkey='other')[0], ref_b)   # other weights under the same version: expanded
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='other')[0], ref_a)
+    ops.flow_layer_fwd(x, wb[:955].contiguous(), 0, 0)                           # a call without a version overwrites layer 0 and clears its stamps
+    assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='other')[0], ref_a)
+    with pytest.raises(ops.FthmcError):                                          # a call that fails early leaves nothing behind (there is no state to leave)
+        ops.ft_force(x[:, :, :6, :6].contiguous(), wb, nl, beta, wkey='other')
+    assert torch.equal(ops.ft_action(x, wb, nl, beta, wkey='other')[0], ref_b)
+    wa.mul_(1.01)                                                                # new content, new version
     ref_a2 = ops.ft_action(x, wa, nl, beta)[0].clone()
     assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v2')[0], ref_a2) and not torch.equal(ref_a2, ref_a)
+    # a graph captured under one version keeps producing the right numbers when other weights passed through its workspace
+    # in between (the advisor's sequence: eager w1 -> replay with w2 -> eager w1)
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        out_b = ops.ft_action(x, wb, nl, beta, wkey='g')[0]                      # warm-up: workspace of this stream
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
+            out_b = ops.ft_action(x, wb, nl, beta, wkey='g')[0]
+        assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v2')[0], ref_a2)
+        g.replay()
+        assert torch.equal(out_b, ref_b)
+        assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v2')[0], ref_a2)
+        g.replay()
+        assert torch.equal(out_b, ref_b)
+    torch.cuda.current_stream().wait_stream(st)
 
 
 # ---------------------------------------------------------------- physical-field driver

@@ -132,6 +132,12 @@ inline SmallArgs small_args(const double* x, const WS& w, int nl, int B, int act
 
 #define FT_TRY(expr) do { int rc_ = (expr); if (rc_ != FTHMC_OK) return rc_; } while (0)
 
+// 1 (default): the training backward of the tiled-exactly shapes computes its weight gradients itself (flow_bwd_train.hip);
+// 0: k_flow_bwd_gather writes the pre-activation gradients and k_flow_wgrad reads them back (rounds 2-5; A/B builds: EXTRA=-DFT_FUSED_WGRAD=0)
+#ifndef FT_FUSED_WGRAD
+#define FT_FUSED_WGRAD 1
+#endif
+
 // Forward sweep x -> X[0..nl-1] (X[l] = output of layer l).  logdet (device [B]) optional.
 // parts_only: leave the log J partials of every layer in w.lj_part ([layer][chain][tile]) and skip the summing launch (the
 // caller folds them into its own reduction: launch_traj_energy); tuned kernels only.
@@ -219,6 +225,16 @@ int force_gp(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, i
         if (stash) {
             a.stash = w.stash + (size_t)l * flow_stash_doubles(B, L, train);
             a.gp_out = galt;
+#if FT_FUSED_WGRAD
+            if (gw && train && flow_bwd_train_shape(L) && flow_stash_fits32(B, L, true)) {
+                // training: the layer's backward and its weight gradients in ONE kernel (flow_bwd_train.hip: the pre-activation
+                // gradients never leave LDS), one partial per workgroup
+                FT_TRY(launch_flow_bwd_train(a, s));
+                FT_TRY(launch_reduce_gw(w.gw_part, flow_bwd_train_nparts(B, L), 1.0, 0, gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
+                double* t_ = gcur; gcur = galt; galt = t_;
+                continue;
+            }
+#endif
             a.gz = train ? w.gz : nullptr;
             FT_TRY(launch_flow_bwd_gather(a, s));
             if (gw) {                                                 // weight gradients from the pre-activation gradients

@@ -1,0 +1,589 @@
+// Training backward of one coupling layer WITH its weight gradients (round 6): k_flow_bwd_gather's adjoint walk and
+// k_flow_wgrad's GEMMs in one kernel.
+//
+// The two-kernel form (flow_bwd_gather.hip writing gz2, gz1, g_out -- 17 doubles per site -- for flow_wgrad.hip to read back
+// beside the stashed h1, h2 windows) moved 109 doubles per site and layer through HBM in a training step (forward 35 written,
+// backward 19 read + 17 written, weight gradients 38 read): at the config-5 shard 29 GB per step.  The pre-activation
+// gradients are BORN in the backward's LDS planes -- gz2 on the tile+2 window after conv3^T, gz1 on tile+1 after conv2^T's
+// epilogue, g_out on tile+3 after the transform adjoint -- and the weight gradient
+//     gw[co][ci][ky][kx] = sum_s gz[co][s] * hin[ci][s + (ky - 1, kx - 1)]
+// needs them at the tile's OWN sites only: here the GEMMs read them where they lie.  What is left of the traffic is the h1, h2
+// windows (stashed by the forward; 20 doubles per site with the halo): 35 + 39 instead of 35 + 74.
+//
+// One 512-thread workgroup per CU (126 KB of LDS, up to 256 VGPRs) WALKS (chain, tile) items of its layer -- the weight
+// gradient's sum over sites simply runs on, its accumulators (four 16 x 16 MFMA tiles per wave) stay in registers -- and
+// writes ONE 955-entry partial at the end (k_reduce_gw sums the partials in a fixed order: bit-deterministic).  Per item the
+// stages are k_flow_bwd_gather's, each followed in the SAME barrier interval by the weight-gradient stage that reads the plane
+// the stage has just consumed or produced:
+//     transform adjoint -> g_out      | h1, h2 windows and the (cos, sin) window into LDS
+//     conv3^T (VALU) -> gz2           | conv3 weight gradient (VALU) from g_out and h2
+//     conv2^T (MFMA) -> gz1           | conv2 weight gradient (MFMA: M = 8 co x 2 row shifts from gz2, N = (ci, kx, ky in {0, 2}))
+//     conv1^T (VALU)                  | conv1 weight gradient (MFMA from gz1 and the net input window)
+// so a tile costs the backward's five barriers and no more.  The GEMM maps are k_flow_wgrad's (flow_wgrad.hip: 75 % useful
+// MACs, the K walk of 17 window rows split over the eight waves, bias sums from the A operand); their A operand comes from
+// the backward's planes, whose rows above and below the tile hold the neighbours' values where k_flow_wgrad had zero rings:
+// the two K steps that would pair them (walk row 0 for the lower row shift, walk row 16 for the upper) select 0 instead.
+//
+// Built for the tiled-exactly shapes (L a power of two >= 32: every BASELINE training shape); anything else keeps the
+// two-kernel form.  Reference: loss.backward() of fthmc/train.py:191-210 through GaugeEquivCouplingLayer.forward
+// (fthmc/utils/layers.py:196-202,348-371) and make_conv_net (:138-167).
+#include "flow_mfma_common.h"
+
+namespace {
+
+using namespace fthmc;
+using namespace fthmc_flow;
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+constexpr int cmax_(int a, int b) { return a > b ? a : b; }
+
+template <int TR, int TC> struct SmemT {
+    // the backward's windows (flow_bwd_gather.hip SmemG)
+    static constexpr int W3R = TR + 6, W3C = TC + 6, N3W = W3R * W3C;   // g_out window (active sites only)
+    static constexpr int W2R = TR + 4, W2C = TC + 4, N2W = W2R * W2C;   // act'(z2) -> gz2
+    static constexpr int W1R = TR + 2, W1C = TC + 2, N1W = W1R * W1C;   // act'(z1) -> gz1; h1, h2, (cos, sin)
+    static constexpr int N3 = TR * TC, NA = N3 / 4;
+    static constexpr int RS2 = W2C + 1;
+    static constexpr int PS2 = ps_round16(W2R * RS2), PS1 = ps_round(N1W);
+    // h1 / h2 / net-input planes on tile+1 (+ one row of slack): stride = 12 (mod 32) as in k_flow_wgrad (its B operand reads
+    // and the fill's writes are free of bank conflicts)
+    static constexpr int NH = N1W, PSH = ((NH + W1C - 12 + 31) / 32) * 32 + 12;
+    static constexpr int NLC = (W3C + 3) / 4, NLR = (W3R + 3) / 4;
+    static constexpr int NSLOT = cmax_(W3R * NLC, NLR * W3C);           // transform tasks
+    static constexpr int NTT = (NSLOT + 63) / 64 * 64;                  // threads that run them (last waves)
+    static constexpr int GO = 0;                                        // [3][N3W] g(s0, s1, t) on the tile+3 window
+    static constexpr int GOC = GO + 3 * N3W;                            // [3][NA]  the same at the own active sites, task order
+    static constexpr int GZ2 = GOC + 3 * NA;                            // [8][PS2] gz2; later conv1^T's channel partials
+    static constexpr int D1 = GZ2 + 8 * PS2;                            // [8][PS1] gz1
+    static constexpr int IN = D1 + 8 * PS1;                             // [2][PSH] cos, sin on tile+1 ((1, 0) off the frozen sites)
+    static constexpr int DIR = IN + 2 * PSH;                            // [2][N3]  layer's contribution at own sites, one buffer per item parity
+    static constexpr int SW = DIR + 2 * N3;                             // [LB_SIZE] backward weight block
+    static constexpr int HA1 = SW + LB_SIZE;                            // [8][PSH] h1 window
+    static constexpr int HA2 = HA1 + 8 * PSH;                           // [8][PSH] h2 window
+    static constexpr int WALK = HA2 + 8 * PSH;
+    // after the walk, over the planes: the waves' accumulators [8][4 tiles][4][64], bias lane sums [8][2][8], conv3 sums [432]
+    static constexpr int RED = 0, RBS = RED + 8 * 4 * 4 * 64, RC3 = RBS + 8 * 2 * 8, RSIZE = RC3 + 432;
+    static constexpr int SIZE = WALK > RSIZE ? WALK : RSIZE;
+    static_assert(TR == 16 && TC == 16 && NA == 64, "thread maps: conv2^T tile map, K split of the weight-gradient GEMMs, one wave per g_out plane");
+    static_assert(W1R % 2 == 0 && NTT <= NT && 2 * N3 <= NT && N1W <= NT && GOC % 2 == 0, "thread maps");
+    static_assert(SIZE * 8 <= 160 * 1024, "one workgroup per CU (160 KB of LDS on gfx950)");
+    static_assert(!FT_RECOMP_D1, "act'(z1) comes through the stash here");
+};
+
+// conv3 (8 -> 3, active sites only) weight gradient: thread = (output (co, ci, tap), half of the active sites); the 32 sites of
+// the half at compile-time offsets from the thread's base (k_flow_wgrad's loop)
+template <int MU, int TC, int W1C>
+__device__ __forceinline__ void conv3_acc(const double* __restrict__ pg, const double* __restrict__ ph, double (&acc)[4]) {
+#pragma unroll
+    for (int a = 0; a < 32; a += 2) {
+        const double2_t g2 = *reinterpret_cast<const double2_t*>(pg + a);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int aa = a + e;
+            const int o = MU == 0 ? (aa / (TC / 4)) * W1C + 4 * (aa % (TC / 4)) : 4 * (aa / TC) * W1C + aa % TC;
+            acc[aa & 3] = fma(e ? g2.y : g2.x, ph[o], acc[aa & 3]);
+        }
+    }
+}
+
+template <int TR, int TC, int MU>
+__global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerArgs A) {
+    using S = SmemT<TR, TC>;
+    constexpr int W3C = S::W3C, N3W = S::N3W, W2R = S::W2R, W2C = S::W2C, N2W = S::N2W;
+    constexpr int W1R = S::W1R, W1C = S::W1C, N3 = S::N3, NA = S::NA, PS1 = S::PS1, PS2 = S::PS2, RS2 = S::RS2;
+    constexpr int NH = S::NH, PSH = S::PSH;
+    __shared__ __attribute__((aligned(16))) double sm[S::SIZE];
+    double* sGO = sm + S::GO;   double* sGOC = sm + S::GOC;  double* sGZ2 = sm + S::GZ2;  double* sD1 = sm + S::D1;
+    double* sIn = sm + S::IN;   double* sW = sm + S::SW;     double* sHA1 = sm + S::HA1;  double* sHA2 = sm + S::HA2;
+
+    const int tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < NT);
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(wave >= 0 && wave < NW);
+    constexpr int mu = MU;
+    const int L = A.L, off = A.off;
+    // what the launcher guarantees (flow_bwd_train_shape)
+    __builtin_assume(off >= 0 && off < 4 && L >= 32 && L <= 8192 && (L & (L - 1)) == 0);
+    const int n = L * L;
+    const int nti_ = L / TR, ntj_ = L / TC, ntiles = nti_ * ntj_;
+    (void)nti_;
+
+    // ---- the walk (k_flow_wgrad's): the ns workgroups resident together on an XCD stand on ns consecutive items at every step
+    //      and move on by ns, so that the halo lines neighbouring tiles share are fetched once into the XCD's L2.
+    //      grid: x = 8 XCDs (blockIdx.x % 8) x rounds x ns; round kr = xcd * R + r covers items [kr * tpw * ns, (kr + 1) * tpw * ns)
+    const int items = A.B * ntiles, tpw = A.tpw, ns = A.wg_ns;
+    const int KR = (items + tpw * ns - 1) / (tpw * ns), R = (KR + 7) >> 3;
+    const int idx = (int)blockIdx.x >> 3, r_ = idx / ns, s_ = idx - r_ * ns, kr = ((int)blockIdx.x & 7) * R + r_;
+    const int first = kr * tpw * ns + s_;
+    if (r_ >= R || first >= items) return;
+    const int grp = kr * ns + s_;                                         // valid groups are a prefix of this numbering
+    const int nwalk = min(tpw, (items - first + ns - 1) / ns);
+    double* gw0 = A.gw_part + (size_t)grp * FLOW_GW_STRIDE;              // the group's partial
+    const double* __restrict__ w = A.wint;
+    const double cb = A.glogj_const;
+    const unsigned Bn = (unsigned)A.B * (unsigned)n;
+    auto ldu2 = [](const double* base, unsigned idx_) {                  // 16-byte load, scalar base + 32-bit element offset
+        return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx_ * 8u);
+    };
+
+    // ---- once per walk: the layer's backward weight block, the zeros behind the windows (read by discarded ky = 3 columns only)
+    {
+        constexpr int NWC = (LB_SIZE + NT - 1) / NT;
+#pragma unroll
+        for (int k = 0; k < NWC; ++k)
+            if (tid + k * NT < LB_SIZE) sW[tid + k * NT] = ldu(w + (mu == 0 ? WBWD1 : WBWD), (unsigned)(tid + k * NT));
+        if (tid < 2 * (PSH - NH)) {
+            const int pl = tid / (PSH - NH), e = NH + tid % (PSH - NH);
+            sIn[pl * PSH + e] = 0.0;
+#pragma unroll
+            for (int ch = pl; ch < 8; ch += 2) { sHA1[ch * PSH + e] = 0.0; sHA2[ch * PSH + e] = 0.0; }
+        }
+    }
+
+    // ---- item-independent thread maps
+    // transform tasks on the last waves: slot `ta` of the tile+3 window's active lines
+    const int ta = tid - (NT - S::NTT);
+    // conv3^T task = (two sites of the same line class, half of the 8 channels)
+    static_assert(W2R % 2 == 0 && W2C % 2 == 0 && N2W <= NT, "site pairs, one round");
+    constexpr int NPR = N2W / 2;
+    static_assert(NPR <= NT / 2, "one half of the channels per half of the workgroup");
+    const int c3half = wave >= NW / 2;
+    const bool c3task = (tid & (NT / 2 - 1)) < NPR;
+    const int c3u = c3task ? (tid & (NT / 2 - 1)) : 0;
+    int c3r, c3c;
+    if (mu == 0) { c3r = fdiv<W2C>(c3u); c3c = c3u - c3r * W2C; }             // (r, c), (r + W2R/2, c)
+    else { c3r = fdiv<W2C / 2>(c3u); c3c = c3u - c3r * (W2C / 2); }         // (r, c), (r, c + W2C/2)
+    // conv2^T tile map (flow_bwd_gather.hip): tiles 0 .. NU-1: u = tile, v = 0 .. 15; tiles NU, NU+1: v = 16, 17 of the even / odd u
+    constexpr int NU = W1C / 2, NTILE1 = NU + 2, NIT1 = (NTILE1 + NW - 1) / NW;
+    static_assert(NIT1 == 2 && W1R == W1C, "two rounds of conv2^T tiles");
+    int pu[NIT1], pv[NIT1];
+    bool pok[NIT1];
+#pragma unroll
+    for (int it = 0; it < NIT1; ++it) {
+        const int T = wave + NW * it, i = lane & 15;
+        if (T < NU) { pu[it] = T; pv[it] = i; pok[it] = true; }
+        else { pu[it] = 2 * (i >> 1) + (T - NU); pv[it] = 16 + (i & 1); pok[it] = T < NTILE1 && pu[it] < NU; if (!pok[it]) { pu[it] = 0; pv[it] = 0; } }
+    }
+    // h1 / h2 windows: tasks (window site, channel quad) in two rounds; the (cos, sin) window: thread = window site
+    constexpr int NITH = 2 * NH, NRH = (NITH + NT - 1) / NT;
+    int hwr[NRH], hwc[NRH], hwq[NRH], hls[NRH];
+#pragma unroll
+    for (int k = 0; k < NRH; ++k) {
+        const int t = min(tid + k * NT, NITH - 1), ws = t >> 1;
+        hwq[k] = t & 1; hwr[k] = fdiv<W1C>(ws); hwc[k] = ws - hwr[k] * W1C;
+        hls[k] = tid + k * NT < NITH ? (4 * hwq[k]) * PSH + hwr[k] * W1C + hwc[k] : -1;
+    }
+    const int fwr = fdiv<W1C>(min(tid, NH - 1)), fwc = min(tid, NH - 1) - fwr * W1C;
+    const bool fwtask = tid < NH;
+    const bool fwfrozen = fwtask && ((((mu == 0 ? fwc : fwr) - 1 - off) & 3) == 1 || (((mu == 0 ? fwc : fwr) - 1 - off) & 3) == 2);   // tile origins are multiples of 4
+    // own sites (final store)
+    const int orr = fdiv<TC>(tid), occ = tid - orr * TC;
+    const bool ovalid = tid < N3;
+    // weight-gradient GEMM lane maps (k_flow_wgrad: A row m = (co, dy), B column n = (ci, kx, kyb), ky = 2 kyb + dy)
+    const int wg_ = lane >> 4, wi_ = lane & 15, wco = wi_ & 7, wdy = wi_ >> 3;
+    const int pa2 = wco * PS2 + (2 - wdy) * RS2 + 2 + wg_;                // gz2 of the tile's site (walk row - dy, 4 cs + g) in the tile+2 plane
+    const int pa1 = wco * PS1 + (1 - wdy) * W1C + 1 + wg_;                // gz1 ... in the tile+1 plane
+    auto pbf = [&](int ncol, int ncols) { const int nc = ncol < ncols ? ncol : 0, ci = nc / 6, kx = (nc % 6) >> 1, kyb = nc & 1; return ci * PSH + 2 * kyb * W1C + kx + wg_; };
+    const int pb0 = pbf(wi_, 48), pb1 = pbf(16 + wi_, 48), pb2 = pbf(32 + wi_, 48), pb3 = pbf(wi_, 12);
+
+    // accumulators of the whole walk
+    double4_t acc[4];                                                      // this wave's K slice of the four N tiles (0..2 conv2, 3 conv1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = double4_t{0.0, 0.0, 0.0, 0.0};
+    double bsum[2] = {0.0, 0.0};                                           // bias sums b2, b1 of the slice: lanes dy = 0
+    double acc3[3] = {0.0, 0.0, 0.0};                                      // conv3: thread = (output, site half) in [0]; wave 7: b3 lane partials
+
+#pragma unroll 1
+    for (int it = 0; it < nwalk; ++it) {
+        // ---- the item (uniform: scalar divisions, once per item)
+        const int item = first + it * ns;
+        const int b = item / ntiles, tl = item - b * ntiles, ti = tl / ntj_, tj = tl - ti * ntj_;
+        const int i0 = ti * TR, j0 = tj * TC;
+        __builtin_assume(i0 >= 0 && i0 < L && j0 >= 0 && j0 < L && b >= 0 && b < (1 << 20));
+        double* sDir = sm + S::DIR + (it & 1) * N3;
+        const unsigned bn = (unsigned)b * (unsigned)n;
+        const double* __restrict__ st1 = uniform_at(A.stash, 8u * bn);
+        const double* __restrict__ stc = uniform_at(A.stash, 16u * Bn + 2u * bn);
+        const double* __restrict__ scs = uniform_at(A.stash, 18u * Bn + bn);
+        const double* __restrict__ sh1 = uniform_at(A.stash, 19u * Bn + 8u * bn);
+        const double* __restrict__ sh2 = uniform_at(A.stash, 27u * Bn + 8u * bn);
+        const unsigned wmagic = (unsigned)(L - 1);
+        auto wi = [&](int k) { return wrap_line<true, true>(i0 + k, L, wmagic); };
+        auto WI = [&](int k) { return mul24(wi(k), L); };
+        auto WJ = [&](int k) { return wrap_line<true, true>(j0 + k, L, wmagic); };
+        const int c0 = (off - (j0 - 3)) & 3, r0 = (off - (i0 - 3)) & 3;    // first active column / row of the tile+3 window
+
+        // ---- load phase (unconditional loads from clamped addresses, what the first stage consumes first)
+        // (1) transform tasks: active site `a` of the tile+3 window, both mixture components
+        int tr3 = 3, tc3 = 3;
+        bool ttask = false;
+        if (ta >= 0) {
+            if (mu == 0) { tr3 = fdiv<S::NLC>(ta); tc3 = c0 + 4 * (ta - tr3 * S::NLC); ttask = tr3 < S::W3R && tc3 < W3C; }
+            else { const int m = fdiv<W3C>(ta); tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
+            if (!ttask) { tr3 = 3; tc3 = 3; }                                // any valid site
+        }
+        double tcv[4 * NMIX], ag[2];
+        {
+            const int i = wi(tr3 - 3), j = WJ(tc3 - 3);
+            const unsigned ia = (unsigned)stash_active_idx(i, j, L, mu);
+#pragma unroll
+            for (int q = 0; q < 4 * NMIX; q += 2) {                          // [k][n/4][A B C E] (struct Stash): 16 bytes per load
+                const double2_t t2 = ldu2(stc + (size_t)(q >> 2) * n, ia * 4u + (q & 3));
+                tcv[q] = t2.x; tcv[q + 1] = t2.y;
+            }
+            const double* gsrc = uniform_at(A.up_gp, bn);                    // upstream gradient: the plaquette-gradient field
+            const int iL = mul24(i, L);
+            ag[0] = ldu(gsrc, (unsigned)(iL + j));
+            ag[1] = ldu(gsrc, (unsigned)(mu == 0 ? iL + WJ(tc3 - 4) : WI(tr3 - 4) + j));
+        }
+        // (2) (cos, sin) of the frozen plaquettes on the tile+1 window (the net input: conv1's weight gradient reads the window,
+        //     conv1^T's adjoint the own sites), one window site per thread
+        double fcs, fsn;
+        {
+            const unsigned ic = fwfrozen ? (unsigned)stash_frozen_idx(wi(fwr - 1), WJ(fwc - 1), L, mu, off) : 0u;
+            fcs = ldu_j(scs, ic); fsn = ldu_j(scs + (n >> 1), ic);
+        }
+        // (3) upstream gradient of the own sites (pass-through term)
+        double gpin = ldu_j(uniform_at(A.up_gp, bn), ovalid ? (unsigned)(mul24(i0 + orr, L) + j0 + occ) : 0u);
+        if (!ovalid) gpin = 0.0;
+        // (4) h2, h1 on the tile+1 window: 32 bytes per task and plane
+        double2_t hv2[NRH][2], hv1[NRH][2];
+        {
+#pragma unroll
+            for (int k = 0; k < NRH; ++k) {
+                const unsigned hat = (unsigned)(WI(hwr[k] - 1) + WJ(hwc[k] - 1)) * 8u + 4u * (unsigned)hwq[k];
+                hv2[k][0] = ldu2(sh2, hat); hv2[k][1] = ldu2(sh2, hat + 2);
+                hv1[k][0] = ldu2(sh1, hat); hv1[k][1] = ldu2(sh1, hat + 2);
+            }
+        }
+        // (5) act'(z2) and act'(z1) straight into the registers of the thread that multiplies by them
+        double d2v[2][4];
+        {
+            const bool c3live = ((mu == 0 ? c3c + 2 - c0 : c3r + 2 - r0) & 3) <= 2;
+#if FT_D2_C
+            const int lx = stash_live_line<true>(mu == 0 ? WJ(c3c - 2) : wi(c3r - 2), L, off);
+            const int goA = !c3live ? 0 : mu == 0 ? mul24(wi(c3r - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ(c3c - 2);
+            const int goB = !c3live ? 0 : mu == 0 ? mul24(wi(c3r + W2R / 2 - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ(c3c + W2C / 2 - 2);
+#else
+            const int goA = c3live ? WI(c3r - 2) + WJ(c3c - 2) : 0;
+            const int goB = !c3live ? 0 : mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
+#endif
+            const double* pl = uniform_at(A.stash, 8u * (Bn + bn) + (unsigned)(c3half * 4));
+            const unsigned oA = ft_off32((unsigned)goA * 8u), oB = ft_off32((unsigned)goB * 8u);
+            auto ldu2o = [](const double* base, unsigned o) { return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + o); };
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                const double2_t va = ldu2o(pl + k, oA), vb = ldu2o(pl + k, oB);
+                d2v[0][k] = va.x; d2v[0][k + 1] = va.y; d2v[1][k] = vb.x; d2v[1][k + 1] = vb.y;
+            }
+        }
+        double d1v[NIT1][4];
+#pragma unroll
+        for (int q = 0; q < NIT1; ++q) {
+            const int ra = mu == 0 ? pv[q] : 2 * pu[q], ca = mu == 0 ? 2 * pu[q] : pv[q];
+            // mu = 0: the act'(z1) plane is stored transposed (FT_D1_T, flow_mfma_common.h): site index j L + i
+            const int ga = (FT_D1_T && mu == 0) ? mul24(WJ(ca - 1), L) + wi(ra - 1) : WI(ra - 1) + WJ(ca - 1);
+            const int gb = mu == 0 ? (FT_D1_T ? mul24(WJ(ca), L) + wi(ra - 1) : WI(ra - 1) + WJ(ca)) : WI(ra) + WJ(ca - 1);
+            const unsigned og = 2u * (unsigned)(lane >> 4);                  // channels 2 g, 2 g + 1: one 16-byte load per site
+            const double2_t va = ldu2(st1, (unsigned)ga * 8u + og), vb = ldu2(st1, (unsigned)gb * 8u + og);
+            d1v[q][0] = va.x; d1v[q][1] = va.y; d1v[q][2] = vb.x; d1v[q][3] = vb.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- stage 1: transform adjoint -> g_out; the windows into LDS --------------------------------------------
+        if (ttask) {
+            // adjoint of the tan-mixture transform (layers.py:66-90) from the forward's coefficients
+            const double gdelta = ag[0] - ag[1];
+            const int at = tr3 * W3C + tc3;
+            double csum = 0.0, esum = 0.0;
+#pragma unroll
+            for (int k = 0; k < NMIX; ++k) { csum += tcv[4 * k + 2]; esum += tcv[4 * k + 3]; }
+            const double tsum = NMIX * csum;                                 // sum_k 1 / D_k
+            double rs = __builtin_amdgcn_rcp(tsum);
+            rs = fma(fma(-tsum, rs, 1.0), rs, rs);
+            rs = fma(fma(-tsum, rs, 1.0), rs, rs);
+            const double cbr = cb * rs;
+            static_assert(NMIX == 2, "g_out record: dL/ds_0, dL/ds_1, dL/dt");
+            const double gs0 = gdelta * tcv[0] + cbr * tcv[1], gs1 = gdelta * tcv[4] + cbr * tcv[5];
+            sGO[at] = gs0; sGO[N3W + at] = gs1;                              // dL/ds_k
+            sGO[2 * N3W + at] = gdelta;                                      // dL/dt
+            const int r = tr3 - 3, c = tc3 - 3;
+            if ((unsigned)r < (unsigned)TR && (unsigned)c < (unsigned)TC) {
+                sDir[r * TC + c] = gdelta * (csum - 1.0) - cbr * esum;
+                // the own active sites once more, compact, in k_flow_wgrad's task order: conv3's weight gradient reads them in pairs
+                const int a = mu == 0 ? r * (TC / 4) + ((c - off) >> 2) : ((r - off) >> 2) * TC + c;
+                sGOC[a] = gs0; sGOC[NA + a] = gs1; sGOC[2 * NA + a] = gdelta;
+            }
+        }
+        if (fwtask) { sIn[tid] = fwfrozen ? fcs : 1.0; sIn[PSH + tid] = fwfrozen ? fsn : 0.0; }
+#pragma unroll
+        for (int k = 0; k < NRH; ++k)
+            if (hls[k] >= 0) {
+                double* p2 = sHA2 + hls[k]; p2[0] = hv2[k][0].x; p2[PSH] = hv2[k][0].y; p2[2 * PSH] = hv2[k][1].x; p2[3 * PSH] = hv2[k][1].y;
+                double* p1 = sHA1 + hls[k]; p1[0] = hv1[k][0].x; p1[PSH] = hv1[k][0].y; p1[2 * PSH] = hv1[k][1].x; p1[3 * PSH] = hv1[k][1].y;
+            }
+        lds_barrier();
+
+        // ---- stage 2: conv3^T on the VALU -> gz2 (flow_bwd_gather.hip); conv3's weight gradient ----------------------
+        if (c3task) {
+            const int half = c3half, r = c3r, c = c3c;
+            const int s2off = mu == 0 ? (W2R / 2) * RS2 : W2C / 2;
+            const int s = r * RS2 + c;
+            const int ksel = mu == 0 ? (c + 2 - c0) & 3 : (r + 2 - r0) & 3;   // the one kx (mu=0) / ky (mu=1)
+            const int s3off = mu == 0 ? (W2R / 2) * W3C : W2C / 2;            // second site in tile+3 coordinates
+            double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0};
+            if (ksel <= 2) {
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    double wv[3][4], g0[3], g1[3];
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
+                        const int at = (r + 2 - ky) * W3C + c + 2 - kx;
+                        g0[kk] = sGO[co * N3W + at]; g1[kk] = sGO[co * N3W + at + s3off];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) wv[kk][k] = sW[LB_W2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            acc0[k] = fma(g0[kk], wv[kk][k], acc0[k]);
+                            acc1[k] = fma(g1[kk], wv[kk][k], acc1[k]);
+                        }
+                }
+            }
+            // dead lines (no active site within reach) get an exact 0, whatever the stash holds there
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double* pz = sGZ2 + (half * 4 + k) * PS2 + s;
+                pz[0] = ksel <= 2 ? d2v[0][k] * acc0[k] : 0.0;
+                pz[s2off] = ksel <= 2 ? d2v[1][k] * acc1[k] : 0.0;
+            }
+        }
+        if (tid < 432) {                                                 // gw2[co][ci][tap] += sum over the own active sites of g_out[co] h2[ci][site + tap]
+            const int hf = tid >= 216 ? 1 : 0, t = tid - 216 * hf;
+            const int co = fdiv<9>(fdiv<8>(t)), ci = fdiv<9>(t) & 7, tap = t - fdiv<9>(t) * 9, ky = fdiv<3>(tap), kx = tap - 3 * ky;
+            const double* pg = sGOC + co * NA + hf * (NA / 2);
+            const double* ph = sHA2 + ci * PSH + ky * W1C + kx;          // h2 at own (r, c) + (ky - 1, kx - 1): window index (r + ky) W1C + c + kx
+            double c3[4] = {0.0, 0.0, 0.0, 0.0};
+            if (mu == 0) conv3_acc<0, TC, W1C>(pg, ph + hf * (NA / 2 / (TC / 4)) * W1C + off, c3);
+            else         conv3_acc<1, TC, W1C>(pg, ph + (off + 4 * hf * (NA / 2 / TC)) * W1C, c3);
+            acc3[0] += (c3[0] + c3[1]) + (c3[2] + c3[3]);
+        } else if (tid >= 448) {                                         // b3: the eighth wave sums the three g_out planes
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc3[k] += sGOC[k * NA + lane];
+        }
+        lds_barrier();
+
+        // ---- stage 3: conv2^T (MFMA) times act'(z1) -> gz1; conv2's weight gradient from gz2 and the h1 window ----------
+        {
+            const int g = lane >> 4, i = lane & 15;
+            const double* wp = sW + LB_T2 + KConv2Row::wlane(g, i & 7, i >> 3);        // the lane part is the same for both K orders
+            const int kd0 = ((mu == 0 ? c0 : r0) + 1) & 3;                             // dead window line of the even pairs (odd: + 2)
+#pragma unroll
+            for (int q = 0; q < NIT1; ++q) {
+                const int T = wave + NW * q;
+                if (T >= NTILE1) break;
+                const int kd = (kd0 + 2 * (T < NU ? T & 1 : T - NU)) & 3;              // wave-uniform
+                const double* a0 = sGZ2 + g * PS2 + (mu == 0 ? pv[q] * RS2 + 2 * pu[q] : 2 * pu[q] * RS2 + pv[q]);
+                double4_t ac;
+                if (mu == 0) {
+                    switch (kd) {
+                        case 0: ac = conv2t_tile<KConv2Col, 4, 0, RS2, PS2>(wp, a0); break;
+                        case 1: ac = conv2t_tile<KConv2Col, 4, 1, RS2, PS2>(wp, a0); break;
+                        case 2: ac = conv2t_tile<KConv2Col, 4, 2, RS2, PS2>(wp, a0); break;
+                        default: ac = conv2t_tile<KConv2Col, 4, 3, RS2, PS2>(wp, a0); break;
+                    }
+                } else {
+                    switch (kd) {
+                        case 0: ac = conv2t_tile<KConv2Row, 3, 0, RS2, PS2>(wp, a0); break;
+                        case 1: ac = conv2t_tile<KConv2Row, 3, 1, RS2, PS2>(wp, a0); break;
+                        case 2: ac = conv2t_tile<KConv2Row, 3, 2, RS2, PS2>(wp, a0); break;
+                        default: ac = conv2t_tile<KConv2Row, 3, 3, RS2, PS2>(wp, a0); break;
+                    }
+                }
+                if (pok[q]) {
+                    const int ra = mu == 0 ? pv[q] : 2 * pu[q], ca = mu == 0 ? 2 * pu[q] : pv[q];   // site 0; site 1 = next column / row
+                    const int ds = mu == 0 ? 1 : W1C;
+                    double* pd = sD1 + 2 * g * PS1 + ra * W1C + ca;          // MFMA rows g, g + 4 = channels 2 g, 2 g + 1 (ft_chan)
+                    pd[0] = ac[0] * d1v[q][0]; pd[PS1] = ac[1] * d1v[q][1]; pd[ds] = ac[2] * d1v[q][2]; pd[PS1 + ds] = ac[3] * d1v[q][3];
+                }
+            }
+        }
+        {
+            // K walk of the weight-gradient GEMMs: wave = window rows 2 wave, 2 wave + 1 (waves 0..3 also the step (row TR, cs = wave)).
+            // Walk row rho pairs gz rows rho - dy with hin rows rho + 2 kyb; the tile's rows -1 (rho = 0, dy = 1) and TR (rho = TR,
+            // dy = 0) are other tiles' sites: 0 instead.
+            const int oa0 = 2 * wave * RS2, ob0 = 2 * wave * W1C;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int cs = 0; cs < TC / 4; ++cs) {
+                    double a2 = sGZ2[pa2 + oa0 + r * RS2 + 4 * cs];
+                    if (r == 0) a2 = (wave == 0 && wdy) ? 0.0 : a2;
+                    const int ob = ob0 + r * W1C + 4 * cs;
+                    const double b0 = sHA1[pb0 + ob], b1 = sHA1[pb1 + ob], b2 = sHA1[pb2 + ob];
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b0, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[2], 0, 0, 0);
+                    bsum[0] += a2;
+                }
+            if (wave < 4) {
+                double a2 = sGZ2[pa2 + TR * RS2 + 4 * wave];
+                a2 = wdy ? a2 : 0.0;
+                const int ob = TR * W1C + 4 * wave;
+                const double b0 = sHA1[pb0 + ob], b1 = sHA1[pb1 + ob], b2 = sHA1[pb2 + ob];
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[2], 0, 0, 0);
+                bsum[0] += a2;
+            }
+        }
+        // conv1^T's 18 weights of this wave's hidden channel: scalar loads from the weight block (constant address space)
+        typedef const double __attribute__((address_space(4))) * cdptr;
+        double w0s[18];
+        {
+            cdptr wq = (cdptr)(size_t)(w + (mu == 0 ? WBWD1 : WBWD) + LB_W0 + wave * 18);
+            typedef double double8c_t __attribute__((ext_vector_type(8)));
+            typedef const double8c_t __attribute__((address_space(4))) * cd8ptr;
+            const double8c_t va = *(cd8ptr)(wq), vb = *(cd8ptr)(wq + 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { w0s[k] = va[k]; w0s[8 + k] = vb[k]; }
+            w0s[16] = wq[16]; w0s[17] = wq[17];
+        }
+        lds_barrier();
+
+        // ---- stage 4: conv1^T at the tile's own frozen plaquettes (wave = hidden channel, two sites per lane; channel partials
+        //      over the gz2 planes, free by now); conv1's weight gradient from gz1 and the net-input window ------------------
+        static_assert(NW == 8 && N3 / 2 == 2 * 64 && 8 * 2 * (N3 / 2) <= 8 * PS2, "one wave per hidden channel, two sites per lane");
+        double* sPart = sGZ2;                                                // [8 co][2: cos, sin][N3 / 2]
+        auto frozen_site = [&](int f, int& r, int& c) {
+            const int h = f >> 4, q = f & 15;
+            if (mu == 0) { r = q; c = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
+            else { c = q; r = 4 * (h >> 1) + ((off + 1 + (h & 1)) & 3); }
+        };
+        {
+            const int co = wave;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                const int f = lane + 64 * sx;
+                int r, c;
+                frozen_site(f, r, c);
+                const double* gz = sD1 + co * PS1 + r * W1C + c;            // window coordinates (r + 2 - ky, c + 2 - kx)
+                double gv[9], gc = 0.0, gs = 0.0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) gv[tp] = gz[(2 - tp / 3) * W1C + 2 - tp % 3];
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) { gc = fma(gv[tp], w0s[tp], gc); gs = fma(gv[tp], w0s[9 + tp], gs); }
+                sPart[(co * 2 + 0) * (N3 / 2) + f] = gc;
+                sPart[(co * 2 + 1) * (N3 / 2) + f] = gs;
+            }
+        }
+        {
+            const int oa0 = 2 * wave * W1C, ob0 = 2 * wave * W1C;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int cs = 0; cs < TC / 4; ++cs) {
+                    double a1 = sD1[pa1 + oa0 + r * W1C + 4 * cs];
+                    if (r == 0) a1 = (wave == 0 && wdy) ? 0.0 : a1;
+                    const double b3 = sIn[pb3 + ob0 + r * W1C + 4 * cs];
+                    acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b3, acc[3], 0, 0, 0);
+                    bsum[1] += a1;
+                }
+            if (wave < 4) {
+                double a1 = sD1[pa1 + TR * W1C + 4 * wave];
+                a1 = wdy ? a1 : 0.0;
+                const double b3 = sIn[pb3 + TR * W1C + 4 * wave];
+                acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b3, acc[3], 0, 0, 0);
+                bsum[1] += a1;
+            }
+        }
+        lds_barrier();
+        if (tid < N3 / 2) {
+            int r, c;
+            frozen_site(tid, r, c);
+            double gct = 0.0, gst = 0.0;
+#pragma unroll
+            for (int co = 0; co < 8; ++co) { gct += sPart[(co * 2 + 0) * (N3 / 2) + tid]; gst += sPart[(co * 2 + 1) * (N3 / 2) + tid]; }
+            const int at = (r + 1) * W1C + c + 1;
+            sDir[r * TC + c] = -sIn[PSH + at] * gct + sIn[at] * gst;
+        }
+        lds_barrier();
+
+        // ---- gP_out = gP_in + this layer's contribution at the own sites (the next item's first stage writes the OTHER sDir) --
+        if (ovalid) {
+            const int cls = ((mu == 0 ? j0 + occ : i0 + orr) - off) & 3;  // 0 active, 1|2 frozen, 3 passive
+            uniform_at(A.gp_out, bn)[mul24(i0 + orr, L) + j0 + occ] = gpin + (cls != 3 ? sDir[tid] : 0.0);
+        }
+    }
+
+    // ---- the group's partial: the waves' K slices summed through LDS in a fixed order (k_flow_wgrad's epilogue)
+    lds_barrier();
+    {
+        double* Rr = sm + S::RED; double* BS = sm + S::RBS; double* C3 = sm + S::RC3;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Rr[((wave * 4 + nt) * 4 + q) * 64 + lane] = acc[nt][q];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                                    // A rows (co, dy = 0): lanes co + 16 g
+            double v = bsum[k];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (lane < 8) BS[(wave * 2 + k) * 8 + lane] = v;
+        }
+        if (tid < 432) C3[tid] = acc3[0];
+        else if (tid >= 448) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double v = ft_wave_sum(acc3[k]);
+                if (lane == 0) gw0[CB2 + k] = v;
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                                    // element e = (nt, q, lane) = D_nt[row g + 4 q][col i]
+            const int e = tid + NT * h, nt = e >> 8, q = (e >> 6) & 3, ln = e & 63;
+            double v = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) v += Rr[wv * 1024 + e];
+            const int g = ln >> 4, i = ln & 15, m = g + 4 * q, co = m & 7, dy = m >> 3;
+            const int ncol = (nt < 3 ? nt * 16 : 0) + i;
+            if (ncol < (nt < 3 ? 48 : 12)) {
+                const int ci = ncol / 6, kx = (ncol % 6) >> 1, ky = 2 * (ncol & 1) + dy;
+                if (ky <= 2) gw0[(nt < 3 ? CW1 + (co * 8 + ci) * 9 : CW0 + (co * 2 + ci) * 9) + ky * 3 + kx] = v;
+            }
+        }
+        if (tid < 16) {
+            double v = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) v += BS[wv * 16 + tid];
+            gw0[(tid < 8 ? CB1 : CB0) + (tid & 7)] = v;
+        }
+        if (tid < 216) gw0[CW2 + tid] = C3[tid] + C3[216 + tid];
+    }
+}
+
+}  // namespace
+
+namespace fthmc {
+
+int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s) {
+    if (!flow_shape_ok(a.B, a.L, a.off)) return FTHMC_ERR_ARG;
+    if (!flow_bwd_train_shape(a.L) || !a.up_gp || a.up_link || a.glogj || !a.stash || !a.gp_out || !a.gw_part) return FTHMC_ERR_UNSUPPORTED;
+    if (!flow_stash_fits32(a.B, a.L, true)) return FTHMC_ERR_UNSUPPORTED;                   // 32-bit plane offsets (uniform_at)
+    FlowLayerArgs b = a;
+    b.tpw = flow_bwd_train_tpw(a.B, a.L);
+    b.wg_ns = flow_bwd_train_ns(a.B, a.L, b.tpw);
+    const int items = a.B * FlowGeom{MG_TR, MG_TC}.ntiles(a.L);
+    const int KR = (items + b.tpw * b.wg_ns - 1) / (b.tpw * b.wg_ns), R = (KR + 7) / 8;
+    const dim3 grid(8 * R * b.wg_ns, 1, 1);
+    if (a.mu == 0) hipLaunchKernelGGL((k_flow_bwd_train<MG_TR, MG_TC, 0>), grid, dim3(NT), 0, s, b);
+    else hipLaunchKernelGGL((k_flow_bwd_train<MG_TR, MG_TC, 1>), grid, dim3(NT), 0, s, b);
+    FT_LAUNCH_CHECK(); return FTHMC_OK;
+}
+
+}  // namespace fthmc

@@ -153,6 +153,28 @@ inline int flow_wgrad_nparts(int B, int L, int tpw) {
     const int k0 = items / (tpw * ns), rem = items - k0 * tpw * ns;
     return k0 * ns + (rem < ns ? rem : ns);
 }
+// flow_bwd_train.hip: the training backward WITH the layer's weight gradients in one kernel (the pre-activation gradients never
+// leave LDS): one workgroup per CU walks (chain, tile) items and writes ONE 955-entry partial to a.gw_part
+// [flow_bwd_train_nparts(B, L)][FLOW_GW_STRIDE]; a.gp_out as launch_flow_bwd_gather.  Built for the shapes 16 x 16 tiles divide with
+// L a power of two (flow_bwd_train_shape); FTHMC_ERR_UNSUPPORTED otherwise: the caller keeps the two-kernel form.
+int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s);
+inline bool flow_bwd_train_shape(int L) { return L >= 32 && (L & (L - 1)) == 0; }
+// items per workgroup: as many as leave one workgroup per CU (256), at most 64
+inline int flow_bwd_train_tpw(int B, int L) {
+    const long items = (long)B * FlowGeom{MG_TR, MG_TC}.ntiles(L);
+    const long t = (items + 255) / 256;
+    return t < 1 ? 1 : t > 64 ? 64 : (int)t;
+}
+// workgroups of one XCD that walk side by side (one per CU: 32; fewer when the launch is smaller than the chip)
+inline int flow_bwd_train_ns(int B, int L, int tpw) {
+    const int items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L), n = (items + 8 * tpw - 1) / (8 * tpw);
+    return n < 1 ? 1 : n > 32 ? 32 : n;
+}
+inline int flow_bwd_train_nparts(int B, int L) {
+    const int tpw = flow_bwd_train_tpw(B, L), items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L), ns = flow_bwd_train_ns(B, L, tpw);
+    const int k0 = items / (tpw * ns), rem = items - k0 * tpw * ns;
+    return k0 * ns + (rem < ns ? rem : ns);
+}
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)
 inline size_t flow_stash_doubles(int B, int L, bool train = false) { return (size_t)B * (train ? 35 : 19) * L * L; }
 // the tuned kernels form a chain's plane offsets inside one layer's stash in 32 bits (flow_mfma_common.h: uniform_at, stash_view)

@@ -52,6 +52,40 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, ws, local
 
 
+_CAPTURE_GROUP = [None, None]      # (the default group it belongs to, the capture group)
+
+
+def capture_group(device=None):
+    """The process group of the CAPTURED collectives (C2 inside GraphTrainer's hipGraph): all ranks, the same backend as the
+    default group, its own RCCL communicator and its own internal stream -- created on first use, by every rank at the same
+    point (GraphTrainer's constructor), the communicator connected there and then (`device_id`: ncclCommInitRank must not
+    happen inside a capture).  NOTHING is ever issued on it eagerly: its first collective is the captured one.
+
+    Why (tools/event_query_probe.py on the MI355X, profiles/r06_event_query_probe.txt): the HIP runtime answers
+    hipErrorCapturedEvent to a query of ANY event whose last record was on a stream that takes part in a capture -- the stream
+    that originates it AND a stream that joined it -- also when the event was recorded there eagerly, long before.  A process
+    group's watchdog thread queries the end events of its EAGER collectives until it has retired them (a polling round every
+    100 ms), and those events live on the group's internal stream, which joins the capture under a captured collective: an
+    un-retired eager collective of the same group is a process abort waiting for the watchdog's next round (what round 5
+    fenced with a 0.5 s sleep).  Work issued DURING a capture is never handed to the watchdog.  So: the group whose
+    collectives are captured has no eager collectives, ever -- the eager first step of a trainer, C1, barriers and the capture
+    agreement run on the default group, whose stream takes no part in any capture and whose events stay queryable
+    (tools/pg_capture_probe.py: 200 asynchronous collectives in flight and a second thread issuing more during the capture).
+    Nothing here waits for a thread's polling round."""
+    if not have_group():
+        return None
+    if _CAPTURE_GROUP[0] is not dist.group.WORLD:          # first use, or the default group was torn down and made again
+        kw = {}
+        if dist.get_backend() == 'nccl' and device is not None:
+            kw['device_id'] = torch.device(device)
+        try:
+            g = dist.new_group(backend=dist.get_backend(), **kw)
+        except TypeError:                                   # a torch without new_group(device_id=...): connects at first use
+            g = dist.new_group(backend=dist.get_backend())
+        _CAPTURE_GROUP[:] = [dist.group.WORLD, g]
+    return _CAPTURE_GROUP[1]
+
+
 def shard_range(n_chains: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous block [lo, hi) of global chain ids owned by `rank` (remainder to the
     first ranks), so that a chain's id -- and with it its RNG stream -- never depends
@@ -117,10 +151,10 @@ class RunStats:
         return out
 
 
-def allreduce_grads(gw: torch.Tensor, world_size: Optional[int] = None) -> torch.Tensor:
+def allreduce_grads(gw: torch.Tensor, world_size: Optional[int] = None, group=None) -> torch.Tensor:
     """C2: SUM all-reduce of the flat weight-gradient buffer (955 * n_layers doubles)."""
     if have_group():
-        dist.all_reduce(gw, op=dist.ReduceOp.SUM)
+        dist.all_reduce(gw, op=dist.ReduceOp.SUM, group=group)
     return gw
 
 
@@ -135,7 +169,7 @@ def global_logsumexp(logw: torch.Tensor) -> torch.Tensor:
     return m + torch.log(torch.exp(logw - m).sum())
 
 
-def global_ess(logw: torch.Tensor, n_global: int) -> torch.Tensor:
+def global_ess(logw: torch.Tensor, n_global: int, group=None) -> torch.Tensor:
     """calc_ess (fthmc/utils/distributions.py:27-37) over the chains of all ranks with ONE collective: every rank contributes
     (m, sum exp(logw - m), sum exp(2 (logw - m))) with its own maximum m, an all-gather of the three doubles lets every rank
     rescale them to the common maximum: ESS = (sum w)^2 / (n sum w^2).  (global_logsumexp twice = four all-reduces.)"""
@@ -144,7 +178,7 @@ def global_ess(logw: torch.Tensor, n_global: int) -> torch.Tensor:
     loc = torch.stack([m, torch.exp(z).sum(), torch.exp(2 * z).sum()])
     if have_group():
         parts = [torch.empty_like(loc) for _ in range(dist.get_world_size())]
-        dist.all_gather(parts, loc)
+        dist.all_gather(parts, loc, group=group)
         allv = torch.stack(parts)
     else:
         allv = loc[None]

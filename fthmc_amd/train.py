@@ -116,7 +116,7 @@ METRIC_KEYS = ('ess', 'logp', 'logq', 'loss_dkl', 'q', 'dq', 'plaq')
 
 
 def _fused_step_device(model: FlowModel, action, batch_size: int, dkl_factor: float, xi: torch.Tensor, row: torch.Tensor = None,
-                       groups: int = None):
+                       groups: int = None, pgroup=None):
     """The device side of one fused training step, enqueue only (no host synchronisation, graph-capturable without a
     process group): d(loss)/d(weights) straight into the flat gradient buffer every conv parameter's .grad is a view of
     (no unpacking, no copies), and the stacked metrics row (ops.train_metrics).  -> (row, x)."""
@@ -139,9 +139,9 @@ def _fused_step_device(model: FlowModel, action, batch_size: int, dkl_factor: fl
         d = r['logq'] - r['logp']
         n = gflat.numel()
         torch.sum(d, dim=0, keepdim=True, out=gext[n:n + 1])
-        parallel.allreduce_grads(gext)
+        parallel.allreduce_grads(gext, group=pgroup)
         row[0] = dkl_factor * gext[n] / n_global
-        row[1] = parallel.global_ess(-d, n_global)
+        row[1] = parallel.global_ess(-d, n_global, group=pgroup)
     return row, r['x']
 
 
@@ -260,35 +260,41 @@ class GraphTrainer:
         group_ok = (not parallel.have_group() or
                     (torch.distributed.get_backend() == 'nccl' and os.environ.get('FTHMC_GRAPH_COLLECTIVES', '1') not in ('', '0')))
         self.use_graph = bool(use_graph) and group_ok
+        # the captured collectives run on a process group of their own, on which nothing is ever issued eagerly
+        # (parallel.capture_group: every rank creates it here, communicator connected)
+        self.pgroup = parallel.capture_group(self.dev) if (self.use_graph and parallel.have_group()) else None
         if self.use_graph and not (getattr(optimizer, 'graph_safe', False) or all(g.get('capturable', False) for g in optimizer.param_groups)):
             raise ValueError('GraphTrainer captures optimizer.step(): pass a FlatAdam (train.make_optimizer) or a torch '
                              'optimizer built with capturable=True, or use_graph=False')
 
-    def _enqueue(self):
+    def _enqueue(self, pgroup=None):
         # seeds of step `counter` for this rank's global chain ids (= parallel.chain_seeds(seed, lo, lo + B, step)); counter += 1
         ops.chain_seeds(self.seed, self.lo, self.B, counter=self.counter, advance=True, out=self.seeds)
         ops.random_uniform(self.seeds, self.xi.shape, -PI, PI, out=self.xi)        # MultivariateUniform(-pi, pi).sample_n
-        _fused_step_device(self.model, self.action, self.B, self.dkl_factor, self.xi, row=self.row)
+        _fused_step_device(self.model, self.action, self.B, self.dkl_factor, self.xi, row=self.row, pgroup=pgroup)
         self.optimizer.step()
 
     def _capture(self):
         """capture one step; under a process group every rank learns whether every rank's capture succeeded"""
         ok = 1.0
         g = torch.cuda.CUDAGraph()
-        if parallel.have_group():
-            # The captured collectives pull RCCL's internal stream into the capture, and the HIP runtime refuses an event
-            # query (hipErrorCapturedEvent) on ANY event of a stream that is capturing -- also one recorded there eagerly
-            # before: the process group's watchdog thread polls exactly such events for collectives issued earlier (a barrier,
-            # an asynchronous C1 all-reduce) and would take the process down.  So: every earlier collective done, and the
-            # watchdog given a few of its 100 ms rounds to retire them, before the capture starts.
-            torch.cuda.synchronize(self.dev)
-            time.sleep(0.5)
+        # No fence: the captured collectives run on parallel.capture_group(), on which nothing was ever issued eagerly -- its
+        # internal stream carries no event the watchdog could be polling when that stream joins the capture (an event query on
+        # a stream that takes part in a capture is hipErrorCapturedEvent; the eager first step ran on the default group, whose
+        # stream stays outside).  Round 5 slept 0.5 s here.
         try:
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
-                self._enqueue()
+                self._enqueue(self.pgroup)
         except Exception as e:                                             # noqa: BLE001 -- whatever the capture objects to
-            if not parallel.have_group() or torch.cuda.is_current_stream_capturing():
-                raise                                                      # no group to agree with / the capture cannot be left: not recoverable here
+            if not parallel.have_group():
+                raise                                                      # no group to agree with
+            if torch.cuda.is_current_stream_capturing():
+                # the capture cannot be left: no collective can be issued to tell the peers -- take the group down instead of
+                # leaving them blocked in the agreement below
+                try:
+                    torch.distributed.distributed_c10d._abort_process_group()
+                finally:
+                    raise
             ok, self.capture_error = 0.0, repr(e)
         if parallel.have_group():
             flag = torch.tensor([ok], dtype=torch.float64, device=self.dev)

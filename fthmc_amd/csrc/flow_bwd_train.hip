@@ -10,19 +10,26 @@
 // needs them at the tile's OWN sites only: here the GEMMs read them where they lie.  What is left of the traffic is the h1, h2
 // windows (stashed by the forward; 20 doubles per site with the halo): 35 + 39 instead of 35 + 74.
 //
-// One 512-thread workgroup per CU (126 KB of LDS, up to 256 VGPRs) WALKS (chain, tile) items of its layer -- the weight
-// gradient's sum over sites simply runs on, its accumulators (four 16 x 16 MFMA tiles per wave) stay in registers -- and
-// writes ONE 955-entry partial at the end (k_reduce_gw sums the partials in a fixed order: bit-deterministic).  Per item the
-// stages are k_flow_bwd_gather's, each followed in the SAME barrier interval by the weight-gradient stage that reads the plane
-// the stage has just consumed or produced:
-//     transform adjoint -> g_out      | h1, h2 windows and the (cos, sin) window into LDS
-//     conv3^T (VALU) -> gz2           | conv3 weight gradient (VALU) from g_out and h2
-//     conv2^T (MFMA) -> gz1           | conv2 weight gradient (MFMA: M = 8 co x 2 row shifts from gz2, N = (ci, kx, ky in {0, 2}))
-//     conv1^T (VALU)                  | conv1 weight gradient (MFMA from gz1 and the net input window)
+// One 512-thread workgroup per CU (129 KB of LDS, 249 VGPRs) WALKS (chain, tile) items of its layer -- the weight gradient's
+// sum over sites simply runs on, its accumulators (four 16 x 16 MFMA tiles per wave) stay in registers -- and writes ONE
+// 955-entry partial at the end (k_reduce_gw sums the partials in a fixed order: bit-deterministic).  Per item the stages are
+// k_flow_bwd_gather's, each sharing its barrier interval with the weight-gradient work that reads the planes the stage has
+// just consumed or produced:
+//     1  transform adjoint -> g_out, the (cos, sin) window into LDS
+//     2  conv3^T (VALU) -> gz2                 | the h1 window into LDS
+//     3  conv2^T (MFMA) -> gz1                 | conv2 weight gradient (MFMA: M = 8 co x 2 row shifts from gz2, N = (ci, kx, ky in {0, 2})
+//                                              |   from the h1 window), the h2 window into LDS
+//     4  conv1^T (VALU)                        | conv1 weight gradient (MFMA from gz1 and the net-input window), conv3 weight
+//                                              |   gradient (VALU from g_out and the h2 window)
 // so a tile costs the backward's five barriers and no more.  The GEMM maps are k_flow_wgrad's (flow_wgrad.hip: 75 % useful
 // MACs, the K walk of 17 window rows split over the eight waves, bias sums from the A operand); their A operand comes from
 // the backward's planes, whose rows above and below the tile hold the neighbours' values where k_flow_wgrad had zero rings:
 // the two K steps that would pair them (walk row 0 for the lower row shift, walk row 16 for the upper) select 0 instead.
+// One workgroup per CU has no second workgroup to hide its loads behind: every group of an item's operands is issued for
+// item i + 1 right behind the stage of item i that consumed the group (registers; barriers wait for LDS only).
+// Measured (round 6, config-5 shard, 32 chains of L = 256 per launch): 286 us against 175 + 159 us of the two-kernel form;
+// per item 19.7 k cycles of which the MFMA pipe is busy 7.8 k (stage 3: 8.4 k for 6.7 k of MFMA) -- the VALU / LDS stages of a
+// lone workgroup run beside an idle matrix pipe, which is what is left to take here (-DFT_BT_STAMPS prints the stage cycles).
 //
 // Built for the tiled-exactly shapes (L a power of two >= 32: every BASELINE training shape); anything else keeps the
 // two-kernel form.  Reference: loss.backward() of fthmc/train.py:191-210 through GaugeEquivCouplingLayer.forward
@@ -194,104 +201,123 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
     double bsum[2] = {0.0, 0.0};                                           // bias sums b2, b1 of the slice: lanes dy = 0
     double acc3[3] = {0.0, 0.0, 0.0};                                      // conv3: thread = (output, site half) in [0]; wave 7: b3 lane partials
 
-#pragma unroll 1
-    for (int it = 0; it < nwalk; ++it) {
-        // ---- the item (uniform: scalar divisions, once per item)
-        const int item = first + it * ns;
-        const int b = item / ntiles, tl = item - b * ntiles, ti = tl / ntj_, tj = tl - ti * ntj_;
-        const int i0 = ti * TR, j0 = tj * TC;
-        __builtin_assume(i0 >= 0 && i0 < L && j0 >= 0 && j0 < L && b >= 0 && b < (1 << 20));
-        double* sDir = sm + S::DIR + (it & 1) * N3;
-        const unsigned bn = (unsigned)b * (unsigned)n;
-        const double* __restrict__ st1 = uniform_at(A.stash, 8u * bn);
+    // ---- what does not depend on the item: tile origins are multiples of 16, so the stripe phase of every window is the layer's
+    const int c0 = (off + 3) & 3, r0 = c0;                                 // first active column / row of the tile+3 window
+    int tr3 = 3, tc3 = 3;                                                  // transform task: active site (tr3, tc3) of the tile+3 window
+    bool ttask = false;
+    if (ta >= 0) {
+        if (mu == 0) { tr3 = fdiv<S::NLC>(ta); tc3 = c0 + 4 * (ta - tr3 * S::NLC); ttask = tr3 < S::W3R && tc3 < W3C; }
+        else { const int m = fdiv<W3C>(ta); tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
+        if (!ttask) { tr3 = 3; tc3 = 3; }                                    // any valid site
+    }
+    const bool c3live = ((mu == 0 ? c3c + 2 - c0 : c3r + 2 - r0) & 3) <= 2;
+    const unsigned wmagic = (unsigned)(L - 1);
+
+    // ---- an item's operands, in registers.  Every load is unconditional, from a clamped address; each GROUP of them is issued for
+    //      item i + 1 right behind the stage of item i that consumed the group (the last item loads itself again: no branch around
+    //      the loads), so nothing of an item's load latency is left in front of its stages -- one workgroup per CU has no second
+    //      workgroup to hide it behind.  Barriers wait for LDS traffic only (lds_barrier): the loads stay in flight across them.
+    double tcv[4 * NMIX], ag[2], fcs, fsn;                                 // group A: transform adjoint, net-input window
+    double d2v[2][4];                                                      // group D2: act'(z2) of the conv3^T task
+    double d1v[NIT1][4];                                                   // group D1: act'(z1) of the conv2^T epilogue
+    double gpin;                                                           // group G: upstream gradient of the own site
+    double2_t hv1[NRH][2], hv2[NRH][2];                                    // groups H1, H2: the h1 / h2 windows
+    struct Item { int b, i0, j0; };
+    auto item_at = [&](int k) {                                            // uniform: scalar divisions
+        const int item = first + (k < nwalk ? k : nwalk - 1) * ns;
+        Item q;
+        q.b = item / ntiles;
+        const int tl = item - q.b * ntiles, ti = tl / ntj_;
+        q.i0 = ti * TR; q.j0 = (tl - ti * ntj_) * TC;
+        return q;
+    };
+#define WI_(q, k) mul24(wrap_line<true, true>((q).i0 + (k), L, wmagic), L)
+#define wi_(q, k) wrap_line<true, true>((q).i0 + (k), L, wmagic)
+#define WJ_(q, k) wrap_line<true, true>((q).j0 + (k), L, wmagic)
+    auto issue_A = [&](const Item& q) {
+        const unsigned bn = (unsigned)q.b * (unsigned)n;
         const double* __restrict__ stc = uniform_at(A.stash, 16u * Bn + 2u * bn);
         const double* __restrict__ scs = uniform_at(A.stash, 18u * Bn + bn);
-        const double* __restrict__ sh1 = uniform_at(A.stash, 19u * Bn + 8u * bn);
-        const double* __restrict__ sh2 = uniform_at(A.stash, 27u * Bn + 8u * bn);
-        const unsigned wmagic = (unsigned)(L - 1);
-        auto wi = [&](int k) { return wrap_line<true, true>(i0 + k, L, wmagic); };
-        auto WI = [&](int k) { return mul24(wi(k), L); };
-        auto WJ = [&](int k) { return wrap_line<true, true>(j0 + k, L, wmagic); };
-        const int c0 = (off - (j0 - 3)) & 3, r0 = (off - (i0 - 3)) & 3;    // first active column / row of the tile+3 window
-
-        // ---- load phase (unconditional loads from clamped addresses, what the first stage consumes first)
-        // (1) transform tasks: active site `a` of the tile+3 window, both mixture components
-        int tr3 = 3, tc3 = 3;
-        bool ttask = false;
-        if (ta >= 0) {
-            if (mu == 0) { tr3 = fdiv<S::NLC>(ta); tc3 = c0 + 4 * (ta - tr3 * S::NLC); ttask = tr3 < S::W3R && tc3 < W3C; }
-            else { const int m = fdiv<W3C>(ta); tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
-            if (!ttask) { tr3 = 3; tc3 = 3; }                                // any valid site
-        }
-        double tcv[4 * NMIX], ag[2];
-        {
-            const int i = wi(tr3 - 3), j = WJ(tc3 - 3);
-            const unsigned ia = (unsigned)stash_active_idx(i, j, L, mu);
+        const int i = wi_(q, tr3 - 3), j = WJ_(q, tc3 - 3);
+        const unsigned ia = (unsigned)stash_active_idx(i, j, L, mu);
 #pragma unroll
-            for (int q = 0; q < 4 * NMIX; q += 2) {                          // [k][n/4][A B C E] (struct Stash): 16 bytes per load
-                const double2_t t2 = ldu2(stc + (size_t)(q >> 2) * n, ia * 4u + (q & 3));
-                tcv[q] = t2.x; tcv[q + 1] = t2.y;
-            }
-            const double* gsrc = uniform_at(A.up_gp, bn);                    // upstream gradient: the plaquette-gradient field
-            const int iL = mul24(i, L);
-            ag[0] = ldu(gsrc, (unsigned)(iL + j));
-            ag[1] = ldu(gsrc, (unsigned)(mu == 0 ? iL + WJ(tc3 - 4) : WI(tr3 - 4) + j));
+        for (int e = 0; e < 4 * NMIX; e += 2) {                              // [k][n/4][A B C E] (struct Stash): 16 bytes per load
+            const double2_t t2 = ldu2(stc + (size_t)(e >> 2) * n, ia * 4u + (e & 3));
+            tcv[e] = t2.x; tcv[e + 1] = t2.y;
         }
-        // (2) (cos, sin) of the frozen plaquettes on the tile+1 window (the net input: conv1's weight gradient reads the window,
-        //     conv1^T's adjoint the own sites), one window site per thread
-        double fcs, fsn;
-        {
-            const unsigned ic = fwfrozen ? (unsigned)stash_frozen_idx(wi(fwr - 1), WJ(fwc - 1), L, mu, off) : 0u;
-            fcs = ldu_j(scs, ic); fsn = ldu_j(scs + (n >> 1), ic);
-        }
-        // (3) upstream gradient of the own sites (pass-through term)
-        double gpin = ldu_j(uniform_at(A.up_gp, bn), ovalid ? (unsigned)(mul24(i0 + orr, L) + j0 + occ) : 0u);
-        if (!ovalid) gpin = 0.0;
-        // (4) h2, h1 on the tile+1 window: 32 bytes per task and plane
-        double2_t hv2[NRH][2], hv1[NRH][2];
-        {
+        const double* gsrc = uniform_at(A.up_gp, bn);                        // upstream gradient: the plaquette-gradient field
+        const int iL = mul24(i, L);
+        ag[0] = ldu(gsrc, (unsigned)(iL + j));
+        ag[1] = ldu(gsrc, (unsigned)(mu == 0 ? iL + WJ_(q, tc3 - 4) : WI_(q, tr3 - 4) + j));
+        // (cos, sin) of the frozen plaquettes on the tile+1 window (the net input: conv1's weight gradient reads the window,
+        // conv1^T's adjoint the own sites), one window site per thread
+        const unsigned ic = fwfrozen ? (unsigned)stash_frozen_idx(wi_(q, fwr - 1), WJ_(q, fwc - 1), L, mu, off) : 0u;
+        fcs = ldu_j(scs, ic); fsn = ldu_j(scs + (n >> 1), ic);
+    };
+    auto issue_G = [&](const Item& q) {
+        gpin = ldu_j(uniform_at(A.up_gp, (unsigned)q.b * (unsigned)n), ovalid ? (unsigned)(mul24(q.i0 + orr, L) + q.j0 + occ) : 0u);
+    };
+    auto issue_H = [&](const Item& q, int plane, double2_t (&hv)[NRH][2]) {  // plane 19: h1, 27: h2 (struct Stash)
+        const double* __restrict__ sh = uniform_at(A.stash, (unsigned)plane * Bn + 8u * (unsigned)q.b * (unsigned)n);
 #pragma unroll
-            for (int k = 0; k < NRH; ++k) {
-                const unsigned hat = (unsigned)(WI(hwr[k] - 1) + WJ(hwc[k] - 1)) * 8u + 4u * (unsigned)hwq[k];
-                hv2[k][0] = ldu2(sh2, hat); hv2[k][1] = ldu2(sh2, hat + 2);
-                hv1[k][0] = ldu2(sh1, hat); hv1[k][1] = ldu2(sh1, hat + 2);
-            }
+        for (int k = 0; k < NRH; ++k) {
+            const unsigned hat = (unsigned)(WI_(q, hwr[k] - 1) + WJ_(q, hwc[k] - 1)) * 8u + 4u * (unsigned)hwq[k];
+            hv[k][0] = ldu2(sh, hat); hv[k][1] = ldu2(sh, hat + 2);
         }
-        // (5) act'(z2) and act'(z1) straight into the registers of the thread that multiplies by them
-        double d2v[2][4];
-        {
-            const bool c3live = ((mu == 0 ? c3c + 2 - c0 : c3r + 2 - r0) & 3) <= 2;
+    };
+    auto issue_D2 = [&](const Item& q) {
+        const unsigned bn = (unsigned)q.b * (unsigned)n;
 #if FT_D2_C
-            const int lx = stash_live_line<true>(mu == 0 ? WJ(c3c - 2) : wi(c3r - 2), L, off);
-            const int goA = !c3live ? 0 : mu == 0 ? mul24(wi(c3r - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ(c3c - 2);
-            const int goB = !c3live ? 0 : mu == 0 ? mul24(wi(c3r + W2R / 2 - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ(c3c + W2C / 2 - 2);
+        const int lx = stash_live_line<true>(mu == 0 ? WJ_(q, c3c - 2) : wi_(q, c3r - 2), L, off);
+        const int goA = !c3live ? 0 : mu == 0 ? mul24(wi_(q, c3r - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ_(q, c3c - 2);
+        const int goB = !c3live ? 0 : mu == 0 ? mul24(wi_(q, c3r + W2R / 2 - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ_(q, c3c + W2C / 2 - 2);
 #else
-            const int goA = c3live ? WI(c3r - 2) + WJ(c3c - 2) : 0;
-            const int goB = !c3live ? 0 : mu == 0 ? WI(c3r + W2R / 2 - 2) + WJ(c3c - 2) : WI(c3r - 2) + WJ(c3c + W2C / 2 - 2);
+        const int goA = c3live ? WI_(q, c3r - 2) + WJ_(q, c3c - 2) : 0;
+        const int goB = !c3live ? 0 : mu == 0 ? WI_(q, c3r + W2R / 2 - 2) + WJ_(q, c3c - 2) : WI_(q, c3r - 2) + WJ_(q, c3c + W2C / 2 - 2);
 #endif
-            const double* pl = uniform_at(A.stash, 8u * (Bn + bn) + (unsigned)(c3half * 4));
-            const unsigned oA = ft_off32((unsigned)goA * 8u), oB = ft_off32((unsigned)goB * 8u);
-            auto ldu2o = [](const double* base, unsigned o) { return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + o); };
+        const double* pl = uniform_at(A.stash, 8u * (Bn + bn) + (unsigned)(c3half * 4));
+        const unsigned oA = ft_off32((unsigned)goA * 8u), oB = ft_off32((unsigned)goB * 8u);
+        auto ldu2o = [](const double* base, unsigned o) { return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + o); };
 #pragma unroll
-            for (int k = 0; k < 4; k += 2) {
-                const double2_t va = ldu2o(pl + k, oA), vb = ldu2o(pl + k, oB);
-                d2v[0][k] = va.x; d2v[0][k + 1] = va.y; d2v[1][k] = vb.x; d2v[1][k + 1] = vb.y;
-            }
+        for (int k = 0; k < 4; k += 2) {
+            const double2_t va = ldu2o(pl + k, oA), vb = ldu2o(pl + k, oB);
+            d2v[0][k] = va.x; d2v[0][k + 1] = va.y; d2v[1][k] = vb.x; d2v[1][k + 1] = vb.y;
         }
-        double d1v[NIT1][4];
+    };
+    auto issue_D1 = [&](const Item& q) {
+        const double* __restrict__ st1 = uniform_at(A.stash, 8u * (unsigned)q.b * (unsigned)n);
 #pragma unroll
-        for (int q = 0; q < NIT1; ++q) {
-            const int ra = mu == 0 ? pv[q] : 2 * pu[q], ca = mu == 0 ? 2 * pu[q] : pv[q];
+        for (int e = 0; e < NIT1; ++e) {
+            const int ra = mu == 0 ? pv[e] : 2 * pu[e], ca = mu == 0 ? 2 * pu[e] : pv[e];
             // mu = 0: the act'(z1) plane is stored transposed (FT_D1_T, flow_mfma_common.h): site index j L + i
-            const int ga = (FT_D1_T && mu == 0) ? mul24(WJ(ca - 1), L) + wi(ra - 1) : WI(ra - 1) + WJ(ca - 1);
-            const int gb = mu == 0 ? (FT_D1_T ? mul24(WJ(ca), L) + wi(ra - 1) : WI(ra - 1) + WJ(ca)) : WI(ra) + WJ(ca - 1);
+            const int ga = (FT_D1_T && mu == 0) ? mul24(WJ_(q, ca - 1), L) + wi_(q, ra - 1) : WI_(q, ra - 1) + WJ_(q, ca - 1);
+            const int gb = mu == 0 ? (FT_D1_T ? mul24(WJ_(q, ca), L) + wi_(q, ra - 1) : WI_(q, ra - 1) + WJ_(q, ca)) : WI_(q, ra) + WJ_(q, ca - 1);
             const unsigned og = 2u * (unsigned)(lane >> 4);                  // channels 2 g, 2 g + 1: one 16-byte load per site
             const double2_t va = ldu2(st1, (unsigned)ga * 8u + og), vb = ldu2(st1, (unsigned)gb * 8u + og);
-            d1v[q][0] = va.x; d1v[q][1] = va.y; d1v[q][2] = vb.x; d1v[q][3] = vb.y;
+            d1v[e][0] = va.x; d1v[e][1] = va.y; d1v[e][2] = vb.x; d1v[e][3] = vb.y;
         }
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+        const Item q0 = item_at(0);                                          // in the order the stages consume them (loads return in order)
+        issue_A(q0); issue_D2(q0); issue_H(q0, 19, hv1); issue_D1(q0); issue_H(q0, 27, hv2); issue_G(q0);
+    }
 
-        // ---- stage 1: transform adjoint -> g_out; the windows into LDS --------------------------------------------
+#ifdef FT_BT_STAMPS       // measurement builds only: cycles per stage, summed over the walk, printed by two workgroups
+    long long stc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stl_ = (long long)__builtin_readcyclecounter();
+#define BT_STAMP(k) do { const long long t_ = (long long)__builtin_readcyclecounter(); stc_[k] += t_ - stl_; stl_ = t_; } while (0)
+#else
+#define BT_STAMP(k) do { } while (0)
+#endif
+#pragma unroll 1
+    for (int it = 0; it < nwalk; ++it) {
+        const Item cur = item_at(it), nxt = item_at(it + 1);
+        BT_STAMP(7);
+        const int i0 = cur.i0, j0 = cur.j0;
+        __builtin_assume(i0 >= 0 && i0 < L && j0 >= 0 && j0 < L && cur.b >= 0 && cur.b < (1 << 20));
+        double* sDir = sm + S::DIR + (it & 1) * N3;
+        const unsigned bn = (unsigned)cur.b * (unsigned)n;
+
+        // ---- stage 1: transform adjoint -> g_out; the net-input window into LDS -----------------------------------
         if (ttask) {
             // adjoint of the tan-mixture transform (layers.py:66-90) from the forward's coefficients
             const double gdelta = ag[0] - ag[1];
@@ -317,15 +343,13 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
             }
         }
         if (fwtask) { sIn[tid] = fwfrozen ? fcs : 1.0; sIn[PSH + tid] = fwfrozen ? fsn : 0.0; }
-#pragma unroll
-        for (int k = 0; k < NRH; ++k)
-            if (hls[k] >= 0) {
-                double* p2 = sHA2 + hls[k]; p2[0] = hv2[k][0].x; p2[PSH] = hv2[k][0].y; p2[2 * PSH] = hv2[k][1].x; p2[3 * PSH] = hv2[k][1].y;
-                double* p1 = sHA1 + hls[k]; p1[0] = hv1[k][0].x; p1[PSH] = hv1[k][0].y; p1[2 * PSH] = hv1[k][1].x; p1[3 * PSH] = hv1[k][1].y;
-            }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_A(nxt);
+        BT_STAMP(0);
         lds_barrier();
+        BT_STAMP(1);
 
-        // ---- stage 2: conv3^T on the VALU -> gz2 (flow_bwd_gather.hip); conv3's weight gradient ----------------------
+        // ---- stage 2: conv3^T on the VALU -> gz2 (flow_bwd_gather.hip); the h1 window into LDS ---------------------------
         if (c3task) {
             const int half = c3half, r = c3r, c = c3c;
             const int s2off = mu == 0 ? (W2R / 2) * RS2 : W2C / 2;
@@ -363,22 +387,15 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
                 pz[s2off] = ksel <= 2 ? d2v[1][k] * acc1[k] : 0.0;
             }
         }
-        if (tid < 432) {                                                 // gw2[co][ci][tap] += sum over the own active sites of g_out[co] h2[ci][site + tap]
-            const int hf = tid >= 216 ? 1 : 0, t = tid - 216 * hf;
-            const int co = fdiv<9>(fdiv<8>(t)), ci = fdiv<9>(t) & 7, tap = t - fdiv<9>(t) * 9, ky = fdiv<3>(tap), kx = tap - 3 * ky;
-            const double* pg = sGOC + co * NA + hf * (NA / 2);
-            const double* ph = sHA2 + ci * PSH + ky * W1C + kx;          // h2 at own (r, c) + (ky - 1, kx - 1): window index (r + ky) W1C + c + kx
-            double c3[4] = {0.0, 0.0, 0.0, 0.0};
-            if (mu == 0) conv3_acc<0, TC, W1C>(pg, ph + hf * (NA / 2 / (TC / 4)) * W1C + off, c3);
-            else         conv3_acc<1, TC, W1C>(pg, ph + (off + 4 * hf * (NA / 2 / TC)) * W1C, c3);
-            acc3[0] += (c3[0] + c3[1]) + (c3[2] + c3[3]);
-        } else if (tid >= 448) {                                         // b3: the eighth wave sums the three g_out planes
 #pragma unroll
-            for (int k = 0; k < 3; ++k) acc3[k] += sGOC[k * NA + lane];
-        }
+        for (int k = 0; k < NRH; ++k)
+            if (hls[k] >= 0) { double* p1 = sHA1 + hls[k]; p1[0] = hv1[k][0].x; p1[PSH] = hv1[k][0].y; p1[2 * PSH] = hv1[k][1].x; p1[3 * PSH] = hv1[k][1].y; }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_D2(nxt); issue_H(nxt, 19, hv1);
         lds_barrier();
+        BT_STAMP(2);
 
-        // ---- stage 3: conv2^T (MFMA) times act'(z1) -> gz1; conv2's weight gradient from gz2 and the h1 window ----------
+        // ---- stage 3: conv2^T (MFMA) times act'(z1) -> gz1; conv2's weight gradient from gz2 and the h1 window; the h2 window into LDS
         {
             const int g = lane >> 4, i = lane & 15;
             const double* wp = sW + LB_T2 + KConv2Row::wlane(g, i & 7, i >> 3);        // the lane part is the same for both K orders
@@ -413,6 +430,8 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_D1(nxt);
         {
             // K walk of the weight-gradient GEMMs: wave = window rows 2 wave, 2 wave + 1 (waves 0..3 also the step (row TR, cs = wave)).
             // Walk row rho pairs gz rows rho - dy with hin rows rho + 2 kyb; the tile's rows -1 (rho = 0, dy = 1) and TR (rho = TR,
@@ -442,6 +461,11 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
                 bsum[0] += a2;
             }
         }
+#pragma unroll
+        for (int k = 0; k < NRH; ++k)
+            if (hls[k] >= 0) { double* p2 = sHA2 + hls[k]; p2[0] = hv2[k][0].x; p2[PSH] = hv2[k][0].y; p2[2 * PSH] = hv2[k][1].x; p2[3 * PSH] = hv2[k][1].y; }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_H(nxt, 27, hv2);
         // conv1^T's 18 weights of this wave's hidden channel: scalar loads from the weight block (constant address space)
         typedef const double __attribute__((address_space(4))) * cdptr;
         double w0s[18];
@@ -455,9 +479,11 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
             w0s[16] = wq[16]; w0s[17] = wq[17];
         }
         lds_barrier();
+        BT_STAMP(3);
 
         // ---- stage 4: conv1^T at the tile's own frozen plaquettes (wave = hidden channel, two sites per lane; channel partials
-        //      over the gz2 planes, free by now); conv1's weight gradient from gz1 and the net-input window ------------------
+        //      over the gz2 planes, free by now); conv1's weight gradient (MFMA) from gz1 and the net-input window; conv3's
+        //      (VALU) from g_out and the h2 window ----------------------------------------------------------------------
         static_assert(NW == 8 && N3 / 2 == 2 * 64 && 8 * 2 * (N3 / 2) <= 8 * PS2, "one wave per hidden channel, two sites per lane");
         double* sPart = sGZ2;                                                // [8 co][2: cos, sin][N3 / 2]
         auto frozen_site = [&](int f, int& r, int& c) {
@@ -502,7 +528,21 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
                 bsum[1] += a1;
             }
         }
+        if (tid < 432) {                                                 // gw2[co][ci][tap] += sum over the own active sites of g_out[co] h2[ci][site + tap]
+            const int hf = tid >= 216 ? 1 : 0, t = tid - 216 * hf;
+            const int co = fdiv<9>(fdiv<8>(t)), ci = fdiv<9>(t) & 7, tap = t - fdiv<9>(t) * 9, ky = fdiv<3>(tap), kx = tap - 3 * ky;
+            const double* pg = sGOC + co * NA + hf * (NA / 2);
+            const double* ph = sHA2 + ci * PSH + ky * W1C + kx;          // h2 at own (r, c) + (ky - 1, kx - 1): window index (r + ky) W1C + c + kx
+            double c3[4] = {0.0, 0.0, 0.0, 0.0};
+            if (mu == 0) conv3_acc<0, TC, W1C>(pg, ph + hf * (NA / 2 / (TC / 4)) * W1C + off, c3);
+            else         conv3_acc<1, TC, W1C>(pg, ph + (off + 4 * hf * (NA / 2 / TC)) * W1C, c3);
+            acc3[0] += (c3[0] + c3[1]) + (c3[2] + c3[3]);
+        } else if (tid >= 448) {                                         // b3: the eighth wave sums the three g_out planes
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc3[k] += sGOC[k * NA + lane];
+        }
         lds_barrier();
+        BT_STAMP(4);
         if (tid < N3 / 2) {
             int r, c;
             frozen_site(tid, r, c);
@@ -519,7 +559,19 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
             const int cls = ((mu == 0 ? j0 + occ : i0 + orr) - off) & 3;  // 0 active, 1|2 frozen, 3 passive
             uniform_at(A.gp_out, bn)[mul24(i0 + orr, L) + j0 + occ] = gpin + (cls != 3 ? sDir[tid] : 0.0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_G(nxt);
+        BT_STAMP(5);
     }
+#ifdef FT_BT_STAMPS
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101))
+        printf("bwd_train wg %d mu %d: %d items; cycles per item: stage1 %lld (+barrier %lld) stage2 %lld stage3 %lld stage4 %lld tail %lld top %lld\n", (int)blockIdx.x, mu, nwalk,
+               stc_[0] / nwalk, stc_[1] / nwalk, stc_[2] / nwalk, stc_[3] / nwalk, stc_[4] / nwalk, stc_[5] / nwalk, stc_[7] / nwalk);
+#endif
+#undef BT_STAMP
+#undef WI_
+#undef wi_
+#undef WJ_
 
     // ---- the group's partial: the waves' K slices summed through LDS in a fixed order (k_flow_wgrad's epilogue)
     lds_barrier();

@@ -7,8 +7,8 @@ PRELOAD=${PRELOAD--mllvm -amdgpu-kernarg-preload-count=16}       # PRELOAD= (emp
 NOLICM=${NOLICM--mllvm -disable-machine-licm}                         # NOLICM= (empty) builds flow_small with MachineLICM
 SHA=$(python3 "$ROOT/tools/csrc_sha.py")
 cd "$ROOT/fthmc_amd/csrc" || exit 1
-for f in wilson flow flow_fwd flow_bwd_gather flow_wgrad flow_small flow_generic rng api; do
-  fl=""; case $f in flow_fwd|flow_bwd_gather) fl="$LDSFLAGS $PRELOAD";; flow_wgrad) fl="$LDSFLAGS";; flow_small) fl="$LDSFLAGS $NOLICM";; esac
+for f in wilson flow flow_fwd flow_bwd_gather flow_bwd_train flow_wgrad flow_small flow_generic rng api; do
+  fl=""; case $f in flow_fwd|flow_bwd_gather) fl="$LDSFLAGS $PRELOAD";; flow_wgrad|flow_bwd_train) fl="$LDSFLAGS";; flow_small) fl="$LDSFLAGS $NOLICM";; esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wno-unused-function $fl $EXTRA -DFTHMC_SRC_SHA=\"$SHA\" -c $f.hip -o $D/$f.o || exit 1 &
 done
 wait

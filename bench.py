@@ -449,7 +449,7 @@ def main():
     if cfg['train']:
         gxi, _ = ops.random_momenta(parallel.chain_seeds(SEED + 31, lo, hi, 0).to(dev), (B, 2, L, L), need_u=False)
         xi = (math.pi * torch.erf(gxi / math.sqrt(2.0))).contiguous()          # prior draw U(-pi, pi), keyed by chain id
-        Gt = ops.default_groups(B, L)
+        Gt = ops.default_train_groups(B, L)
 
         def tstep():
             r = ops.train_grad(xi, w, N_LAYERS, BETA, groups=Gt)

@@ -43,17 +43,32 @@ class LazyHistory(dict):
             fn, self._fill_fn = self._fill_fn, None
             super().update(fn())
 
+    # every way of looking at, copying or changing a dict fills first: a caller written against the reference's plain history dict
+    # (ft_hmc.py:272-346) never sees (or overwrites) an empty one
     def __getitem__(self, k): self._fill(); return super().__getitem__(k)
+    def __setitem__(self, k, v): self._fill(); return super().__setitem__(k, v)
+    def __delitem__(self, k): self._fill(); return super().__delitem__(k)
     def __contains__(self, k): self._fill(); return super().__contains__(k)
     def __iter__(self): self._fill(); return super().__iter__()
+    def __reversed__(self): self._fill(); return super().__reversed__()
     def __len__(self): self._fill(); return super().__len__()
+    def __bool__(self): self._fill(); return super().__len__() > 0
+    def __or__(self, other): self._fill(); return dict(super().items()) | dict(other)
+    def __ror__(self, other): self._fill(); return dict(other) | dict(super().items())
+    def __ior__(self, other): self._fill(); super().update(other); return self
     def get(self, k, d=None): self._fill(); return super().get(k, d)
     def keys(self): self._fill(); return super().keys()
     def values(self): self._fill(); return super().values()
     def items(self): self._fill(); return super().items()
     def setdefault(self, k, d=None): self._fill(); return super().setdefault(k, d)
+    def pop(self, *a): self._fill(); return super().pop(*a)
+    def popitem(self): self._fill(); return super().popitem()
+    def update(self, *a, **kw): self._fill(); return super().update(*a, **kw)
+    def clear(self): self._fill_fn = None; return super().clear()
+    def copy(self): self._fill(); return dict(super().items())
     def __repr__(self): self._fill(); return super().__repr__()
     def __eq__(self, other): self._fill(); return super().__eq__(other)
+    __hash__ = None
     def __reduce__(self): self._fill(); return (dict, (dict(super().items()),))     # pickles / copies as the plain dict it stands for
 
 

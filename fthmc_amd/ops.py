@@ -643,6 +643,15 @@ def default_groups(B: int, L: int) -> int:
     return 2 if B >= 16 and B * L * L >= (1 << 17) else 1
 
 
+def default_train_groups(B: int, L: int) -> int:
+    """Chain groups of a training gradient.  On the shapes the fused training backward serves (csrc/flow_bwd_train.hip: L a power
+    of two >= 32) ONE: that kernel holds a CU by itself (137 KB of LDS, 253 VGPRs), a second stream finds no room beside it and
+    only halves the walks (measured at the config-5 shard: 7.41 ms on one stream, 7.47-7.59 on two); elsewhere as the sampler."""
+    if L >= 32 and (L & (L - 1)) == 0 and get_variant() == 1:
+        return 1
+    return default_groups(B, L)
+
+
 def _side_streams(device, n: int):
     key = device.index
     pool = _SIDE_STREAMS.setdefault(key, [])

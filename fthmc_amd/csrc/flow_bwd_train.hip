@@ -41,6 +41,7 @@
 // (fthmc/utils/layers.py:196-202,348-371) and make_conv_net (:138-167).
 #include "flow_mfma_common.h"
 
+#if !FT_RECOMP_D1       // the act'(z1)-recompute build (an A/B switch of the force path) keeps the two-kernel form
 namespace {
 
 using namespace fthmc;
@@ -79,7 +80,6 @@ template <int TR, int TC> struct SmemT {
     static_assert(TR == 16 && TC == 16 && NA == 64, "thread maps: conv2^T tile map, K split of the weight-gradient GEMMs, one wave per g_out plane");
     static_assert(W1R % 2 == 0 && NTT <= NT && 2 * N3 <= NT && N1W <= NT && GOC % 2 == 0, "thread maps");
     static_assert(SIZE * 8 <= 160 * 1024, "one workgroup per CU (160 KB of LDS on gfx950)");
-    static_assert(!FT_RECOMP_D1, "act'(z1) comes through the stash here");
 };
 
 // conv3 (8 -> 3, active sites only) weight gradient: thread = (output (co, ci, tap), half of the active sites); the 32 sites of
@@ -638,10 +638,17 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
 }
 
 }  // namespace
+#endif
 
 namespace fthmc {
 
+bool flow_bwd_train_built() { return !FT_RECOMP_D1; }
+
 int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s) {
+#if FT_RECOMP_D1
+    (void)a; (void)s;
+    return FTHMC_ERR_UNSUPPORTED;
+#else
     if (!flow_shape_ok(a.B, a.L, a.off)) return FTHMC_ERR_ARG;
     if (!flow_bwd_train_shape(a.L) || !a.up_gp || a.up_link || a.glogj || !a.stash || !a.gp_out || !a.gw_part) return FTHMC_ERR_UNSUPPORTED;
     if (!flow_stash_fits32(a.B, a.L, true)) return FTHMC_ERR_UNSUPPORTED;                   // 32-bit plane offsets (uniform_at)
@@ -654,6 +661,7 @@ int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s) {
     if (a.mu == 0) hipLaunchKernelGGL((k_flow_bwd_train<MG_TR, MG_TC, 0>), grid, dim3(NT), 0, s, b);
     else hipLaunchKernelGGL((k_flow_bwd_train<MG_TR, MG_TC, 1>), grid, dim3(NT), 0, s, b);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
+#endif
 }
 
 }  // namespace fthmc

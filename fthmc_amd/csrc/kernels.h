@@ -158,6 +158,7 @@ inline int flow_wgrad_nparts(int B, int L, int tpw) {
 // [flow_bwd_train_nparts(B, L)][FLOW_GW_STRIDE]; a.gp_out as launch_flow_bwd_gather.  Built for the shapes 16 x 16 tiles divide with
 // L a power of two (flow_bwd_train_shape); FTHMC_ERR_UNSUPPORTED otherwise: the caller keeps the two-kernel form.
 int launch_flow_bwd_train(const FlowLayerArgs& a, hipStream_t s);
+bool flow_bwd_train_built();          // false in the act'(z1)-recompute build (FT_RECOMP_D1: the fused kernel reads act'(z1) from the stash)
 inline bool flow_bwd_train_shape(int L) { return L >= 32 && (L & (L - 1)) == 0; }
 // items per workgroup: as many as leave one workgroup per CU (256), at most 64
 inline int flow_bwd_train_tpw(int B, int L) {

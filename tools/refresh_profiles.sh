@@ -4,7 +4,8 @@
 # bench lines of configs 3, 1, 2, 5 (+ config 2 on the tiled path); rocprofv3 kernel stats of the headline and of config 2;
 # the counter passes (in-bench launches, full-batch launches, the small-lattice kernel, the plain-HMC leapfrog kernels);
 # instructions per stage (needs experiments/lib_diag.so = the -DFT_DIAG build of HEAD); workgroup lifetimes; the A/B of the
-# act'(z1)-recompute build (experiments/lib_recomp_d1.so = make EXTRA=-DFT_RECOMP_D1=1) with its HBM traffic.
+# act'(z1)-recompute build (experiments/lib_recomp_d1.so = make -C fthmc_amd/csrc recomp) with its HBM traffic; round 6: the fused
+# training backward's stage cycles and its A/B against the two-kernel form (lib_bt_stamps.so, lib_twokernel.so: tools/build_variant.sh).
 ROOT=$(pwd); OUT=$1; COMMIT=${2:-unknown}; mkdir -p "$OUT"; export TMPDIR=/tmp
 case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT";; esac
 for c in 3 1 2 5; do
@@ -51,6 +52,10 @@ for g in "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_L
 done
 python3 tools/pmc_by_kernel.py "$OUT"/pmct/pass* > "$OUT/pmc_train_shard.txt"
 python3 tools/lifetime.py 512 2>&1 | grep -v "flow_fwd\|flow_bwd:" > "$OUT/workgroup_lifetime_train.txt"
+# round 6: the fused training backward (flow_bwd_train.hip): cycles per stage and item (experiments/lib_bt_stamps.so = tools/build_variant.sh bt_stamps
+# -DFT_BT_STAMPS at HEAD) and the alternating A/B against the two-kernel form (experiments/lib_twokernel.so = -DFT_FUSED_WGRAD=0 at HEAD)
+FTHMC_LIB=$ROOT/experiments/lib_bt_stamps.so python3 tools/bt_stamp_run.py 2>&1 | grep "bwd_train wg" >> "$OUT/workgroup_lifetime_train.txt"
+bash tools/ab_train.sh 2 fthmc_amd/libfthmc_hip.so experiments/lib_twokernel.so > "$OUT/ab_train_fused_vs_two_kernels.txt" 2>&1
 echo "[refresh] training done"
 rm -rf "$OUT/stats" "$OUT/stats2" "$OUT/stats3" "$OUT/stats4" "$OUT"/pmc*/pass*/ "$OUT/stg/stop"*
 echo "[refresh] done"

@@ -81,6 +81,12 @@ __global__ void k_pack_weights(const double* __restrict__ w, int n_layers, doubl
                 const int ky = col ? a3 : l5, kx = col ? l5 : a3;
                 v = (l5 >= 0 && l5 <= 2) ? c[CW1 + (co * 8 + ci) * 9 + (2 - ky) * 3 + (2 - kx)] : 0.0;
             }
+        } else if (t >= WT3R && t < WT3C + LT3_SIZE) {                    // conv3^T tables (flow_common.h): pairs = rows, pairs = columns
+            const int col = t >= WT3C, u = t - (col ? WT3C : WT3R);
+            const int tt = u / LT3_T, co = (u % LT3_T) / LT3_CO, e = u % LT3_CO, l5 = e / 8 - 1, ci = ft_chan(e % 8);
+            // col (mu = 0): across the lines = kx, along = ky;  rows (mu = 1): across = ky, along = kx
+            const int ky = col ? tt : l5, kx = col ? l5 : tt;
+            v = (co < 3 && e < 40 && l5 >= 0 && l5 <= 2) ? c[CW2 + (co * 8 + ci) * 9 + ky * 3 + kx] : 0.0;
         }
         d[t] = v;
     }
@@ -632,7 +638,7 @@ namespace fthmc {
 
 int launch_pack_weights(const double* w, int n_layers, double* wint, hipStream_t s, unsigned long long token) {
     if (n_layers <= 0) return FTHMC_OK;
-    static_assert(WBWD1 + LB_SIZE <= FLOW_WSTAMP0, "the stamps sit behind the last weight block");
+    static_assert(WT3C + LT3_SIZE <= FLOW_WSTAMP0, "the stamps sit behind the last weight block");
     hipLaunchKernelGGL(k_pack_weights, dim3(n_layers, FLOW_WSTAMPS), dim3(256), 0, s, w, n_layers, wint, token);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }

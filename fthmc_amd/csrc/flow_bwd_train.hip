@@ -16,7 +16,7 @@
 // k_flow_bwd_gather's, each sharing its barrier interval with the weight-gradient work that reads the planes the stage has
 // just consumed or produced:
 //     1  transform adjoint -> g_out, the (cos, sin) window into LDS
-//     2  conv3^T (VALU) -> gz2                 | the h1 window into LDS
+//     2  conv3^T (MFMA, 3 steps per tile) -> gz2 | the h1 window into LDS
 //     3  conv2^T (MFMA) -> gz1                 | conv2 weight gradient (MFMA: M = 8 co x 2 row shifts from gz2, N = (ci, kx, ky in {0, 2})
 //                                              |   from the h1 window), the h2 window into LDS
 //     4  conv1^T (VALU)                        | conv1 weight gradient (MFMA from gz1 and the net-input window)
@@ -71,7 +71,8 @@ template <int TR, int TC> struct SmemT {
     static constexpr int IN = D1 + 8 * PS1;                             // [2][2][PSH] cos, sin on tile+1 ((1, 0) off the frozen sites), per item parity
     static constexpr int DIR = IN + 4 * PSH;                            // [2][N3]  transform's contribution at the own active sites, per item parity
     static constexpr int SW = DIR + 2 * N3;                             // [LB_SIZE] backward weight block
-    static constexpr int HA1 = SW + LB_SIZE;                            // [8][PSH] h1 window
+    static constexpr int T3 = SW + LB_SIZE;                             // [LT3_SIZE] conv3^T's weight table (flow_common.h)
+    static constexpr int HA1 = T3 + LT3_SIZE;                           // [8][PSH] h1 window
     static constexpr int HA2 = HA1 + 8 * PSH;                           // [8][PSH] h2 window
     static constexpr int WALK = HA2 + 8 * PSH;
     // after the walk, over the planes: the waves' accumulators [8][4 tiles][4][64], bias lane sums [8][2][8], conv3 sums [432]
@@ -86,15 +87,24 @@ template <int TR, int TC> struct SmemT {
 // the half at compile-time offsets from the thread's base (k_flow_wgrad's loop)
 template <int MU, int TC, int W1C>
 __device__ __forceinline__ void conv3_acc(const double* __restrict__ pg, const double* __restrict__ ph, double (&acc)[4]) {
+    // in batches of eight sites: the eight h2 reads and the four 16-byte g_out reads of a batch are issued together, then its
+    // eight FMAs (left to itself the scheduler of the mu = 0 instance put a full LDS wait behind every single read: 2.2 k cycles
+    // for this loop against 1.0 k in the mu = 1 instance with the same instructions)
 #pragma unroll
-    for (int a = 0; a < 32; a += 2) {
-        const double2_t g2 = *reinterpret_cast<const double2_t*>(pg + a);
+    for (int a0 = 0; a0 < 32; a0 += 8) {
+        double2_t g2[4];
+        double hv[8];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int aa = a + e;
-            const int o = MU == 0 ? (aa / (TC / 4)) * W1C + 4 * (aa % (TC / 4)) : 4 * (aa / TC) * W1C + aa % TC;
-            acc[aa & 3] = fma(e ? g2.y : g2.x, ph[o], acc[aa & 3]);
+        for (int e = 0; e < 4; ++e) g2[e] = *reinterpret_cast<const double2_t*>(pg + a0 + 2 * e);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int aa = a0 + e;
+            hv[e] = ph[MU == 0 ? (aa / (TC / 4)) * W1C + 4 * (aa % (TC / 4)) : 4 * (aa / TC) * W1C + aa % TC];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e & 3] = fma((e & 1) ? g2[e >> 1].y : g2[e >> 1].x, hv[e], acc[e & 3]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -145,6 +155,9 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
 #pragma unroll
         for (int k = 0; k < NWC; ++k)
             if (tid + k * NT < LB_SIZE) sW[tid + k * NT] = ldu(w + (mu == 0 ? WBWD1 : WBWD), (unsigned)(tid + k * NT));
+#pragma unroll
+        for (int k = 0; k < (LT3_SIZE + NT - 1) / NT; ++k)
+            if (tid + k * NT < LT3_SIZE) sm[S::T3 + tid + k * NT] = ldu(w + (mu == 0 ? WT3C : WT3R), (unsigned)(tid + k * NT));
         if (tid < 2 * (PSH - NH)) {
             const int pl = tid / (PSH - NH), e = NH + tid % (PSH - NH);
             sm[S::IN + pl * PSH + e] = 0.0; sm[S::IN + (2 + pl) * PSH + e] = 0.0;
@@ -156,16 +169,11 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
     // ---- item-independent thread maps
     // transform tasks on the last waves: slot `ta` of the tile+3 window's active lines
     const int ta = tid - (NT - S::NTT);
-    // conv3^T task = (two sites of the same line class, half of the 8 channels)
-    static_assert(W2R % 2 == 0 && W2C % 2 == 0 && N2W <= NT, "site pairs, one round");
-    constexpr int NPR = N2W / 2;
-    static_assert(NPR <= NT / 2, "one half of the channels per half of the workgroup");
-    const int c3half = wave >= NW / 2;
-    const bool c3task = (tid & (NT / 2 - 1)) < NPR;
-    const int c3u = c3task ? (tid & (NT / 2 - 1)) : 0;
-    int c3r, c3c;
-    if (mu == 0) { c3r = fdiv<W2C>(c3u); c3c = c3u - c3r * W2C; }             // (r, c), (r + W2R/2, c)
-    else { c3r = fdiv<W2C / 2>(c3u); c3c = c3u - c3r * (W2C / 2); }         // (r, c), (r, c + W2C/2)
+    // conv3^T on the matrix cores (flow_mfma_common.h Conv3T: here the matrix pipe idles through the VALU stages of the lone
+    // workgroup, so the 42 MFMAs cost less than the VALU stage's 72 FMAs on 62 LDS instructions per thread did -- in
+    // k_flow_bwd_gather, two workgroups per CU on a saturated DP pipe, the same change LOST 1 %: profiles/r06_ab_bwd_conv3t_mfma.txt)
+    using C3 = Conv3T<mu, W2R>;
+    static_assert(W2R == W2C && C3::NIT == 2 && N2W <= NT, "square window, two rounds of conv3^T tiles");
     // conv2^T tile map (flow_bwd_gather.hip): tiles 0 .. NU-1: u = tile, v = 0 .. 15; tiles NU, NU+1: v = 16, 17 of the even / odd u
     constexpr int NU = W1C / 2, NTILE1 = NU + 2, NIT1 = (NTILE1 + NW - 1) / NW;
     static_assert(NIT1 == 2 && W1R == W1C, "two rounds of conv2^T tiles");
@@ -215,7 +223,6 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
         else { const int m = fdiv<W3C>(ta); tc3 = ta - m * W3C; tr3 = r0 + 4 * m; ttask = tr3 < S::W3R; }
         if (!ttask) { tr3 = 3; tc3 = 3; }                                    // any valid site
     }
-    const bool c3live = ((mu == 0 ? c3c + 2 - c0 : c3r + 2 - r0) & 3) <= 2;
     const unsigned wmagic = (unsigned)(L - 1);
 
     // ---- an item's operands, in registers.  Every load is unconditional, from a clamped address; each GROUP of them is issued for
@@ -223,7 +230,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
     //      the loads), so nothing of an item's load latency is left in front of its stages -- one workgroup per CU has no second
     //      workgroup to hide it behind.  Barriers wait for LDS traffic only (lds_barrier): the loads stay in flight across them.
     double tcv[4 * NMIX], ag[2], fcs, fsn;                                 // group A: transform adjoint, net-input window
-    double d2v[2][4];                                                      // group D2: act'(z2) of the conv3^T task
+    double d2v[C3::NIT][4];                                                // group D2: act'(z2) of the lane's conv3^T pairs (channels 2 g, 2 g + 1 of both members)
     double d1v[NIT1][4];                                                   // group D1: act'(z1) of the conv2^T epilogue
     double gpin;                                                           // group G: upstream gradient of the own site
     double2_t hv1[NRH][2], hv2[NRH][2];                                    // groups H1, H2: the h1 / h2 windows
@@ -271,22 +278,24 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
         }
     };
     auto issue_D2 = [&](const Item& q) {
-        const unsigned bn = (unsigned)q.b * (unsigned)n;
-#if FT_D2_C
-        const int lx = stash_live_line<true>(mu == 0 ? WJ_(q, c3c - 2) : wi_(q, c3r - 2), L, off);
-        const int goA = !c3live ? 0 : mu == 0 ? mul24(wi_(q, c3r - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ_(q, c3c - 2);
-        const int goB = !c3live ? 0 : mu == 0 ? mul24(wi_(q, c3r + W2R / 2 - 2), 3 * (L >> 2)) + lx : mul24(lx, L) + WJ_(q, c3c + W2C / 2 - 2);
-#else
-        const int goA = c3live ? WI_(q, c3r - 2) + WJ_(q, c3c - 2) : 0;
-        const int goB = !c3live ? 0 : mu == 0 ? WI_(q, c3r + W2R / 2 - 2) + WJ_(q, c3c - 2) : WI_(q, c3r - 2) + WJ_(q, c3c + W2C / 2 - 2);
-#endif
-        const double* pl = uniform_at(A.stash, 8u * (Bn + bn) + (unsigned)(c3half * 4));
-        const unsigned oA = ft_off32((unsigned)goA * 8u), oB = ft_off32((unsigned)goB * 8u);
+        const double* pl = uniform_at(A.stash, 8u * (Bn + (unsigned)q.b * (unsigned)n));
         auto ldu2o = [](const double* base, unsigned o) { return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + o); };
 #pragma unroll
-        for (int k = 0; k < 4; k += 2) {
-            const double2_t va = ldu2o(pl + k, oA), vb = ldu2o(pl + k, oB);
-            d2v[0][k] = va.x; d2v[0][k + 1] = va.y; d2v[1][k] = vb.x; d2v[1][k + 1] = vb.y;
+        for (int e = 0; e < C3::NIT; ++e) {
+            const C3 P(wave + NW * e, lane, c0);
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd) {
+                // on a dead line (no active site within reach: an exact 0 there) the stash holds nothing: record 0 instead
+                const bool live = P.ok && !P.dead(dd);
+                const int i = wi_(q, P.row(dd) - 2), j = WJ_(q, P.col(dd) - 2);
+#if FT_D2_C
+                const int go = mu == 0 ? mul24(i, 3 * (L >> 2)) + stash_live_line<true>(j, L, off) : mul24(stash_live_line<true>(i, L, off), L) + j;
+#else
+                const int go = mul24(i, L) + j;
+#endif
+                const double2_t vd = ldu2o(pl, ft_off32((unsigned)(live ? go : 0) * 8u) + 16u * (unsigned)(lane >> 4));
+                d2v[e][2 * dd] = vd.x; d2v[e][2 * dd + 1] = vd.y;
+            }
         }
     };
     auto issue_D1 = [&](const Item& q) {
@@ -326,7 +335,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
         }
     };
 #ifdef FT_BT_STAMPS       // measurement builds only: cycles per stage, summed over the walk, printed by two workgroups
-    long long stc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stl_ = (long long)__builtin_readcyclecounter();
+    long long stc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stl_ = (long long)__builtin_readcyclecounter();
 #define BT_STAMP(k) do { const long long t_ = (long long)__builtin_readcyclecounter(); stc_[k] += t_ - stl_; stl_ = t_; } while (0)
 #else
 #define BT_STAMP(k) do { } while (0)
@@ -370,47 +379,28 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
         if (fwtask) { sIn[tid] = fwfrozen ? fcs : 1.0; sIn[PSH + tid] = fwfrozen ? fsn : 0.0; }
         __builtin_amdgcn_sched_barrier(0);
         issue_A(nxt);
+        BT_STAMP(8);
         if (it > 0) conv3_wgrad(sm + S::GOC + ((it - 1) & 1) * 3 * NA);      // of the item before
         BT_STAMP(0);
         lds_barrier();
         BT_STAMP(1);
 
-        // ---- stage 2: conv3^T on the VALU -> gz2 (flow_bwd_gather.hip); the h1 window into LDS ---------------------------
-        if (c3task) {
-            const int half = c3half, r = c3r, c = c3c;
-            const int s2off = mu == 0 ? (W2R / 2) * RS2 : W2C / 2;
-            const int s = r * RS2 + c;
-            const int ksel = mu == 0 ? (c + 2 - c0) & 3 : (r + 2 - r0) & 3;   // the one kx (mu=0) / ky (mu=1)
-            const int s3off = mu == 0 ? (W2R / 2) * W3C : W2C / 2;            // second site in tile+3 coordinates
-            double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0};
-            if (ksel <= 2) {
+        // ---- stage 2: conv3^T on the matrix cores -> gz2; the h1 window into LDS -------------------------------------
+        {
+            const int g = lane >> 4;
 #pragma unroll
-                for (int co = 0; co < 3; ++co) {
-                    double wv[3][4], g0[3], g1[3];
-#pragma unroll
-                    for (int kk = 0; kk < 3; ++kk) {
-                        const int ky = mu == 0 ? kk : ksel, kx = mu == 0 ? ksel : kk;
-                        const int at = (r + 2 - ky) * W3C + c + 2 - kx;
-                        g0[kk] = sGO[co * N3W + at]; g1[kk] = sGO[co * N3W + at + s3off];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) wv[kk][k] = sW[LB_W2 + (co * 8 + half * 4 + k) * 9 + ky * 3 + kx];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int kk = 0; kk < 3; ++kk)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            acc0[k] = fma(g0[kk], wv[kk][k], acc0[k]);
-                            acc1[k] = fma(g1[kk], wv[kk][k], acc1[k]);
-                        }
+            for (int e = 0; e < C3::NIT; ++e) {
+                const int T = wave + NW * e;
+                if (T >= C3::NTILE) break;
+                const C3 P(T, lane, c0);
+                const double4_t z = conv3t_tile<mu, W2R, W3C, N3W>(sGO, sm + S::T3, P, lane);
+                if (P.ok) {
+                    // z[q]: channel 2 g + (q & 1) at member q >> 1; dead lines get an exact 0, whatever the stash holds there
+                    const int s0 = P.row(0) * RS2 + P.col(0), ds = mu == 0 ? 1 : RS2;
+                    double* pz = sGZ2 + 2 * g * PS2 + s0;
+                    pz[0] = P.dead(0) ? 0.0 : z[0] * d2v[e][0]; pz[PS2] = P.dead(0) ? 0.0 : z[1] * d2v[e][1];
+                    pz[ds] = P.dead(1) ? 0.0 : z[2] * d2v[e][2]; pz[PS2 + ds] = P.dead(1) ? 0.0 : z[3] * d2v[e][3];
                 }
-            }
-            // dead lines (no active site within reach) get an exact 0, whatever the stash holds there
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double* pz = sGZ2 + (half * 4 + k) * PS2 + s;
-                pz[0] = ksel <= 2 ? d2v[0][k] * acc0[k] : 0.0;
-                pz[s2off] = ksel <= 2 ? d2v[1][k] * acc1[k] : 0.0;
             }
         }
 #pragma unroll
@@ -583,8 +573,8 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
     conv3_wgrad(sm + S::GOC + ((nwalk - 1) & 1) * 3 * NA);               // of the last item
 #ifdef FT_BT_STAMPS
     if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 101))
-        printf("bwd_train wg %d mu %d: %d items; cycles per item: stage1 %lld (+barrier %lld) stage2 %lld stage3 %lld stage4 %lld tail %lld top %lld\n", (int)blockIdx.x, mu, nwalk,
-               stc_[0] / nwalk, stc_[1] / nwalk, stc_[2] / nwalk, stc_[3] / nwalk, stc_[4] / nwalk, stc_[5] / nwalk, stc_[7] / nwalk);
+        printf("bwd_train wg %d mu %d: %d items; cycles per item: stage1 %lld [of it: fill + issue_A %lld] (+barrier %lld) stage2 %lld stage3 %lld stage4 %lld tail %lld top %lld\n", (int)blockIdx.x, mu, nwalk,
+               (stc_[0] + stc_[8]) / nwalk, stc_[8] / nwalk, stc_[1] / nwalk, stc_[2] / nwalk, stc_[3] / nwalk, stc_[4] / nwalk, stc_[5] / nwalk, stc_[7] / nwalk);
 #endif
 #undef BT_STAMP
 #undef WI_

@@ -62,7 +62,15 @@ constexpr int LF_P1 = LF_SIZE, LF_BC = 288, LF_P1_SIZE = LF_BC + 64, LF_LDS = LF
 constexpr int LF_W2 = LF_LDS, LF_BLOCK = LF_W2 + 216;   // conv3's weights: never copied to LDS (wave-uniform: scalar loads into SGPRs)
 constexpr int LB_W0 = 0, LB_W2 = 144, LB_T2 = 360, LB_SIZE = LB_T2 + 960;
 constexpr int WFWD0 = 2944, WFWD1 = WFWD0 + LF_BLOCK, WBWD = WFWD1 + LF_BLOCK, WBWD1 = WBWD + LB_SIZE;   // WBWD: rows, WBWD1: columns
-static_assert(WBWD1 + LB_SIZE <= FLOW_WINT, "weight layout");
+// conv3^T on the matrix cores (flow_mfma_common.h conv3t_mfma; the tiled backward kernels): the upstream gradient g_out lives on
+// the ACTIVE stripe lines only, so -- as for conv1 in the forward -- output sites are paired ACROSS the lines: a pair's window is
+// four consecutive lines of which exactly one is active, K = that line's 3 taps along it x 3 channels (padded to 4) = 3 MFMA
+// steps.  Table (one per pairing direction): T3[t 3: tap along the line][co 4: stride 48][l5 5: stride 8][cN 8] =
+// w2[co][ft_chan(cN)][tap across = l5 - 1][tap along = t] (zero for l5 = 0, 4 and co = 3): the weight of (active window line u,
+// pair member dd) is the entry l5 = dd + 3 - u, so the operand address is (lane part) + t * 192 -- no VALU in the K loop.
+constexpr int LT3_CO = 48, LT3_T = 4 * LT3_CO, LT3_SIZE = 3 * LT3_T;            // 576
+constexpr int WT3R = WBWD1 + LB_SIZE, WT3C = WT3R + LT3_SIZE;                    // pairs = rows (mu = 1) / columns (mu = 0)
+static_assert(WT3C + LT3_SIZE <= FLOW_WSTAMP0, "weight layout: the stamps of k_pack_weights sit behind the last block");
 
 // exp(x) for either sign (|x| clamped to the finite range): range reduction by ln2 (hi/lo split) + degree-13
 // Taylor (|r| <= ln2/2: truncation 4e-18) + v_ldexp.  ~20 dependent DP ops instead of ocml exp's ~60, < 1.5 ulp.

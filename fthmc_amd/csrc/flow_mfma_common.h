@@ -342,6 +342,51 @@ __device__ __forceinline__ double4_t conv2t_tile(const double* __restrict__ wp, 
     return accs[0] + accs[1];
 }
 
+// conv3^T of the tiled backward kernels on the matrix cores (flow_bwd_gather.hip, flow_bwd_train.hip; weight table T3 and the
+// idea: flow_common.h LT3_*).  Output = gz2 on the tile+2 window (W2 x W2 sites, LDS planes [8][PS2], row stride RS2) = act'(z2)
+// times the sum over (co, taps) of g_out on the tile+3 window (planes [3][N3W], row stride W3C; written on the active lines only).
+// Pairs across the stripe lines: position pu across (sites 2 pu, 2 pu + 1), v along.  A pair's four-line window starts at line
+// 2 pu - 1; its active line is window line u = (a1 - 2 pu) & 3 (a1 = first active line of the tile+3 window: c0 / r0 of the
+// kernels), i.e. tile+3 line 2 pu + u, and member dd sees it through the tap across ka = dd + 2 - u -- outside 0..2 the member
+// sits on a DEAD line (no active site within reach): its weights are the table's zero lines, its act'(z2) was never stashed, the
+// result is an exact 0.  The weights are the MFMA's A operand, shared by the 16 pairs of a tile: u must be the tile's, and it
+// depends on the parity of pu only -- tiles are class-pure: class cls = pu & 1, NTC tiles per class, pair index inside the
+// class with the coordinate that runs along a lattice ROW fastest (the act'(z2) records of a tile's lanes are then close in
+// the stash).
+template <int MU, int W2> struct Conv3T {
+    static constexpr int NU = W2 / 2, NCL = NU / 2, NPC = NCL * W2, NTC = (NPC + 15) / 16, NTILE = 2 * NTC, NIT = (NTILE + NW - 1) / NW;
+    static_assert(NU % 2 == 0, "as many even as odd pair positions");
+    int pu, v, u;            // this lane's pair of the tile; u: window line of the active line (tile-uniform)
+    bool ok;                 // a pair of the window (the last tile of a class is not full)
+    __device__ __forceinline__ Conv3T(int tile, int lane, int a1) {
+        const int cls = tile >= NTC ? 1 : 0, p_ = (tile - cls * NTC) * 16 + (lane & 15);
+        ok = tile < NTILE && p_ < NPC;
+        const int p = ok ? p_ : 0;
+        int k;
+        if (MU == 0) { v = fdiv<NCL>(p); k = p - v * NCL; } else { k = fdiv<W2>(p); v = p - k * W2; }
+        pu = 2 * k + cls;
+        u = (a1 - 2 * cls) & 3;
+    }
+    __device__ __forceinline__ bool dead(int dd) const { return dd ? u == 0 : u == 3; }
+    // tile+2 coordinates of member dd
+    __device__ __forceinline__ int row(int dd) const { return MU == 0 ? v : 2 * pu + dd; }
+    __device__ __forceinline__ int col(int dd) const { return MU == 0 ? 2 * pu + dd : v; }
+};
+// one tile: 3 MFMAs; returns z[q] = (channel 2 g + (q & 1), member q >> 1) of the lane's pair, BEFORE the act'(z2) factor
+template <int MU, int W2, int W3C, int N3W>
+__device__ __forceinline__ double4_t conv3t_tile(const double* __restrict__ sGO, const double* __restrict__ sT3, const Conv3T<MU, W2>& P, int lane) {
+    const int g = lane >> 4, i = lane & 15, cN = i & 7, dd = i >> 3;
+    const double* wp = sT3 + g * LT3_CO + (dd + 3 - P.u) * 8 + cN;
+    const int la3 = 2 * P.pu + P.u;                                        // the active line in tile+3 coordinates
+    const double* a0 = sGO + (g < 3 ? g : 0) * N3W + (MU == 0 ? (P.v + 2) * W3C + la3 : la3 * W3C + P.v + 2);
+    constexpr int astep = MU == 0 ? W3C : 1;                               // LDS step along the lines: tap t reads position v + 1 - t
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wp[t * LT3_T], a0[-t * astep], acc, 0, 0, 0);
+    return acc;
+}
+
 // Live-line map of a window whose every 4th line (first one d0) is dead: index of the l-th live line.
 // (the quotient by 3 through fdiv: a plain `/ 3` compiles to the quarter-rate v_mul_hi_u32)
 __device__ __forceinline__ int live_line(int l, int d0) {

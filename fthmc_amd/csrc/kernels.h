@@ -53,7 +53,7 @@ int launch_chain_seeds(int64_t seed, int64_t lo, int B, int64_t traj, int64_t* c
 constexpr int FLOW_TILE = 16;                 // VALU variant (flow.hip): 16 x 16 sites per tile
 constexpr int FLOW_R0 = FLOW_TILE + 6;        // plaquette / net-input window edge
 constexpr int FLOW_N0 = FLOW_R0 * FLOW_R0;    // window size of one gP partial
-constexpr int FLOW_WINT = 8768;               // doubles per layer, kernel-side weight layout
+constexpr int FLOW_WINT = 9856;               // doubles per layer, kernel-side weight layout
 // The expansion of layer l is guarded by STAMPS inside the layer's own region (its last FLOW_WSTAMPS doubles, one per
 // workgroup of k_pack_weights): a workgroup that finds its stamp equal to the token of the call (caller's weight version,
 // address of the canonical weights, layer) leaves at once, otherwise it expands its slice and writes the token.  The

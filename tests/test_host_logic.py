@@ -155,6 +155,15 @@ lw = torch.arange(lo, hi, dtype=torch.float64) * 0.3
 lse = float(P.global_logsumexp(lw)); mean = float(P.global_mean(lw, B))
 ess = float(P.global_ess(1000.0 * torch.sin(torch.arange(lo, hi, dtype=torch.float64)), B))     # one all-gather (C2 of a training step)
 g = torch.full((3,), float(rank + 1)); P.allreduce_grads(g)
+# the C2 collectives of a captured training step run on a process group of their own (parallel.capture_group): same numbers
+if world > 1:
+    cg = P.capture_group()
+    assert cg is not None and cg is P.capture_group() and cg is not dist.group.WORLD
+    g2 = torch.full((3,), float(rank + 1)); P.allreduce_grads(g2, group=cg)
+    ess2 = float(P.global_ess(1000.0 * torch.sin(torch.arange(lo, hi, dtype=torch.float64)), B, group=cg))
+    assert float(g2[0]) == float(g[0]) and ess2 == ess, (float(g2[0]), float(g[0]), ess2, ess)
+else:
+    assert P.capture_group() is None
 if rank == 0:
     print("RESULT", m["n"], m["acc"], m["plaq"], m["q"], m["dh"], lse, mean, float(g[0]), ess)
 if world > 1: dist.destroy_process_group()

@@ -10,7 +10,7 @@
 // needs them at the tile's OWN sites only: here the GEMMs read them where they lie.  What is left of the traffic is the h1, h2
 // windows (stashed by the forward; 20 doubles per site with the halo): 35 + 39 instead of 35 + 74.
 //
-// One 512-thread workgroup per CU (129 KB of LDS, 249 VGPRs) WALKS (chain, tile) items of its layer -- the weight gradient's
+// One 512-thread workgroup per CU (141 KB of LDS, 241 VGPRs) WALKS (chain, tile) items of its layer -- the weight gradient's
 // sum over sites simply runs on, its accumulators (four 16 x 16 MFMA tiles per wave) stay in registers -- and writes ONE
 // 955-entry partial at the end (k_reduce_gw sums the partials in a fixed order: bit-deterministic).  Per item the stages are
 // k_flow_bwd_gather's, each sharing its barrier interval with the weight-gradient work that reads the planes the stage has
@@ -28,12 +28,14 @@
 // the two K steps that would pair them (walk row 0 for the lower row shift, walk row 16 for the upper) select 0 instead.
 // One workgroup per CU has no second workgroup to hide its loads behind: every group of an item's operands is issued for
 // item i + 1 right behind the stage of item i that consumed the group (registers; barriers wait for LDS only).
-// Measured (round 6, config-5 shard, 32 chains of L = 256 per launch; profiles/r06_ab_train_fused_backward.txt):
-// fthmc_train_grad 7.41 ms against 8.30-8.42 ms of the two-kernel form on the same device; per item 18.8 k (mu = 1) / 20.0 k
-// (mu = 0) cycles of which the matrix pipe is busy 7.8 k (stage 3: 8.4 k for 6.7 k of MFMA) -- the VALU / LDS stages of a lone
-// workgroup run beside an idle matrix pipe.  What did NOT take that (same file): pieces of the weight-gradient GEMMs moved into
-// the VALU stages (both waves of a SIMD run the same stage: nothing overlaps, 7.41 -> 7.55), the two waves of a SIMD in opposite
-// order (the kernel outgrows the instruction cache: 8.3), gz2 planes at the conflict-free stride for the GEMM's A operand (+-0).
+// Measured (round 6, config-5 shard, 32 chains of L = 256 per launch; profiles/r06_ab_train_fused_backward.txt,
+// r06_ab_train_fused_vs_two_kernels.txt): fthmc_train_grad 7.11 ms against 8.41-8.43 ms of the two-kernel form on the same
+// device, the kernel 257 us per launch against 175 + 159; per item 18.1 k cycles of which the matrix pipe is busy 8.2 k (the
+// MFMA stage: 8.55 k for 105 MFMAs per SIMD) -- the VALU / LDS stages of a lone workgroup run beside an idle matrix pipe.  What
+// did NOT take that (same file): pieces of the weight-gradient GEMMs moved into the VALU stages (both waves of a SIMD run the
+// same stage: nothing overlaps, +2 %), the two waves of a SIMD in opposite order (the kernel outgrows the instruction cache:
+// +12 %), gz2 planes at the conflict-free stride for the GEMM's A operand, MFMA operand reads pipelined ahead in registers of
+// their own, the store's partial reads batched (all +-0).
 // -DFT_BT_STAMPS prints the stage cycles.
 //
 // Built for the tiled-exactly shapes (L a power of two >= 32: every BASELINE training shape); anything else keeps the

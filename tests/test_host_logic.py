@@ -166,7 +166,10 @@ else:
     assert P.capture_group() is None
 if rank == 0:
     print("RESULT", m["n"], m["acc"], m["plaq"], m["q"], m["dh"], lse, mean, float(g[0]), ess)
-if world > 1: dist.destroy_process_group()
+if world > 1:
+    dist.barrier()                       # nobody tears a group down while a peer is still inside a collective of it
+    dist.destroy_process_group(P.capture_group())
+    dist.destroy_process_group()
 '''
 
 

@@ -366,14 +366,14 @@ template <int L, bool TRAIN> struct Chain {
             double acc[3] = {0.0, 0.0, 0.0};
             int ro[3], co_[3];
             wrap3<L>(ai, ro); wrap3<L>(aj, co_);
+            double hv9[9];                                               // the nine taps first, then the 27 FMAs (see the transform below)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int tp = 0; tp < 9; ++tp) hv9[tp] = sH2[wave * PSZ + ro[tp / 3] * RS + co_[tp % 3]];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const double v = sH2[wave * PSZ + ro[ky] * RS + co_[kx]];
+            for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) acc[k] = fma(v, w3[k * 9 + ky * 3 + kx], acc[k]);
-                }
+                for (int k = 0; k < 3; ++k) acc[k] = fma(hv9[tp], w3[k * 9 + tp], acc[k]);
 #pragma unroll
             for (int k = 0; k < 3; ++k) sST[(wave * 3 + k) * NAS + lane] = acc[k];
         }
@@ -384,10 +384,16 @@ template <int L, bool TRAIN> struct Chain {
         //      arithmetic); then ONE wave: the new plaquette, log J and the link update of the lane's own active link
         double* sT2 = sm + G::T2;
         if (wave < NMIX && alane) {
-            double sk = sWc[LF_B2 + wave];
+            // the eight partials first, then their sum in channel order: one chain's latency IS this kernel's time, and left to
+            // itself the scheduler (short of registers at L = 16) waits for every read before it issues the next
+            double sq[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sk += sST[(q * 3 + wave) * NAS + lane];
+            for (int q = 0; q < 8; ++q) sq[q] = sST[(q * 3 + wave) * NAS + lane];
             const double cs = sPA[NAS + lane], sn = sPA[2 * NAS + lane];
+            double sk = sWc[LF_B2 + wave];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sk += sq[q];
             const double es = ft_exp(sk), ems = ft_rcp(es);
             const double cs2 = cs * cs, sn2 = sn * sn, sincs = sn * cs;
             const double invD = ft_rcp(ems * cs2 + es * sn2);
@@ -401,9 +407,13 @@ template <int L, bool TRAIN> struct Chain {
             }
         }
         if (wave == NMIX && alane) {
-            double tv = sWc[LF_B2 + NMIX];
+            double tq[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) tv += sST[(q * 3 + NMIX) * NAS + lane];
+            for (int q = 0; q < 8; ++q) tq[q] = sST[(q * 3 + NMIX) * NAS + lane];
+            double tv = sWc[LF_B2 + NMIX];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tv += tq[q];
             sT2[2 * NMIX * NAS + lane] = tv;
         }
         if (nl_ >= 0) weights_commit();
@@ -636,6 +646,7 @@ template <int L, bool TRAIN> struct Chain {
             double gv[9], gc = 0.0, gs = 0.0;
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) gv[tp] = gz[ro[2 - tp / 3] * RS + co_[2 - tp % 3]];
+            __builtin_amdgcn_sched_barrier(0);                             // all nine reads in flight before the first FMA waits
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) { gc = fma(gv[tp], w0s[tp], gc); gs = fma(gv[tp], w0s[9 + tp], gs); }
             sPart[(wave * 2 + 0) * NF + f] = gc;
@@ -645,10 +656,15 @@ template <int L, bool TRAIN> struct Chain {
         stamp(11);
         // the (cos, sin) adjoint lands in the gradient of the frozen plaquette itself: nothing else touches it in this pass
         if (ftask) {
+            double pc[8], ps[8];                                        // all sixteen partials first (see the transform above)
+#pragma unroll
+            for (int co = 0; co < 8; ++co) { pc[co] = sPart[(co * 2 + 0) * NF + tid]; ps[co] = sPart[(co * 2 + 1) * NF + tid]; }
+            const double gp0 = sGP[fr * L + fc];
+            __builtin_amdgcn_sched_barrier(0);
             double gct = 0.0, gst = 0.0;
 #pragma unroll
-            for (int co = 0; co < 8; ++co) { gct += sPart[(co * 2 + 0) * NF + tid]; gst += sPart[(co * 2 + 1) * NF + tid]; }
-            sGP[fr * L + fc] += -pre.fsn * gct + pre.fcs * gst;
+            for (int co = 0; co < 8; ++co) { gct += pc[co]; gst += ps[co]; }
+            sGP[fr * L + fc] = gp0 + (-pre.fsn * gct + pre.fcs * gst);
         }
         if (refill) issue_cs(tid, nl_, pre);
         if (nl_ >= 0) weights_commit();

@@ -82,6 +82,13 @@ def capture_group(device=None):
             g = dist.new_group(backend=dist.get_backend(), **kw)
         except TypeError:                                   # a torch without new_group(device_id=...): connects at first use
             g = dist.new_group(backend=dist.get_backend())
+        if kw:
+            # new_group connects the communicator now only where the backend "supports splitting"; ask for it in any case
+            # (ncclCommInitRank inside a capture is what this avoids; a second request for an existing communicator is a lookup)
+            try:
+                g._get_backend(kw['device_id']).eager_connect_single_device(kw['device_id'])
+            except (AttributeError, RuntimeError):
+                pass
         _CAPTURE_GROUP[:] = [dist.group.WORLD, g]
     return _CAPTURE_GROUP[1]
 

@@ -81,14 +81,6 @@ def release_workspaces():
     _WS_RETIRED.clear()
 
 
-def drop_stream_workspaces(streams):
-    """Forget the workspaces of streams nobody will run on again (a captured loop that was replaced: its graph is gone with it)."""
-    for st in streams:
-        for key in [k for k in _WS if k[1] == st.cuda_stream]:
-            _WS.pop(key, None)
-            _WS_CAPTURED.discard(key)
-
-
 def weights_version(wkey) -> int:
     """The caller's statement of the weights' CONTENT version (`wkey`: any hashable -- FieldTransformation: parameter
     versions + the flat buffer's generation, utils/layers.py weights_generation) as the 64-bit number of the C ABI's `_v`

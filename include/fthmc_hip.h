@@ -86,7 +86,7 @@ int fthmc_arch_params(const fthmc_arch_t* arch);   /* doubles per layer; 955 for
 int fthmc_set_small_path(int on);
 
 /* Weight versions (the `_v` entry points below and fthmc_pack_weights).  The tuned kernels read a kernel-layout EXPANSION of
- * the canonical weights (70 KB per layer) that every entry point which runs the net writes into the head of its workspace
+ * the canonical weights (77 KB per layer) that every entry point which runs the net writes into the head of its workspace
  * first (one launch, ~7 us; the reference packs nothing: its convs read nn.Conv2d parameters, fthmc/utils/layers.py:138-167).
  * A caller whose weights stay put between calls -- a sampler replaying a captured trajectory -- states their CONTENT VERSION
  * (any 64-bit number it changes whenever the weights' contents change; 0 = no statement): the launch then compares, on the

@@ -535,3 +535,18 @@ def test_lazy_history_behaves_like_the_plain_dict_it_stands_for():
     assert bool(mk()) and 'dh' in mk() and mk().get('nope', 7) == 7 and sorted(mk().keys()) == ['acc', 'dh']
     assert pickle.loads(pickle.dumps(mk())) == full and copy.deepcopy(mk()) == full and type(copy.copy(mk())) is dict
     n = len(calls); h = mk(); _ = h['acc'], h['dh'], len(h), list(h.items()); assert len(calls) == n + 1      # filled once
+
+
+def test_nothing_that_travels_to_a_gpu_box_asks_for_a_sanitizer():
+    """The GPU pool refuses snapshots whose build files carry sanitizer flags (GPU sanitizers / XNACK are off there): the host-side
+    sanitizer recipe lives in csrc/san.mk, which -- with the libraries it builds -- is listed in .gpurunignore."""
+    ignore = open(os.path.join(ROOT, '.gpurunignore')).read().split()
+    for f in ('fthmc_amd/csrc/san.mk', 'fthmc_amd/libfthmc_hip_san.so', 'fthmc_amd/libfthmc_torch_san.so'):
+        assert f in ignore, f
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'fthmc_amd')):
+        for name in files:
+            rel = os.path.relpath(os.path.join(dirpath, name), ROOT)
+            if rel in ignore or name.endswith(('.so', '.o', '.pyc')):
+                continue
+            text = open(os.path.join(dirpath, name), errors='ignore').read()
+            assert '-fsanitize' not in text and 'xnack+' not in text and 'HSA_XNACK' not in text, rel

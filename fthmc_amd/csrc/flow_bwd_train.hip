@@ -204,10 +204,23 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
     const bool ovalid = tid < N3;
     // weight-gradient GEMM lane maps (k_flow_wgrad: A row m = (co, dy), B column n = (ci, kx, kyb), ky = 2 kyb + dy)
     const int wg_ = lane >> 4, wi_ = lane & 15, wco = wi_ & 7, wdy = wi_ >> 3;
-    const int pa2 = wco * PS2 + (2 - wdy) * RS2 + 2 + wg_;                // gz2 of the tile's site (walk row - dy, 4 cs + g) in the tile+2 plane
-    const int pa1 = wco * PS1 + (1 - wdy) * W1C + 1 + wg_;                // gz1 ... in the tile+1 plane
+    // conv1 (row pairs, all sixteen columns of a walk row in four K steps):
+    const int pa1 = wco * PS1 + (1 - wdy) * W1C + 1 + wg_;                // gz1 of the tile's site (walk row - dy, 4 cs + g) in the tile+1 plane
     auto pbf = [&](int ncol, int ncols) { const int nc = ncol < ncols ? ncol : 0, ci = nc / 6, kx = (nc % 6) >> 1, kyb = nc & 1; return ci * PSH + 2 * kyb * W1C + kx + wg_; };
-    const int pb0 = pbf(wi_, 48), pb1 = pbf(16 + wi_, 48), pb2 = pbf(32 + wi_, 48), pb3 = pbf(wi_, 12);
+    const int pb3 = pbf(wi_, 12);
+    // conv2: gz2 is an exact 0 on every fourth stripe line (no active site within reach), so its GEMM walks the LIVE lines
+    // only -- twelve of a tile's sixteen, three K steps where the dense walk takes four (153 MFMAs per item instead of 204) --
+    // and pairs the shifted copies of gz2 ALONG the lines, so that the K lanes run across them: mu = 0 (lines = columns) as
+    // conv1 above (M = (co, dy), N = (ci, kx, kyb), the walk goes down the rows), mu = 1 (lines = rows) transposed (M = (co,
+    // dx), N = (ci, ky, kxb), kx = 2 kxb + dx, the walk goes along the columns).  K lane g of K step cs = live line 4 cs + g.
+    auto live_line_of = [&](int cs, int kl) {                             // live line of K step cs, K lane kl (tile coordinate across the stripe lines)
+        const int l = 4 * cs + kl, q = fdiv<3>(l);
+        return 4 * q + ((off + 3 + (l - 3 * q)) & 3);                     // stripe classes 3, 0, 1 of quad q
+    };
+    // A: gz2 at (walk - d along the walk, live line across), tile+2 plane; B: h1 at (walk + 2 kb, line + ka), tile+1 plane
+    const int pa2 = wco * PS2 + (mu == 0 ? (2 - wdy) * RS2 + 2 : 2 * RS2 + (2 - wdy));
+    auto pb2f = [&](int ncol) { const int ci = ncol / 6, ka = (ncol % 6) >> 1, kb = ncol & 1; return ci * PSH + (mu == 0 ? 2 * kb * W1C + ka : ka * W1C + 2 * kb); };
+    const int pb0 = pb2f(wi_), pb1 = pb2f(16 + wi_), pb2 = pb2f(32 + wi_);
 
     // accumulators of the whole walk
     double4_t acc[4];                                                      // this wave's K slice of the four N tiles (0..2 conv2, 3 conv1)
@@ -454,29 +467,28 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
             // K walk of the weight-gradient GEMMs: wave = window rows 2 wave, 2 wave + 1 (waves 0..3 also the step (row TR, cs = wave)).
             // Walk row rho pairs gz rows rho - dy with hin rows rho + 2 kyb; the tile's rows -1 (rho = 0, dy = 1) and TR (rho = TR,
             // dy = 0) are other tiles' sites: 0 instead.
-            const int oa0 = 2 * wave * RS2, ob0 = 2 * wave * W1C;
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int cs = 0; cs < TC / 4; ++cs) {
-                    double a2 = sGZ2[pa2 + oa0 + r * RS2 + 4 * cs];
-                    if (r == 0) a2 = (wave == 0 && wdy) ? 0.0 : a2;
-                    const int ob = ob0 + r * W1C + 4 * cs;
-                    const double b0 = sHA1[pb0 + ob], b1 = sHA1[pb1 + ob], b2 = sHA1[pb2 + ob];
-                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b0, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[2], 0, 0, 0);
-                    bsum[0] += a2;
-                }
-            if (wave < 4) {
-                double a2 = sGZ2[pa2 + TR * RS2 + 4 * wave];
-                a2 = wdy ? a2 : 0.0;
-                const int ob = TR * W1C + 4 * wave;
+            constexpr int SA = mu == 0 ? RS2 : 1, SB = mu == 0 ? W1C : 1;      // plane steps of one walk position
+            auto step = [&](int oa, int ob, int zero_d) {                   // zero_d: the shift d whose source line lies outside the tile (-1: none)
+                double a2 = sGZ2[pa2 + oa];
+                if (zero_d >= 0) a2 = (wdy == zero_d) ? 0.0 : a2;
                 const double b0 = sHA1[pb0 + ob], b1 = sHA1[pb1 + ob], b2 = sHA1[pb2 + ob];
                 acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b0, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[2], 0, 0, 0);
                 bsum[0] += a2;
+            };
+            // wave = walk positions 2 wave, 2 wave + 1; position TR's three K steps on waves 3 and 7 (their SIMD has the fewest
+            // conv2^T tiles)
+            constexpr int LA = mu == 0 ? 1 : RS2, LB = mu == 0 ? 1 : W1C;      // plane steps of one line across
+            int wgv = wg_;
+            asm volatile("" : "+v"(wgv));                                    // the lines' addresses are worked out HERE, per item: hoisted out of the walk they cost twelve registers for all of it
+#pragma unroll
+            for (int cs = 0; cs < 3; ++cs) {
+                const int line = live_line_of(cs, wgv), oa = line * LA, ob = line * LB;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) step((2 * wave + r) * SA + oa, (2 * wave + r) * SB + ob, (r == 0 && wave == 0) ? 1 : -1);
+                if ((wave == 3 && cs < 2) || (wave == 7 && cs == 2)) step(TR * SA + oa, TR * SB + ob, 0);
+                __builtin_amdgcn_sched_barrier(0);                           // bounds how many operand reads are hoisted ahead (registers)
             }
         }
 #pragma unroll
@@ -615,8 +627,11 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
             const int g = ln >> 4, i = ln & 15, m = g + 4 * q, co = m & 7, dy = m >> 3;
             const int ncol = (nt < 3 ? nt * 16 : 0) + i;
             if (ncol < (nt < 3 ? 48 : 12)) {
-                const int ci = ncol / 6, kx = (ncol % 6) >> 1, ky = 2 * (ncol & 1) + dy;
-                if (ky <= 2) gw0[(nt < 3 ? CW1 + (co * 8 + ci) * 9 : CW0 + (co * 2 + ci) * 9) + ky * 3 + kx] = v;
+                // conv1 (nt = 3) and conv2 of a mu = 0 layer: columns (ci, kx, kyb), ky = 2 kyb + d; conv2 of a mu = 1 layer: (ci, ky, kxb), kx = 2 kxb + d
+                const bool tr = nt < 3 && mu == 1;
+                const int ci = ncol / 6, ka = (ncol % 6) >> 1, kb2 = 2 * (ncol & 1) + dy;
+                const int ky = tr ? ka : kb2, kx = tr ? kb2 : ka;
+                if (kb2 <= 2) gw0[(nt < 3 ? CW1 + (co * 8 + ci) * 9 : CW0 + (co * 2 + ci) * 9) + ky * 3 + kx] = v;
             }
         }
         if (tid < 16) {

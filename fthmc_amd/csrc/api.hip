@@ -27,6 +27,7 @@ struct WS {
     double *wint, *X, *gp, *gp2, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *gw_tmp, *stash, *gz;
     double *hbuf, *gbuf;   // generic net shapes (flow_generic.hip): activation scratch, gradient ping-pong
     size_t n2;       // doubles per field batch: B * 2 * L * L
+    size_t gw_rows, gw_tmp_rows;   // rows of FLOW_GW_STRIDE doubles in gw_part / gw_tmp
     size_t total;    // doubles
 };
 
@@ -73,8 +74,16 @@ WS ws_layout(const FlowArch& A, double* base, int B, int L, int nl, bool train =
     w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
     // small lattices in training: the weight-gradient partials (and reduction rows) of ALL layers at once
     const size_t nlw = train && A.is_default() && ft_small_shape(L, nl) ? (size_t)nl : 1;
-    w.gw_part = take(nl > 0 ? nlw * B * nt * FLOW_GW_STRIDE : 0);
-    w.gw_tmp = take(nl > 0 ? nlw * FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE : 0);
+    w.gw_rows = nl > 0 ? nlw * B * nt : 0;
+    w.gw_tmp_rows = nl > 0 ? nlw * FLOW_REDUCE_GROUPS : 0;
+    if (train && nl > 0 && A.is_default() && flow_bwd_train_shape(L)) {
+        // the fused training backward (flow_bwd_train.hip) leaves every layer's partials side by side: ONE reduction behind the sweep
+        const size_t np = (size_t)flow_bwd_train_nparts(B, L), ng = (size_t)flow_reduce_groups((int)np);
+        if (w.gw_rows < (size_t)nl * np) w.gw_rows = (size_t)nl * np;
+        if (w.gw_tmp_rows < (size_t)nl * ng) w.gw_tmp_rows = (size_t)nl * ng;
+    }
+    w.gw_part = take(w.gw_rows * FLOW_GW_STRIDE);
+    w.gw_tmp = take(w.gw_tmp_rows * FLOW_GW_STRIDE);
     const bool gen = !A.is_default();
     // activation stash of a force evaluation (generic shapes: every layer's planes, at least one region as scratch)
     w.stash = take(gen ? (size_t)(nl > 0 ? nl : 1) * A.stash_doubles(B, L) : (size_t)nl * flow_stash_doubles(B, L, train));
@@ -213,6 +222,13 @@ int force_gp(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, i
     double* gcur = (stash && (nl & 1)) ? w.gp2 : w.gp;
     double* galt = gcur == w.gp ? w.gp2 : w.gp;
     FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, gcur, s));
+#if FT_FUSED_WGRAD
+    const bool fused = gw && train && flow_bwd_train_built() && flow_bwd_train_shape(L) && flow_stash_fits32(B, L, true);
+    const int npf = fused ? flow_bwd_train_nparts(B, L) : 0;
+    // the layers' partials side by side and ONE reduction behind the sweep (two launches instead of two per layer), where the
+    // workspace has the rows (a training layout: ws_layout)
+    const bool one_reduction = fused && (size_t)nl * npf <= w.gw_rows && (size_t)nl * flow_reduce_groups(npf) <= w.gw_tmp_rows;
+#endif
     for (int l = nl - 1; l >= 0; --l) {
         FlowLayerArgs a{};
         a.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
@@ -226,11 +242,12 @@ int force_gp(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, i
             a.stash = w.stash + (size_t)l * flow_stash_doubles(B, L, train);
             a.gp_out = galt;
 #if FT_FUSED_WGRAD
-            if (gw && train && flow_bwd_train_built() && flow_bwd_train_shape(L) && flow_stash_fits32(B, L, true)) {
+            if (fused) {
                 // training: the layer's backward and its weight gradients in ONE kernel (flow_bwd_train.hip: the pre-activation
                 // gradients never leave LDS), one partial per workgroup
+                if (one_reduction) a.gw_part = w.gw_part + (size_t)l * npf * FLOW_GW_STRIDE;
                 FT_TRY(launch_flow_bwd_train(a, s));
-                FT_TRY(launch_reduce_gw(w.gw_part, flow_bwd_train_nparts(B, L), 1.0, 0, gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
+                if (!one_reduction) FT_TRY(launch_reduce_gw(w.gw_part, npf, 1.0, 0, gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
                 double* t_ = gcur; gcur = galt; galt = t_;
                 continue;
             }
@@ -251,6 +268,9 @@ int force_gp(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, i
                                         gw + (size_t)l * FTHMC_W_PER_LAYER, w.gw_tmp, s));
         FT_TRY(launch_gather_gp(w.gp_part, B, L, flow_geom(false), 1, gcur, s));
     }
+#if FT_FUSED_WGRAD
+    if (one_reduction && nl > 0) FT_TRY(launch_reduce_gw(w.gw_part, npf, 1.0, 0, gw, w.gw_tmp, s, nl, (size_t)npf * FLOW_GW_STRIDE));
+#endif
     return FTHMC_OK;
 }
 

@@ -674,16 +674,16 @@ int launch_reduce_gw(const double* gw_part, int nparts, double scale, int accumu
                      double* tmp, hipStream_t s, int nlayers, size_t part_lstride) {
     const int nb = (FTHMC_W_PER_LAYER + 63) / 64;
     const unsigned nz = nlayers > 1 ? nlayers : 1;
+    static_assert(4 * RG_SL == 64, "flow_reduce_groups (kernels.h) states the same threshold");
     if (nparts <= 4 * RG_SL || !tmp) {                     // a thread sums at most four rows: one level
         hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1, nz), dim3(64 * RG_SL), 0, s, gw_part, nparts, nparts, scale, accumulate, gw,
                            part_lstride, (size_t)FTHMC_W_PER_LAYER);
         FT_LAUNCH_CHECK(); return FTHMC_OK;
     }
     // groups of ~32 rows (two per thread), at most FLOW_REDUCE_GROUPS of them (the size of tmp)
-    int groups = (nparts + 31) / 32; if (groups > FLOW_REDUCE_GROUPS) groups = FLOW_REDUCE_GROUPS;
-    const int chunk = (nparts + groups - 1) / groups;
-    groups = (nparts + chunk - 1) / chunk;
-    const size_t tmp_l = (size_t)FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE;
+    const int groups = flow_reduce_groups(nparts), g0 = (nparts + 31) / 32 > FLOW_REDUCE_GROUPS ? FLOW_REDUCE_GROUPS : (nparts + 31) / 32;
+    const int chunk = (nparts + g0 - 1) / g0;
+    const size_t tmp_l = (size_t)groups * FLOW_GW_STRIDE;   // the layers' rows side by side
     hipLaunchKernelGGL(k_reduce_gw, dim3(nb, groups, nz), dim3(64 * RG_SL), 0, s, gw_part, nparts, chunk, 1.0, 0, tmp, part_lstride, tmp_l);
     FT_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_reduce_gw, dim3(nb, 1, nz), dim3(64 * RG_SL), 0, s, tmp, groups, groups, scale, accumulate, gw, tmp_l,

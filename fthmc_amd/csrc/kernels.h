@@ -265,7 +265,14 @@ int launch_adj_add(const double* gp, const double* gy, int B, int L, double* gx,
 // gw[idx] (+)= scale * sum_p gw_part[p][idx], idx < 955
 // tmp: FLOW_REDUCE_GROUPS * FLOW_GW_STRIDE doubles of scratch (two-level reduction), or null
 constexpr int FLOW_REDUCE_GROUPS = 128;
+// rows of tmp the two-level reduction of `nparts` partials uses per layer (0: one level, no tmp)
+inline int flow_reduce_groups(int nparts) {
+    if (nparts <= 64) return 0;
+    int groups = (nparts + 31) / 32; if (groups > FLOW_REDUCE_GROUPS) groups = FLOW_REDUCE_GROUPS;
+    const int chunk = (nparts + groups - 1) / groups;
+    return (nparts + chunk - 1) / chunk;
+}
 int launch_reduce_gw(const double* gw_part, int nparts, double scale, int accumulate, double* gw,
-                     double* tmp, hipStream_t s, int nlayers = 1, size_t part_lstride = 0);   // nlayers > 1: layer l reads gw_part + l * part_lstride, writes gw + l * 955; tmp: nlayers * FLOW_REDUCE_GROUPS rows
+                     double* tmp, hipStream_t s, int nlayers = 1, size_t part_lstride = 0);   // nlayers > 1: layer l reads gw_part + l * part_lstride, writes gw + l * 955; tmp: nlayers * flow_reduce_groups(nparts) rows
 
 }  // namespace fthmc

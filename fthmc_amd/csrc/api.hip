@@ -24,7 +24,7 @@ constexpr size_t ALIGN = 32;   // doubles (256 B)
 inline size_t up(size_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
 
 struct WS {
-    double *wint, *X, *gp, *gp2, *gp_part, *lj_part, *scal, *xa, *va, *xb, *vb, *gw_part, *gw_tmp, *stash, *gz;
+    double *wint, *X, *gp, *gp2, *gp_part, *lj_part, *scal, *act_part, *xa, *va, *xb, *vb, *gw_part, *gw_tmp, *stash, *gz;
     double *hbuf, *gbuf;   // generic net shapes (flow_generic.hip): activation scratch, gradient ping-pong
     size_t n2;       // doubles per field batch: B * 2 * L * L
     size_t gw_rows, gw_tmp_rows;   // rows of FLOW_GW_STRIDE doubles in gw_part / gw_tmp
@@ -71,6 +71,7 @@ WS ws_layout(const FlowArch& A, double* base, int B, int L, int nl, bool train =
     w.gp_part = take(nl > 0 ? (size_t)B * flow_gp_part_max(L) : 0);
     w.lj_part = take((size_t)(nl > 0 ? nl : 1) * B * nt);               // logJ partials [layer][chain][tile] of a sweep
     w.scal = take((size_t)SC_N * B);
+    w.act_part = take((size_t)32 * B);                   // launch_action_charge's wave sums (few chains of a large lattice)
     w.xa = take(n2); w.va = take(n2); w.xb = take(n2); w.vb = take(n2);
     // small lattices in training: the weight-gradient partials (and reduction rows) of ALL layers at once
     const size_t nlw = train && A.is_default() && ft_small_shape(L, nl) ? (size_t)nl : 1;
@@ -188,7 +189,7 @@ int eval_action(const Ctx& C, const double* x, const WS& w, int nl, int B, int L
     double* ld = logdet ? logdet : w.scal + (size_t)SC_LOGDET * B;
     if (nl > 0) FT_TRY(sweep_forward(C, x, w, nl, B, L, act, ld, s));
     double* S = w.scal + (size_t)SC_S * B;
-    FT_TRY(launch_action_charge(phys_field(x, w, nl), B, L, beta, S, Q, plaq, s));
+    FT_TRY(launch_action_charge(phys_field(x, w, nl), B, L, beta, S, Q, plaq, s, w.act_part));
     if (S_eff) FT_TRY(launch_lincomb(S, 1.0, nl > 0 ? ld : nullptr, -1.0, 0.0, S_eff, B, s));
     return FTHMC_OK;
 }
@@ -437,8 +438,8 @@ int fthmc_train_metrics(const double* xi, const double* x, const double* logq, c
     FT_CTX(nullptr);
     FT_WS(0);
     double* q = W.scal + (size_t)SC_Q * B; double* qi = W.scal + (size_t)SC_OLD0 * B;
-    FT_TRY(launch_action_charge(x, B, L, beta, nullptr, q, nullptr, s));
-    FT_TRY(launch_action_charge(xi, B, L, beta, nullptr, qi, nullptr, s));
+    FT_TRY(launch_action_charge(x, B, L, beta, nullptr, q, nullptr, s, W.act_part));
+    FT_TRY(launch_action_charge(xi, B, L, beta, nullptr, qi, nullptr, s, W.act_part));
     return launch_train_metrics(logq, logp, q, qi, B, 1.0 / (beta * L * L), dkl_factor, row, s);
 }
 
@@ -936,7 +937,7 @@ int fthmc_train_grad(const double* xi, const double* w, const fthmc_arch_t* arch
     const bool mfma = C.mfma || C.gen();       // paths whose backward reads the forward's stash
     FT_TRY(sweep_forward(C, xi, W, n_layers, B, L, act, ld, s, mfma && gw != nullptr, mfma && gw != nullptr));
     if (x || logq || logp) {
-        FT_TRY(launch_action_charge(phys_field(xi, W, n_layers), B, L, beta, S, nullptr, nullptr, s));
+        FT_TRY(launch_action_charge(phys_field(xi, W, n_layers), B, L, beta, S, nullptr, nullptr, s, W.act_part));
         const double lp0 = -(double)(2 * L * L) * log(FT_TWO_PI);
         if (logq) FT_TRY(launch_lincomb(ld, -1.0, nullptr, 0.0, lp0, logq, B, s));
         if (logp) FT_TRY(launch_lincomb(S, -1.0, nullptr, 0.0, 0.0, logp, B, s));

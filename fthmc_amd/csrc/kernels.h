@@ -10,8 +10,10 @@ namespace fthmc {
 int launch_wrap(const double* x, double* o, size_t n, int reg, hipStream_t s);
 int launch_axpy(const double* x, const double* p, double a, double* o, size_t n, hipStream_t s);
 int launch_plaq(const double* x, double* P, int B, int L, hipStream_t s);
+// wave_part (optional): 32 B doubles of scratch; with it a few chains of a large lattice (B < 128, L >= 128) run one wave per
+// workgroup instead of one workgroup per chain -- the same sums in the same order, bit-identical
 int launch_action_charge(const double* x, int B, int L, double beta, double* S, double* Q,
-                         double* plaq, hipStream_t s);
+                         double* plaq, hipStream_t s, double* wave_part = nullptr);
 int launch_kinetic(const double* v, int B, int L, double* K, hipStream_t s);
 int launch_lincomb(const double* a, double ca, const double* b, double cb, double c0, double* out,
                    int B, hipStream_t s);

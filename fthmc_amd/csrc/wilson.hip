@@ -38,13 +38,15 @@ __global__ void k_plaq(const double* __restrict__ x, double* __restrict__ P, int
 
 // One workgroup per chain: S = -beta sum cos P, Q = sum wrap(P) / 2pi.
 // xform: 0 none, 1 regularize links first (end of an HMC trajectory).
+// (tid of nthr: the thread's place in the chain's workgroup -- k_action_charge_waves runs the workgroup's waves as workgroups of
+// their own)
 template <int XFORM>
-__device__ __forceinline__ void chain_action_charge(const double* __restrict__ x0, int L,
+__device__ __forceinline__ void chain_action_charge(const double* __restrict__ x0, int L, int tid, int nthr,
                                                     double& csum, double& qsum) {
     const int n = L * L;
     const double* x1 = x0 + n;
     double c = 0.0, q = 0.0;
-    for (int s = threadIdx.x; s < n; s += blockDim.x) {
+    for (int s = tid; s < n; s += nthr) {
         const int i = s / L, j = s - i * L;
         const int ip = i + 1 == L ? 0 : i + 1, jp = j + 1 == L ? 0 : j + 1;
         double a = x0[s], bb = x1[s], cc = x0[i * L + jp], d = x1[ip * L + j];
@@ -53,6 +55,11 @@ __device__ __forceinline__ void chain_action_charge(const double* __restrict__ x
         q += ft_wrap(a - bb - cc + d);       // summation order of batch_plaqs
     }
     csum = c; qsum = q;
+}
+
+template <int XFORM>
+__device__ __forceinline__ void chain_action_charge(const double* __restrict__ x0, int L, double& csum, double& qsum) {
+    chain_action_charge<XFORM>(x0, L, (int)threadIdx.x, (int)blockDim.x, csum, qsum);
 }
 
 __global__ void k_action_charge(const double* __restrict__ x, int L, double beta,
@@ -70,6 +77,30 @@ __global__ void k_action_charge(const double* __restrict__ x, int L, double beta
         if (Q) Q[b] = q / FT_TWO_PI;
         if (plaq) plaq[b] = (-s) / (beta * (double)(L * L));
     }
+}
+
+// The same sums by the same threads in the same order, for a FEW chains of a LARGE lattice (a training shard: 32 chains of
+// L = 256 kept 32 of 256 CUs busy for 87 us): wave w of chain b's workgroup runs as a workgroup of its own (grid nw x B), leaves
+// its two wave sums in part[b][w][2], and k_action_charge_fin adds them as ft_block_sum does (0.0 + wave 0 + wave 1 + ...):
+// bit-identical to k_action_charge with nw waves.
+__global__ __launch_bounds__(FT_WAVE) void k_action_charge_waves(const double* __restrict__ x, int L, double* __restrict__ part) {
+    const int b = blockIdx.y, w = blockIdx.x, nw = gridDim.x;
+    double c, q;
+    chain_action_charge<0>(x + (size_t)b * 2 * L * L, L, w * FT_WAVE + (int)threadIdx.x, nw * FT_WAVE, c, q);
+    c = ft_wave_sum(c);
+    q = ft_wave_sum(q);
+    if (threadIdx.x == 0) { part[((size_t)b * nw + w) * 2] = c; part[((size_t)b * nw + w) * 2 + 1] = q; }
+}
+__global__ void k_action_charge_fin(const double* __restrict__ part, int nw, int B, int L, double beta, double* __restrict__ S,
+                                    double* __restrict__ Q, double* __restrict__ plaq) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double c = 0.0, q = 0.0;
+    for (int w = 0; w < nw; ++w) { c += part[((size_t)b * nw + w) * 2]; q += part[((size_t)b * nw + w) * 2 + 1]; }
+    const double s = (-beta) * c;
+    if (S) S[b] = s;
+    if (Q) Q[b] = q / FT_TWO_PI;
+    if (plaq) plaq[b] = (-s) / (beta * (double)(L * L));
 }
 
 __global__ void k_kinetic(const double* __restrict__ v, int n, double* __restrict__ K) {
@@ -628,8 +659,15 @@ int launch_plaq(const double* x, double* P, int B, int L, hipStream_t s) {
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }
 int launch_action_charge(const double* x, int B, int L, double beta, double* S, double* Q,
-                         double* plaq, hipStream_t s) {
+                         double* plaq, hipStream_t s, double* wave_part) {
     const int nt = L * L >= 4096 ? 1024 : (L * L >= 1024 ? 512 : 256);
+    if (wave_part && B < 128 && L >= 128) {                 // fewer workgroups than half the CUs, each busy for tens of us
+        const int nw = nt / FT_WAVE;
+        hipLaunchKernelGGL(k_action_charge_waves, dim3(nw, B), dim3(FT_WAVE), 0, s, x, L, wave_part);
+        FT_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_action_charge_fin, dim3((B + 63) / 64), dim3(64), 0, s, wave_part, nw, B, L, beta, S, Q, plaq);
+        FT_LAUNCH_CHECK(); return FTHMC_OK;
+    }
     hipLaunchKernelGGL(k_action_charge, dim3(B), dim3(nt), 0, s, x, L, beta, S, Q, plaq);
     FT_LAUNCH_CHECK(); return FTHMC_OK;
 }

@@ -87,3 +87,27 @@ def test_fused_training_backward_leaves_the_force_path_alone():
     fd = (loss(w + eps * dw) - loss(w - eps * dw)) / (2 * eps)
     an = float((r1['gw'] * dw).sum())
     assert abs(an - fd) < 1e-5 * max(1.0, abs(an)), (an, fd)
+
+
+@pytest.mark.parametrize('B,L', [(5, 128), (32, 256), (127, 128)])
+def test_wave_split_action_sums_are_bit_identical(B, L):
+    """few chains of a large lattice (B < 128, L >= 128) with a workspace at hand: the action / charge sums run one WAVE per
+    workgroup (csrc/wilson.hip k_action_charge_waves) -- the same threads' sums added in the same order as the one-workgroup-
+    per-chain kernel, which fthmc_wilson_action_charge (no workspace) still launches: every output bit-equal; the sum over a
+    sweep's log J partials with one wave per layer (k_sum_parts) against the layers' own log J, added in order"""
+    gen = torch.Generator().manual_seed(7 + B)
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    beta = 3.0
+    S0, Q0, p0 = ops.wilson_action_charge(x, beta)
+    S1, ld, p1, Q1 = ops.ft_action(x, torch.zeros(0, dtype=torch.float64, device='cuda'), 0, beta)
+    assert torch.equal(S0, S1) and torch.equal(Q0, Q1) and torch.equal(p0, p1) and float(ld.abs().max()) == 0.0
+    if B <= 32:
+        nl = 3
+        flow = R.default_flow(nl, gen)
+        w = ops.pack_weights(flow, device='cuda')
+        S, ld, _, _ = ops.ft_action(x, w, nl, beta)
+        y, tot = x, torch.zeros(B, dtype=torch.float64, device='cuda')
+        for l in range(nl):
+            y, lj = ops.flow_layer_fwd(y, w[l * 955:(l + 1) * 955], l % 2, (l // 2) % 4)
+            tot = tot + lj
+        assert torch.equal(ld, tot)

@@ -77,7 +77,7 @@ WS ws_layout(const FlowArch& A, double* base, int B, int L, int nl, bool train =
     const size_t nlw = train && A.is_default() && ft_small_shape(L, nl) ? (size_t)nl : 1;
     w.gw_rows = nl > 0 ? nlw * B * nt : 0;
     w.gw_tmp_rows = nl > 0 ? nlw * FLOW_REDUCE_GROUPS : 0;
-    if (train && nl > 0 && A.is_default() && flow_bwd_train_shape(L)) {
+    if (train && nl > 0 && A.is_default() && flow_bwd_train_shape(L) && flow_stash_fits32(B, L, true)) {   // the shapes force_gp takes the fused path on
         // the fused training backward (flow_bwd_train.hip) leaves every layer's partials side by side: ONE reduction behind the sweep
         const size_t np = (size_t)flow_bwd_train_nparts(B, L), ng = (size_t)flow_reduce_groups((int)np);
         if (w.gw_rows < (size_t)nl * np) w.gw_rows = (size_t)nl * np;
@@ -225,7 +225,7 @@ int force_gp(const Ctx& C, const double* x, const WS& w, int nl, int B, int L, i
     FT_TRY(launch_wilson_gp(phys_field(x, w, nl), B, L, beta_scaled, gcur, s));
 #if FT_FUSED_WGRAD
     const bool fused = gw && train && flow_bwd_train_built() && flow_bwd_train_shape(L) && flow_stash_fits32(B, L, true);
-    const int npf = fused ? flow_bwd_train_nparts(B, L) : 0;
+    const int npf = fused ? (int)flow_bwd_train_nparts(B, L) : 0;
     // the layers' partials side by side and ONE reduction behind the sweep (two launches instead of two per layer), where the
     // workspace has the rows (a training layout: ws_layout)
     const bool one_reduction = fused && (size_t)nl * npf <= w.gw_rows && (size_t)nl * flow_reduce_groups(npf) <= w.gw_tmp_rows;

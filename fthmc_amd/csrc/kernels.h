@@ -170,12 +170,15 @@ inline int flow_bwd_train_tpw(int B, int L) {
 }
 // workgroups of one XCD that walk side by side (one per CU: 32; fewer when the launch is smaller than the chip)
 inline int flow_bwd_train_ns(int B, int L, int tpw) {
-    const int items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L), n = (items + 8 * tpw - 1) / (8 * tpw);
-    return n < 1 ? 1 : n > 32 ? 32 : n;
+    const long items = (long)B * FlowGeom{MG_TR, MG_TC}.ntiles(L), n = (items + 8 * tpw - 1) / (8 * tpw);
+    return n < 1 ? 1 : n > 32 ? 32 : (int)n;
 }
-inline int flow_bwd_train_nparts(int B, int L) {
-    const int tpw = flow_bwd_train_tpw(B, L), items = B * FlowGeom{MG_TR, MG_TC}.ntiles(L), ns = flow_bwd_train_ns(B, L, tpw);
-    const int k0 = items / (tpw * ns), rem = items - k0 * tpw * ns;
+// partials of one launch (= its workgroups that walk at least one item); the launcher serves flow_stash_fits32 shapes only, where
+// this fits an int with room to spare -- the arithmetic is 64-bit for the callers that ask before they check (ws_layout)
+inline long flow_bwd_train_nparts(int B, int L) {
+    const int tpw = flow_bwd_train_tpw(B, L), ns = flow_bwd_train_ns(B, L, tpw);
+    const long items = (long)B * FlowGeom{MG_TR, MG_TC}.ntiles(L);
+    const long k0 = items / ((long)tpw * ns), rem = items - k0 * tpw * ns;
     return k0 * ns + (rem < ns ? rem : ns);
 }
 // doubles per layer of the stash (layout: flow_mfma_common.h struct Stash): 19 per site, 35 with h1, h2 (training)

@@ -153,7 +153,8 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
     } else { tr3 = 3; tc3 = 3; }
     typedef double double2_t __attribute__((ext_vector_type(2)));
     auto ldu2 = [](const double* base, unsigned idx) {               // 16-byte load, scalar base + 32-bit element offset
-        return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx * 8u);
+        const double2_t* p = reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx * 8u);
+        return FT_NT_LOAD >= 2 ? __builtin_nontemporal_load(p) : *p;
     };
     double tcv[4 * NMIX], ag[2];
     const double cb = has_glogj ? A0.glogj[b] : A.glogj_const;
@@ -246,7 +247,10 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 4) void k_flow_bwd_gather(const doub
         // channel-minor stash (struct Stash): the task's four channels of a site are 32 contiguous bytes
         const double* pl = uniform_at(A.stash, 8u * (Bn + bn) + (unsigned)(c3half * 4));
         const unsigned oA = ft_off32((unsigned)goA * 8u), oB = ft_off32((unsigned)goB * 8u);       // byte offsets of the two records
-        auto ldu2o = [](const double* base, unsigned o) { return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + o); };
+        auto ldu2o = [](const double* base, unsigned o) {
+            const double2_t* p = reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + o);
+            return FT_NT_LOAD >= 2 ? __builtin_nontemporal_load(p) : *p;
+        };
 #pragma unroll
         for (int k = 0; k < 4; k += 2) {
             const double2_t va = ldu2o(pl + k, oA), vb = ldu2o(pl + k, oB);

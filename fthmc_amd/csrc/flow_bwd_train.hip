@@ -148,7 +148,8 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
     const double cb = A.glogj_const;
     const unsigned Bn = (unsigned)A.B * (unsigned)n;
     auto ldu2 = [](const double* base, unsigned idx_) {                  // 16-byte load, scalar base + 32-bit element offset
-        return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx_ * 8u);
+        const double2_t* p = reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + idx_ * 8u);
+        return FT_NT_LOAD >= 1 ? __builtin_nontemporal_load(p) : *p;
     };
 
     // ---- once per walk: the layer's backward weight block, the zeros behind the windows (read by discarded ky = 3 columns only)
@@ -294,7 +295,10 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, 2) void k_flow_bwd_train(FlowLayerAr
     };
     auto issue_D2 = [&](const Item& q) {
         const double* pl = uniform_at(A.stash, 8u * (Bn + (unsigned)q.b * (unsigned)n));
-        auto ldu2o = [](const double* base, unsigned o) { return *reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + o); };
+        auto ldu2o = [](const double* base, unsigned o) {
+            const double2_t* p = reinterpret_cast<const double2_t*>(reinterpret_cast<const char*>(base) + o);
+            return FT_NT_LOAD >= 1 ? __builtin_nontemporal_load(p) : *p;
+        };
 #pragma unroll
         for (int e = 0; e < C3::NIT; ++e) {
             const C3 P(wave + NW * e, lane, c0);

@@ -61,14 +61,16 @@ template <int TR, int TC> struct SmemF {
 // conditions and the code behind the other outcome leave the kernel, and so do the cycle stamps of the diagnostic launches
 // (tools/lifetime.py, fthmc_profile_stages: those run SWEEP = 2, the same specialization WITH the stamps).  SWEEP = 3: a layer
 // of an ACTION sweep (the H1 sweep of a trajectory, ft_action: link field in and out, log J, no stash).  SWEEP = 4: a layer of a
-// TRAINING sweep (fthmc_train_grad: stash with h1 / h2, log J).  0: whatever the argument block says.
+// TRAINING sweep (fthmc_train_grad: stash with h1 / h2, log J).  5, 6: SWEEP = 1, 4 with NON-TEMPORAL stash stores, for a stash
+// nobody finds in a cache again (launch_fwd: a layer's stash beyond FT_NT_MIN_BYTES).  0: whatever the argument block says.
 template <int TR, int TC, bool FASTW, bool REV, int MU, bool EXACT, bool SILU, int SWEEP>
 __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const double* hx, const double* hw, double* hy, double* hstash, double* hlogj,
                                                                           int hB, int hL, unsigned hoa, FlowLayerArgs A0) {
     FlowLayerArgs A = A0;
     A.x = hx; A.wint = hw; A.y = hy; A.stash = hstash; A.logj_part = hlogj; A.B = hB; A.L = hL;
     A.off = (int)(hoa & 0xffu); A.act = (int)((hoa >> 8) & 0xffu);
-    constexpr bool FS = SWEEP == 1 || SWEEP == 2, ES = SWEEP == 3, TS = SWEEP == 4, SW = FS || ES || TS;
+    constexpr bool FS = SWEEP == 1 || SWEEP == 2 || SWEEP == 5, ES = SWEEP == 3, TS = SWEEP == 4 || SWEEP == 6, SW = FS || ES || TS;
+    constexpr bool NTS = SWEEP == 5 || SWEEP == 6;                    // stash stores with the non-temporal hint (launch_fwd: big stashes)
     const bool has_pout = !SW && (hoa & FWD_HAS_POUT) != 0, has_pin = !SW && (hoa & FWD_HAS_PIN) != 0;
     const bool has_dbg = (SWEEP == 0 || SWEEP == 2) && (hoa & FWD_HAS_DBG) != 0;
     const bool has_stash = FS || TS || (!ES && A.stash != nullptr), has_y = SW || A.y != nullptr;
@@ -193,7 +195,7 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
                     (unsigned)(c - 3) < (unsigned)(EXACT ? TC : min(TC, L - j0))) {         // the net input of the tile's own frozen sites
                     double* cs_ = uniform_at(A.stash, 18u * (unsigned)A.B * (unsigned)n + bn);
                     const unsigned fi = (unsigned)stash_frozen_idx(i0 + r - 3, j0 + c - 3, L, mu, off);
-                    stu(cs_, fi, cs); stu(cs_, fi + (unsigned)(n >> 1), sn);
+                    sts<NTS>(cs_, fi, cs); sts<NTS>(cs_, fi + (unsigned)(n >> 1), sn);
                 }
             }
         }
@@ -273,12 +275,12 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
                 // act'(z1) of a mu = 0 layer: transposed site index (FT_D1_T): the lanes of a tile run down a column
                 const int atd = (FT_D1_T && mu == 0) ? mul24(j0 + c0, L) + i0 + r0 : at, datd = (FT_D1_T && mu == 0) ? L : dat;
                 if ((unsigned)r0 < (unsigned)rmax && (unsigned)c0 < (unsigned)cmax) {
-                    if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)atd + stg, double2_t{d[0], d[1]});
-                    if (stash_h) stu2(st_h1, 8u * (unsigned)at + stg, double2_t{h[0], h[1]});
+                    if (!FT_RECOMP_D1) sts2<NTS>(st_d1, 8u * (unsigned)atd + stg, double2_t{d[0], d[1]});
+                    if (stash_h) sts2<NTS>(st_h1, 8u * (unsigned)at + stg, double2_t{h[0], h[1]});
                 }
                 if ((unsigned)r1 < (unsigned)rmax && (unsigned)c1 < (unsigned)cmax) {
-                    if (!FT_RECOMP_D1) stu2(st_d1, 8u * (unsigned)(atd + datd) + stg, double2_t{d[2], d[3]});
-                    if (stash_h) stu2(st_h1, 8u * (unsigned)(at + dat) + stg, double2_t{h[2], h[3]});
+                    if (!FT_RECOMP_D1) sts2<NTS>(st_d1, 8u * (unsigned)(atd + datd) + stg, double2_t{d[2], d[3]});
+                    if (stash_h) sts2<NTS>(st_h1, 8u * (unsigned)(at + dat) + stg, double2_t{h[2], h[3]});
                 }
             }
         };
@@ -308,8 +310,8 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
             const int rr = r - 2, cc = c - 2;
             if ((unsigned)rr < (unsigned)rmax && (unsigned)cc < (unsigned)cmax) {
                 const int at = mul24(i0 + rr, L) + j0 + cc;
-                if (!FT_RECOMP_D1) stu(st_d1, 8u * (unsigned)((FT_D1_T && mu == 0) ? mul24(j0 + cc, L) + i0 + rr : at) + (unsigned)co, d);
-                if (stash_h) stu(st_h1, 8u * (unsigned)at + (unsigned)co, h);
+                if (!FT_RECOMP_D1) sts<NTS>(st_d1, 8u * (unsigned)((FT_D1_T && mu == 0) ? mul24(j0 + cc, L) + i0 + rr : at) + (unsigned)co, d);
+                if (stash_h) sts<NTS>(st_h1, 8u * (unsigned)at + (unsigned)co, h);
             }
         }
     }
@@ -348,8 +350,8 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
             for (int q = 0; q < 2; ++q)
                 if ((unsigned)(r - 1 + q * dr) < (unsigned)rmax && (unsigned)(c - 1 + q * dc) < (unsigned)cmax) {
                     const int aq = at + q * (dr * L + dc);
-                    stu2(st_d2, 8u * (unsigned)(a2 + q * da2) + stg, double2_t{d[2 * q], d[2 * q + 1]});
-                    if (stash_h) stu2(st_h2, 8u * (unsigned)aq + stg, double2_t{h[2 * q], h[2 * q + 1]});
+                    sts2<NTS>(st_d2, 8u * (unsigned)(a2 + q * da2) + stg, double2_t{d[2 * q], d[2 * q + 1]});
+                    if (stash_h) sts2<NTS>(st_h2, 8u * (unsigned)aq + stg, double2_t{h[2 * q], h[2 * q + 1]});
                 }
         }
     };
@@ -546,9 +548,9 @@ __global__ FT_LDS_B64 __launch_bounds__(NT, REV ? 4 : 6) void k_flow_fwd(const d
             // wrote the two 32-byte halves of every 64-byte record at different times)
             double* tc = uniform_ptr(sv.tc, (size_t)wave * n);
             const unsigned ti = 4u * (unsigned)stash_active_idx(ai, aj, L, mu);
-            stu2(tc, ti, double2_t{sinP * invD / NMIX,                                             // A_k
+            sts2<NTS>(tc, ti, double2_t{sinP * invD / NMIX,                                             // A_k
                                    (ems * cs2 - es * sn2) * invD2});                               // B_k
-            stu2(tc, ti + 2u, double2_t{invD / NMIX,                                               // C_k
+            sts2<NTS>(tc, ti + 2u, double2_t{invD / NMIX,                                               // C_k
                                         sinP * 0.5 * (es - ems) * invD2});                         // E_k
         }
     }
@@ -613,8 +615,10 @@ namespace {
 #define FWD_LAUNCH(...) do { if (a.act != FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, false, 0); else FWD_LAUNCH_(__VA_ARGS__, true, 0); } while (0)
 // ... and with the sweep specializations (SWEEP template parameter): the forward map on the tiled-exactly shapes, silu
 #define FWD_LAUNCH_SWEEPS(...) do { if (a.act != FTHMC_ACT_SILU) FWD_LAUNCH_(__VA_ARGS__, false, 0); \
+                             else if (force_sweep && !a.dbg && nt_stash) FWD_LAUNCH_(__VA_ARGS__, true, 5); \
                              else if (force_sweep && !a.dbg) FWD_LAUNCH_(__VA_ARGS__, true, 1); \
                              else if (force_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 2); else if (action_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 3); \
+                             else if (train_sweep && nt_stash) FWD_LAUNCH_(__VA_ARGS__, true, 6); \
                              else if (train_sweep) FWD_LAUNCH_(__VA_ARGS__, true, 4); \
                              else FWD_LAUNCH_(__VA_ARGS__, true, 0); } while (0)
 template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hipStream_t s) {
@@ -624,6 +628,11 @@ template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hi
     const bool force_sweep = !REV && a.y && a.stash && !a.stash_h && !a.logj_part && !a.pin && !a.pout;
     const bool action_sweep = !REV && a.y && !a.stash && a.logj_part && !a.pin && !a.pout && !a.dbg;
     const bool train_sweep = !REV && a.y && a.stash && a.stash_h && a.logj_part && !a.pin && !a.pout && !a.dbg;
+    // A stash the backward will not find in a cache again is stored past the caches: one layer's stash of a training shard (32
+    // chains of L = 256: 587 MB) is more than the 256 MB Infinity Cache, and its stores with the hint took 4.5 % off the whole
+    // training step (6.92 -> 6.6 ms); the 40 MB per layer and chain group of the headline shape come back from the caches in the
+    // backward, and the same hint there cost 0.8 % (profiles/r06_ab_nontemporal_stash.txt).
+    const bool nt_stash = FT_NT_STASH && a.stash && fthmc::flow_stash_doubles(a.B, a.L, a.stash_h != 0) * sizeof(double) >= FT_NT_MIN_BYTES;
     const bool fast = wrap_fast_ok(a.L, TR, TC);
     const bool exact = fast && a.L % TR == 0 && a.L % TC == 0 && (a.L & (a.L - 1)) == 0;
     if (a.mu == 0) {
@@ -635,7 +644,7 @@ template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hi
         else if (fast) FWD_LAUNCH(TR, TC, true, REV, 1, false);
         else FWD_LAUNCH(TR, TC, false, REV, 1, false);
     }
-    (void)force_sweep; (void)action_sweep; (void)train_sweep;
+    (void)force_sweep; (void)action_sweep; (void)train_sweep; (void)nt_stash;
 }
 }  // namespace
 

@@ -44,6 +44,18 @@
 #ifndef FT_D1_T
 #define FT_D1_T 1
 #endif
+// 1 (default): the forward's stash stores carry the non-temporal hint where one layer's stash is FT_NT_MIN_BYTES or more (flow_fwd.hip
+// launch_fwd: the SWEEP = 5, 6 instances); 0: never (A/B knob)
+#ifndef FT_NT_STASH
+#define FT_NT_STASH 1
+#endif
+#ifndef FT_NT_MIN_BYTES
+#define FT_NT_MIN_BYTES ((size_t)128 << 20)
+#endif
+// 1: the training backward's stash LOADS carry the hint too; 2: also k_flow_bwd_gather's (A/B knob)
+#ifndef FT_NT_LOAD
+#define FT_NT_LOAD 0
+#endif
 // 1 (default): the act'(z2) plane holds the live stripe lines only, in order (stash_live_idx).  conv3 reads h2 within one site of
 // an active line, so every fourth line (x = off + 2 mod 4) is dead: never written, never used.  Row-major storage left the dead
 // COLUMNS of a mu = 0 layer inside the cache lines the backward fetches (record = 64 B, line = 128 B: a window row cost 10 lines
@@ -117,6 +129,16 @@ __device__ __forceinline__ void stu(double* base, unsigned idx, double v) {
 }
 __device__ __forceinline__ void stu2(double* base, unsigned idx, double2u_t v) {
     *(FT_G double2u_t*)((FT_G char*)base + idx * 8u) = v;
+}
+// ... and the same with the non-temporal hint (NTS, a template flag of the caller's instance): the stash of a TRAINING sweep is
+// 280 bytes per site and layer that nobody reads before the whole sweep has gone by (FT_NT_STASH, flow_fwd.hip)
+template <bool NTS> __device__ __forceinline__ void sts(double* base, unsigned idx, double v) {
+    FT_G double* p = (FT_G double*)((FT_G char*)base + idx * 8u);
+    if (NTS) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <bool NTS> __device__ __forceinline__ void sts2(double* base, unsigned idx, double2u_t v) {
+    FT_G double2u_t* p = (FT_G double2u_t*)((FT_G char*)base + idx * 8u);
+    if (NTS) __builtin_nontemporal_store(v, p); else *p = v;
 }
 // Wrapped lattice coordinate (v mod L) of window line v, -L <= v.  FAST (L exceeds the window by a
 // margin, chosen at launch): the line wraps at most once, two selects.  Otherwise (small test lattices)

@@ -111,3 +111,33 @@ def test_wave_split_action_sums_are_bit_identical(B, L):
             y, lj = ops.flow_layer_fwd(y, w[l * 955:(l + 1) * 955], l % 2, (l // 2) % 4)
             tot = tot + lj
         assert torch.equal(ld, tot)
+
+
+def test_non_temporal_stash_instances_agree_with_the_cached_ones():
+    """a layer's stash of 128 MB or more is stored past the caches (csrc/flow_fwd.hip launch_fwd: the SWEEP = 5 / 6 instances of
+    the forward) -- the same kernel with another store instruction: a batch big enough to take them gives, chain by chain, what
+    the chains give alone (small stash: the cached instances), and the first chain agrees with the oracle"""
+    gen = torch.Generator().manual_seed(61)
+    L, nl, beta = 256, 2, 3.0
+    flow = R.default_flow(nl, gen)
+    w = ops.pack_weights(flow, device='cuda')
+    # training sweep: 8 chains x 65536 sites x 280 bytes = 147 MB per layer
+    B = 8
+    xi = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    r = ops.train_grad(xi, w, nl, beta, groups=1)
+    alone = [ops.train_grad(xi[c:c + 1], w, nl, beta, groups=1) for c in range(B)]
+    assert torch.equal(r['logq'], torch.cat([a['logq'] for a in alone])) and torch.equal(r['logp'], torch.cat([a['logp'] for a in alone]))
+    close(r['gw'], sum(a['gw'] for a in alone) / B, rtol=1e-9, atol=1e-11)
+    out, grads = R.train_grads(xi[:1].cpu(), flow, beta)
+    close(alone[0]['logq'], out['logq'], rtol=1e-11)
+    gws = ops.unpack_weight_grads(alone[0]['gw'], nl)
+    for li in range(nl):
+        for pi in range(6):
+            scale = float(grads[li][pi].abs().max())
+            close(gws[li][pi], grads[li][pi], rtol=1e-8, atol=1e-10 * max(scale, 1.0))
+    # force sweep: 16 chains x 65536 sites x 152 bytes = 159 MB per layer
+    B = 16
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    F = ops.ft_force(x, w, nl, beta)
+    for c in (0, 7, 15):
+        assert torch.equal(F[c:c + 1], ops.ft_force(x[c:c + 1], w, nl, beta))

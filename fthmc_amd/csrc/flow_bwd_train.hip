@@ -17,8 +17,9 @@
 // just consumed or produced:
 //     1  transform adjoint -> g_out, the (cos, sin) window into LDS
 //     2  conv3^T (MFMA, 3 steps per tile) -> gz2 | the h1 window into LDS
-//     3  conv2^T (MFMA) -> gz1                 | conv2 weight gradient (MFMA: M = 8 co x 2 row shifts from gz2, N = (ci, kx, ky in {0, 2})
-//                                              |   from the h1 window), the h2 window into LDS
+//     3  conv2^T (MFMA) -> gz1                 | conv2 weight gradient (MFMA: M = 8 co x 2 shifts along the walk from gz2, N = (ci, tap across
+//                                              |   the walk, tap along it in {0, 2}) from the h1 window; K = the tile's twelve LIVE stripe
+//                                              |   lines -- gz2 is an exact 0 on every fourth), the h2 window into LDS
 //     4  conv1^T (VALU)                        | conv1 weight gradient (MFMA from gz1 and the net-input window)
 //     (1 of the next item)                     | conv3 weight gradient (VALU from g_out, compact per item parity, and the h2 window)
 // so a tile costs FOUR barriers (the backward's five less the one between conv1^T's channel partials and the store: the
@@ -30,8 +31,10 @@
 // item i + 1 right behind the stage of item i that consumed the group (registers; barriers wait for LDS only).
 // Measured (round 6, config-5 shard, 32 chains of L = 256 per launch; profiles/r06_ab_train_fused_backward.txt,
 // r06_ab_train_fused_vs_two_kernels.txt): fthmc_train_grad 7.11 ms against 8.41-8.43 ms of the two-kernel form on the same
-// device, the kernel 257 us per launch against 175 + 159; per item 18.1 k cycles of which the matrix pipe is busy 8.2 k (the
-// MFMA stage: 8.55 k for 105 MFMAs per SIMD) -- the VALU / LDS stages of a lone workgroup run beside an idle matrix pipe.  What
+// device, the kernel 257 us per launch against 175 + 159; then 7.00 with conv2's GEMM on the live lines (stage 3: 8.5 k ->
+// 7.7-7.9 k cycles per item for 92 MFMAs per SIMD instead of 105) and 6.9 with the layers' partials reduced in one go (api.hip
+// force_gp) -- per item 17.3 k cycles of which the matrix pipe is busy 7.4 k: the VALU / LDS stages of a lone workgroup run
+// beside an idle matrix pipe.  What
 // did NOT take that (same file): pieces of the weight-gradient GEMMs moved into the VALU stages (both waves of a SIMD run the
 // same stage: nothing overlaps, +2 %), the two waves of a SIMD in opposite order (the kernel outgrows the instruction cache:
 // +12 %), gz2 planes at the conflict-free stride for the GEMM's A operand, MFMA operand reads pipelined ahead in registers of

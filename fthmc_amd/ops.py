@@ -638,7 +638,8 @@ def default_groups(B: int, L: int) -> int:
 def default_train_groups(B: int, L: int) -> int:
     """Chain groups of a training gradient.  On the shapes the fused training backward serves (csrc/flow_bwd_train.hip: L a power
     of two >= 32) ONE: that kernel holds a CU by itself (141 KB of LDS, 241 VGPRs), a second stream finds no room beside it and
-    only halves the walks (measured at the config-5 shard: 7.11 ms on one stream, 7.20-7.25 on two); elsewhere as the sampler."""
+    only halves the walks (measured at the config-5 shard: 7.11 ms on one stream, 7.20-7.25 on two; level since the layers'
+    partials are reduced in one go); elsewhere as the sampler."""
     if L >= 32 and (L & (L - 1)) == 0 and get_variant() == 1:
         return 1
     return default_groups(B, L)

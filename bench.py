@@ -268,7 +268,7 @@ def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))
-    from fthmc_amd import ops, parallel
+    from fthmc_amd import graph_loop, ops, parallel
     rank, world, local = parallel.init()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: start with `python bench.py --gpus {args.gpus}` '
@@ -378,11 +378,11 @@ def main():
             # The weights do not change while sampling: every trajectory call states their content version (wkey -> the C ABI's
             # `_v` entry points), the library expands them once and finds its stamps on the device from then on.
             # thread_local: the process group's watchdog thread may poll its events while this thread captures
-            with torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
+            with graph_loop.capture(graph, stream):
                 enqueue()
             if flowed:                      # the stateless variant of the same trajectory, for the side figure below
                 graph_sl = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_sl, stream=stream, capture_error_mode='thread_local'):
+                with graph_loop.capture(graph_sl, stream):
                     enqueue(stateless=True)
 
     traj = [0]

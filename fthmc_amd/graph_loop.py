@@ -9,10 +9,31 @@ for the training loop.)
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 from typing import Callable, List, Optional
 
 import numpy as np
 import torch
+
+
+@contextlib.contextmanager
+def capture(graph: "torch.cuda.CUDAGraph", stream: "torch.cuda.Stream"):
+    """`torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local')` with Python's cyclic garbage collector held
+    off until the capture has ended.  An automatic collection that starts in the capturing thread may finalise an object left
+    over from earlier work -- an older captured graph with its memory pool, a stream, an event -- whose destructor calls into the
+    HIP runtime (hipGraphExecDestroy, hipFree, ...): not permitted while this thread captures, and an error inside a destructor
+    ends the process (seen once: `Fatal Python error: Aborted`, `Garbage-collecting`, under the `enqueue` of a re-capture).
+    torch.cuda.graph collects once on entry; what becomes garbage during the capture waits for its end.  thread_local: another
+    thread (a process group's watchdog) may go on calling the runtime."""
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 class GraphLoop:
@@ -47,7 +68,7 @@ class GraphLoop:
                 self.enqueue()
                 self.stream.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
+                with capture(g, self.stream):
                     self.enqueue()
                 self.graph = g
             elif self.use_graph:

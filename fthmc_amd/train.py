@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from . import ops, parallel
+from . import graph_loop, ops, parallel
 from .config import DTYPE, FlowModel, Param, TrainConfig, device
 from .utils import qed_helpers as qed
 from .utils.distributions import MultivariateUniform, calc_dkl, calc_ess
@@ -283,7 +283,7 @@ class GraphTrainer:
         # a stream that takes part in a capture is hipErrorCapturedEvent; the eager first step ran on the default group, whose
         # stream stays outside).  Round 5 slept 0.5 s here.
         try:
-            with torch.cuda.graph(g, stream=self.stream, capture_error_mode='thread_local'):
+            with graph_loop.capture(g, self.stream):
                 self._enqueue(self.pgroup)
         except Exception as e:                                             # noqa: BLE001 -- whatever the capture objects to
             if not parallel.have_group():

@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from conftest import ROOT, golden_flow, load_golden
+from fthmc_amd.graph_loop import capture       # torch.cuda.graph with the garbage collector held off (see there)
 
 pytestmark = pytest.mark.gpu
 
@@ -197,11 +198,11 @@ def test_workspace_survives_growth_after_capture():
         st.synchronize()
         out = torch.empty_like(xs)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=st):
+        with capture(graph, st):
             out.copy_(ops.ft_force(xs, w, nl, beta))
         with pytest.raises(FthmcError, match='graph capture'):
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=st):
+            with capture(g2, st):
                 ops.ft_force(xl, w, nl, beta)                     # would have to grow the workspace while capturing
         big = ops.ft_force(xl, w, nl, beta)                       # eager: the workspace is replaced, the old one retired
         big2 = ops.ft_force(xl, w, nl, beta)

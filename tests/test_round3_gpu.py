@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from conftest import ROOT, golden_flow, load_golden
+from fthmc_amd.graph_loop import capture       # torch.cuda.graph with the garbage collector held off (see there)
 
 pytestmark = pytest.mark.gpu
 
@@ -307,7 +308,7 @@ def test_small_lattice_path_against_the_oracle_and_in_a_graph():
         ops.ft_trajectory(xd, vd, ud, w, nl, beta, dt, nstep, out=out)
         st.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st):
+        with capture(g, st):
             ops.ft_trajectory(xd, vd, ud, w, nl, beta, dt, nstep, out=out)
         for t in out.values():
             t.zero_()

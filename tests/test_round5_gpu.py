@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from conftest import ROOT  # noqa: F401
+from fthmc_amd.graph_loop import capture       # torch.cuda.graph with the garbage collector held off (see there)
 
 pytestmark = pytest.mark.gpu
 
@@ -228,7 +229,7 @@ def test_weight_versions_are_checked_on_the_device():
         out_b = ops.ft_action(x, wb, nl, beta, wkey='g')[0]                      # warm-up: workspace of this stream
         st.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):
+        with capture(g, st):
             out_b = ops.ft_action(x, wb, nl, beta, wkey='g')[0]
         assert torch.equal(ops.ft_action(x, wa, nl, beta, wkey='v2')[0], ref_a2)
         g.replay()

@@ -141,3 +141,28 @@ def test_non_temporal_stash_instances_agree_with_the_cached_ones():
     F = ops.ft_force(x, w, nl, beta)
     for c in (0, 7, 15):
         assert torch.equal(F[c:c + 1], ops.ft_force(x[c:c + 1], w, nl, beta))
+
+
+def test_capture_holds_the_garbage_collector_off():
+    """graph_loop.capture: no automatic collection starts in the capturing thread (a finaliser that calls into the HIP runtime --
+    an older graph's, a stream's -- would end the process there); the collector's state comes back, also after an error"""
+    import gc
+    from fthmc_amd.graph_loop import capture
+    st, t = torch.cuda.Stream(), torch.zeros(4, dtype=torch.float64, device='cuda')
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        t.add_(1.0)
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        assert gc.isenabled()
+        with capture(g, st):
+            assert not gc.isenabled()
+            t.add_(1.0)
+        assert gc.isenabled()
+        g.replay(); g.replay()
+        st.synchronize()
+        assert float(t[0]) == 3.0
+        with pytest.raises(ZeroDivisionError):
+            with capture(torch.cuda.CUDAGraph(), st):
+                1 / 0
+        assert gc.isenabled() and not torch.cuda.is_current_stream_capturing()

@@ -167,6 +167,9 @@ int sweep_forward(const Ctx& C, const double* x, const WS& w, int nl, int B, int
         FlowLayerArgs a{};
         a.stash = stash ? w.stash + (size_t)l * flow_stash_doubles(B, L, train) : nullptr;
         a.stash_h = train ? 1 : 0;
+        // the layers behind this one write their stash before the backward reads this one's: beyond FT_STASH_FAR_BYTES of it the
+        // 256 MB Infinity Cache will have let go of this layer's (the forward then stores it past the caches: flow_fwd.hip)
+        a.stash_far = stash && (size_t)(nl - 1 - l) * flow_stash_doubles(B, L, train) * sizeof(double) >= FT_STASH_FAR_BYTES ? 1 : 0;
         a.x = l == 0 ? x : w.X + (size_t)(l - 1) * w.n2;
         a.wint = w.wint + (size_t)l * FLOW_WINT;
         a.y = w.X + (size_t)l * w.n2;

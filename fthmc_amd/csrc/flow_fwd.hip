@@ -630,9 +630,11 @@ template <bool REV> void launch_fwd(const fthmc::FlowLayerArgs& a, dim3 grid, hi
     const bool train_sweep = !REV && a.y && a.stash && a.stash_h && a.logj_part && !a.pin && !a.pout && !a.dbg;
     // A stash the backward will not find in a cache again is stored past the caches: one layer's stash of a training shard (32
     // chains of L = 256: 587 MB) is more than the 256 MB Infinity Cache, and its stores with the hint took 4.5 % off the whole
-    // training step (6.92 -> 6.6 ms); the 40 MB per layer and chain group of the headline shape come back from the caches in the
-    // backward, and the same hint there cost 0.8 % (profiles/r06_ab_nontemporal_stash.txt).
-    const bool nt_stash = FT_NT_STASH && a.stash && fthmc::flow_stash_doubles(a.B, a.L, a.stash_h != 0) * sizeof(double) >= FT_NT_MIN_BYTES;
+    // training step (6.92 -> 6.6 ms).  At the headline shape (40 MB per layer and chain group) the backward finds the LAST layers'
+    // stash in the caches -- the hint on every layer cost 0.8 % there, on all but the last two (stash_far) it gains 0.3-1.1 %
+    // (profiles/r06_ab_nontemporal_stash.txt).
+    const bool nt_stash = FT_NT_STASH && a.stash && ((FT_NT_STASH <= 2 && fthmc::flow_stash_doubles(a.B, a.L, a.stash_h != 0) * sizeof(double) >= FT_NT_MIN_BYTES) ||
+                                                      (FT_NT_STASH >= 2 && a.stash_far));
     const bool fast = wrap_fast_ok(a.L, TR, TC);
     const bool exact = fast && a.L % TR == 0 && a.L % TC == 0 && (a.L & (a.L - 1)) == 0;
     if (a.mu == 0) {

@@ -44,10 +44,12 @@
 #ifndef FT_D1_T
 #define FT_D1_T 1
 #endif
-// 1 (default): the forward's stash stores carry the non-temporal hint where one layer's stash is FT_NT_MIN_BYTES or more (flow_fwd.hip
-// launch_fwd: the SWEEP = 5, 6 instances); 0: never (A/B knob)
+// The forward's stash stores carry the non-temporal hint (flow_fwd.hip launch_fwd: the SWEEP = 5, 6 instances) where the backward
+// will not find the stash in a cache again.  2 (default): one layer's stash is FT_NT_MIN_BYTES or more, OR the layers behind this
+// one write FT_STASH_FAR_BYTES (kernels.h) or more before the backward comes back to it (FlowLayerArgs::stash_far: at the headline
+// shape every layer but the last two); 1: the first rule only; 3: the second only; 0: never (A/B knob)
 #ifndef FT_NT_STASH
-#define FT_NT_STASH 1
+#define FT_NT_STASH 2
 #endif
 #ifndef FT_NT_MIN_BYTES
 #define FT_NT_MIN_BYTES ((size_t)128 << 20)

@@ -4,6 +4,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// FlowLayerArgs::stash_far (api.hip sweep_forward): a layer's stash counts as gone from the caches when the layers behind it write this
+// much before the backward returns to it -- the 256 MB Infinity Cache over two chain groups, each writing and reading back
+#ifndef FT_STASH_FAR_BYTES
+#define FT_STASH_FAR_BYTES ((size_t)64 << 20)
+#endif
+
 namespace fthmc {
 
 // ---- wilson.hip
@@ -107,6 +113,7 @@ struct FlowLayerArgs {
     long long* dbg;          // optional: per-(chain,tile) stage time stamps [16] (diagnostic runs only)
     double* stash;           // optional: this layer's activation stash (MFMA forward writes, stash backward reads)
     int stash_h;             // forward: also stash h1, h2 (training: the weight gradients need them)
+    int stash_far;           // forward: this layer's stash will have left the caches when the backward comes for it (sweep_forward)
     double* gz;              // training: gradients wrt the pre-activations of this layer, written by the backward kernel at
                              // every tile's own sites and read by k_flow_wgrad: per chain gz2 [n][8], gz1 [n][8]
                              // (channel-minor), g_out [n/4][4] (dL/ds_0, dL/ds_1, dL/dt, 0 at the active sites, compact)

@@ -4,7 +4,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd); NAME=$1; EXTRA=$2; D=/tmp/fthmc_$NAME; mkdir -p $D
 LDSFLAGS="-mllvm -amdgpu-load-store-vectorizer=0"
 PRELOAD=${PRELOAD--mllvm -amdgpu-kernarg-preload-count=16}       # PRELOAD= (empty) builds without kernel-argument preload
-NOLICM=${NOLICM--mllvm -disable-machine-licm}                         # NOLICM= (empty) builds flow_small with MachineLICM
+NOLICM=${NOLICM--mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-memory-clause}                         # NOLICM= (empty) builds flow_small with MachineLICM
 SHA=$(python3 "$ROOT/tools/csrc_sha.py")
 cd "$ROOT/fthmc_amd/csrc" || exit 1
 for f in wilson flow flow_fwd flow_bwd_gather flow_bwd_train flow_wgrad flow_small flow_generic rng api; do

@@ -214,8 +214,9 @@ def rocprof_launch(kernel):
                     continue
                 targs = [t.strip() for t in m.group(1).split(',')]
                 # k_flow_fwd<TR, TC, FASTW, REV, MU, EXACT, SILU, SWEEP> / k_flow_bwd_gather<TR, TC, FASTW, MU, EXACT, SWEEP>: the
-                # force-sweep instances (SWEEP = 1: what the HIP-event figure of this run times), never the inverse map (REV)
-                if kernel == 'k_flow_fwd' and (targs[3] != 'false' or (len(targs) >= 8 and targs[7] != '1')):
+                # force-sweep instances (SWEEP = 1: what the HIP-event figure of this run times; for the forward also 5, the same kernel
+                # with non-temporal stash stores, which a sweep's early layers run), never the inverse map (REV)
+                if kernel == 'k_flow_fwd' and (targs[3] != 'false' or (len(targs) >= 8 and targs[7] not in ('1', '5'))):
                     continue
                 if kernel == 'k_flow_bwd_gather' and len(targs) >= 6 and targs[5] != '1':
                     continue

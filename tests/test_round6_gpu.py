@@ -141,6 +141,16 @@ def test_non_temporal_stash_instances_agree_with_the_cached_ones():
     F = ops.ft_force(x, w, nl, beta)
     for c in (0, 7, 15):
         assert torch.equal(F[c:c + 1], ops.ft_force(x[c:c + 1], w, nl, beta))
+    # ... and by POSITION in the sweep (csrc/api.hip sweep_forward: FlowLayerArgs::stash_far): a chain group of the headline shape
+    # (64 chains of L = 64, 8 layers: 38 MiB of stash per layer) stores the stash of every layer but the last two past the caches
+    L, nl, B = 64, 8, 64
+    flow = R.default_flow(nl, gen)
+    w = ops.pack_weights(flow, device='cuda')
+    x = ((torch.rand(B, 2, L, L, generator=gen, dtype=torch.float64) * 2 - 1) * math.pi).cuda()
+    F = ops.ft_force(x, w, nl, 6.0)
+    for c in (0, 31, 63):
+        assert torch.equal(F[c:c + 1], ops.ft_force(x[c:c + 1], w, nl, 6.0))
+    close(F[:1], R.ft_force(x[:1].cpu(), flow, 6.0), rtol=1e-9, atol=1e-9)
 
 
 def test_capture_holds_the_garbage_collector_off():
